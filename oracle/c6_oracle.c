@@ -1,0 +1,919 @@
+/*
+ * c6_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * Plain-C restatement of Connect6/libconnect6 (reference, Rust); see c6_oracle.h.
+ * Compile with -ffp-contract=off: the float arithmetic below mirrors the
+ * reference's unfused f32/f64 operations one by one.
+ */
+#include "c6_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ===================================================================== */
+/* game                                                                   */
+/* ===================================================================== */
+
+/* game/player/mod.rs:24-30 */
+int c6o_player_switch(int p) { return p == C6O_BLACK ? C6O_WHITE : (p == C6O_WHITE ? C6O_BLACK : C6O_NONE); }
+
+/* game/game_impl/mod.rs:125-131: Black to move, one stone, empty board */
+void c6o_game_new(c6o_game *g, int n) {
+    memset(g, 0, sizeof(*g));
+    g->n = n;
+    g->turn = C6O_BLACK;
+    g->num_remain = 1;
+}
+
+/* game/game_impl/mod.rs:148-169 */
+int c6o_game_set(c6o_game *g, int row, int col, c6o_set_result *out) {
+    int n = g->n;
+    /* usize arguments in the reference: a negative index cannot occur there; treat as invalid */
+    if (row < 0 || col < 0 || row >= n || col >= n) return C6O_ERR_INVALID_POSITION;
+    if (g->board[row * n + col] != C6O_NONE) return C6O_ERR_ALREADY_SET;
+    g->board[row * n + col] = (int8_t)g->turn;
+    g->num_remain -= 1;
+    if (out) { /* SetResult::with_game: snapshot after the decrement, before the reset (:158-160) */
+        out->player = g->turn;
+        out->num_remain = g->num_remain;
+        out->row = row;
+        out->col = col;
+    }
+    if (g->num_remain <= 0) {
+        g->num_remain = 2;
+        g->turn = c6o_player_switch(g->turn);
+    }
+    return C6O_OK;
+}
+
+/* game/game_impl/mod.rs:66-100 (Error::description strings) */
+const char *c6o_strerror(int err) {
+    switch (err) {
+    case C6O_OK: return "ok";
+    case C6O_ERR_INVALID_POSITION: return "invalid position";
+    case C6O_ERR_ALREADY_SET: return "already set position";
+    default: return "unknown";
+    }
+}
+
+/* search_winner/mod.rs:36-184: Cumulative + Block (two rolling rows with a 1-cell halo) */
+typedef struct { int c[4]; } cumul; /* right, down, right_down, left_down */
+typedef struct {
+    int flag;
+    cumul mem[2][C6O_MAXN + 2];
+} block;
+
+static void block_update_row(block *b, int n) { /* :176-183 */
+    b->flag = 1 - b->flag;
+    memset(b->mem[1 - b->flag], 0, sizeof(cumul) * (size_t)(n + 2));
+}
+
+/* :206-222 path_iter: returns 1 when some direction reaches >= 6 */
+static int block_path_iter(block *b, int col0) {
+    int col = col0 + 1;
+    cumul *prev = b->mem[b->flag], *now = b->mem[1 - b->flag];
+    for (int p = 0; p < 4; p++) {
+        const cumul *src; /* Block::get_prev :131-139 */
+        switch (p) {
+        case 0: src = &now[col - 1]; break;  /* Right */
+        case 1: src = &prev[col]; break;     /* Down */
+        case 2: src = &prev[col - 1]; break; /* RightDown */
+        default: src = &prev[col + 1]; break;/* LeftDown */
+        }
+        int updated = src->c[p] + 1;
+        if (updated >= 6) return 1;
+        now[col].c[p] = updated;
+    }
+    return 0;
+}
+
+/* search_winner/mod.rs:201-246 */
+int c6o_search(const int8_t *board, int n) {
+    block black, white;
+    memset(&black, 0, sizeof black);
+    memset(&white, 0, sizeof white);
+    for (int row = 0; row < n; row++) {
+        block_update_row(&black, n);
+        block_update_row(&white, n);
+        for (int col = 0; col < n; col++) {
+            int8_t v = board[row * n + col];
+            if (v == C6O_NONE) continue;
+            if (v == C6O_BLACK) {
+                if (block_path_iter(&black, col)) return C6O_BLACK;
+            } else {
+                if (block_path_iter(&white, col)) return C6O_WHITE;
+            }
+        }
+    }
+    return C6O_NONE;
+}
+
+int c6o_game_is_end(const c6o_game *g) { return c6o_search(g->board, g->n); }
+
+/* ===================================================================== */
+/* simulate                                                               */
+/* ===================================================================== */
+
+/* simulate/mod.rs:120-127 + Node::from_board :58-69 (row-major empties) */
+void c6o_sim_from_game(c6o_sim *s, const c6o_game *g) {
+    int n = g->n;
+    s->n = n;
+    s->turn = g->turn;
+    s->num_remain = g->num_remain;
+    memcpy(s->board, g->board, (size_t)(n * n));
+    s->npossible = 0;
+    for (int i = 0; i < n * n; i++)
+        if (g->board[i] == C6O_NONE) s->possible[s->npossible++] = (int16_t)i;
+}
+
+int c6o_sim_validate(const c6o_sim *s, int row, int col) {
+    if (row < 0 || col < 0 || row >= s->n || col >= s->n) return 0;
+    return s->board[row * s->n + col] == C6O_NONE;
+}
+
+int c6o_sim_next_turn(const c6o_sim *s) { return s->num_remain <= 1 ? c6o_player_switch(s->turn) : s->turn; }
+
+static void sim_remove_possible(c6o_sim *s, int cell) {
+    int i = 0;
+    while (i < s->npossible && s->possible[i] != cell) i++;
+    if (i == s->npossible) { fprintf(stderr, "c6o: simulate on a non-empty cell\n"); abort(); } /* unwrap() */
+    memmove(&s->possible[i], &s->possible[i + 1], sizeof(int16_t) * (size_t)(s->npossible - i - 1));
+    s->npossible--;
+}
+
+/* simulate/mod.rs:262-274 */
+void c6o_sim_simulate_in(c6o_sim *s, int row, int col) {
+    int cell = row * s->n + col;
+    sim_remove_possible(s, cell);
+    s->board[cell] = (int8_t)s->turn;
+    s->num_remain -= 1;
+    if (s->num_remain <= 0) {
+        s->num_remain = 2;
+        s->turn = c6o_player_switch(s->turn);
+    }
+}
+
+/* simulate/mod.rs:290-301 */
+void c6o_sim_rollback_in(c6o_sim *s, int row, int col) {
+    int cell = row * s->n + col;
+    s->board[cell] = C6O_NONE;
+    s->possible[s->npossible++] = (int16_t)cell;
+    s->num_remain += 1;
+    if (s->num_remain > 2) {
+        s->num_remain = 1;
+        s->turn = c6o_player_switch(s->turn);
+    }
+}
+
+/* default_policy/mod.rs:74-83 */
+int c6o_diff_board(const int8_t *b1, const int8_t *b2, int n) {
+    for (int i = 0; i < n * n; i++)
+        if (b1[i] != b2[i]) return i;
+    return -1;
+}
+
+/* ===================================================================== */
+/* augment                                                                */
+/* ===================================================================== */
+
+#define DEF_AUG(T, SUF)                                                                         \
+    void c6o_rotate_left_##SUF(T *b, int n) { /* augment.rs:7-15 */                              \
+        T r[C6O_MAXCELLS];                                                                      \
+        for (int i = 0; i < n; i++)                                                             \
+            for (int j = 0; j < n; j++) r[(n - j - 1) * n + i] = b[i * n + j];                  \
+        memcpy(b, r, sizeof(T) * (size_t)(n * n));                                              \
+    }                                                                                           \
+    void c6o_rotate_right_##SUF(T *b, int n) { /* augment.rs:17-25 */                            \
+        T r[C6O_MAXCELLS];                                                                      \
+        for (int i = 0; i < n; i++)                                                             \
+            for (int j = 0; j < n; j++) r[j * n + (n - i - 1)] = b[i * n + j];                  \
+        memcpy(b, r, sizeof(T) * (size_t)(n * n));                                              \
+    }                                                                                           \
+    void c6o_flip_vertical_##SUF(T *b, int n) { /* augment.rs:27-35, axis | */                   \
+        for (int i = 0; i < n; i++)                                                             \
+            for (int j = 0; j < n / 2; j++) {                                                   \
+                T t = b[i * n + (n - j - 1)];                                                   \
+                b[i * n + (n - j - 1)] = b[i * n + j];                                          \
+                b[i * n + j] = t;                                                               \
+            }                                                                                   \
+    }
+DEF_AUG(int8_t, i8)
+DEF_AUG(float, f32)
+
+/* augment.rs:37-47, axis -- (unused on the path, kept for the known-answer test) */
+void c6o_flip_horizontal_i8(int8_t *b, int n) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n / 2; j++) {
+            int8_t t = b[(n - j - 1) * n + i];
+            b[(n - j - 1) * n + i] = b[j * n + i];
+            b[j * n + i] = t;
+        }
+}
+
+/* augment.rs:60-73 */
+void c6o_augment_way8(const int8_t *board, int n, int8_t *out8) {
+    int8_t b[C6O_MAXCELLS];
+    size_t sz = (size_t)(n * n);
+    memcpy(b, board, sz);
+    for (int i = 0; i < 4; i++) {
+        c6o_rotate_left_i8(b, n);
+        memcpy(out8 + (size_t)(2 * i) * sz, b, sz);
+        memcpy(out8 + (size_t)(2 * i + 1) * sz, b, sz);
+        c6o_flip_vertical_i8(out8 + (size_t)(2 * i + 1) * sz, n);
+    }
+}
+
+/* augment.rs:75-92; summation order kept exactly */
+void c6o_recover_way8(float *probs8, int n, float *out) {
+    size_t sz = (size_t)(n * n);
+    for (size_t k = 0; k < sz; k++) out[k] = 0.f;
+    for (int i = 0; i < 4; i++) {
+        float *a = probs8 + (size_t)(2 * i) * sz, *f = probs8 + (size_t)(2 * i + 1) * sz;
+        c6o_flip_vertical_f32(f, n);
+        for (size_t k = 0; k < sz; k++) a[k] = a[k] + f[k];
+        for (int r = 0; r < i + 1; r++) c6o_rotate_right_f32(a, n);
+        for (size_t k = 0; k < sz; k++) out[k] = out[k] + a[k];
+    }
+    for (size_t k = 0; k < sz; k++) out[k] /= 8.f;
+}
+
+/* ===================================================================== */
+/* C6RNG (spec in DESIGN.md): Philox4x32-10 + deterministic f64 math       */
+/* ===================================================================== */
+
+void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline double bits2d(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+static inline uint64_t d2bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+/* natural log, x > 0 normal; only + - * / and bit operations (bit-identical on every IEEE machine) */
+double c6o_det_log(double x) {
+    uint64_t b = d2bits(x);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    double m = bits2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1,2) */
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double f = (m - 1.0) / (m + 1.0), f2 = f * f;
+    double p = 1.0 / 23.0;
+    p = p * f2 + 1.0 / 21.0;
+    p = p * f2 + 1.0 / 19.0;
+    p = p * f2 + 1.0 / 17.0;
+    p = p * f2 + 1.0 / 15.0;
+    p = p * f2 + 1.0 / 13.0;
+    p = p * f2 + 1.0 / 11.0;
+    p = p * f2 + 1.0 / 9.0;
+    p = p * f2 + 1.0 / 7.0;
+    p = p * f2 + 1.0 / 5.0;
+    p = p * f2 + 1.0 / 3.0;
+    p = p * f2 + 1.0;
+    double lm = 2.0 * f * p;
+    double de = (double)e;
+    return de * 6.93147180369123816490e-01 + (lm + de * 1.90821492927058770002e-10);
+}
+
+/* exp, same rules; x <= ~709 */
+double c6o_det_exp(double x) {
+    if (x < -746.0) return 0.0;
+    double t = x * 1.44269504088896338700e+00;
+    long long k = (long long)(t + (t >= 0 ? 0.5 : -0.5));
+    double dk = (double)k;
+    double r = (x - dk * 6.93147180369123816490e-01) - dk * 1.90821492927058770002e-10;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    /* scale by 2^k in two exact-power steps so that gradual underflow rounds once */
+    long long k1 = k / 2, k2 = k - k1;
+    double s1 = bits2d((uint64_t)(k1 + 1023) << 52), s2 = bits2d((uint64_t)(k2 + 1023) << 52);
+    return (p * s1) * s2;
+}
+
+/* 53-bit uniform strictly inside (0,1) */
+static inline double open01(uint32_t hi, uint32_t lo) {
+    uint64_t v = ((uint64_t)hi << 21) | (uint64_t)(lo >> 11);
+    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+/*
+ * Gamma(alpha, 1), alpha < 1 -- the algorithm of rand 0.6 `Gamma` (GammaSmallShape:
+ * Marsaglia-Tsang for shape alpha+1 times U^(1/alpha)), which is what
+ * `Dirichlet::new_with_param(alpha, n).sample` draws per component
+ * (called from alphazero_policy/mod.rs:262,283).  Normal deviates come from the
+ * polar method so that only log/sqrt are needed.
+ */
+double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth) {
+    const double shape = alpha + 1.0;
+    const double d = shape - 1.0 / 3.0;
+    const double c = 1.0 / sqrt(9.0 * d);
+    uint32_t key[2] = {k0, k1};
+    for (uint32_t att = 0;; att++) {
+        uint32_t ctr[4] = {cell, 2 * att, search, (uint32_t)C6O_TAG_NOISE | (depth << 8)}, w[4];
+        c6o_philox4x32_10(ctr, key, w);
+        double v1 = 2.0 * open01(w[0], w[1]) - 1.0, v2 = 2.0 * open01(w[2], w[3]) - 1.0;
+        double s = v1 * v1 + v2 * v2;
+        if (s >= 1.0 || s == 0.0) continue;
+        double x = v1 * sqrt(-2.0 * c6o_det_log(s) / s);
+        double vc = 1.0 + c * x;
+        if (vc <= 0.0) continue;
+        double v = vc * vc * vc;
+        ctr[1] = 2 * att + 1;
+        c6o_philox4x32_10(ctr, key, w);
+        double u = open01(w[0], w[1]), u2 = open01(w[2], w[3]);
+        double x2 = x * x;
+        if (u < 1.0 - 0.0331 * x2 * x2 || c6o_det_log(u) < 0.5 * x2 + d * (1.0 - v + c6o_det_log(v))) {
+            double g = d * v;
+            return g * c6o_det_exp(c6o_det_log(u2) / alpha);
+        }
+    }
+}
+
+double c6o_butterfly_sum64(const double part[64]) {
+    double v[64], t[64];
+    memcpy(v, part, sizeof v);
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
+        memcpy(v, t, sizeof v);
+    }
+    return v[0];
+}
+
+void c6o_dirichlet_noise(double alpha, uint32_t k0, uint32_t k1, uint32_t search, uint32_t depth,
+                         const int8_t *board, int n, float *noise) {
+    double g[C6O_MAXCELLS], part[64];
+    int cells = n * n;
+    for (int l = 0; l < 64; l++) part[l] = 0.0;
+    for (int c = 0; c < cells; c++) {
+        g[c] = 0.0;
+        if (board[c] == C6O_NONE) {
+            g[c] = c6o_gamma_draw(alpha, k0, k1, (uint32_t)c, search, depth);
+            part[c & 63] = part[c & 63] + g[c]; /* ascending within a lane: c, c+64, ... */
+        }
+    }
+    double sum = c6o_butterfly_sum64(part);
+    for (int c = 0; c < cells; c++) noise[c] = board[c] == C6O_NONE ? (float)(g[c] / sum) : 0.f;
+}
+
+/* ===================================================================== */
+/* AlphaZero policy                                                       */
+/* ===================================================================== */
+
+/* alphazero_policy/mod.rs:26-36 */
+typedef struct node {
+    uint64_t h;
+    int visit;
+    float value, q_sum, q_value, n_prob;
+    float *prob; /* NULL == all zeros (never expanded) */
+    int num_player;
+    int n_next;
+    struct node **next; /* children in `possible` order; the reference stores their hashes */
+    int16_t *next_cell;
+    int8_t board[C6O_MAXCELLS];
+} node;
+
+struct c6o_az {
+    int n, cells;
+    c6o_hyper hp;
+    int eval_kind;
+    c6o_eval_fn fn;
+    void *ctx;
+    uint32_t k0, k1;
+    uint32_t nsearch;    /* C6RNG `search` coordinate: searches since the game started */
+    int root_level;      /* stones on the board at the last init() */
+    uint64_t zob[2][C6O_MAXCELLS];
+    node **tab;          /* open addressing, pointers */
+    size_t cap, len;
+    uint64_t depth_sum, depth_cnt;
+};
+
+static uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+/* stands in for alphazero_policy/mod.rs:456-460 (SipHash of the board): only used as a
+ * table key; full boards are compared on every hit, so there are no collisions at all */
+static uint64_t az_hash(const c6o_az *az, const int8_t *board) {
+    uint64_t h = 0x1234567ULL;
+    for (int i = 0; i < az->cells; i++)
+        if (board[i] != C6O_NONE) h ^= az->zob[board[i] == C6O_WHITE][i];
+    return h;
+}
+
+static node *map_get(const c6o_az *az, uint64_t h, const int8_t *board) {
+    size_t mask = az->cap - 1, i = (size_t)h & mask;
+    while (az->tab[i]) {
+        node *nd = az->tab[i];
+        if (nd->h == h && memcmp(nd->board, board, (size_t)az->cells) == 0) return nd;
+        i = (i + 1) & mask;
+    }
+    return NULL;
+}
+
+static void map_put_raw(node **tab, size_t cap, node *nd) {
+    size_t mask = cap - 1, i = (size_t)nd->h & mask;
+    while (tab[i]) i = (i + 1) & mask;
+    tab[i] = nd;
+}
+
+static void map_insert(c6o_az *az, node *nd) {
+    if ((az->len + 1) * 2 > az->cap) {
+        size_t ncap = az->cap * 2;
+        node **nt = (node **)calloc(ncap, sizeof(node *));
+        for (size_t i = 0; i < az->cap; i++)
+            if (az->tab[i]) map_put_raw(nt, ncap, az->tab[i]);
+        free(az->tab);
+        az->tab = nt;
+        az->cap = ncap;
+    }
+    map_put_raw(az->tab, az->cap, nd);
+    az->len++;
+}
+
+static void node_free(node *nd) {
+    free(nd->prob);
+    free(nd->next);
+    free(nd->next_cell);
+    free(nd);
+}
+
+/* Node::new_with_num :62-74 */
+static node *node_new(const c6o_az *az, const int8_t *board, uint64_t h, int num_player) {
+    node *nd = (node *)calloc(1, sizeof(node));
+    nd->h = h;
+    nd->num_player = num_player;
+    memcpy(nd->board, board, (size_t)az->cells);
+    return nd;
+}
+
+static int count_stones(const int8_t *b, int cells) {
+    int c = 0;
+    for (int i = 0; i < cells; i++) c += b[i] != C6O_NONE;
+    return c;
+}
+
+static int random_eval(void *ctx, int turn, int n, int len, const int8_t *boards, float *values, float *policies);
+static int uniform_eval(void *ctx, int turn, int n, int len, const int8_t *boards, float *values, float *policies);
+
+c6o_az *c6o_az_new(int n, const c6o_hyper *hp, int eval_kind, c6o_eval_fn fn, void *ctx, uint64_t seed,
+                   uint32_t game_uid) {
+    c6o_az *az = (c6o_az *)calloc(1, sizeof(*az));
+    az->n = n;
+    az->cells = n * n;
+    az->hp = *hp;
+    az->eval_kind = eval_kind;
+    az->fn = fn;
+    az->ctx = ctx;
+    if (eval_kind == C6O_EVAL_RANDOM) { az->fn = random_eval; az->ctx = az; }
+    if (eval_kind == C6O_EVAL_UNIFORM) { az->fn = uniform_eval; az->ctx = az; }
+    az->k0 = (uint32_t)seed;
+    az->k1 = (uint32_t)(seed >> 32) + game_uid;
+    uint64_t s = 0xC6C6C6C6ULL;
+    for (int c = 0; c < 2; c++)
+        for (int i = 0; i < C6O_MAXCELLS; i++) az->zob[c][i] = splitmix64(&s);
+    az->cap = 1024;
+    az->tab = (node **)calloc(az->cap, sizeof(node *));
+    return az;
+}
+
+void c6o_az_free(c6o_az *az) {
+    if (!az) return;
+    for (size_t i = 0; i < az->cap; i++)
+        if (az->tab[i]) node_free(az->tab[i]);
+    free(az->tab);
+    free(az);
+}
+
+size_t c6o_az_map_len(const c6o_az *az) { return az->len; }
+uint32_t c6o_az_search_count(const c6o_az *az) { return az->nsearch; }
+double c6o_az_mean_depth(const c6o_az *az) { return az->depth_cnt ? (double)az->depth_sum / (double)az->depth_cnt : 0.0; }
+
+/* RandomEvaluator, alphazero_policy/mod.rs:137-169: value and every policy cell ~ U[-1,1) */
+static inline float u11(uint32_t w) { return 2.0f * ((float)(w >> 8) * (1.0f / 16777216.0f)) - 1.0f; }
+
+static int random_eval(void *ctx, int turn, int n, int len, const int8_t *boards, float *values, float *policies) {
+    (void)turn; (void)boards;
+    c6o_az *az = (c6o_az *)ctx;
+    uint32_t key[2] = {az->k0, az->k1}, w[4];
+    int cells = n * n;
+    for (int k = 0; k < len; k++) {
+        uint32_t cv[4] = {(uint32_t)k, 0, az->nsearch, C6O_TAG_EVAL_V};
+        c6o_philox4x32_10(cv, key, w);
+        values[k] = u11(w[0]);
+        for (int c = 0; c < cells; c++) {
+            if ((c & 3) == 0) {
+                uint32_t cp[4] = {(uint32_t)(c >> 2), (uint32_t)k, az->nsearch, C6O_TAG_EVAL_P};
+                c6o_philox4x32_10(cp, key, w);
+            }
+            policies[k * cells + c] = u11(w[c & 3]);
+        }
+    }
+    return 0;
+}
+
+static int uniform_eval(void *ctx, int turn, int n, int len, const int8_t *boards, float *values, float *policies) {
+    (void)ctx; (void)turn; (void)boards;
+    int cells = n * n;
+    for (int k = 0; k < len; k++) {
+        values[k] = 0.f;
+        for (int c = 0; c < cells; c++) policies[k * cells + c] = 1.0f / (float)cells;
+    }
+    return 0;
+}
+
+/* alphazero_policy/mod.rs:218-234 */
+static int az_get_from(c6o_az *az, int turn, const int8_t *board, float *value, float *prob) {
+    int8_t aug[8 * C6O_MAXCELLS];
+    float vals[8], pols[8 * C6O_MAXCELLS];
+    c6o_augment_way8(board, az->n, aug);
+    memset(vals, 0, sizeof vals);
+    /* cppeval/mod.rs:34-35: on entry `policies` holds the boards as floats */
+    for (int i = 0; i < 8 * az->cells; i++) pols[i] = (float)aug[i];
+    if (az->fn(az->ctx, turn, az->n, 8, aug, vals, pols) != 0) return -1;
+    float s = 0.f;
+    for (int k = 0; k < 8; k++) s = s + vals[k]; /* iter().sum::<f32>() */
+    *value = s / 8.f;
+    c6o_recover_way8(pols, az->n, prob);
+    for (int i = 0; i < az->cells; i++) prob[i] *= (float)(board[i] == C6O_NONE); /* masking :226-231 */
+    return 0;
+}
+
+/* alphazero_policy/mod.rs:302-306 */
+void c6o_az_init(c6o_az *az, const c6o_sim *s) {
+    uint64_t h = az_hash(az, s->board);
+    az->root_level = count_stones(s->board, az->cells);
+    if (!map_get(az, h, s->board)) map_insert(az, node_new(az, s->board, h, az->root_level)); /* Node::new :43-59 */
+}
+
+/* alphazero_policy/mod.rs:243-296; returns the chosen child */
+static node *az_maximum_from(c6o_az *az, const c6o_sim *s) {
+    node *tn = map_get(az, az_hash(az, s->board), s->board); /* unwrap() */
+    if (!tn) { fprintf(stderr, "c6o: maximum_from on unknown node\n"); abort(); }
+    int nc = tn->n_next;
+    if (nc == 0) return NULL;
+    if (nc == 1) return tn->next[0]; /* heuristic :255-258 */
+
+    float epsilon = az->hp.epsilon, c_puct = az->hp.c_puct;
+    uint32_t depth = (uint32_t)(count_stones(s->board, az->cells) - az->root_level);
+    float noise[C6O_MAXCELLS];
+    c6o_dirichlet_noise(az->hp.dirichlet_alpha, az->k0, az->k1, az->nsearch, depth, s->board, az->n, noise);
+
+    int vs = 0;
+    for (int i = 0; i < nc; i++) vs += tn->next[i]->visit;
+    float visit_sum = (float)vs;
+    if (s->turn == C6O_NONE) { fprintf(stderr, "c6o: maximum_from with player none\n"); abort(); }
+
+    float best = 0.f, score[C6O_MAXCELLS];
+    int have = 0;
+    for (int i = 0; i < nc; i++) {
+        const node *ch = tn->next[i];
+        float nz = noise[tn->next_cell[i]];
+        float visit = (float)ch->visit;
+        float prob = epsilon * nz + (1.f - epsilon) * ch->n_prob;
+        float puct = prob * sqrtf(visit_sum - visit) / (1.f + visit);
+        float q = s->turn == C6O_BLACK ? -ch->q_value : ch->q_value;
+        float sc = q + c_puct * puct;
+        if (sc != sc) { fprintf(stderr, "c6o: NaN score (partial_cmp unwrap)\n"); abort(); }
+        score[i] = sc;
+        if (!have || sc > best) { best = sc; have = 1; }
+    }
+    int cnt = 0;
+    for (int i = 0; i < nc; i++) cnt += score[i] == best;
+    int pick = 0;
+    if (cnt > 1) { /* `choose` among exact ties :291-295 -- uniform on the C6RNG TIE stream */
+        uint32_t key[2] = {az->k0, az->k1}, w[4];
+        uint32_t ctr[4] = {0, 0, az->nsearch, (uint32_t)C6O_TAG_TIE | (depth << 8)};
+        c6o_philox4x32_10(ctr, key, w);
+        pick = (int)(open01(w[0], w[1]) * (double)cnt);
+        if (pick >= cnt) pick = cnt - 1;
+    }
+    for (int i = 0; i < nc; i++)
+        if (score[i] == best && pick-- == 0) return tn->next[i];
+    return NULL;
+}
+
+/* alphazero_policy/mod.rs:313-323 */
+int c6o_az_select(c6o_az *az, const c6o_sim *s) {
+    node *tn = map_get(az, az_hash(az, s->board), s->board);
+    node *ch = az_maximum_from(az, s);
+    if (!ch) return -1;
+    return c6o_diff_board(ch->board, tn->board, az->n);
+}
+
+/* alphazero_policy/mod.rs:331-381 */
+void c6o_az_expand(c6o_az *az, const c6o_sim *s) {
+    node *parent = map_get(az, az_hash(az, s->board), s->board);
+    if (!parent) { fprintf(stderr, "c6o: expand on unknown node\n"); abort(); }
+    float cost = (float)s->turn;
+    if (parent->num_player == az->cells) {
+        int winner = c6o_search(s->board, az->n);
+        if (winner == s->turn) parent->value = cost;
+        else if (winner != C6O_NONE) parent->value = -cost;
+        return;
+    }
+    float value, prob[C6O_MAXCELLS];
+    if (az_get_from(az, s->turn, s->board, &value, prob) != 0) {
+        fprintf(stderr, "alpha_zero::expand couldn't get value, prob\n");
+        abort();
+    }
+    parent->value = value;
+    if (!parent->prob) parent->prob = (float *)malloc(sizeof(float) * (size_t)az->cells);
+    memcpy(parent->prob, prob, sizeof(float) * (size_t)az->cells);
+    parent->visit += 1;
+    int child_num = parent->num_player + 1;
+
+    int np = s->npossible;
+    node **kids = (node **)malloc(sizeof(node *) * (size_t)(parent->n_next + np));
+    int16_t *kcell = (int16_t *)malloc(sizeof(int16_t) * (size_t)(parent->n_next + np));
+    if (parent->n_next) { /* next_node.push appends (:376-378) */
+        memcpy(kids, parent->next, sizeof(node *) * (size_t)parent->n_next);
+        memcpy(kcell, parent->next_cell, sizeof(int16_t) * (size_t)parent->n_next);
+    }
+    int8_t b[C6O_MAXCELLS];
+    memcpy(b, s->board, (size_t)az->cells);
+    uint64_t ph = parent->h;
+    for (int i = 0; i < np; i++) {
+        int cell = s->possible[i];
+        b[cell] = (int8_t)s->turn; /* sim.simulate(row, col) :361 */
+        uint64_t h = ph ^ az->zob[s->turn == C6O_WHITE][cell];
+        node *ch = map_get(az, h, b);
+        if (!ch) { ch = node_new(az, b, h, child_num); map_insert(az, ch); } /* entry().or_insert :366-369 */
+        ch->n_prob = prob[cell];                                              /* overwrite :370 */
+        kids[parent->n_next + i] = ch;
+        kcell[parent->n_next + i] = (int16_t)cell;
+        b[cell] = C6O_NONE;
+    }
+    free(parent->next);
+    free(parent->next_cell);
+    parent->next = kids;
+    parent->next_cell = kcell;
+    parent->n_next += np;
+}
+
+/* alphazero_policy/mod.rs:386-408 */
+void c6o_az_update(c6o_az *az, const c6o_sim *s, const int16_t *path, int len) {
+    if (len == 0) return;
+    node *leaf = map_get(az, az_hash(az, s->board), s->board);
+    float value = leaf->value;
+    c6o_sim c = *s; /* deep_clone */
+    int n = az->n;
+    {
+        c6o_sim c2 = *s;
+        c6o_sim_rollback_in(&c2, path[len - 1] / n, path[len - 1] % n);
+        node *p = map_get(az, az_hash(az, c2.board), c2.board);
+        p->q_sum += value;
+    }
+    for (int i = len - 1; i >= 0; i--) {
+        c6o_sim_rollback_in(&c, path[i] / n, path[i] % n);
+        node *p = map_get(az, az_hash(az, c.board), c.board);
+        p->visit += 1;
+        p->q_value = p->q_sum / (float)p->visit; /* recalc_q :77-79 */
+    }
+}
+
+/* alphazero_policy/mod.rs:411-426 */
+void c6o_az_search(c6o_az *az, const c6o_sim *root) {
+    c6o_az_init(az, root);
+    c6o_sim s = *root; /* deep_clone (simulate/mod.rs:133-143): `possible` rebuilt row-major */
+    s.npossible = 0;
+    for (int i = 0; i < az->cells; i++)
+        if (s.board[i] == C6O_NONE) s.possible[s.npossible++] = (int16_t)i;
+    int16_t path[C6O_MAXCELLS];
+    int len = 0, cell;
+    while ((cell = c6o_az_select(az, &s)) >= 0) {
+        path[len++] = (int16_t)cell;
+        c6o_sim_simulate_in(&s, cell / az->n, cell % az->n);
+    }
+    az->depth_sum += (uint64_t)len;
+    az->depth_cnt += 1;
+    c6o_az_expand(az, &s);
+    c6o_az_update(az, &s, path, len);
+    az->nsearch += 1;
+}
+
+/* alphazero_policy/mod.rs:433-452 */
+int c6o_az_policy(c6o_az *az, const c6o_sim *s) {
+    node *tn = map_get(az, az_hash(az, s->board), s->board);
+    if (!tn || tn->n_next == 0) return -1;
+    int vs = 0;
+    for (int i = 0; i < tn->n_next; i++) vs += tn->next[i]->visit;
+    float visit_sum = (float)vs;
+    int best = -1;
+    float bp = 0.f;
+    for (int i = 0; i < tn->n_next; i++) {
+        float visit = (float)tn->next[i]->visit;
+        float p = visit / (visit_sum - visit + 1.f);
+        if (best < 0 || !(p < bp)) { best = i; bp = p; } /* Iterator::max_by keeps the LAST maximum */
+    }
+    return c6o_diff_board(s->board, tn->next[best]->board, az->n);
+}
+
+/* alphazero_policy/mod.rs:473-487: drop every node with the root's stone count, re-insert the root */
+void c6o_az_prune(c6o_az *az, const c6o_sim *s) {
+    node *root = map_get(az, az_hash(az, s->board), s->board);
+    int num_player = root->num_player;
+    node **nt = (node **)calloc(az->cap, sizeof(node *));
+    size_t nlen = 0;
+    for (size_t i = 0; i < az->cap; i++) {
+        node *nd = az->tab[i];
+        if (!nd) continue;
+        if (nd->num_player == num_player && nd != root) { node_free(nd); continue; }
+        map_put_raw(nt, az->cap, nd);
+        nlen++;
+    }
+    free(az->tab);
+    az->tab = nt;
+    az->len = nlen;
+}
+
+/* alphazero_policy/mod.rs:464-489 */
+int c6o_az_next(c6o_az *az, const c6o_game *g) {
+    c6o_sim s;
+    c6o_sim_from_game(&s, g);
+    c6o_az_init(az, &s);
+    for (int i = 0; i < az->hp.num_simulation; i++) c6o_az_search(az, &s);
+    int res = c6o_az_policy(az, &s);
+    c6o_az_prune(az, &s);
+    return res;
+}
+
+void c6o_az_node_info(const c6o_az *az, const int8_t *board, c6o_node_info *out) {
+    memset(out, 0, sizeof *out);
+    const node *nd = map_get(az, az_hash(az, board), board);
+    if (!nd) return;
+    out->found = 1;
+    out->visit = nd->visit;
+    out->value = nd->value;
+    out->q_sum = nd->q_sum;
+    out->q_value = nd->q_value;
+    out->n_prob = nd->n_prob;
+    out->num_player = nd->num_player;
+    out->n_next = nd->n_next;
+    out->has_prob = nd->prob != NULL;
+}
+
+int c6o_az_node_prob(const c6o_az *az, const int8_t *board, float *prob) {
+    const node *nd = map_get(az, az_hash(az, board), board);
+    if (!nd) return 0;
+    for (int i = 0; i < az->cells; i++) prob[i] = nd->prob ? nd->prob[i] : 0.f;
+    return 1;
+}
+
+int c6o_az_children(const c6o_az *az, const int8_t *board, int *visit, float *q_value, float *n_prob) {
+    const node *nd = map_get(az, az_hash(az, board), board);
+    for (int i = 0; i < az->cells; i++) { visit[i] = -1; q_value[i] = 0.f; n_prob[i] = 0.f; }
+    if (!nd) return 0;
+    for (int i = 0; i < nd->n_next; i++) {
+        int c = nd->next_cell[i];
+        visit[c] = nd->next[i]->visit;
+        q_value[c] = nd->next[i]->q_value;
+        n_prob[c] = nd->next[i]->n_prob;
+    }
+    return 1;
+}
+
+/* ===================================================================== */
+/* agent                                                                  */
+/* ===================================================================== */
+
+/* agent/agent_impl/mod.rs:121-178 */
+void c6o_agent_play(int n, c6o_policy_fn fn, void *ctx, c6o_play_result *out) {
+    c6o_game g;
+    c6o_game_new(&g, n);
+    int cap = 64;
+    out->winner = C6O_NONE;
+    out->len = 0;
+    out->err = C6O_OK;
+    out->pi = NULL;
+    out->path = (c6o_path *)malloc(sizeof(c6o_path) * (size_t)cap);
+    for (;;) {
+        int row = -1, col = -1;
+        if (!fn(ctx, &g, &row, &col)) break; /* policy couldn't generate a selection :135-137 */
+        if (out->len == cap) { cap *= 2; out->path = (c6o_path *)realloc(out->path, sizeof(c6o_path) * (size_t)cap); }
+        c6o_path *p = &out->path[out->len++];
+        p->turn = g.turn;
+        p->row = row;
+        p->col = col;
+        memcpy(p->board, g.board, sizeof g.board);
+        int err = c6o_game_set(&g, p->row, p->col, NULL);
+        if (err != C6O_OK) { out->err = err; return; } /* Err(err) => return Err(err) :163 */
+        int w = c6o_game_is_end(&g);
+        if (w != C6O_NONE) { out->winner = w; break; }
+    }
+}
+
+void c6o_play_result_free(c6o_play_result *r) {
+    free(r->path);
+    free(r->pi);
+    r->path = NULL;
+    r->pi = NULL;
+}
+
+typedef struct {
+    c6o_az *az;
+    int want_pi;
+    int32_t *pi;
+    int pi_cap, pi_len, cells;
+} az_policy_ctx;
+
+static int az_policy_fn(void *ctx, const c6o_game *g, int *row, int *col) {
+    az_policy_ctx *pc = (az_policy_ctx *)ctx;
+    if (!pc->want_pi) {
+        int cell = c6o_az_next(pc->az, g);
+        if (cell < 0) return 0;
+        *row = cell / g->n;
+        *col = cell % g->n;
+        return 1;
+    }
+    /* next() with the root child visit counts captured before the prune */
+    c6o_az *az = pc->az;
+    c6o_sim s;
+    c6o_sim_from_game(&s, g);
+    c6o_az_init(az, &s);
+    for (int i = 0; i < az->hp.num_simulation; i++) c6o_az_search(az, &s);
+    int res = c6o_az_policy(az, &s);
+    if (res >= 0) {
+        if (pc->pi_len == pc->pi_cap) {
+            pc->pi_cap = pc->pi_cap ? pc->pi_cap * 2 : 64;
+            pc->pi = (int32_t *)realloc(pc->pi, sizeof(int32_t) * (size_t)pc->pi_cap * (size_t)pc->cells);
+        }
+        int32_t *dst = pc->pi + (size_t)pc->pi_len * (size_t)pc->cells;
+        float q[C6O_MAXCELLS], np[C6O_MAXCELLS];
+        int vis[C6O_MAXCELLS];
+        c6o_az_children(az, s.board, vis, q, np);
+        for (int i = 0; i < pc->cells; i++) dst[i] = vis[i] < 0 ? 0 : vis[i];
+        pc->pi_len++;
+    }
+    c6o_az_prune(az, &s);
+    if (res < 0) return 0;
+    *row = res / g->n;
+    *col = res % g->n;
+    return 1;
+}
+
+typedef struct {
+    int n;
+    const c6o_hyper *hp;
+    int eval_kind;
+    c6o_eval_fn fn;
+    void *ctx;
+    uint64_t seed;
+    uint32_t uid_base;
+    int num, want_pi;
+    c6o_play_result *out;
+    int next;
+    pthread_mutex_t mu;
+} sp_job;
+
+static void *sp_worker(void *arg) {
+    sp_job *job = (sp_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(&job->mu);
+        int id = job->next++;
+        pthread_mutex_unlock(&job->mu);
+        if (id >= job->num) break;
+        /* one policy per game: policy_gen, async_agent/mod.rs:105 */
+        c6o_az *az = c6o_az_new(job->n, job->hp, job->eval_kind, job->fn, job->ctx, job->seed, job->uid_base + (uint32_t)id);
+        az_policy_ctx pc = {az, job->want_pi, NULL, 0, 0, job->n * job->n};
+        c6o_agent_play(job->n, az_policy_fn, &pc, &job->out[id]);
+        job->out[id].pi = pc.pi;
+        c6o_az_free(az);
+    }
+    return NULL;
+}
+
+/* agent/async_agent/mod.rs:100-137: `num` independent games on a pool of worker threads */
+void c6o_self_play(int n, const c6o_hyper *hp, int eval_kind, c6o_eval_fn fn, void *ctx, uint64_t seed,
+                   uint32_t uid_base, int num, int threads, int want_pi, c6o_play_result *out) {
+    sp_job job = {n, hp, eval_kind, fn, ctx, seed, uid_base, num, want_pi, out, 0, PTHREAD_MUTEX_INITIALIZER};
+    if (threads < 1) threads = 1;
+    if (threads > num) threads = num;
+    if (threads == 1) { sp_worker(&job); return; }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, sp_worker, &job);
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    free(th);
+}

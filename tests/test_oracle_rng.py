@@ -1,0 +1,61 @@
+"""C6RNG: the documented random stream the oracle (and, independently, the HIP kernels) implement.
+The reference draws from unseeded thread_rng (alphazero_policy/mod.rs:145,163,262,283,294), so the
+stream itself is unpinned; what is checked here is the published Philox4x32-10 known answers and that
+the sampled distributions are the reference's: Gamma(alpha,1)/Dirichlet(alpha) and U[-1,1)."""
+import math
+
+import numpy as np
+
+import c6oracle as o
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert o.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert o.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert o.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_det_log_exp_accuracy():
+    L = o.lib()
+    rng = np.random.default_rng(0)
+    for x in np.concatenate([rng.uniform(1e-300, 1, 2000), rng.uniform(1, 1e6, 500), 10.0 ** rng.uniform(-30, 0, 500)]):
+        assert abs(L.c6o_det_log(x) - math.log(x)) <= 4e-16 * max(1.0, abs(math.log(x)))
+    for x in rng.uniform(-700, 50, 3000):
+        assert abs(L.c6o_det_exp(x) - math.exp(x)) <= 1e-14 * math.exp(x)
+    assert L.c6o_det_exp(-800.0) == 0.0
+    assert 0 < L.c6o_det_exp(-740.0) < 1e-300  # gradual underflow
+
+
+def test_gamma_moments():
+    L = o.lib()
+    for alpha in (0.03, 0.5):
+        xs = np.array([L.c6o_gamma_draw(alpha, 1, 2, c, s, 0) for s in range(40) for c in range(361)])
+        n = xs.size
+        assert abs(xs.mean() - alpha) < 5 * math.sqrt(alpha / n)            # E = alpha
+        assert abs((xs ** 2).mean() - alpha * (alpha + 1)) < 0.2 * alpha     # E x^2 = alpha(alpha+1)
+        assert (xs >= 0).all()
+
+
+def test_dirichlet_noise_shape():
+    b = np.zeros((19, 19), np.int8)
+    b[3, 4] = 1
+    b[9, 9] = -1
+    nz = o.dirichlet_noise(0.03, 5, 6, 0, 0, b)
+    assert nz[3, 4] == 0 and nz[9, 9] == 0
+    assert abs(float(nz.astype(np.float64).sum()) - 1.0) < 1e-6
+    assert (nz >= 0).all() and nz.max() > 0.05          # alpha = 0.03: mass sits on a few cells
+    nz2 = o.dirichlet_noise(0.03, 5, 6, 0, 1, b)         # depth is part of the counter (mod.rs:260-262)
+    assert (nz != nz2).any()
+
+
+def test_butterfly_sum_order():
+    rng = np.random.default_rng(1)
+    part = rng.uniform(0, 1, 64) * 10.0 ** rng.integers(-12, 3, 64)
+    v = part.copy()
+    for off in (32, 16, 8, 4, 2, 1):
+        v = v + v[np.arange(64) ^ off]
+    import ctypes as C
+    got = o.lib().c6o_butterfly_sum64(part.ctypes.data_as(C.POINTER(C.c_double)))
+    assert got == v[0]
