@@ -1,0 +1,456 @@
+"""Host-side mirror (ctypes) of libconnect6_amd.so -- the MI355X-native Connect6 self-play engine.
+
+The product is the HIP library next to this file (built by csrc/Makefile, see
+__graft_entry__.build()); this module only binds its C ABI (include/connect6_amd.h).
+There is NO CPU fallback: importing works without a GPU (so that symbols can be checked),
+every compute call raises C6Error when the library or a gfx950 device is missing.
+
+The directory name has a hyphen, so load it with `load_package()` from c6amd_loader.py or
+`importlib` (tests/conftest.py, bench.py and __graft_entry__.py do).
+
+Reference interfaces mirrored here:
+  self_play / default_param   Connect6/pybind/pyconnect6/__init__.py:9-56
+  Param builder               Connect6/cppbind/headers/connect6.hpp:272-309
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libconnect6_amd.so")
+
+BLACK, NONE, WHITE = -1, 0, 1
+EVAL_RANDOM, EVAL_UNIFORM, EVAL_NET, EVAL_CALLBACK = 1, 2, 3, 4
+OK, ERR_NO_GPU, ERR_BAD_ARG, ERR_OVERFLOW, ERR_HIP, ERR_INVALID_POSITION, ERR_ALREADY_SET = range(7)
+REF_N = 15
+
+DROPIN_SYMBOLS = ["cpp_play", "cpp_self_play", "cpp_play_with", "test_new_raw_path", "test_with_raw_path",
+                  "test_echo_raw_path", "test_with_raw_play_result", "test_echo_raw_play_result", "test_with_raw_vec",
+                  "test_echo_raw_vec", "test_echo_cppeval", "test_cpp_policy"]
+ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_config", "c6_engine_create",
+                  "c6_engine_destroy", "c6_net_blob_floats", "c6_engine_load_weights", "c6_engine_set_callback",
+                  "c6_engine_step", "c6_engine_run", "c6_engine_sync", "c6_engine_stats", "c6_engine_fetch_games",
+                  "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
+                  "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
+                  "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_dirichlet_noise"]
+
+
+class C6Error(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("board_size", C.c_int), ("num_games", C.c_int), ("num_simulation", C.c_int), ("epsilon", C.c_float),
+                ("dirichlet_alpha", C.c_double), ("c_puct", C.c_float), ("seed", C.c_uint64),
+                ("game_uid_base", C.c_uint32), ("game_uid_stride", C.c_uint32), ("evaluator", C.c_int),
+                ("net_channels", C.c_int), ("net_blocks", C.c_int), ("records_per_game", C.c_int), ("recycle", C.c_int),
+                ("stagger", C.c_int), ("device", C.c_int), ("net_chunk_boards", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rounds", C.c_uint64), ("simulations", C.c_uint64), ("select_steps", C.c_uint64), ("stones", C.c_uint64),
+                ("games_finished", C.c_uint64), ("tuples", C.c_uint64), ("live_games", C.c_uint32),
+                ("overflow_games", C.c_uint32), ("max_records_used", C.c_uint32), ("max_depth", C.c_uint32)]
+
+
+class RootInfo(C.Structure):
+    _fields_ = [("turn", C.c_int), ("remain", C.c_int), ("stones", C.c_int), ("status", C.c_int), ("winner", C.c_int),
+                ("root_visit", C.c_int), ("root_value", C.c_float), ("root_q_sum", C.c_float), ("root_q_value", C.c_float),
+                ("nsearch", C.c_uint32), ("records_used", C.c_int)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("conv_ms", C.c_double), ("conv_launches", C.c_uint64), ("conv_flops", C.c_double), ("select_ms", C.c_double),
+                ("expand_ms", C.c_double), ("eval_other_ms", C.c_double), ("move_ms", C.c_double),
+                ("select_launches", C.c_uint64), ("expand_launches", C.c_uint64)]
+
+
+class Path(C.Structure):  # cppbind/.../rawobj/mod.rs:29-36
+    _fields_ = [("turn", C.c_int), ("board", (C.c_int * REF_N) * REF_N), ("row", C.c_int), ("col", C.c_int)]
+
+
+class PlayResult(C.Structure):  # rawobj/mod.rs:38-43
+    _fields_ = [("winner", C.c_int), ("paths", C.POINTER(Path)), ("len", C.c_int)]
+
+
+class Vec(C.Structure):  # rawobj/mod.rs:45-50
+    _fields_ = [("vec", C.POINTER(PlayResult)), ("len", C.c_int)]
+
+
+class VecInt(C.Structure):
+    _fields_ = [("vec", C.POINTER(C.c_int)), ("len", C.c_int)]
+
+
+class VecFloat(C.Structure):
+    _fields_ = [("vec", C.POINTER(C.c_float)), ("len", C.c_int)]
+
+
+CALLBACK = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int)
+POLICY_CALLBACK = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.POINTER(C.c_int))
+ALLOC_PATH = C.CFUNCTYPE(C.POINTER(Path), C.c_int)
+ALLOC_RESULT = C.CFUNCTYPE(C.POINTER(PlayResult), C.c_int)
+ALLOC_INT = C.CFUNCTYPE(C.POINTER(C.c_int), C.c_int)
+ALLOC_FLOAT = C.CFUNCTYPE(C.POINTER(C.c_float), C.c_int)
+
+_lib = None
+
+
+def lib():
+    """Load libconnect6_amd.so; fail loudly if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise C6Error(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    i8p, u8p, f32p, i32p, u32p, i16p = (C.POINTER(t) for t in (C.c_int8, C.c_uint8, C.c_float, C.c_int32, C.c_uint32, C.c_int16))
+    L.c6_last_error.restype = C.c_char_p
+    L.c6_version.restype = C.c_char_p
+    L.c6_default_config.argtypes = [C.POINTER(Config)]
+    L.c6_engine_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.c6_engine_destroy.argtypes = [C.c_void_p]
+    L.c6_net_blob_floats.restype = C.c_size_t
+    L.c6_net_blob_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.c6_engine_load_weights.argtypes = [C.c_void_p, f32p, C.c_size_t]
+    L.c6_engine_set_callback.argtypes = [C.c_void_p, CALLBACK]
+    L.c6_engine_step.argtypes = [C.c_void_p, C.c_int]
+    L.c6_engine_run.argtypes = [C.c_void_p, C.c_long]
+    L.c6_engine_sync.argtypes = [C.c_void_p]
+    L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.c6_engine_fetch_games.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), i32p, i32p, u32p, i16p]
+    L.c6_tuple_stride.restype = C.c_size_t
+    L.c6_tuple_stride.argtypes = [C.c_int]
+    L.c6_engine_set_tuple_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.c6_engine_enable_tuples.argtypes = [C.c_void_p, C.c_size_t]
+    L.c6_engine_fetch_tuples.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    L.c6_engine_root.argtypes = [C.c_void_p, C.c_int, C.POINTER(RootInfo), i8p, i32p, f32p, f32p]
+    L.c6_engine_profile.argtypes = [C.c_void_p, C.c_int]
+    L.c6_engine_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile), C.c_int]
+    L.c6_board_step.argtypes = [C.c_int, C.c_int, i8p, i8p, i8p, i32p, i8p, i8p]
+    L.c6_search_winner.argtypes = [C.c_int, C.c_int, i8p, i8p]
+    L.c6_legal_mask.argtypes = [C.c_int, C.c_int, i8p, u8p]
+    L.c6_augment8.argtypes = [C.c_int, C.c_int, i8p, i8p]
+    L.c6_recover8.argtypes = [C.c_int, C.c_int, i8p, f32p, f32p, f32p, f32p]
+    L.c6_net_forward.argtypes = [C.c_int, C.c_int, C.c_int, f32p, C.c_size_t, C.c_int, i8p, i8p, f32p, f32p]
+    L.c6_dirichlet_noise.argtypes = [C.c_int, C.c_int, C.c_double, u32p, u32p, u32p, u32p, i8p, f32p]
+    L.cpp_self_play.restype = Vec
+    L.cpp_self_play.argtypes = [CALLBACK, ALLOC_PATH, ALLOC_RESULT, C.c_int, C.c_float, C.c_double, C.c_float, C.c_bool, C.c_int]
+    L.cpp_play.restype = Vec
+    L.cpp_play.argtypes = [POLICY_CALLBACK, ALLOC_PATH, ALLOC_RESULT, C.c_bool, C.c_int]
+    L.test_new_raw_path.restype = Path
+    L.test_with_raw_path.restype = Path
+    L.test_echo_raw_path.restype = Path
+    L.test_echo_raw_path.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    L.test_with_raw_play_result.restype = PlayResult
+    L.test_with_raw_play_result.argtypes = [ALLOC_PATH]
+    L.test_echo_raw_play_result.restype = PlayResult
+    L.test_echo_raw_play_result.argtypes = [C.c_int, C.POINTER(Path), C.c_int, ALLOC_PATH]
+    L.test_with_raw_vec.restype = VecInt
+    L.test_with_raw_vec.argtypes = [ALLOC_INT]
+    L.test_echo_raw_vec.restype = VecInt
+    L.test_echo_raw_vec.argtypes = [C.POINTER(C.c_int), C.c_int, ALLOC_INT]
+    L.test_echo_cppeval.restype = VecFloat
+    L.test_echo_cppeval.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, CALLBACK, ALLOC_FLOAT]
+    L.test_cpp_policy.restype = VecInt
+    L.test_cpp_policy.argtypes = [C.POINTER(C.c_float), POLICY_CALLBACK, ALLOC_INT]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != OK:
+        raise C6Error(f"libconnect6_amd error {rc}: {lib().c6_last_error().decode()}")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def device_count():
+    return lib().c6_device_count()
+
+
+# ---------------------------------------------------------------------------------------------
+# caller-side allocators (connect6.hpp:17-23 `new T[n]`): memory is owned by the Python side
+# ---------------------------------------------------------------------------------------------
+class _Arena:
+    def __init__(self):
+        self.keep = []
+        self.alloc_path = ALLOC_PATH(lambda n: self._mk(Path, n))
+        self.alloc_result = ALLOC_RESULT(lambda n: self._mk(PlayResult, n))
+        self.alloc_int = ALLOC_INT(lambda n: self._mk(C.c_int, n))
+        self.alloc_float = ALLOC_FLOAT(lambda n: self._mk(C.c_float, n))
+
+    def _mk(self, t, n):
+        arr = (t * max(int(n), 1))()
+        self.keep.append(arr)
+        return C.addressof(arr)
+
+
+def _vec_to_py(v):
+    """GameResult::from_vec (connect6.hpp:251-263) -> [(winner, [(turn, board[15][15], (row, col)), ...])]"""
+    out = []
+    for i in range(v.len):
+        r = v.vec[i]
+        paths = []
+        for k in range(r.len):
+            p = r.paths[k]
+            board = np.ctypeslib.as_array(p.board).astype(np.int8).reshape(REF_N, REF_N).copy()
+            paths.append((p.turn, board, (p.row, p.col)))
+        out.append((r.winner, paths))
+    return out
+
+
+def default_param():
+    """pyconnect6.default_param (Connect6/pybind/pyconnect6/__init__.py:47-56)"""
+    return {"num_simulation": 800, "epsilon": 0.25, "dirichlet_alpha": 0.03, "c_puct": 1.0, "debug": False, "num_game_thread": 1}
+
+
+def self_play(policy, param=None):
+    """pyconnect6.self_play (pybind/pyconnect6/__init__.py:9-33) through the reference C ABI cpp_self_play.
+
+    policy(turn:int, boards: np.ndarray[len, 225] of -1/0/1) -> (values[len], probs[len, 225]);
+    returns [(winner, [(turn, board, (row, col)), ...]), ...], one entry per game.
+    """
+    prm = default_param()
+    prm.update(param or {})
+
+    def tramp(player, values, policies, n):
+        pol = np.ctypeslib.as_array(policies, shape=(n, REF_N * REF_N))
+        val = np.ctypeslib.as_array(values, shape=(n,))
+        v, p = policy(player, pol.astype(np.int8))
+        val[:] = np.asarray(v, dtype=np.float32).reshape(n)
+        pol[:] = np.asarray(p, dtype=np.float32).reshape(n, REF_N * REF_N)
+
+    cb = CALLBACK(tramp)
+    arena = _Arena()
+    v = lib().cpp_self_play(cb, arena.alloc_path, arena.alloc_result, prm["num_simulation"], prm["epsilon"],
+                            prm["dirichlet_alpha"], prm["c_puct"], bool(prm["debug"]), prm["num_game_thread"])
+    return _vec_to_py(v)
+
+
+def play(policy, debug=False, num_game_thread=1):
+    """Connect6::play (connect6.hpp:311-323) through cpp_play: policy(board[15,15] float) -> (row, col) or None"""
+
+    def tramp(board, position):
+        b = np.ctypeslib.as_array(board, shape=(REF_N, REF_N))
+        pos = policy(b)
+        if pos is not None:
+            position[0], position[1] = int(pos[0]), int(pos[1])
+
+    cb = POLICY_CALLBACK(tramp)
+    arena = _Arena()
+    v = lib().cpp_play(cb, arena.alloc_path, arena.alloc_result, bool(debug), num_game_thread)
+    return _vec_to_py(v)
+
+
+# ---------------------------------------------------------------------------------------------
+# engine
+# ---------------------------------------------------------------------------------------------
+class Engine:
+    """G concurrent AlphaZero self-play games resident on one MI355X (c6_engine)."""
+
+    def __init__(self, board_size=15, num_games=1, num_simulation=800, epsilon=0.25, dirichlet_alpha=0.03, c_puct=1.0,
+                 seed=0, evaluator=EVAL_RANDOM, net_channels=256, net_blocks=10, records_per_game=0, recycle=False,
+                 stagger=False, device=0, game_uid_base=0, game_uid_stride=0, net_chunk_boards=0):
+        L = lib()
+        cfg = Config()
+        L.c6_default_config(C.byref(cfg))
+        cfg.board_size, cfg.num_games, cfg.num_simulation = board_size, num_games, num_simulation
+        cfg.epsilon, cfg.dirichlet_alpha, cfg.c_puct, cfg.seed = epsilon, dirichlet_alpha, c_puct, seed
+        cfg.evaluator, cfg.net_channels, cfg.net_blocks = evaluator, net_channels, net_blocks
+        cfg.records_per_game, cfg.recycle, cfg.stagger, cfg.device = records_per_game, int(recycle), int(stagger), device
+        cfg.game_uid_base, cfg.game_uid_stride, cfg.net_chunk_boards = game_uid_base, game_uid_stride, net_chunk_boards
+        self.cfg = cfg
+        self.n, self.cells, self.G = board_size, board_size * board_size, num_games
+        self.h = C.c_void_p()
+        self._cb = None
+        _chk(L.c6_engine_create(C.byref(cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().c6_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        _chk(lib().c6_engine_load_weights(self.h, _p(blob, C.c_float), blob.size))
+
+    def set_callback(self, fn):
+        """fn(player, boards int8 [len, N*N]) -> (values [len], policies [len, N*N])"""
+        cells = self.cells
+
+        def tramp(player, values, policies, n):
+            pol = np.ctypeslib.as_array(policies, shape=(n, cells))
+            val = np.ctypeslib.as_array(values, shape=(n,))
+            v, p = fn(player, pol.astype(np.int8))
+            val[:] = np.asarray(v, dtype=np.float32).reshape(n)
+            pol[:] = np.asarray(p, dtype=np.float32).reshape(n, cells)
+
+        self._cb = CALLBACK(tramp)
+        _chk(lib().c6_engine_set_callback(self.h, self._cb))
+
+    def step(self, rounds=1):
+        _chk(lib().c6_engine_step(self.h, rounds))
+
+    def run(self, max_rounds=0):
+        _chk(lib().c6_engine_run(self.h, max_rounds))
+
+    def sync(self):
+        _chk(lib().c6_engine_sync(self.h))
+
+    def stats(self):
+        s = Stats()
+        _chk(lib().c6_engine_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def fetch_games(self, cap=None):
+        cap = cap or 4 * self.G
+        winners = np.zeros(cap, np.int32)
+        lens = np.zeros(cap, np.int32)
+        uids = np.zeros(cap, np.uint32)
+        moves = np.zeros((cap, self.cells), np.int16)
+        cnt = C.c_int()
+        _chk(lib().c6_engine_fetch_games(self.h, cap, C.byref(cnt), _p(winners, C.c_int32), _p(lens, C.c_int32),
+                                         _p(uids, C.c_uint32), _p(moves, C.c_int16)))
+        k = cnt.value
+        return [dict(winner=int(winners[i]), uid=int(uids[i]), moves=moves[i, :lens[i]].copy()) for i in range(k)]
+
+    def enable_tuples(self, capacity):
+        _chk(lib().c6_engine_enable_tuples(self.h, capacity))
+
+    def set_tuple_buffer(self, dev_ptr, capacity, count_dev_ptr):
+        _chk(lib().c6_engine_set_tuple_buffer(self.h, C.c_void_p(dev_ptr), capacity, C.c_void_p(count_dev_ptr)))
+
+    def fetch_tuples(self, cap):
+        stride = lib().c6_tuple_stride(self.n)
+        buf = np.zeros((cap, stride), np.uint8)
+        cnt = C.c_size_t()
+        _chk(lib().c6_engine_fetch_tuples(self.h, cap, C.byref(cnt), buf.ctypes.data_as(C.c_void_p)))
+        return decode_tuples(buf[:cnt.value], self.n)
+
+    def root(self, g=0):
+        info = RootInfo()
+        board = np.zeros(self.cells, np.int8)
+        visits = np.zeros(self.cells, np.int32)
+        q = np.zeros(self.cells, np.float32)
+        prior = np.zeros(self.cells, np.float32)
+        _chk(lib().c6_engine_root(self.h, g, C.byref(info), _p(board, C.c_int8), _p(visits, C.c_int32), _p(q, C.c_float),
+                                  _p(prior, C.c_float)))
+        d = {k: getattr(info, k) for k, _ in RootInfo._fields_}
+        d.update(board=board.reshape(self.n, self.n), visits=visits, q=q, prior=prior)
+        return d
+
+    def profile(self, enable=True):
+        _chk(lib().c6_engine_profile(self.h, int(enable)))
+
+    def profile_read(self, reset=True):
+        p = Profile()
+        _chk(lib().c6_engine_profile_read(self.h, C.byref(p), int(reset)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+def decode_tuples(buf, n):
+    """[state int8 N*N | pad | pi u16 N*N | ... | turn int8 | z int8] records -> dict of arrays"""
+    cells = n * n
+    buf = np.ascontiguousarray(buf)
+    k = buf.shape[0]
+    off = cells + (cells & 1)
+    state = buf[:, :cells].view(np.int8).reshape(k, n, n)
+    pi = buf[:, off:off + 2 * cells].copy().view(np.uint16).reshape(k, cells)
+    turn = buf[:, -2].view(np.int8)
+    z = buf[:, -1].view(np.int8)
+    return dict(state=state.copy(), pi=pi, turn=turn.copy(), z=z.copy())
+
+
+def replay_moves(n, moves):
+    """Host replay of a move list: [(turn, board_before, cell)], Agent::play bookkeeping (agent_impl/mod.rs:139-145)"""
+    board = np.zeros(n * n, np.int8)
+    turn, remain = BLACK, 1
+    out = []
+    for m in moves:
+        out.append((turn, board.reshape(n, n).copy(), int(m)))
+        board[int(m)] = turn
+        remain -= 1
+        if remain <= 0:
+            remain, turn = 2, -turn
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# stand-alone batched operators (host arrays in/out)
+# ---------------------------------------------------------------------------------------------
+def to_soa(boards):
+    """[G, N, N] or [G, N*N] int8 -> SoA [N*N, G]"""
+    b = np.asarray(boards, dtype=np.int8)
+    return np.ascontiguousarray(b.reshape(b.shape[0], -1).T)
+
+
+def board_step(n, boards_soa, turn, remain, pos):
+    b = np.ascontiguousarray(boards_soa, dtype=np.int8).copy()
+    G = b.shape[1]
+    t = np.ascontiguousarray(turn, dtype=np.int8).copy()
+    r = np.ascontiguousarray(remain, dtype=np.int8).copy()
+    p = np.ascontiguousarray(pos, dtype=np.int32)
+    w = np.zeros(G, np.int8)
+    e = np.zeros(G, np.int8)
+    _chk(lib().c6_board_step(n, G, _p(b, C.c_int8), _p(t, C.c_int8), _p(r, C.c_int8), _p(p, C.c_int32), _p(w, C.c_int8), _p(e, C.c_int8)))
+    return b, t, r, w, e
+
+
+def search_winner(n, boards_soa):
+    b = np.ascontiguousarray(boards_soa, dtype=np.int8)
+    w = np.zeros(b.shape[1], np.int8)
+    _chk(lib().c6_search_winner(n, b.shape[1], _p(b, C.c_int8), _p(w, C.c_int8)))
+    return w
+
+
+def legal_mask(n, boards_soa):
+    b = np.ascontiguousarray(boards_soa, dtype=np.int8)
+    G = b.shape[1]
+    m = np.zeros(((n * n + 7) // 8, G), np.uint8)
+    _chk(lib().c6_legal_mask(n, G, _p(b, C.c_int8), _p(m, C.c_uint8)))
+    return m
+
+
+def augment8(n, boards):
+    b = np.ascontiguousarray(boards, dtype=np.int8).reshape(-1, n * n)
+    out = np.zeros((b.shape[0], 8, n, n), np.int8)
+    _chk(lib().c6_augment8(n, b.shape[0], _p(b, C.c_int8), _p(out, C.c_int8)))
+    return out
+
+
+def recover8(n, boards, values8, policies8):
+    b = np.ascontiguousarray(boards, dtype=np.int8).reshape(-1, n * n)
+    v8 = np.ascontiguousarray(values8, dtype=np.float32).reshape(-1, 8)
+    p8 = np.ascontiguousarray(policies8, dtype=np.float32).reshape(-1, 8, n * n)
+    val = np.zeros(b.shape[0], np.float32)
+    pri = np.zeros((b.shape[0], n, n), np.float32)
+    _chk(lib().c6_recover8(n, b.shape[0], _p(b, C.c_int8), _p(v8, C.c_float), _p(p8, C.c_float), _p(val, C.c_float), _p(pri, C.c_float)))
+    return val, pri
+
+
+def net_forward(n, channels, blocks, blob, boards, player):
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    b = np.ascontiguousarray(boards, dtype=np.int8).reshape(-1, n * n)
+    pl = np.ascontiguousarray(np.broadcast_to(np.asarray(player, dtype=np.int8), (b.shape[0],)))
+    pol = np.zeros((b.shape[0], n * n), np.float32)
+    val = np.zeros(b.shape[0], np.float32)
+    _chk(lib().c6_net_forward(n, channels, blocks, _p(blob, C.c_float), blob.size, b.shape[0], _p(b, C.c_int8), _p(pl, C.c_int8),
+                              _p(pol, C.c_float), _p(val, C.c_float)))
+    return pol, val
+
+
+def dirichlet_noise(n, alpha, k0, k1, search, depth, boards):
+    b = np.ascontiguousarray(boards, dtype=np.int8).reshape(-1, n * n)
+    num = b.shape[0]
+    a = [np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.uint32), (num,))) for x in (k0, k1, search, depth)]
+    out = np.zeros((num, n, n), np.float32)
+    _chk(lib().c6_dirichlet_noise(n, num, alpha, _p(a[0], C.c_uint32), _p(a[1], C.c_uint32), _p(a[2], C.c_uint32),
+                                  _p(a[3], C.c_uint32), _p(b, C.c_int8), _p(out, C.c_float)))
+    return out

@@ -1,0 +1,252 @@
+// abi_dropin.cpp -- the reference's C ABI (Connect6/cppbind/libcppconnect6, N = 15) on top of the
+// GPU engine.  Symbol for symbol what Connect6/cppbind/headers/connect6.hpp:44-93 declares, so the
+// reference's C++ wrapper, samples and trainers link against libconnect6_amd.so unchanged.
+#include "../../include/connect6_amd.h"
+#include "c6_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+static const int N = C6_REF_BOARD_SIZE, CELLS = C6_REF_BOARD_CAPACITY;
+
+static void die(const char *what) {
+    // the reference panics across the FFI on errors (lib.rs:40,107 `unwrap()`); never unwind through C
+    std::fprintf(stderr, "libconnect6_amd: %s: %s\n", what, c6_last_error());
+    std::abort();
+}
+
+static uint64_t pick_seed() {
+    if (const char *s = std::getenv("C6_SEED")) return std::strtoull(s, nullptr, 0);
+    std::random_device rd;   // the reference seeds from the OS (thread_rng)
+    return ((uint64_t)rd() << 32) | rd();
+}
+
+// RawPath::with_path + RawPlayResult::with_result (rawobj/mod.rs:66-107): replay the stones on the
+// host to rebuild "board BEFORE the move" (agent/agent_impl/mod.rs:139-143)
+static c6_play_result make_result(int winner, int len, const int16_t *moves, c6_alloc_path alloc_path) {
+    c6_play_result r;
+    r.winner = winner;
+    r.len = len;
+    r.paths = alloc_path(len);
+    int board[C6_REF_BOARD_CAPACITY] = {0};
+    int turn = -1, remain = 1;   // Game::new, game_impl/mod.rs:125-131
+    for (int k = 0; k < len; k++) {
+        c6_path &p = r.paths[k];
+        p.turn = turn;
+        std::memcpy(p.board, board, sizeof board);
+        p.row = moves[k] / N;
+        p.col = moves[k] % N;
+        board[moves[k]] = turn;
+        if (--remain <= 0) { remain = 2; turn = -turn; }   // game_impl/mod.rs:160-167
+    }
+    return r;
+}
+
+extern "C" c6_vec cpp_self_play(c6_callback callback, c6_alloc_path alloc_path, c6_alloc_result alloc_result, int num_simulation,
+                                float epsilon, double dirichlet_alpha, float c_puct, bool debug, int num_game_thread) {
+    c6_config cfg;
+    c6_default_config(&cfg);
+    cfg.board_size = N;
+    cfg.num_games = num_game_thread < 1 ? 1 : num_game_thread;
+    cfg.num_simulation = num_simulation;
+    cfg.epsilon = epsilon;
+    cfg.dirichlet_alpha = dirichlet_alpha;
+    cfg.c_puct = c_puct;
+    cfg.seed = pick_seed();
+    cfg.evaluator = C6_EVAL_CALLBACK;
+    c6_engine *e = nullptr;
+    if (c6_engine_create(&cfg, &e) != C6_OK) die("cpp_self_play: engine");
+    c6_engine_set_callback(e, callback);
+    if (c6_engine_run(e, 0) != C6_OK) die("cpp_self_play: run");
+    const int G = cfg.num_games;
+    std::vector<int> winners(G), lens(G);
+    std::vector<int16_t> moves((size_t)G * CELLS);
+    int count = 0;
+    if (c6_engine_fetch_games(e, G, &count, winners.data(), lens.data(), nullptr, moves.data()) != C6_OK) die("cpp_self_play: fetch");
+    c6_stats st;
+    c6_engine_stats(e, &st);
+    if (st.overflow_games) { c6_engine_destroy(e); die("cpp_self_play: a game overflowed its node pool"); }
+    c6_vec v;
+    v.len = count;
+    v.vec = alloc_result(count);                              // RawVec::with_vec, rawobj/mod.rs:112-123
+    for (int i = 0; i < count; i++) {
+        v.vec[i] = make_result(winners[i], lens[i], &moves[(size_t)i * CELLS], alloc_path);
+        if (debug)
+            std::printf("run: %d, winner %d, %d stones\n", i, winners[i], lens[i]);   // async_agent/mod.rs:117-124
+    }
+    c6_engine_destroy(e);
+    return v;
+}
+
+extern "C" c6_vec cpp_play(c6_policy_callback callback, c6_alloc_path alloc_path, c6_alloc_result alloc_result, bool debug,
+                           int num_game_thread) {
+    const int G = num_game_thread < 1 ? 1 : num_game_thread;
+    // Agent::play with a CppPolicy (cpp_policy/mod.rs:22-43) for G games; Game::set / is_game_end on the GPU
+    std::vector<int8_t> boards((size_t)CELLS * G, 0), turn(G, -1), remain(G, 1), winner(G, 0), err(G, 0);
+    std::vector<int32_t> pos(G);
+    std::vector<std::vector<int16_t>> hist(G);
+    std::vector<char> done(G, 0);
+    std::vector<int> result(G, 0);
+    int live = G;
+    while (live > 0) {
+        for (int g = 0; g < G; g++) {
+            pos[g] = -1;
+            if (done[g]) continue;
+            float fb[C6_REF_BOARD_CAPACITY];
+            for (int c = 0; c < CELLS; c++) fb[c] = (float)boards[(size_t)c * G + g];   // board_to_float, cpp_support.rs:10-18
+            int p[2] = {-1, -1};
+            callback(fb, p);
+            if (p[0] == -1) {            // "no move" -> game ends as a draw, agent_impl/mod.rs:135-137
+                done[g] = 1;
+                live--;
+                continue;
+            }
+            // rows/cols outside the board become an out-of-range cell: "invalid position"
+            const bool inside = p[0] >= 0 && p[0] < N && p[1] >= 0 && p[1] < N;
+            pos[g] = inside ? p[0] * N + p[1] : CELLS;
+            hist[g].push_back((int16_t)(inside ? pos[g] : 0));
+        }
+        if (live == 0) break;
+        if (c6_board_step(N, G, boards.data(), turn.data(), remain.data(), pos.data(), winner.data(), err.data()) != C6_OK) die("cpp_play");
+        for (int g = 0; g < G; g++) {
+            if (done[g] || pos[g] < 0) continue;
+            if (err[g] != C6_OK) {       // the reference returns Err and `unwrap()` aborts (lib.rs:40)
+                std::fprintf(stderr, "libconnect6_amd: cpp_play: %s\n", err[g] == C6_ERR_ALREADY_SET ? "already set position" : "invalid position");
+                std::abort();
+            }
+            if (winner[g] != 0) { result[g] = winner[g]; done[g] = 1; live--; }
+        }
+    }
+    c6_vec v;
+    v.len = G;
+    v.vec = alloc_result(G);
+    for (int g = 0; g < G; g++) {
+        v.vec[g] = make_result(result[g], (int)hist[g].size(), hist[g].data(), alloc_path);
+        if (debug) std::printf("run: %d, winner %d, %d stones\n", g, result[g], (int)hist[g].size());
+    }
+    return v;
+}
+
+extern "C" c6_play_result cpp_play_with(c6_callback, c6_alloc_path alloc_path, int, float, double, float) {
+    std::fprintf(stderr, "libconnect6_amd: cpp_play_with (stdin human play, lib.rs:140-169) is out of scope of the self-play engine\n");
+    c6_play_result r;
+    r.winner = 0;
+    r.len = 0;
+    r.paths = alloc_path(0);
+    return r;
+}
+
+// ---- FFI echo hooks (ffi_test/mod.rs), host only ---------------------------------------------
+
+extern "C" c6_path test_new_raw_path(void) {   // RawPath::new, rawobj/mod.rs:53-61
+    c6_path p;
+    std::memset(&p, 0, sizeof p);
+    return p;
+}
+
+extern "C" c6_path test_with_raw_path(void) {  // ffi_test/mod.rs:19-34
+    c6_path p;
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) p.board[i][j] = (i * N + j) % 3 - 1;
+    p.turn = 1;
+    p.row = 0;
+    p.col = N % 5 + 1;
+    return p;
+}
+
+extern "C" c6_path test_echo_raw_path(int turn, int *board, int row, int col) {   // ffi_test/mod.rs:38-57
+    c6_path p;
+    p.turn = turn;
+    std::memcpy(p.board, board, sizeof p.board);
+    p.row = row;
+    p.col = col;
+    return p;
+}
+
+static int player_from(int v) { return v == -1 ? -1 : (v == 1 ? 1 : 0); }   // From<i32>, player/mod.rs:53-61
+
+extern "C" c6_play_result test_with_raw_play_result(c6_alloc_path allocator) {   // ffi_test/mod.rs:61-86
+    c6_play_result r;
+    r.winner = -1;
+    r.len = 10;
+    r.paths = allocator(10);
+    int player = -1;
+    for (int i = 0; i < 10; i++) {
+        c6_path &p = r.paths[i];
+        std::memset(&p, 0, sizeof p);
+        for (int j = 0; j < i + 1; j++) p.board[j][j] = player_from((i + j) % 3 - 1);
+        p.turn = player;
+        p.row = i;
+        p.col = i + 1;
+        player = -player;
+    }
+    return r;
+}
+
+extern "C" c6_play_result test_echo_raw_play_result(int winner, c6_path *path, int len, c6_alloc_path allocator) {   // :90-121
+    c6_play_result r;
+    r.winner = player_from(winner);
+    r.len = len;
+    r.paths = allocator(len);
+    for (int i = 0; i < len; i++) {
+        c6_path &p = r.paths[i];
+        p.turn = player_from(path[i].turn);
+        for (int j = 0; j < N; j++)
+            for (int k = 0; k < N; k++) p.board[j][k] = player_from(path[i].board[j][k]);
+        p.row = path[i].row;
+        p.col = path[i].col;
+    }
+    return r;
+}
+
+extern "C" c6_vec_int test_with_raw_vec(c6_alloc_int allocator) {   // ffi_test/mod.rs:125-129
+    c6_vec_int v;
+    v.len = 6;
+    v.vec = allocator(6);
+    for (int i = 0; i < 6; i++) v.vec[i] = i;
+    return v;
+}
+
+extern "C" c6_vec_int test_echo_raw_vec(int *ptr, int len, c6_alloc_int allocator) {   // ffi_test/mod.rs:133-145
+    c6_vec_int v;
+    v.len = len;
+    v.vec = allocator(len);
+    for (int i = 0; i < len; i++) v.vec[i] = ptr[i];
+    return v;
+}
+
+extern "C" c6_vec_float test_echo_cppeval(int turn, int *boards, int len, c6_callback callback, c6_alloc_float allocator) {   // :149-197
+    const int player = player_from(turn);
+    std::vector<float> values((size_t)len, 0.f), policies((size_t)len * CELLS);
+    for (size_t i = 0; i < policies.size(); i++) policies[i] = (float)player_from(boards[i]);   // CppEval::callback, cppeval/mod.rs:27-44
+    callback(player, values.data(), policies.data(), len);
+    c6_vec_float v;
+    v.len = len + len * CELLS;
+    v.vec = allocator(v.len);
+    for (int i = 0; i < len; i++) v.vec[i] = values[i];
+    for (size_t i = 0; i < policies.size(); i++) v.vec[len + i] = policies[i];
+    return v;
+}
+
+extern "C" c6_vec_int test_cpp_policy(float *board, c6_policy_callback callback, c6_alloc_int allocator) {   // ffi_test/mod.rs:201-224
+    float fb[C6_REF_BOARD_CAPACITY];
+    for (int c = 0; c < CELLS; c++) fb[c] = (float)player_from((int)board[c]);
+    int p[2] = {-1, -1};
+    callback(fb, p);                           // CppPolicy::callback, cpp_policy/mod.rs:22-36
+    c6_vec_int v;
+    if (p[0] == -1) {
+        v.len = 0;
+        v.vec = allocator(0);
+    } else {
+        v.len = 2;
+        v.vec = allocator(2);
+        v.vec[0] = p[0];
+        v.vec[1] = p[1];
+    }
+    return v;
+}

@@ -1,0 +1,141 @@
+// c6_engine.h -- HBM layout of the self-play engine and the kernel launchers.
+//
+// One engine = one GPU = G concurrent games.  Canonical game state is the
+// structure-of-arrays board  board_soa[cell][game]  (int8: -1 black, 0 empty, +1 white;
+// game/player/mod.rs:8-12) that the board kernel K1 reads with lane == game.  The tree
+// kernels run one wave per game and keep, per game:
+//   * an AoS copy of the root position (root_board, root_key, root_sig),
+//   * a pool of R "expanded node" records (edge-major: prior[N*N] per record) and an
+//     open-addressed table  board key -> record  (64-bit Zobrist), which together
+//     reproduce the reference's HashMap<u64, Node> (alphazero_policy/mod.rs:186-190)
+//     without materialising the N*N children of every expansion.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct C6HtEntry {       // 16 bytes
+    unsigned long long key;   // 0 = empty slot
+    uint32_t idx1;            // record index + 1
+    uint32_t pad;
+};
+
+#define C6_MAXD 64        // longest select path kept per search
+
+enum { C6_ST_PLAYING = 0, C6_ST_FINISHED = 1, C6_ST_ERROR = 2 };
+enum { C6_LEAF_NONE = 0, C6_LEAF_EVAL = 1, C6_LEAF_TERMINAL = 2 };
+enum { C6_CNT_SIMS = 0, C6_CNT_SELECT, C6_CNT_STONES, C6_CNT_FINISHED, C6_CNT_TUPLES, C6_CNT_OVERFLOW, C6_CNT_MAXDEPTH,
+       C6_CNT_MAXREC, C6_CNT_LIVE, C6_CNT_FETCHQ, C6_CNT_N };
+
+struct C6Dev {
+    // geometry / hyper-parameters (policy/alphazero_policy/mod.rs:91-96)
+    int N, cells, cellsP, G, Gpad, S, R, H;
+    float eps, cpuct;
+    double alpha, gam_d, gam_c;
+    uint32_t seed_lo, seed_hi, uid_base, uid_stride;
+    int recycle;
+    // canonical game state (SoA over games)
+    int8_t *board_soa;     // [cells][Gpad]
+    int8_t *turn, *remain; // [Gpad]
+    int8_t *winner, *err;  // [Gpad] written by K1
+    int8_t *status;        // [G]
+    int16_t *nstones;      // [G]
+    uint32_t *game_uid, *nsearch;
+    int *sim_in_move;
+    // root copy for the tree kernels
+    int8_t *root_board;    // [G][cellsP]
+    unsigned long long *root_key;
+    uint32_t *root_sig;    // [G][4] = sum/sumsq of (cell+1) for black, white
+    int *root_rec;
+    uint16_t *moves;       // [G][cells] cell of stone k
+    uint16_t *hist_pi;     // [G][cells][cells] root child visits at move k
+    // expanded-node records
+    unsigned long long *rec_key; // [G][R]
+    int *rec_visit;
+    float *rec_value, *rec_qsum, *rec_q;
+    int16_t *rec_level;    // -1 = free
+    uint32_t *rec_sig;     // [G][R][4]
+    float *rec_prior;      // [G][R][cells]  n_prob of the child at each empty cell
+    C6HtEntry *ht;         // [G][H]
+    uint16_t *free_stack;  // [G][R]
+    int *free_top;         // [G]
+    // per-round leaf exchange
+    int8_t *leaf_board;    // [G][cellsP]
+    int8_t *leaf_turn, *leaf_kind;
+    unsigned long long *leaf_key;
+    uint32_t *leaf_sig;    // [G][4]
+    int16_t *leaf_level;
+    int *path_len;
+    uint16_t *path_rec;    // [G][C6_MAXD]
+    float *eval_value;     // [G]
+    float *eval_prior;     // [G][cells]
+    float *img_val;        // [G][8]
+    float *img_pol;        // [G][8][cells]
+    // move exchange
+    int32_t *move_pos;     // [Gpad] -2: not moving, -1: no move (draw), else cell
+    int8_t *move_turn;     // [G]
+    // finished games queue
+    int *fin_winner, *fin_len;   // [finq_cap]
+    uint32_t *fin_uid;
+    int16_t *fin_moves;          // [finq_cap][cells]
+    int finq_cap;
+    // training tuples
+    uint8_t *tuple_buf;
+    unsigned long long tuple_cap;
+    uint32_t *tuple_count;
+    int tuple_stride;
+    // constant tables
+    const unsigned long long *zob; // [2][C6_MAXCELLS]
+    const int16_t *aug_map;        // [8][cells] image k, cell c -> source cell of the board
+    const int16_t *rec_map;        // [8][cells] image k, output cell c -> cell of image k's policy
+    unsigned long long *counters;  // [C6_CNT_N]
+};
+
+// tree_kernels.hip
+void c6_launch_select(const C6Dev &d, hipStream_t s);
+void c6_launch_expand(const C6Dev &d, hipStream_t s);
+void c6_launch_eval_builtin(const C6Dev &d, int kind, hipStream_t s);
+void c6_launch_recover(const C6Dev &d, hipStream_t s);
+void c6_launch_augment(const C6Dev &d, float *img_boards, hipStream_t s);
+void c6_launch_move_select(const C6Dev &d, hipStream_t s);
+void c6_launch_post_move(const C6Dev &d, hipStream_t s);
+void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s);
+void c6_launch_noise_op(int N, int num, double alpha, double gd, double gc, const uint32_t *k0, const uint32_t *k1,
+                        const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise, hipStream_t s);
+void c6_launch_augment_op(int N, int num, const int8_t *boards, const int16_t *aug_map, int8_t *out, hipStream_t s);
+void c6_launch_recover_op(int N, int num, const int8_t *boards, const float *values8, const float *policies8,
+                          const int16_t *rec_map, float *value, float *prior, hipStream_t s);
+
+// board_kernel.hip  (K1)
+void c6_launch_board_step(int N, int Gpad, int8_t *boards_soa, int8_t *turn, int8_t *remain, const int32_t *pos,
+                          int8_t *winner, int8_t *err, hipStream_t s);
+void c6_launch_search_winner(int N, int Gpad, const int8_t *boards_soa, int8_t *winner, hipStream_t s);
+void c6_launch_legal_mask(int N, int Gpad, const int8_t *boards_soa, uint8_t *mask, hipStream_t s);
+
+// net_kernels.hip  (K3 + K4)
+struct C6NetDev {
+    int N, cells, C, blocks;
+    // packed weights (BatchNorm folded), see net_kernels.hip
+    const float *stem_w;  // [9][2][C]
+    const float *stem_b;  // [C]
+    const float *conv_w;  // [(blocks-1)*2][packed 9*C*C]
+    const float *conv_b;  // [(blocks-1)*2][C]
+    const float *pc_w;    // [2][C] folded
+    const float *pc_b;    // [2]
+    const float *pl_wT;   // [2*cells][cells]
+    const float *pl_b;    // [cells]
+    const float *vc_w;    // [C]
+    float vc_b;
+    const float *vn_scale, *vn_shift; // [cells]
+    const float *v1_wT;   // [cells][256]
+    const float *v1_b;    // [256]
+    const float *v2_w;    // [256]
+    float v2_b;
+};
+// boards: int8 [nleaf][cellsP]; player int8 [nleaf]; images = 8 (dihedral, aug_map) or 1 (identity).
+// act0/act1/act2: [nleaf*images][cells][C] f32 scratch.  Outputs pol [nleaf*images][cells], val [nleaf*images].
+struct C6NetTimers;
+void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t *boards, int board_stride,
+                        const int8_t *player, const int16_t *aug_map, float *act0, float *act1, float *act2, float *ph,
+                        float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers);
+size_t c6_conv_packed_floats(int C);
+void c6_pack_conv_weights(int C, const float *w_oihw_folded, float *packed);

@@ -1,0 +1,882 @@
+// engine.cpp -- host side of libconnect6_amd.so: engine object, weight loading, the round loop
+// (select -> evaluate -> expand/backup -> move), and the extended C ABI of include/connect6_amd.h.
+// The reference's orchestration being replaced: AsyncAgent::run (agent/async_agent/mod.rs:100-137),
+// Agent::play (agent/agent_impl/mod.rs:121-178) and AlphaZero::next (alphazero_policy/mod.rs:464-489).
+#include "../../include/connect6_amd.h"
+#include "c6_device.h"
+#include "c6_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct C6NetTimers;
+C6NetTimers *c6_timers_new();
+void c6_timers_free(C6NetTimers *t);
+void c6_timers_enable(C6NetTimers *t, bool on);
+void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches, double *flops, bool reset);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                                          \
+    do {                                                                                                   \
+        hipError_t e_ = (x);                                                                               \
+        if (e_ != hipSuccess) return fail(C6_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+extern "C" const char *c6_last_error(void) { return g_err.c_str(); }
+extern "C" const char *c6_version(void) { return "connect6_amd 0.1 (gfx950)"; }
+extern "C" int c6_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int require_gpu(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(C6_ERR_NO_GPU, "libconnect6_amd: no HIP device visible; this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(C6_ERR_BAD_ARG, "bad device ordinal");
+    HIPCHK(hipSetDevice(device));
+    return C6_OK;
+}
+
+// ---- constant tables ----------------------------------------------------------------------
+
+static uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static void rot_left(std::vector<int16_t> &b, int n) {   // augment.rs:7-15
+    std::vector<int16_t> r(b.size());
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) r[(n - j - 1) * n + i] = b[i * n + j];
+    b.swap(r);
+}
+static void rot_right(std::vector<int16_t> &b, int n) {  // augment.rs:17-25
+    std::vector<int16_t> r(b.size());
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) r[j * n + (n - i - 1)] = b[i * n + j];
+    b.swap(r);
+}
+static void flip_v(std::vector<int16_t> &b, int n) {     // augment.rs:27-35
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n / 2; j++) std::swap(b[i * n + j], b[i * n + (n - j - 1)]);
+}
+
+// aug[k][c]: image k of augment_way8 takes its cell c from board cell aug[k][c] (augment.rs:60-73)
+// rec[k][c]: output cell c of recover_way8 takes image k's policy at cell rec[k][c] (augment.rs:75-92)
+static void build_maps(int n, std::vector<int16_t> &aug, std::vector<int16_t> &rec) {
+    const int cells = n * n;
+    aug.assign(8 * cells, 0);
+    rec.assign(8 * cells, 0);
+    std::vector<int16_t> id(cells);
+    for (int c = 0; c < cells; c++) id[c] = (int16_t)c;
+    std::vector<int16_t> b = id;
+    for (int i = 0; i < 4; i++) {
+        rot_left(b, n);
+        std::copy(b.begin(), b.end(), aug.begin() + (2 * i) * cells);
+        std::vector<int16_t> f = b;
+        flip_v(f, n);
+        std::copy(f.begin(), f.end(), aug.begin() + (2 * i + 1) * cells);
+    }
+    for (int i = 0; i < 4; i++) {
+        std::vector<int16_t> a = id, f = id;
+        flip_v(f, n);
+        for (int r = 0; r < i + 1; r++) { rot_right(a, n); rot_right(f, n); }
+        std::copy(a.begin(), a.end(), rec.begin() + (2 * i) * cells);
+        std::copy(f.begin(), f.end(), rec.begin() + (2 * i + 1) * cells);
+    }
+}
+
+static void build_zobrist(std::vector<unsigned long long> &z) {
+    z.resize(2 * C6_MAXCELLS);
+    uint64_t s = 0xA11CE5EEDULL;
+    for (auto &v : z) { do { v = splitmix64(s); } while (v == 0); }
+}
+
+// ---- device buffer bookkeeping ------------------------------------------------------------
+
+struct DevPool {
+    std::vector<void *> ptrs;
+    size_t bytes = 0;
+    template <typename T> int alloc(T **p, size_t n, bool zero = true) {
+        void *q = nullptr;
+        const size_t sz = std::max<size_t>(n * sizeof(T), 16);
+        hipError_t e = hipMalloc(&q, sz);
+        if (e != hipSuccess) return fail(C6_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        if (zero) hipMemset(q, 0, sz);
+        ptrs.push_back(q);
+        bytes += sz;
+        *p = reinterpret_cast<T *>(q);
+        return C6_OK;
+    }
+    void release() {
+        for (void *p : ptrs) hipFree(p);
+        ptrs.clear();
+    }
+};
+#define ALLOC(p, n)                                     \
+    do {                                                \
+        int rc_ = pool.alloc(&(p), (size_t)(n));        \
+        if (rc_ != C6_OK) return rc_;                   \
+    } while (0)
+
+// ---- resident net ---------------------------------------------------------------------------
+
+struct NetHost {
+    C6NetDev dev{};
+    DevPool pool;
+    bool loaded = false;
+};
+
+extern "C" size_t c6_net_blob_floats(int n, int C, int nb) {
+    const size_t n2 = (size_t)n * n, c = (size_t)C;
+    size_t t = 0;
+    t += c * 2 * 9 + c + 4 * c;
+    t += (size_t)(nb - 1) * 2 * (c * c * 9 + c + 4 * c);
+    t += 2 * c + 2 + 8 + n2 * 2 * n2 + n2;
+    t += c + 1 + 4 * n2 + 256 * n2 + 256 + 256 + 1;
+    return t;
+}
+
+template <typename T> static int upload(DevPool &pool, const std::vector<T> &h, const T **d) {
+    T *p = nullptr;
+    int rc = pool.alloc(&p, h.size(), false);
+    if (rc != C6_OK) return rc;
+    HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *d = p;
+    return C6_OK;
+}
+
+// blob layout: AlphaZero/cpp_weighted/model.hpp:10-50 registration order, PyTorch layouts
+static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t nfloats) {
+    if (C != 64 && C != 128 && C != 256) return fail(C6_ERR_BAD_ARG, "net_channels must be 64, 128 or 256");
+    if (nb < 1) return fail(C6_ERR_BAD_ARG, "net_blocks must be >= 1");
+    if (nfloats != c6_net_blob_floats(n, C, nb)) return fail(C6_ERR_BAD_ARG, "weight blob has the wrong size");
+    nh.pool.release();
+    const int cells = n * n;
+    const float eps = 1e-5f;
+    const float *p = blob;
+    auto take = [&](size_t k) { const float *r = p; p += k; return r; };
+    C6NetDev &d = nh.dev;
+    d.N = n; d.cells = cells; d.C = C; d.blocks = nb;
+
+    {   // stem
+        const float *w = take((size_t)C * 2 * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
+        std::vector<float> sw((size_t)9 * 2 * C), sb(C);
+        for (int co = 0; co < C; co++) {
+            const float s = g[co] / std::sqrt(v[co] + eps);
+            sb[co] = (b[co] - m[co]) * s + be[co];
+            for (int ch = 0; ch < 2; ch++)
+                for (int t = 0; t < 9; t++) sw[(size_t)(t * 2 + ch) * C + co] = w[((size_t)co * 2 + ch) * 9 + t] * s;
+        }
+        int rc;
+        if ((rc = upload(nh.pool, sw, &d.stem_w)) || (rc = upload(nh.pool, sb, &d.stem_b))) return rc;
+    }
+    {   // tower
+        const int L = 2 * (nb - 1);
+        const size_t wsz = c6_conv_packed_floats(C);
+        std::vector<float> cw((size_t)std::max(L, 1) * wsz), cb((size_t)std::max(L, 1) * C), folded((size_t)C * C * 9);
+        for (int l = 0; l < L; l++) {
+            const float *w = take((size_t)C * C * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
+            for (int co = 0; co < C; co++) {
+                const float s = g[co] / std::sqrt(v[co] + eps);
+                cb[(size_t)l * C + co] = (b[co] - m[co]) * s + be[co];
+                for (size_t k = 0; k < (size_t)C * 9; k++) folded[(size_t)co * C * 9 + k] = w[(size_t)co * C * 9 + k] * s;
+            }
+            c6_pack_conv_weights(C, folded.data(), cw.data() + (size_t)l * wsz);
+        }
+        int rc;
+        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cb, &d.conv_b))) return rc;
+    }
+    {   // policy head
+        const float *w = take((size_t)2 * C), *b = take(2), *bn = take(8);
+        std::vector<float> pw((size_t)2 * C), pb(2);
+        for (int ch = 0; ch < 2; ch++) {
+            const float s = bn[ch] / std::sqrt(bn[6 + ch] + eps);
+            pb[ch] = (b[ch] - bn[4 + ch]) * s + bn[2 + ch];
+            for (int c = 0; c < C; c++) pw[(size_t)ch * C + c] = w[(size_t)ch * C + c] * s;
+        }
+        const float *lw = take((size_t)cells * 2 * cells), *lb = take(cells);
+        std::vector<float> wT((size_t)2 * cells * cells), lbv(lb, lb + cells);
+        for (int o = 0; o < cells; o++)
+            for (int k = 0; k < 2 * cells; k++) wT[(size_t)k * cells + o] = lw[(size_t)o * 2 * cells + k];
+        int rc;
+        if ((rc = upload(nh.pool, pw, &d.pc_w)) || (rc = upload(nh.pool, pb, &d.pc_b)) || (rc = upload(nh.pool, wT, &d.pl_wT)) ||
+            (rc = upload(nh.pool, lbv, &d.pl_b)))
+            return rc;
+    }
+    {   // value head
+        const float *w = take(C), *b = take(1), *bn = take((size_t)4 * cells);
+        std::vector<float> vw(w, w + C), sc(cells), sh(cells);
+        d.vc_b = b[0];
+        for (int i = 0; i < cells; i++) {
+            sc[i] = bn[i] / std::sqrt(bn[3 * cells + i] + eps);
+            sh[i] = bn[cells + i] - bn[2 * cells + i] * sc[i];
+        }
+        const float *w1 = take((size_t)256 * cells), *b1 = take(256), *w2 = take(256), *b2 = take(1);
+        std::vector<float> w1T((size_t)cells * 256), b1v(b1, b1 + 256), w2v(w2, w2 + 256);
+        for (int h = 0; h < 256; h++)
+            for (int k = 0; k < cells; k++) w1T[(size_t)k * 256 + h] = w1[(size_t)h * cells + k];
+        d.v2_b = b2[0];
+        int rc;
+        if ((rc = upload(nh.pool, vw, &d.vc_w)) || (rc = upload(nh.pool, sc, &d.vn_scale)) || (rc = upload(nh.pool, sh, &d.vn_shift)) ||
+            (rc = upload(nh.pool, w1T, &d.v1_wT)) || (rc = upload(nh.pool, b1v, &d.v1_b)) || (rc = upload(nh.pool, w2v, &d.v2_w)))
+            return rc;
+    }
+    nh.loaded = true;
+    return C6_OK;
+}
+
+// ---- engine -----------------------------------------------------------------------------------
+
+struct PhaseTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<hipEvent_t> pool;
+    double ms = 0;
+    unsigned long long n = 0;
+    hipEvent_t get() {
+        hipEvent_t e;
+        if (!pool.empty()) { e = pool.back(); pool.pop_back(); } else hipEventCreate(&e);
+        return e;
+    }
+    void collect() {
+        for (auto &p : ev) {
+            float m = 0;
+            hipEventSynchronize(p.second);
+            hipEventElapsedTime(&m, p.first, p.second);
+            ms += m;
+            n++;
+            pool.push_back(p.first);
+            pool.push_back(p.second);
+        }
+        ev.clear();
+    }
+    void destroy() {
+        collect();
+        for (auto e : pool) hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+struct c6_engine {
+    c6_config cfg{};
+    C6Dev d{};
+    DevPool pool;
+    NetHost net;
+    hipStream_t stream = nullptr;
+    C6NetTimers *timers = nullptr;
+    bool profiling = false;
+    PhaseTimer t_select, t_expand, t_eval, t_move;
+    c6_callback cb = nullptr;
+    // net scratch
+    float *act0 = nullptr, *act1 = nullptr, *act2 = nullptr, *ph = nullptr, *vh = nullptr;
+    int chunk_leaves = 0;
+    // callback scratch
+    float *img_boards = nullptr;   // device [G][8][cells]
+    std::vector<float> h_img, h_pol, h_val, h_cbp, h_cbv;
+    std::vector<int8_t> h_kind, h_turn;
+    // owned tuple buffer
+    uint8_t *own_tuple = nullptr;
+    uint32_t *own_tuple_count = nullptr;
+    uint64_t rounds = 0;
+    int round_in_move = 0;
+    unsigned long long fetched = 0;   // finished games already handed to the caller
+};
+
+extern "C" void c6_default_config(c6_config *cfg) {
+    memset(cfg, 0, sizeof *cfg);
+    cfg->board_size = 15;            // libconnect6/src/lib.rs:21
+    cfg->num_games = 1;
+    cfg->num_simulation = 800;       // HyperParameter::default, alphazero_policy/mod.rs:98-108
+    cfg->epsilon = 0.25f;
+    cfg->dirichlet_alpha = 0.03;
+    cfg->c_puct = 1.0f;
+    cfg->evaluator = C6_EVAL_RANDOM;
+    cfg->net_channels = 256;         // AlphaZero/cpp_weighted/model.hpp:12
+    cfg->net_blocks = 10;            // AlphaZero/cpp_weighted/main.cpp:12
+}
+
+extern "C" size_t c6_tuple_stride(int n) {
+    const size_t cells = (size_t)n * n;
+    return (cells + (cells & 1) + 2 * cells + 2 + 3) & ~(size_t)3;
+}
+
+static int engine_alloc(c6_engine *e) {
+    const c6_config &c = e->cfg;
+    C6Dev &d = e->d;
+    DevPool &pool = e->pool;
+    const int N = c.board_size, cells = N * N, G = c.num_games;
+    d.N = N; d.cells = cells; d.cellsP = (cells + 15) & ~15; d.G = G; d.Gpad = (G + 3) & ~3;
+    d.S = c.num_simulation;
+    d.R = c.records_per_game > 0 ? c.records_per_game : 4 * c.num_simulation + 64;
+    if (d.R > 65000) return fail(C6_ERR_BAD_ARG, "records_per_game too large (max 65000)");
+    int H = 64;
+    while (H < 2 * d.R) H <<= 1;
+    d.H = H;
+    d.eps = c.epsilon; d.cpuct = c.c_puct; d.alpha = c.dirichlet_alpha;
+    d.gam_d = (c.dirichlet_alpha + 1.0) - 1.0 / 3.0;       // Marsaglia-Tsang constants at shape alpha + 1
+    d.gam_c = 1.0 / std::sqrt(9.0 * d.gam_d);
+    d.seed_lo = (uint32_t)c.seed; d.seed_hi = (uint32_t)(c.seed >> 32);
+    d.uid_base = c.game_uid_base;
+    d.uid_stride = c.game_uid_stride ? c.game_uid_stride : (uint32_t)G;
+    d.recycle = c.recycle;
+
+    ALLOC(d.board_soa, (size_t)cells * d.Gpad);
+    ALLOC(d.turn, d.Gpad); ALLOC(d.remain, d.Gpad); ALLOC(d.winner, d.Gpad); ALLOC(d.err, d.Gpad);
+    ALLOC(d.status, G); ALLOC(d.nstones, G); ALLOC(d.game_uid, G); ALLOC(d.nsearch, G); ALLOC(d.sim_in_move, G);
+    ALLOC(d.root_board, (size_t)G * d.cellsP); ALLOC(d.root_key, G); ALLOC(d.root_sig, (size_t)G * 4); ALLOC(d.root_rec, G);
+    ALLOC(d.moves, (size_t)G * cells); ALLOC(d.hist_pi, (size_t)G * cells * cells);
+    const size_t GR = (size_t)G * d.R;
+    ALLOC(d.rec_key, GR); ALLOC(d.rec_visit, GR); ALLOC(d.rec_value, GR); ALLOC(d.rec_qsum, GR); ALLOC(d.rec_q, GR);
+    ALLOC(d.rec_level, GR); ALLOC(d.rec_sig, GR * 4); ALLOC(d.rec_prior, GR * cells);
+    ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.free_stack, GR); ALLOC(d.free_top, G);
+    ALLOC(d.leaf_board, (size_t)G * d.cellsP); ALLOC(d.leaf_turn, G); ALLOC(d.leaf_kind, G); ALLOC(d.leaf_key, G);
+    ALLOC(d.leaf_sig, (size_t)G * 4); ALLOC(d.leaf_level, G); ALLOC(d.path_len, G); ALLOC(d.path_rec, (size_t)G * C6_MAXD);
+    ALLOC(d.eval_value, G); ALLOC(d.eval_prior, (size_t)G * cells);
+    ALLOC(d.move_pos, d.Gpad); ALLOC(d.move_turn, G);
+    d.finq_cap = std::max(4 * G, 1024);
+    ALLOC(d.fin_winner, d.finq_cap); ALLOC(d.fin_len, d.finq_cap); ALLOC(d.fin_uid, d.finq_cap);
+    ALLOC(d.fin_moves, (size_t)d.finq_cap * cells);
+    ALLOC(d.counters, C6_CNT_N);
+    d.tuple_stride = (int)c6_tuple_stride(N);
+
+    std::vector<unsigned long long> zob;
+    build_zobrist(zob);
+    std::vector<int16_t> aug, rec;
+    build_maps(N, aug, rec);
+    int rc;
+    if ((rc = upload(pool, zob, &d.zob)) || (rc = upload(pool, aug, &d.aug_map)) || (rc = upload(pool, rec, &d.rec_map))) return rc;
+
+    if (c.evaluator == C6_EVAL_NET || c.evaluator == C6_EVAL_CALLBACK) {
+        ALLOC(d.img_val, (size_t)G * 8);
+        ALLOC(d.img_pol, (size_t)G * 8 * cells);
+    }
+    if (c.evaluator == C6_EVAL_CALLBACK) ALLOC(e->img_boards, (size_t)G * 8 * cells);
+    if (c.evaluator == C6_EVAL_NET) {
+        int chunk_boards = c.net_chunk_boards > 0 ? c.net_chunk_boards : 32768;
+        int chunk_leaves = std::max(1, chunk_boards / 8);
+        chunk_leaves = std::min(chunk_leaves, G);
+        e->chunk_leaves = chunk_leaves;
+        const size_t nb = (size_t)chunk_leaves * 8, act = nb * cells * c.net_channels;
+        ALLOC(e->act0, act); ALLOC(e->act1, act); ALLOC(e->act2, act);
+        ALLOC(e->ph, nb * 2 * cells); ALLOC(e->vh, nb * cells);
+    }
+    return C6_OK;
+}
+
+extern "C" int c6_engine_create(const c6_config *cfg, c6_engine **out) {
+    if (!cfg || !out) return fail(C6_ERR_BAD_ARG, "null argument");
+    const int N = cfg->board_size;
+    if (N != 9 && N != 15 && N != 19) return fail(C6_ERR_BAD_ARG, "board_size must be 9, 15 or 19");
+    if (cfg->num_games < 1 || cfg->num_simulation < 1) return fail(C6_ERR_BAD_ARG, "num_games and num_simulation must be >= 1");
+    if (cfg->evaluator < C6_EVAL_RANDOM || cfg->evaluator > C6_EVAL_CALLBACK) return fail(C6_ERR_BAD_ARG, "bad evaluator kind");
+    int rc = require_gpu(cfg->device);
+    if (rc != C6_OK) return rc;
+    c6_engine *e = new c6_engine();
+    e->cfg = *cfg;
+    if (hipStreamCreate(&e->stream) != hipSuccess) { delete e; return fail(C6_ERR_HIP, "hipStreamCreate failed"); }
+    e->timers = c6_timers_new();
+    rc = engine_alloc(e);
+    if (rc != C6_OK) { c6_engine_destroy(e); return rc; }
+    c6_launch_reset_games(e->d, cfg->stagger, e->stream);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) { c6_engine_destroy(e); return fail(C6_ERR_HIP, "engine reset failed"); }
+    *out = e;
+    return C6_OK;
+}
+
+extern "C" void c6_engine_destroy(c6_engine *e) {
+    if (!e) return;
+    if (e->stream) hipStreamSynchronize(e->stream);
+    e->t_select.destroy(); e->t_expand.destroy(); e->t_eval.destroy(); e->t_move.destroy();
+    c6_timers_free(e->timers);
+    e->pool.release();
+    e->net.pool.release();
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int c6_engine_load_weights(c6_engine *e, const float *blob, size_t nfloats) {
+    if (!e || !blob) return fail(C6_ERR_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    return net_load(e->net, e->cfg.board_size, e->cfg.net_channels, e->cfg.net_blocks, blob, nfloats);
+}
+
+extern "C" int c6_engine_set_callback(c6_engine *e, c6_callback cb) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    e->cb = cb;
+    return C6_OK;
+}
+
+extern "C" int c6_engine_set_tuple_buffer(c6_engine *e, void *dev_buf, size_t capacity_records, uint32_t *count_dev) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->d.tuple_buf = reinterpret_cast<uint8_t *>(dev_buf);
+    e->d.tuple_cap = capacity_records;
+    e->d.tuple_count = count_dev;
+    return C6_OK;
+}
+
+static int ensure_own_tuples(c6_engine *e, size_t cap) {
+    if (e->d.tuple_buf) return C6_OK;
+    DevPool &pool = e->pool;
+    ALLOC(e->own_tuple, cap * (size_t)e->d.tuple_stride);
+    ALLOC(e->own_tuple_count, 1);
+    e->d.tuple_buf = e->own_tuple;
+    e->d.tuple_cap = cap;
+    e->d.tuple_count = e->own_tuple_count;
+    return C6_OK;
+}
+
+struct Scoped {
+    PhaseTimer *t;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr;
+    Scoped(PhaseTimer *t_, hipStream_t s_, bool on) : t(on ? t_ : nullptr), s(s_) {
+        if (t) { e0 = t->get(); hipEventRecord(e0, s); }
+    }
+    ~Scoped() {
+        if (t) { hipEvent_t e1 = t->get(); hipEventRecord(e1, s); t->ev.emplace_back(e0, e1); }
+    }
+};
+
+static int evaluate_callback(c6_engine *e) {
+    C6Dev &d = e->d;
+    const int G = d.G, cells = d.cells;
+    if (!e->cb) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_CALLBACK but no callback is set");
+    c6_launch_augment(d, e->img_boards, e->stream);
+    e->h_kind.resize(G); e->h_turn.resize(G);
+    e->h_img.resize((size_t)G * 8 * cells); e->h_pol.resize((size_t)G * 8 * cells); e->h_val.resize((size_t)G * 8);
+    HIPCHK(hipMemcpyAsync(e->h_kind.data(), d.leaf_kind, G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_turn.data(), d.leaf_turn, G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_img.data(), e->img_boards, e->h_img.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    // the callback takes ONE `player` for all boards (cppeval/mod.rs:8-13): batch per side to move
+    for (int player = -1; player <= 1; player += 2) {
+        std::vector<int> idx;
+        for (int g = 0; g < G; g++)
+            if (e->h_kind[g] == C6_LEAF_EVAL && e->h_turn[g] == player) idx.push_back(g);
+        if (idx.empty()) continue;
+        const size_t per = (size_t)8 * cells;
+        e->h_cbp.resize(idx.size() * per);
+        e->h_cbv.assign(idx.size() * 8, 0.f);                 // values zero-filled, cppeval/mod.rs:34
+        for (size_t k = 0; k < idx.size(); k++)
+            memcpy(&e->h_cbp[k * per], &e->h_img[(size_t)idx[k] * per], per * sizeof(float));
+        e->cb(player, e->h_cbv.data(), e->h_cbp.data(), (int)(idx.size() * 8));
+        for (size_t k = 0; k < idx.size(); k++) {
+            memcpy(&e->h_pol[(size_t)idx[k] * per], &e->h_cbp[k * per], per * sizeof(float));
+            memcpy(&e->h_val[(size_t)idx[k] * 8], &e->h_cbv[k * 8], 8 * sizeof(float));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(d.img_pol, e->h_pol.data(), e->h_pol.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.img_val, e->h_val.data(), e->h_val.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    c6_launch_recover(d, e->stream);
+    return C6_OK;
+}
+
+static int evaluate(c6_engine *e) {
+    C6Dev &d = e->d;
+    switch (e->cfg.evaluator) {
+    case C6_EVAL_RANDOM: c6_launch_eval_builtin(d, 1, e->stream); return C6_OK;
+    case C6_EVAL_UNIFORM: c6_launch_eval_builtin(d, 2, e->stream); return C6_OK;
+    case C6_EVAL_NET: {
+        if (!e->net.loaded) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_NET but no weights are loaded");
+        for (int l0 = 0; l0 < d.G; l0 += e->chunk_leaves) {
+            const int nl = std::min(e->chunk_leaves, d.G - l0);
+            c6_net_forward_dev(e->net.dev, nl, 8, d.leaf_board + (size_t)l0 * d.cellsP, d.cellsP, d.leaf_turn + l0, d.aug_map,
+                               e->act0, e->act1, e->act2, e->ph, e->vh, d.img_pol + (size_t)l0 * 8 * d.cells,
+                               d.img_val + (size_t)l0 * 8, e->stream, e->timers);
+        }
+        c6_launch_recover(d, e->stream);
+        return C6_OK;
+    }
+    case C6_EVAL_CALLBACK: return evaluate_callback(e);
+    default: return fail(C6_ERR_BAD_ARG, "bad evaluator");
+    }
+}
+
+extern "C" int c6_engine_step(c6_engine *e, int rounds) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    C6Dev &d = e->d;
+    for (int r = 0; r < rounds; r++) {
+        { Scoped t(&e->t_select, e->stream, e->profiling); c6_launch_select(d, e->stream); }
+        {
+            Scoped t(&e->t_eval, e->stream, e->profiling);
+            int rc = evaluate(e);
+            if (rc != C6_OK) return rc;
+        }
+        { Scoped t(&e->t_expand, e->stream, e->profiling); c6_launch_expand(d, e->stream); }
+        e->rounds++;
+        e->round_in_move++;
+        // aligned games all move on the same round; staggered games move a few at a time every round
+        if (e->cfg.stagger || e->round_in_move >= d.S) {
+            Scoped t(&e->t_move, e->stream, e->profiling);
+            c6_launch_move_select(d, e->stream);
+            c6_launch_board_step(d.N, d.Gpad, d.board_soa, d.turn, d.remain, d.move_pos, d.winner, d.err, e->stream);
+            c6_launch_post_move(d, e->stream);
+            if (e->round_in_move >= d.S) e->round_in_move = 0;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return C6_OK;
+}
+
+extern "C" int c6_engine_sync(c6_engine *e) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return C6_OK;
+}
+
+static int live_games(c6_engine *e, int *live, int *errors) {
+    std::vector<int8_t> st(e->d.G);
+    HIPCHK(hipMemcpyAsync(st.data(), e->d.status, e->d.G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int l = 0, er = 0;
+    for (int8_t s : st) { l += s == C6_ST_PLAYING; er += s == C6_ST_ERROR; }
+    *live = l;
+    *errors = er;
+    return C6_OK;
+}
+
+extern "C" int c6_engine_run(c6_engine *e, long max_rounds) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    long done = 0;
+    for (;;) {
+        int live = 0, errs = 0;
+        int rc = live_games(e, &live, &errs);
+        if (rc != C6_OK) return rc;
+        if (live == 0) break;
+        if (max_rounds > 0 && done >= max_rounds) break;
+        int chunk = e->cfg.stagger ? std::min(e->d.S, 64) : e->d.S - e->round_in_move;
+        if (max_rounds > 0) chunk = (int)std::min<long>(chunk, max_rounds - done);
+        rc = c6_engine_step(e, chunk);
+        if (rc != C6_OK) return rc;
+        done += chunk;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return C6_OK;
+}
+
+extern "C" int c6_engine_stats(c6_engine *e, c6_stats *out) {
+    if (!e || !out) return fail(C6_ERR_BAD_ARG, "null argument");
+    unsigned long long c[C6_CNT_N];
+    HIPCHK(hipMemcpyAsync(c, e->d.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
+    int live = 0, errs = 0;
+    int rc = live_games(e, &live, &errs);
+    if (rc != C6_OK) return rc;
+    out->rounds = e->rounds;
+    out->simulations = c[C6_CNT_SIMS];
+    out->select_steps = c[C6_CNT_SELECT];
+    out->stones = c[C6_CNT_STONES];
+    out->games_finished = c[C6_CNT_FINISHED];
+    out->tuples = c[C6_CNT_TUPLES];
+    out->live_games = (uint32_t)live;
+    out->overflow_games = (uint32_t)errs;
+    out->max_records_used = (uint32_t)c[C6_CNT_MAXREC];
+    out->max_depth = (uint32_t)c[C6_CNT_MAXDEPTH];
+    return C6_OK;
+}
+
+extern "C" int c6_engine_fetch_games(c6_engine *e, int cap, int *count, int *winners, int *lens, uint32_t *uids, int16_t *moves) {
+    if (!e || !count) return fail(C6_ERR_BAD_ARG, "null argument");
+    C6Dev &d = e->d;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    unsigned long long q = 0;
+    HIPCHK(hipMemcpy(&q, d.counters + C6_CNT_FETCHQ, sizeof q, hipMemcpyDeviceToHost));
+    if (q > (unsigned long long)d.finq_cap) q = d.finq_cap;
+    const int n = (int)std::min<unsigned long long>(q, (unsigned long long)std::max(cap, 0));
+    if (n > 0) {
+        HIPCHK(hipMemcpy(winners, d.fin_winner, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lens, d.fin_len, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (uids) HIPCHK(hipMemcpy(uids, d.fin_uid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (moves) HIPCHK(hipMemcpy(moves, d.fin_moves, (size_t)n * d.cells * sizeof(int16_t), hipMemcpyDeviceToHost));
+    }
+    // the queue is drained as a whole: callers pass cap >= the number of finished games
+    if ((unsigned long long)n == q) HIPCHK(hipMemset(d.counters + C6_CNT_FETCHQ, 0, sizeof(unsigned long long)));
+    *count = n;
+    return C6_OK;
+}
+
+extern "C" int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, void *host_buf) {
+    if (!e || !count) return fail(C6_ERR_BAD_ARG, "null argument");
+    C6Dev &d = e->d;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!d.tuple_buf) { *count = 0; return C6_OK; }
+    uint32_t n = 0;
+    HIPCHK(hipMemcpy(&n, d.tuple_count, sizeof n, hipMemcpyDeviceToHost));
+    size_t m = std::min<size_t>(std::min<size_t>(n, d.tuple_cap), cap);
+    if (m && host_buf) HIPCHK(hipMemcpy(host_buf, d.tuple_buf, m * d.tuple_stride, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(d.tuple_count, 0, sizeof(uint32_t)));
+    *count = m;
+    return C6_OK;
+}
+
+// enable tuple recording into an engine-owned buffer of `capacity_records`
+extern "C" int c6_engine_enable_tuples(c6_engine *e, size_t capacity_records) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ensure_own_tuples(e, capacity_records);
+}
+
+__global__ void c6_root_probe_kernel(C6Dev E, int g, int32_t *visits, float *q, float *prior, int *root_stats, float *root_f) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cells = E.cells;
+    const int p = E.root_rec[g];
+    const size_t rbase = (size_t)g * E.R;
+    if (c == 0) {
+        root_stats[0] = p >= 0 ? E.rec_visit[rbase + p] : 0;
+        root_stats[1] = E.R - E.free_top[g];
+        root_f[0] = p >= 0 ? E.rec_value[rbase + p] : 0.f;
+        root_f[1] = p >= 0 ? E.rec_qsum[rbase + p] : 0.f;
+        root_f[2] = p >= 0 ? E.rec_q[rbase + p] : 0.f;
+    }
+    if (c >= cells) return;
+    const int8_t v = E.root_board[(size_t)g * E.cellsP + c];
+    visits[c] = -1; q[c] = 0.f; prior[c] = 0.f;
+    if (v != 0 || p < 0) { if (v == 0) visits[c] = 0; return; }
+    const int turn = E.turn[g];
+    const unsigned long long key = E.root_key[g] ^ E.zob[(turn == C6_WHITE ? C6_MAXCELLS : 0) + c];
+    const C6HtEntry *ht = E.ht + (size_t)g * E.H;
+    uint32_t slot = (uint32_t)(key ^ (key >> 32)) & (uint32_t)(E.H - 1);
+    int idx = -1;
+    for (int it = 0; it < E.H; it++) {
+        const C6HtEntry en = ht[slot];
+        if (en.key == key) { idx = (int)en.idx1 - 1; break; }
+        if (en.key == 0ull) break;
+        slot = (slot + 1) & (uint32_t)(E.H - 1);
+    }
+    visits[c] = idx >= 0 ? E.rec_visit[rbase + idx] : 0;
+    q[c] = idx >= 0 ? E.rec_q[rbase + idx] : 0.f;
+    prior[c] = E.rec_prior[(rbase + p) * (size_t)cells + c];
+}
+
+extern "C" int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *board, int32_t *visits, float *q, float *prior) {
+    if (!e || g < 0 || g >= e->d.G) return fail(C6_ERR_BAD_ARG, "bad game index");
+    C6Dev &d = e->d;
+    const int cells = d.cells;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int32_t *dv; float *dq, *dp, *drf; int *drs;
+    HIPCHK(hipMalloc(&dv, cells * 4)); HIPCHK(hipMalloc(&dq, cells * 4)); HIPCHK(hipMalloc(&dp, cells * 4));
+    HIPCHK(hipMalloc(&drs, 8)); HIPCHK(hipMalloc(&drf, 12));
+    hipLaunchKernelGGL(c6_root_probe_kernel, dim3((cells + 63) / 64), dim3(64), 0, e->stream, d, g, dv, dq, dp, drs, drf);
+    std::vector<int32_t> hv(cells); std::vector<float> hq(cells), hp(cells);
+    int rs[2]; float rf[3];
+    HIPCHK(hipMemcpy(hv.data(), dv, cells * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hq.data(), dq, cells * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hp.data(), dp, cells * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rs, drs, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rf, drf, 12, hipMemcpyDeviceToHost));
+    hipFree(dv); hipFree(dq); hipFree(dp); hipFree(drs); hipFree(drf);
+    if (visits) memcpy(visits, hv.data(), cells * 4);
+    if (q) memcpy(q, hq.data(), cells * 4);
+    if (prior) memcpy(prior, hp.data(), cells * 4);
+    if (board) HIPCHK(hipMemcpy(board, d.root_board + (size_t)g * d.cellsP, cells, hipMemcpyDeviceToHost));
+    if (info) {
+        int8_t t, r, st, w; int16_t ns; uint32_t nsr;
+        HIPCHK(hipMemcpy(&t, d.turn + g, 1, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&r, d.remain + g, 1, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&st, d.status + g, 1, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&w, d.winner + g, 1, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&ns, d.nstones + g, 2, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&nsr, d.nsearch + g, 4, hipMemcpyDeviceToHost));
+        info->turn = t; info->remain = r; info->stones = ns; info->status = st; info->winner = w;
+        info->root_visit = rs[0]; info->records_used = rs[1];
+        info->root_value = rf[0]; info->root_q_sum = rf[1]; info->root_q_value = rf[2];
+        info->nsearch = nsr;
+    }
+    return C6_OK;
+}
+
+extern "C" int c6_engine_profile(c6_engine *e, int enable) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    e->profiling = enable != 0;
+    c6_timers_enable(e->timers, e->profiling);
+    return C6_OK;
+}
+
+extern "C" int c6_engine_profile_read(c6_engine *e, c6_profile *out, int reset) {
+    if (!e || !out) return fail(C6_ERR_BAD_ARG, "null argument");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    memset(out, 0, sizeof *out);
+    unsigned long long n = 0;
+    c6_timers_collect(e->timers, &out->conv_ms, &n, &out->conv_flops, reset != 0);
+    out->conv_launches = n;
+    e->t_select.collect(); e->t_expand.collect(); e->t_eval.collect(); e->t_move.collect();
+    out->select_ms = e->t_select.ms; out->select_launches = e->t_select.n;
+    out->expand_ms = e->t_expand.ms; out->expand_launches = e->t_expand.n;
+    out->eval_other_ms = e->t_eval.ms - out->conv_ms;
+    out->move_ms = e->t_move.ms;
+    if (reset) {
+        for (PhaseTimer *t : {&e->t_select, &e->t_expand, &e->t_eval, &e->t_move}) { t->ms = 0; t->n = 0; }
+    }
+    return C6_OK;
+}
+
+// ---- stand-alone operators ------------------------------------------------------------------
+
+struct TmpDev {
+    std::vector<void *> p;
+    ~TmpDev() { for (void *q : p) hipFree(q); }
+    template <typename T> T *get(size_t n, const T *src = nullptr) {
+        void *q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(n * sizeof(T), 16)) != hipSuccess) return nullptr;
+        p.push_back(q);
+        if (src) hipMemcpy(q, src, n * sizeof(T), hipMemcpyHostToDevice);
+        else hipMemset(q, 0, std::max<size_t>(n * sizeof(T), 16));
+        return reinterpret_cast<T *>(q);
+    }
+};
+
+static int check_n(int n) {
+    if (n != 9 && n != 15 && n != 19) return fail(C6_ERR_BAD_ARG, "board_size must be 9, 15 or 19");
+    return C6_OK;
+}
+
+// SoA host arrays may have any G; the kernels need G % 4 == 0, so the device copy is padded
+static int8_t *soa_to_dev(TmpDev &t, int cells, int G, int Gpad, const int8_t *h) {
+    int8_t *d = t.get<int8_t>((size_t)cells * Gpad);
+    if (d && h) hipMemcpy2D(d, Gpad, h, G, G, cells, hipMemcpyHostToDevice);
+    return d;
+}
+
+extern "C" int c6_board_step(int n, int G, int8_t *boards, int8_t *turn, int8_t *remain, const int32_t *pos, int8_t *winner,
+                             int8_t *err) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const int cells = n * n, Gpad = (G + 3) & ~3;
+    TmpDev t;
+    int8_t *db = soa_to_dev(t, cells, G, Gpad, boards), *dt = t.get<int8_t>(Gpad), *dr = t.get<int8_t>(Gpad), *dw = t.get<int8_t>(Gpad),
+           *de = t.get<int8_t>(Gpad);
+    int32_t *dp = t.get<int32_t>(Gpad);
+    if (!db || !dt || !dr || !dw || !de || !dp) return fail(C6_ERR_HIP, "hipMalloc failed");
+    HIPCHK(hipMemset(dp, 0xff, (size_t)Gpad * 4));   // padding games: pos = -1 (no move)
+    HIPCHK(hipMemcpy(dt, turn, G, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dr, remain, G, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dp, pos, (size_t)G * 4, hipMemcpyHostToDevice));
+    c6_launch_board_step(n, Gpad, db, dt, dr, dp, dw, de, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy2D(boards, G, db, Gpad, G, cells, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(turn, dt, G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(remain, dr, G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(winner, dw, G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(err, de, G, hipMemcpyDeviceToHost));
+    return C6_OK;
+}
+
+extern "C" int c6_search_winner(int n, int G, const int8_t *boards, int8_t *winner) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const int cells = n * n, Gpad = (G + 3) & ~3;
+    TmpDev t;
+    int8_t *db = soa_to_dev(t, cells, G, Gpad, boards), *dw = t.get<int8_t>(Gpad);
+    if (!db || !dw) return fail(C6_ERR_HIP, "hipMalloc failed");
+    c6_launch_search_winner(n, Gpad, db, dw, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(winner, dw, G, hipMemcpyDeviceToHost));
+    return C6_OK;
+}
+
+extern "C" int c6_legal_mask(int n, int G, const int8_t *boards, uint8_t *mask) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const int cells = n * n, Gpad = (G + 3) & ~3, NB = (cells + 7) / 8;
+    TmpDev t;
+    int8_t *db = soa_to_dev(t, cells, G, Gpad, boards);
+    uint8_t *dm = t.get<uint8_t>((size_t)NB * Gpad);
+    if (!db || !dm) return fail(C6_ERR_HIP, "hipMalloc failed");
+    c6_launch_legal_mask(n, Gpad, db, dm, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy2D(mask, G, dm, Gpad, G, NB, hipMemcpyDeviceToHost));
+    return C6_OK;
+}
+
+extern "C" int c6_augment8(int n, int num, const int8_t *boards, int8_t *out) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const int cells = n * n;
+    std::vector<int16_t> aug, rec;
+    build_maps(n, aug, rec);
+    TmpDev t;
+    int8_t *db = t.get<int8_t>((size_t)num * cells, boards), *dout = t.get<int8_t>((size_t)num * 8 * cells);
+    int16_t *dm = t.get<int16_t>(aug.size(), aug.data());
+    if (!db || !dout || !dm) return fail(C6_ERR_HIP, "hipMalloc failed");
+    c6_launch_augment_op(n, num, db, dm, dout, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout, (size_t)num * 8 * cells, hipMemcpyDeviceToHost));
+    return C6_OK;
+}
+
+extern "C" int c6_recover8(int n, int num, const int8_t *boards, const float *values8, const float *policies8, float *value, float *prior) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const int cells = n * n;
+    std::vector<int16_t> aug, rec;
+    build_maps(n, aug, rec);
+    TmpDev t;
+    int8_t *db = t.get<int8_t>((size_t)num * cells, boards);
+    float *dv8 = t.get<float>((size_t)num * 8, values8), *dp8 = t.get<float>((size_t)num * 8 * cells, policies8);
+    float *dv = t.get<float>(num), *dp = t.get<float>((size_t)num * cells);
+    int16_t *dm = t.get<int16_t>(rec.size(), rec.data());
+    if (!db || !dv8 || !dp8 || !dv || !dp || !dm) return fail(C6_ERR_HIP, "hipMalloc failed");
+    c6_launch_recover_op(n, num, db, dv8, dp8, dm, dv, dp, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(value, dv, (size_t)num * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(prior, dp, (size_t)num * cells * 4, hipMemcpyDeviceToHost));
+    return C6_OK;
+}
+
+extern "C" int c6_dirichlet_noise(int n, int num, double alpha, const uint32_t *k0, const uint32_t *k1, const uint32_t *search,
+                                  const uint32_t *depth, const int8_t *boards, float *noise) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const int cells = n * n;
+    TmpDev t;
+    uint32_t *d0 = t.get<uint32_t>(num, k0), *d1 = t.get<uint32_t>(num, k1), *ds = t.get<uint32_t>(num, search), *dd = t.get<uint32_t>(num, depth);
+    int8_t *db = t.get<int8_t>((size_t)num * cells, boards);
+    float *dn = t.get<float>((size_t)num * cells);
+    if (!d0 || !d1 || !ds || !dd || !db || !dn) return fail(C6_ERR_HIP, "hipMalloc failed");
+    const double gd = (alpha + 1.0) - 1.0 / 3.0, gc = 1.0 / std::sqrt(9.0 * gd);
+    c6_launch_noise_op(n, num, alpha, gd, gc, d0, d1, ds, dd, db, dn, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(noise, dn, (size_t)num * cells * 4, hipMemcpyDeviceToHost));
+    return C6_OK;
+}
+
+extern "C" int c6_net_forward(int n, int C, int blocks, const float *blob, size_t nfloats, int num, const int8_t *boards,
+                              const int8_t *player, float *policy, float *value) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const int cells = n * n;
+    NetHost nh;
+    rc = net_load(nh, n, C, blocks, blob, nfloats);
+    if (rc) { nh.pool.release(); return rc; }
+    std::vector<int16_t> aug, rec;
+    build_maps(n, aug, rec);
+    TmpDev t;
+    const size_t act = (size_t)num * cells * C;
+    int8_t *db = t.get<int8_t>((size_t)num * cells, boards), *dpl = t.get<int8_t>(num, player);
+    int16_t *dm = t.get<int16_t>(aug.size(), aug.data());
+    float *a0 = t.get<float>(act), *a1 = t.get<float>(act), *a2 = t.get<float>(act), *ph = t.get<float>((size_t)num * 2 * cells),
+          *vh = t.get<float>((size_t)num * cells), *dp = t.get<float>((size_t)num * cells), *dv = t.get<float>(num);
+    if (!db || !dpl || !dm || !a0 || !a1 || !a2 || !ph || !vh || !dp || !dv) { nh.pool.release(); return fail(C6_ERR_HIP, "hipMalloc failed"); }
+    c6_net_forward_dev(nh.dev, num, 1, db, cells, dpl, dm, a0, a1, a2, ph, vh, dp, dv, nullptr, nullptr);
+    hipError_t he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = hipMemcpy(policy, dp, (size_t)num * cells * 4, hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipMemcpy(value, dv, (size_t)num * 4, hipMemcpyDeviceToHost);
+    nh.pool.release();
+    if (he != hipSuccess) return fail(C6_ERR_HIP, hipGetErrorString(he));
+    return C6_OK;
+}

@@ -1,0 +1,747 @@
+// tree_kernels.hip -- K2: batched AlphaZero MCTS (select / expand / backup / move / prune) and
+// K3: dihedral augment / recover, one wave (64 lanes) per game.
+//
+// Reference being reproduced (Connect6/libconnect6/src/policy/alphazero_policy/mod.rs):
+//   maximum_from :243-296   select :313-323   expand :331-381   update :386-408
+//   search :411-426         policy :433-452   next (prune) :464-489   get_from :218-234
+// and augment.rs:60-92, agent/agent_impl/mod.rs:121-178 (game loop).
+//
+// Data structure.  The reference keeps a HashMap<board hash, Node> in which EVERY legal child of
+// every expanded node is a full Node.  Only three facts about an unexpanded node are ever read:
+// visit == 0, q_value == 0 and n_prob (the prior written by the LAST expanded parent, :366-370).
+// So the engine stores records only for EXPANDED nodes, each carrying prior[cell] = n_prob of its
+// child at that cell, plus a table  Zobrist key -> record  through which a child's shared
+// visit / q_value are found (children reached by different move orders are one node, as in the
+// reference).  The last-writer rule is kept exact: when a node Q is expanded, every expanded node
+// P on the same level with P + i == Q + s (one stone swapped) gets prior_P[i] = prob_Q[s].  Such P
+// are found from per-record (sum, sum of squares) of stone cells per colour, verified by key.
+//
+// A lane owns cells lane, lane+64, ... (row-major order == child order of the reference, which
+// lists children in `possible` order, simulate/mod.rs:58-69).
+#include "c6_device.h"
+#include "c6_engine.h"
+
+#define WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ int ht_find(const C6HtEntry *ht, int H, unsigned long long key) {
+    uint32_t slot = (uint32_t)(key ^ (key >> 32)) & (uint32_t)(H - 1);
+    for (int it = 0; it < H; it++) {
+        const C6HtEntry e = ht[slot];
+        if (e.key == key) return (int)e.idx1 - 1;
+        if (e.key == 0ull) return -1;
+        slot = (slot + 1) & (uint32_t)(H - 1);
+    }
+    return -1;
+}
+
+// concurrent insert (distinct keys); returns false if the table is full
+__device__ __forceinline__ bool ht_insert(C6HtEntry *ht, int H, unsigned long long key, int idx) {
+    uint32_t slot = (uint32_t)(key ^ (key >> 32)) & (uint32_t)(H - 1);
+    for (int it = 0; it < H; it++) {
+        unsigned long long prev = atomicCAS(&ht[slot].key, 0ull, key);
+        if (prev == 0ull || prev == key) {
+            ht[slot].idx1 = (uint32_t)(idx + 1);
+            return true;
+        }
+        slot = (slot + 1) & (uint32_t)(H - 1);
+    }
+    return false;
+}
+
+__device__ __forceinline__ void next_turn(int &turn, int &remain) {   // simulate/mod.rs:268-273
+    remain -= 1;
+    if (remain <= 0) { remain = 2; turn = -turn; }
+}
+
+// ------------------------------------------------------------------------------------------
+// select: walk from the root by PUCT + Dirichlet noise until a node without record (leaf)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G) return;
+    if (E.status[g] != C6_ST_PLAYING) {
+        if (lane == 0) E.leaf_kind[g] = C6_LEAF_NONE;
+        return;
+    }
+    const int cells = E.cells;
+    const C6HtEntry *ht = E.ht + (size_t)g * E.H;
+    const size_t rbase = (size_t)g * E.R;
+
+    unsigned long long key = E.root_key[g];
+    uint32_t sg0 = E.root_sig[g * 4 + 0], sg1 = E.root_sig[g * 4 + 1], sg2 = E.root_sig[g * 4 + 2], sg3 = E.root_sig[g * 4 + 3];
+    int p = E.root_rec[g];
+    int turn = E.turn[g], remain = E.remain[g], level = E.nstones[g];
+    const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.game_uid[g], t = E.nsearch[g];
+
+    int8_t st[C6_MAXJ];
+#pragma unroll
+    for (int j = 0; j < C6_MAXJ; j++) {
+        const int c = lane + 64 * j;
+        st[j] = c < cells ? E.root_board[(size_t)g * E.cellsP + c] : (int8_t)2;
+    }
+
+    int d = 0;
+    int kind = C6_LEAF_EVAL;
+    while (p >= 0) {
+        const int nchild = cells - level;
+        if (nchild == 0) break;                 // cannot happen: full boards are never records
+        if (d >= C6_MAXD) { kind = -1; break; } // path overflow
+        const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
+        const float *prior = E.rec_prior + (rbase + p) * (size_t)cells;
+
+        int cidx[C6_MAXJ], cvis[C6_MAXJ];
+        float cq[C6_MAXJ], cpr[C6_MAXJ];
+        int vs = 0;
+#pragma unroll
+        for (int j = 0; j < C6_MAXJ; j++) {
+            const int c = lane + 64 * j;
+            cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f; cpr[j] = 0.f;
+            if (st[j] == 0) {
+                const int idx = ht_find(ht, E.H, key ^ zk[c]);
+                cidx[j] = idx;
+                if (idx >= 0) { cvis[j] = E.rec_visit[rbase + idx]; cq[j] = E.rec_q[rbase + idx]; }
+                cpr[j] = prior[c];
+                vs += cvis[j];
+            }
+        }
+
+        int chosen;
+        if (nchild == 1) {                       // heuristic, mod.rs:255-258
+            int mine = -1;
+#pragma unroll
+            for (int j = 0; j < C6_MAXJ; j++) if (st[j] == 0) mine = lane + 64 * j;
+            chosen = c6_wave_max_i32(mine);
+        } else {
+            const float visit_sum = (float)c6_wave_sum_i32(vs);
+            // Dirichlet noise: Gamma draws normalised by their sum (C6RNG), mod.rs:260-262,283
+            double gam[C6_MAXJ], part = 0.0;
+#pragma unroll
+            for (int j = 0; j < C6_MAXJ; j++) {
+                gam[j] = 0.0;
+                if (st[j] == 0) {
+                    gam[j] = c6_gamma_draw(E.alpha, E.gam_d, E.gam_c, k0, k1, (uint32_t)(lane + 64 * j), t, (uint32_t)d);
+                    part = part + gam[j];
+                }
+            }
+            const double gsum = c6_butterfly_sum(part);
+            float sc[C6_MAXJ], best = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < C6_MAXJ; j++) {
+                sc[j] = -INFINITY;
+                if (st[j] == 0) {                // mod.rs:265-280
+                    const float noise = (float)(gam[j] / gsum);
+                    const float visit = (float)cvis[j];
+                    const float prob = E.eps * noise + (1.f - E.eps) * cpr[j];
+                    const float puct = prob * sqrtf(visit_sum - visit) / (1.f + visit);
+                    const float q = turn == C6_BLACK ? -cq[j] : cq[j];
+                    sc[j] = q + E.cpuct * puct;
+                    best = sc[j] > best ? sc[j] : best;
+                }
+            }
+            best = c6_wave_max_f32(best);
+            // exact ties -> uniform choice (mod.rs:287-295), C6RNG TIE draw
+            unsigned long long tie[C6_MAXJ];
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < C6_MAXJ; j++) {
+                tie[j] = __ballot(st[j] == 0 && sc[j] == best);
+                cnt += __popcll(tie[j]);
+            }
+            int pick = 0;
+            if (cnt > 1) {
+                const c6_u4 w = c6_philox(0u, 0u, t, C6_TAG_TIE | ((uint32_t)d << 8), k0, k1);
+                pick = (int)(c6_open01(w.x, w.y) * (double)cnt);
+                if (pick >= cnt) pick = cnt - 1;
+            }
+            chosen = -1;
+#pragma unroll
+            for (int j = 0; j < C6_MAXJ; j++) {
+                const int pc = __popcll(tie[j]);
+                if (chosen < 0) {
+                    if (pick < pc) chosen = c6_nth_set_bit(tie[j], pick) + 64 * j;
+                    else pick -= pc;
+                }
+            }
+            if (chosen < 0) { kind = -1; break; }   // NaN scores: the reference panics (partial_cmp().unwrap())
+        }
+
+        // step into the child: diff_board + simulate_in (mod.rs:417-420)
+        const int cl = chosen & 63, cj = chosen >> 6;
+        int child = -1;
+#pragma unroll
+        for (int j = 0; j < C6_MAXJ; j++) if (j == cj) child = cidx[j];
+        child = __shfl(child, cl, 64);
+        if (lane == 0) E.path_rec[(size_t)g * C6_MAXD + d] = (uint16_t)p;
+        d++;
+        key ^= zk[chosen];
+        const uint32_t c1 = (uint32_t)chosen + 1u;
+        if (turn == C6_BLACK) { sg0 += c1; sg1 += c1 * c1; } else { sg2 += c1; sg3 += c1 * c1; }
+#pragma unroll
+        for (int j = 0; j < C6_MAXJ; j++) if (j == cj && lane == cl) st[j] = (int8_t)turn;
+        next_turn(turn, remain);
+        level++;
+        p = child;
+    }
+    if (kind == C6_LEAF_EVAL && level == cells) kind = C6_LEAF_TERMINAL;   // board full, mod.rs:338
+
+#pragma unroll
+    for (int j = 0; j < C6_MAXJ; j++) {
+        const int c = lane + 64 * j;
+        if (c < cells) E.leaf_board[(size_t)g * E.cellsP + c] = st[j];
+    }
+    if (lane == 0) {
+        if (kind < 0) {   // overflow / NaN: stop this game, reported through status
+            E.status[g] = C6_ST_ERROR;
+            E.leaf_kind[g] = C6_LEAF_NONE;
+            atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull);
+        } else {
+            E.leaf_kind[g] = (int8_t)kind;
+            E.leaf_turn[g] = (int8_t)turn;
+            E.leaf_key[g] = key;
+            E.leaf_sig[g * 4 + 0] = sg0; E.leaf_sig[g * 4 + 1] = sg1; E.leaf_sig[g * 4 + 2] = sg2; E.leaf_sig[g * 4 + 3] = sg3;
+            E.leaf_level[g] = (int16_t)level;
+            E.path_len[g] = d;
+            atomicAdd(&E.counters[C6_CNT_SELECT], (unsigned long long)d);
+            atomicMax(&E.counters[C6_CNT_MAXDEPTH], (unsigned long long)d);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// recover_way8 + mask (get_from, mod.rs:218-234) -- shared by every evaluator kind
+// ------------------------------------------------------------------------------------------
+// p(k, cell) returns image k's policy at `cell`; v(k) image k's value.
+template <typename PF, typename VF>
+__device__ __forceinline__ void recover_wave(int cells, int lane, const int16_t *rec_map, const int8_t *board, PF p, VF v,
+                                             float *out_value, float *out_prior) {
+    for (int c = lane; c < cells; c += 64) {
+        float total = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {   // augment.rs:79-88: (p[2i] + flipV(p[2i+1])) rotated right i+1 times
+            const float a = p(2 * i, (int)rec_map[(2 * i) * cells + c]);
+            const float b = p(2 * i + 1, (int)rec_map[(2 * i + 1) * cells + c]);
+            total = total + (a + b);
+        }
+        total = total / 8.f;
+        out_prior[c] = total * (float)(board[c] == 0);   // masking, mod.rs:226-231
+    }
+    if (lane == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s = s + v(k);        // iter().sum::<f32>() / 8., mod.rs:224
+        *out_value = s / 8.f;
+    }
+}
+
+// RandomEvaluator (mod.rs:137-169) / uniform evaluator, evaluated on device
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_eval_builtin_kernel(C6Dev E, int kind) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G || E.leaf_kind[g] != C6_LEAF_EVAL) return;
+    const int cells = E.cells;
+    const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.game_uid[g], t = E.nsearch[g];
+    const int8_t *board = E.leaf_board + (size_t)g * E.cellsP;
+    float *prior = E.eval_prior + (size_t)g * cells;
+    if (kind == 1) {
+        auto pf = [&](int k, int cell) -> float {
+            const c6_u4 w = c6_philox((uint32_t)(cell >> 2), (uint32_t)k, t, C6_TAG_EVAL_P, k0, k1);
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+            return c6_u11(ws[cell & 3]);
+        };
+        auto vf = [&](int k) -> float { return c6_u11(c6_philox((uint32_t)k, 0u, t, C6_TAG_EVAL_V, k0, k1).x); };
+        recover_wave(cells, lane, E.rec_map, board, pf, vf, &E.eval_value[g], prior);
+    } else {
+        const float u = 1.0f / (float)cells;
+        auto pf = [&](int, int) -> float { return u; };
+        auto vf = [&](int) -> float { return 0.f; };
+        recover_wave(cells, lane, E.rec_map, board, pf, vf, &E.eval_value[g], prior);
+    }
+}
+
+// net / callback evaluators: img_pol [G][8][cells], img_val [G][8]
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_recover_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G || E.leaf_kind[g] != C6_LEAF_EVAL) return;
+    const int cells = E.cells;
+    const float *pol = E.img_pol + (size_t)g * 8 * cells;
+    const float *val = E.img_val + (size_t)g * 8;
+    auto pf = [&](int k, int cell) -> float { return pol[k * cells + cell]; };
+    auto vf = [&](int k) -> float { return val[k]; };
+    recover_wave(cells, lane, E.rec_map, E.leaf_board + (size_t)g * E.cellsP, pf, vf, &E.eval_value[g],
+                 E.eval_prior + (size_t)g * cells);
+}
+
+// augment_way8 (augment.rs:60-73) of the leaf boards as f32 for the host callback
+// (board_to_float, cppbind/.../cpp_support.rs:10-18): img[g][k][c]
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_augment_kernel(C6Dev E, float *img) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G || E.leaf_kind[g] != C6_LEAF_EVAL) return;
+    const int cells = E.cells;
+    const int8_t *board = E.leaf_board + (size_t)g * E.cellsP;
+    for (int k = 0; k < 8; k++)
+        for (int c = lane; c < cells; c += 64) img[((size_t)g * 8 + k) * cells + c] = (float)board[E.aug_map[k * cells + c]];
+}
+
+// ------------------------------------------------------------------------------------------
+// expand + update (one-level backup)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_winner(const int8_t *board, int N, int lane) {
+    // search_winner/mod.rs:201-246 on a full board: first cell (row-major) ending a run >= 6
+    const int cells = N * N;
+    int first = 1 << 20;
+    for (int c = lane; c < cells; c += 64) {
+        const int v = board[c];
+        if (v == 0) continue;
+        const int r = c / N, q = c % N;
+        const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, 0, 1, -1};
+        bool six = false;
+#pragma unroll
+        for (int dir = 0; dir < 4; dir++) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 1; k < 6; k++) {
+                const int rr = r - k * dr[dir], cc = q - k * dc[dir];
+                ok = ok && rr >= 0 && cc >= 0 && cc < N && board[rr * N + cc] == v;
+            }
+            six = six || ok;
+        }
+        if (six && c < first) first = c;
+    }
+    first = c6_wave_min_i32(first);
+    return first < cells ? (int)board[first] : 0;
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G) return;
+    const int kind = E.leaf_kind[g];
+    if (kind == C6_LEAF_NONE) return;
+    const int cells = E.cells;
+    const size_t rbase = (size_t)g * E.R;
+    const int len = E.path_len[g];
+    const int level = E.leaf_level[g];
+    const int turn = E.leaf_turn[g];
+    float value;
+
+    if (kind == C6_LEAF_TERMINAL) {   // mod.rs:338-348: value by winner, no visit increment, no children
+        const int w = wave_winner(E.leaf_board + (size_t)g * E.cellsP, E.N, lane);
+        const float cost = (float)turn;
+        value = w == turn ? cost : (w != 0 ? -cost : 0.f);
+    } else {
+        // allocate the record of the newly expanded node
+        int idx = -1;
+        if (lane == 0) {
+            const int top = E.free_top[g];
+            if (top > 0) { idx = E.free_stack[rbase + top - 1]; E.free_top[g] = top - 1; }
+        }
+        idx = __shfl(idx, 0, 64);
+        if (idx < 0) {
+            if (lane == 0) { E.status[g] = C6_ST_ERROR; atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull); }
+            return;
+        }
+        value = E.eval_value[g];
+        const float *prob = E.eval_prior + (size_t)g * cells;
+        float *prior = E.rec_prior + (rbase + idx) * (size_t)cells;
+        for (int c = lane; c < cells; c += 64) prior[c] = prob[c];      // child.n_prob = prob[r][c], mod.rs:370
+        const unsigned long long key = E.leaf_key[g];
+        const uint32_t q0 = E.leaf_sig[g * 4 + 0], q1 = E.leaf_sig[g * 4 + 1], q2 = E.leaf_sig[g * 4 + 2], q3 = E.leaf_sig[g * 4 + 3];
+        if (lane == 0) {
+            E.rec_key[rbase + idx] = key;
+            E.rec_visit[rbase + idx] = 1;          // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
+            E.rec_value[rbase + idx] = value;
+            E.rec_qsum[rbase + idx] = 0.f;
+            E.rec_q[rbase + idx] = 0.f;
+            E.rec_sig[(rbase + idx) * 4 + 0] = q0; E.rec_sig[(rbase + idx) * 4 + 1] = q1;
+            E.rec_sig[(rbase + idx) * 4 + 2] = q2; E.rec_sig[(rbase + idx) * 4 + 3] = q3;
+            if (!ht_insert(E.ht + (size_t)g * E.H, E.H, key, idx)) E.status[g] = C6_ST_ERROR;
+            if (len == 0) E.root_rec[g] = idx;
+            const unsigned long long used = (unsigned long long)(E.R - E.free_top[g]);
+            atomicMax(&E.counters[C6_CNT_MAXREC], used);
+        }
+        // last-writer rule for transposed children (entry().or_insert + n_prob overwrite, mod.rs:366-370):
+        // every expanded P on this level with P + i == Q + s sees its child i's prior become prob_Q[s]
+        const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
+        const uint32_t ms = turn == C6_BLACK ? q0 : q2, mq = turn == C6_BLACK ? q1 : q3;   // mover colour sums of Q
+        const uint32_t os = turn == C6_BLACK ? q2 : q0, oq = turn == C6_BLACK ? q3 : q1;
+        for (int r = lane; r < E.R; r += 64) {
+            if (r == idx || E.rec_level[rbase + r] != level) continue;
+            const uint32_t *sg = E.rec_sig + (rbase + r) * 4;
+            const uint32_t pms = turn == C6_BLACK ? sg[0] : sg[2], pmq = turn == C6_BLACK ? sg[1] : sg[3];
+            const uint32_t pos_ = turn == C6_BLACK ? sg[2] : sg[0], poq = turn == C6_BLACK ? sg[3] : sg[1];
+            if (pos_ != os || poq != oq) continue;
+            const long long D1 = (long long)pms - (long long)ms, D2 = (long long)pmq - (long long)mq;   // s1 - i1, s1^2 - i1^2
+            if (D1 == 0 || D2 % D1 != 0) continue;
+            const long long T = D2 / D1;          // s1 + i1
+            if (((T + D1) & 1) != 0) continue;
+            const long long s1 = (T + D1) / 2, i1 = (T - D1) / 2;
+            if (s1 < 1 || i1 < 1 || s1 > cells || i1 > cells) continue;
+            const int s = (int)s1 - 1, i = (int)i1 - 1;
+            if (E.rec_key[rbase + r] != (key ^ zk[i] ^ zk[s])) continue;
+            E.rec_prior[(rbase + r) * (size_t)cells + i] = prob[s];
+        }
+        if (lane == 0) E.rec_level[rbase + idx] = (int16_t)level;   // after the scan: Q never matches itself
+    }
+
+    // update, mod.rs:386-408 (one-level backup)
+    if (lane == 0) {
+        if (len > 0) {
+            const uint16_t *path = E.path_rec + (size_t)g * C6_MAXD;
+            const int par = path[len - 1];
+            E.rec_qsum[rbase + par] += value;
+            for (int i = len - 1; i >= 0; i--) {
+                const int r = path[i];
+                const int v = E.rec_visit[rbase + r] + 1;
+                E.rec_visit[rbase + r] = v;
+                E.rec_q[rbase + r] = E.rec_qsum[rbase + r] / (float)v;   // recalc_q :77-79
+            }
+        }
+        E.nsearch[g] += 1;
+        E.sim_in_move[g] += 1;
+        atomicAdd(&E.counters[C6_CNT_SIMS], 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// move: policy() (mod.rs:433-452) for games whose simulation budget is spent
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_move_select_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G) return;
+    if (E.status[g] != C6_ST_PLAYING || E.sim_in_move[g] < E.S) {
+        if (lane == 0) E.move_pos[g] = -2;
+        return;
+    }
+    const int cells = E.cells;
+    const int p = E.root_rec[g];
+    const int level = E.nstones[g];
+    const int turn = E.turn[g];
+    int pos = -1;
+    if (p >= 0 && level < cells) {
+        const C6HtEntry *ht = E.ht + (size_t)g * E.H;
+        const size_t rbase = (size_t)g * E.R;
+        const unsigned long long key = E.root_key[g];
+        const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
+        const int8_t *board = E.root_board + (size_t)g * E.cellsP;
+        int cv[C6_MAXJ];
+        int vs = 0;
+#pragma unroll
+        for (int j = 0; j < C6_MAXJ; j++) {
+            const int c = lane + 64 * j;
+            cv[j] = -1;
+            if (c < cells && board[c] == 0) {
+                const int idx = ht_find(ht, E.H, key ^ zk[c]);
+                cv[j] = idx >= 0 ? E.rec_visit[rbase + idx] : 0;
+                vs += cv[j];
+            }
+        }
+        const float visit_sum = (float)c6_wave_sum_i32(vs);
+        float best = -INFINITY;
+        float sc[C6_MAXJ];
+#pragma unroll
+        for (int j = 0; j < C6_MAXJ; j++) {
+            sc[j] = -INFINITY;
+            if (cv[j] >= 0) {
+                const float visit = (float)cv[j];
+                sc[j] = visit / (visit_sum - visit + 1.f);
+                best = sc[j] > best ? sc[j] : best;
+            }
+        }
+        best = c6_wave_max_f32(best);
+        int mine = -1;   // Iterator::max_by returns the LAST maximum
+#pragma unroll
+        for (int j = 0; j < C6_MAXJ; j++) if (cv[j] >= 0 && sc[j] == best) mine = lane + 64 * j;
+        pos = c6_wave_max_i32(mine);
+        // pi = root child visit counts (build-side extension)
+        uint16_t *pi = E.hist_pi + ((size_t)g * cells + level) * cells;
+#pragma unroll
+        for (int j = 0; j < C6_MAXJ; j++) {
+            const int c = lane + 64 * j;
+            if (c < cells) pi[c] = (uint16_t)(cv[j] > 0 ? (cv[j] > 65535 ? 65535 : cv[j]) : 0);
+        }
+    }
+    if (lane == 0) {
+        E.move_pos[g] = pos;
+        E.move_turn[g] = (int8_t)turn;
+    }
+}
+
+__device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane, uint32_t uid, int presims) {
+    const int cells = E.cells;
+    for (int c = lane; c < cells; c += 64) {
+        E.board_soa[(size_t)c * E.Gpad + g] = 0;
+        E.root_board[(size_t)g * E.cellsP + c] = 0;
+    }
+    const size_t rbase = (size_t)g * E.R;
+    for (int r = lane; r < E.R; r += 64) {
+        E.rec_level[rbase + r] = -1;
+        E.free_stack[rbase + r] = (uint16_t)(E.R - 1 - r);   // pop order 0,1,2,...
+    }
+    C6HtEntry *ht = E.ht + (size_t)g * E.H;
+    for (int i = lane; i < E.H; i += 64) { ht[i].key = 0ull; ht[i].idx1 = 0; }
+    if (lane == 0) {
+        E.turn[g] = C6_BLACK;       // Game::new, game_impl/mod.rs:125-131
+        E.remain[g] = 1;
+        E.winner[g] = 0;
+        E.err[g] = 0;
+        E.status[g] = C6_ST_PLAYING;
+        E.nstones[g] = 0;
+        E.game_uid[g] = uid;
+        E.nsearch[g] = 0;
+        E.sim_in_move[g] = presims;
+        E.root_key[g] = C6_EMPTY_BOARD_KEY;
+        E.root_sig[g * 4 + 0] = 0; E.root_sig[g * 4 + 1] = 0; E.root_sig[g * 4 + 2] = 0; E.root_sig[g * 4 + 3] = 0;
+        E.root_rec[g] = -1;
+        E.free_top[g] = E.R;
+        E.leaf_kind[g] = C6_LEAF_NONE;
+        E.move_pos[g] = -2;
+    }
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_reset_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G) return;
+    reset_game_wave(E, g, lane, E.uid_base + (uint32_t)g, 0);
+}
+
+// after K1 placed the stones: advance the root, prune (next(), mod.rs:473-487), finish / recycle games
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G) return;
+    const int pos = E.move_pos[g];
+    if (pos == -2) return;
+    const int cells = E.cells;
+    const size_t rbase = (size_t)g * E.R;
+    const int old_level = E.nstones[g];
+    const unsigned long long old_key = E.root_key[g];
+    unsigned long long new_key = old_key;
+    bool finished = false;
+    int win = 0;
+    int nst = old_level;
+
+    if (pos < 0) {
+        finished = true;                       // policy returned None -> draw, agent_impl/mod.rs:135-137
+    } else if (E.err[g] != 0) {
+        if (lane == 0) E.status[g] = C6_ST_ERROR;
+        return;
+    } else {
+        const int mover = E.move_turn[g];
+        nst = old_level + 1;
+        win = E.winner[g];
+        finished = win != 0;                   // agent_impl/mod.rs:167-171
+        new_key = old_key ^ E.zob[(mover == C6_WHITE ? C6_MAXCELLS : 0) + pos];
+        if (lane == 0) {
+            E.root_board[(size_t)g * E.cellsP + pos] = (int8_t)mover;
+            E.root_key[g] = new_key;
+            const uint32_t c1 = (uint32_t)pos + 1u;
+            const int o = mover == C6_BLACK ? 0 : 2;
+            E.root_sig[g * 4 + o] += c1;
+            E.root_sig[g * 4 + o + 1] += c1 * c1;
+            E.moves[(size_t)g * cells + old_level] = (uint16_t)pos;
+            E.nstones[g] = (int16_t)nst;
+            E.sim_in_move[g] = 0;
+            atomicAdd(&E.counters[C6_CNT_STONES], 1ull);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    if (!finished) {
+        // prune: nodes of the old root's level are dropped (mod.rs:473-484).  The re-inserted old root
+        // (:486) and older levels can never be reached again, so they are dropped too.
+        int top = E.free_top[g];
+        for (int r0 = 0; r0 < E.R; r0 += 64) {
+            const int r = r0 + lane;
+            bool kill = false;
+            if (r < E.R) {
+                const int lv = E.rec_level[rbase + r];
+                kill = lv >= 0 && lv <= old_level;
+            }
+            const unsigned long long m = __ballot(kill);
+            if (kill) {
+                const int off = __popcll(m & ((1ull << lane) - 1ull));
+                E.free_stack[rbase + top + off] = (uint16_t)r;
+                E.rec_level[rbase + r] = -1;
+            }
+            top += __popcll(m);
+        }
+        C6HtEntry *ht = E.ht + (size_t)g * E.H;
+        for (int i = lane; i < E.H; i += 64) { ht[i].key = 0ull; ht[i].idx1 = 0; }
+        __threadfence_block();
+        int rr = -1;   // record of the new root, if that child was expanded (tree reuse)
+        for (int r = lane; r < E.R; r += 64)
+            if (E.rec_level[rbase + r] >= 0) {
+                const unsigned long long k = E.rec_key[rbase + r];
+                ht_insert(ht, E.H, k, r);
+                if (k == new_key) rr = r;
+            }
+        rr = c6_wave_max_i32(rr);
+        if (lane == 0) {
+            E.free_top[g] = top;
+            E.root_rec[g] = rr;
+        }
+        return;
+    }
+
+    // game over: PlayResult (agent_impl/mod.rs:41-44) + training tuples (state, pi, turn, z)
+    const uint32_t uid = E.game_uid[g];
+    int slot = -1;
+    unsigned long long tbase = 0;
+    if (lane == 0) {
+        slot = (int)atomicAdd(&E.counters[C6_CNT_FETCHQ], 1ull);
+        atomicAdd(&E.counters[C6_CNT_FINISHED], 1ull);
+        if (E.tuple_buf) tbase = (unsigned long long)atomicAdd(E.tuple_count, (uint32_t)nst);
+    }
+    slot = __shfl(slot, 0, 64);
+    tbase = (unsigned long long)__shfl((long long)tbase, 0, 64);
+    if (slot < E.finq_cap) {
+        if (lane == 0) { E.fin_winner[slot] = win; E.fin_len[slot] = nst; E.fin_uid[slot] = uid; }
+        for (int k = lane; k < nst; k += 64)
+            E.fin_moves[(size_t)slot * cells + k] = (int16_t)((pos >= 0 && k == old_level) ? pos : E.moves[(size_t)g * cells + k]);
+    }
+    if (E.tuple_buf) {
+        // replay the game: record k holds the board BEFORE stone k (agent_impl/mod.rs:139-143)
+        int8_t st[C6_MAXJ];
+#pragma unroll
+        for (int j = 0; j < C6_MAXJ; j++) st[j] = 0;
+        int t = C6_BLACK, rem = 1;
+        for (int k = 0; k < nst; k++) {
+            const unsigned long long rec = tbase + (unsigned long long)k;
+            const int mv = (pos >= 0 && k == old_level) ? pos : (int)E.moves[(size_t)g * cells + k];
+            if (rec < E.tuple_cap) {
+                uint8_t *out = E.tuple_buf + rec * (unsigned long long)E.tuple_stride;
+                const uint16_t *pi = E.hist_pi + ((size_t)g * cells + k) * cells;
+#pragma unroll
+                for (int j = 0; j < C6_MAXJ; j++) {
+                    const int c = lane + 64 * j;
+                    if (c < cells) {
+                        out[c] = (uint8_t)st[j];
+                        reinterpret_cast<uint16_t *>(out + cells + (cells & 1))[c] = pi[c];
+                    }
+                }
+                if (lane == 0) {
+                    out[E.tuple_stride - 2] = (uint8_t)(int8_t)t;
+                    out[E.tuple_stride - 1] = (uint8_t)(int8_t)win;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < C6_MAXJ; j++) if ((mv >> 6) == j && (mv & 63) == lane) st[j] = (int8_t)t;
+            next_turn(t, rem);
+        }
+        if (lane == 0) atomicAdd(&E.counters[C6_CNT_TUPLES], (unsigned long long)nst);
+    }
+    if (E.recycle) {
+        reset_game_wave(E, g, lane, uid + E.uid_stride, 0);
+    } else if (lane == 0) {
+        E.status[g] = C6_ST_FINISHED;
+        E.winner[g] = (int8_t)win;
+    }
+}
+
+// stagger: pretend game g already spent (g mod S) simulations of its first move
+__global__ void c6_stagger_kernel(C6Dev E) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < E.G) E.sim_in_move[g] = g % E.S;
+}
+
+static inline int wave_grid(int G) { return (G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }
+
+void c6_launch_select(const C6Dev &d, hipStream_t s) {
+    hipLaunchKernelGGL(c6_select_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
+}
+void c6_launch_expand(const C6Dev &d, hipStream_t s) {
+    hipLaunchKernelGGL(c6_expand_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
+}
+void c6_launch_eval_builtin(const C6Dev &d, int kind, hipStream_t s) {
+    hipLaunchKernelGGL(c6_eval_builtin_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d, kind);
+}
+void c6_launch_recover(const C6Dev &d, hipStream_t s) {
+    hipLaunchKernelGGL(c6_recover_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
+}
+void c6_launch_augment(const C6Dev &d, float *img, hipStream_t s) {
+    hipLaunchKernelGGL(c6_augment_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d, img);
+}
+void c6_launch_move_select(const C6Dev &d, hipStream_t s) {
+    hipLaunchKernelGGL(c6_move_select_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
+}
+void c6_launch_post_move(const C6Dev &d, hipStream_t s) {
+    hipLaunchKernelGGL(c6_post_move_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
+}
+void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s) {
+    hipLaunchKernelGGL(c6_reset_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
+    if (stagger) hipLaunchKernelGGL(c6_stagger_kernel, dim3((d.G + 255) / 256), dim3(256), 0, s, d);
+}
+
+// ---- stand-alone operators for the parity tests ---------------------------------------------
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_noise_op_kernel(int N, int num, double alpha, double gd, double gc,
+                                                                           const uint32_t *k0, const uint32_t *k1,
+                                                                           const uint32_t *search, const uint32_t *depth,
+                                                                           const int8_t *boards, float *noise) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= num) return;
+    const int cells = N * N;
+    const int8_t *board = boards + (size_t)b * cells;
+    double gam[C6_MAXJ], part = 0.0;
+#pragma unroll
+    for (int j = 0; j < C6_MAXJ; j++) {
+        const int c = lane + 64 * j;
+        gam[j] = 0.0;
+        if (c < cells && board[c] == 0) {
+            gam[j] = c6_gamma_draw(alpha, gd, gc, k0[b], k1[b], (uint32_t)c, search[b], depth[b]);
+            part = part + gam[j];
+        }
+    }
+    const double gsum = c6_butterfly_sum(part);
+#pragma unroll
+    for (int j = 0; j < C6_MAXJ; j++) {
+        const int c = lane + 64 * j;
+        if (c < cells) noise[(size_t)b * cells + c] = board[c] == 0 ? (float)(gam[j] / gsum) : 0.f;
+    }
+}
+
+void c6_launch_noise_op(int N, int num, double alpha, double gd, double gc, const uint32_t *k0, const uint32_t *k1,
+                        const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise, hipStream_t s) {
+    hipLaunchKernelGGL(c6_noise_op_kernel, dim3(wave_grid(num)), dim3(64 * WAVES_PER_BLOCK), 0, s, N, num, alpha, gd, gc, k0, k1,
+                       search, depth, boards, noise);
+}
+
+__global__ void c6_augment_op_kernel(int cells, int num, const int8_t *boards, const int16_t *aug_map, int8_t *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)num * 8 * cells;
+    if (i >= total) return;
+    const int c = (int)(i % cells), k = (int)((i / cells) % 8);
+    const size_t b = i / ((size_t)8 * cells);
+    out[i] = boards[b * cells + aug_map[k * cells + c]];
+}
+
+void c6_launch_augment_op(int N, int num, const int8_t *boards, const int16_t *aug_map, int8_t *out, hipStream_t s) {
+    const size_t total = (size_t)num * 8 * N * N;
+    hipLaunchKernelGGL(c6_augment_op_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, N * N, num, boards, aug_map, out);
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_recover_op_kernel(int N, int num, const int8_t *boards, const float *values8,
+                                                                             const float *policies8, const int16_t *rec_map,
+                                                                             float *value, float *prior) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= num) return;
+    const int cells = N * N;
+    const float *pol = policies8 + (size_t)b * 8 * cells;
+    const float *val = values8 + (size_t)b * 8;
+    auto pf = [&](int k, int cell) -> float { return pol[k * cells + cell]; };
+    auto vf = [&](int k) -> float { return val[k]; };
+    recover_wave(cells, lane, rec_map, boards + (size_t)b * cells, pf, vf, &value[b], prior + (size_t)b * cells);
+}
+
+void c6_launch_recover_op(int N, int num, const int8_t *boards, const float *values8, const float *policies8,
+                          const int16_t *rec_map, float *value, float *prior, hipStream_t s) {
+    hipLaunchKernelGGL(c6_recover_op_kernel, dim3(wave_grid(num)), dim3(64 * WAVES_PER_BLOCK), 0, s, N, num, boards, values8,
+                       policies8, rec_map, value, prior);
+}

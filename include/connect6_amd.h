@@ -1,0 +1,255 @@
+/*
+ * connect6_amd.h -- C ABI of libconnect6_amd.so, the MI355X-native self-play engine.
+ *
+ * Part 1 is the DROP-IN boundary: exactly the symbols, struct layouts and callback
+ * conventions of the reference's C++ binding (staticlib `cppconnect6`), so that the
+ * reference's single-header wrapper Connect6/cppbind/headers/connect6.hpp links
+ * against this library unchanged.  Each declaration cites the reference interface it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Part 2 is the extended engine API (prefix c6_): run-time board size, thousands of
+ * concurrent games resident in HBM, seeded C6RNG stream, resident policy/value net,
+ * per-move pi / value outputs, steady-state stepping for benchmarks.  Plain pointers
+ * and sizes only; no torch types.
+ *
+ * The library needs a gfx950 GPU for every compute entry point and fails loudly
+ * (non-zero status + message from c6_last_error()) when none is present; there is
+ * no CPU fallback.
+ */
+#ifndef CONNECT6_AMD_H
+#define CONNECT6_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================== */
+/* Part 1 -- drop-in boundary (N = 15, the reference's compiled BOARD_SIZE,  */
+/*           Connect6/libconnect6/src/lib.rs:21, connect6.hpp:11)            */
+/* ======================================================================== */
+
+#define C6_REF_BOARD_SIZE 15
+#define C6_REF_BOARD_CAPACITY (C6_REF_BOARD_SIZE * C6_REF_BOARD_SIZE)
+
+/* cppbind/libcppconnect6/src/cppbind/cppeval/mod.rs:8-13, connect6.hpp:14.
+ * On entry `policies` holds `len` boards as row-major f32 in {-1,0,+1} and `values`
+ * is zero; the callee overwrites policies[len][N*N] and values[len].  The reference
+ * always passes len == 8; this engine passes len == 8 * (games whose leaf has side
+ * `player` to move), which a conforming callback (it loops over len) accepts. */
+typedef void (*c6_callback)(int player, float *values, float *policies, int len);
+
+/* cppbind/.../cpp_policy/mod.rs:8, connect6.hpp:15: board N*N f32, position preset to {-1,-1} */
+typedef void (*c6_policy_callback)(float *board, int *position);
+
+/* cppbind/.../rawobj/mod.rs:29-36 (RawPath), connect6.hpp:26-31.  sizeof == 912 */
+typedef struct c6_path {
+    int turn;
+    int board[C6_REF_BOARD_SIZE][C6_REF_BOARD_SIZE];
+    int row;
+    int col;
+} c6_path;
+
+/* cppbind/.../rawobj/mod.rs:38-43 (RawPlayResult), connect6.hpp:33-37.  sizeof == 24 */
+typedef struct c6_play_result {
+    int winner;
+    c6_path *paths;
+    int len;
+} c6_play_result;
+
+/* cppbind/.../rawobj/mod.rs:45-50 (RawVec<RawPlayResult>), connect6.hpp:39-42.  sizeof == 16 */
+typedef struct c6_vec {
+    c6_play_result *vec;
+    int len;
+} c6_vec;
+
+/* cppbind/.../rawobj/mod.rs:8 (AllocatorType<T>), connect6.hpp:17-23: caller-supplied `new T[n]` */
+typedef c6_path *(*c6_alloc_path)(int size);
+typedef c6_play_result *(*c6_alloc_result)(int size);
+typedef int *(*c6_alloc_int)(int size);
+typedef float *(*c6_alloc_float)(int size);
+
+/* cppbind/libcppconnect6/src/lib.rs:20-58, connect6.hpp:44-48.
+ * `num_game_thread` games driven by `callback`; stones are placed and winners found by the
+ * HIP board kernel. */
+c6_vec cpp_play(c6_policy_callback callback, c6_alloc_path alloc_path, c6_alloc_result alloc_result,
+                bool debug, int num_game_thread);
+
+/* cppbind/libcppconnect6/src/lib.rs:75-126, connect6.hpp:50-58.
+ * `num_game_thread` concurrent AlphaZero self-play games on the GPU; leaves are evaluated by
+ * `callback`, batched across games per side to move. */
+c6_vec cpp_self_play(c6_callback callback, c6_alloc_path alloc_path, c6_alloc_result alloc_result,
+                     int num_simulation, float epsilon, double dirichlet_alpha, float c_puct, bool debug,
+                     int num_game_thread);
+
+/* cppbind/libcppconnect6/src/lib.rs:140-169, connect6.hpp:60-65: human-vs-net play on stdin.
+ * Out of scope: exported so that connect6.hpp links; prints a message and returns
+ * an empty result. */
+c6_play_result cpp_play_with(c6_callback callback, c6_alloc_path alloc_path, int num_simulation, float epsilon,
+                             double dirichlet_alpha, float c_puct);
+
+/* FFI echo hooks, cppbind/.../ffi_test/mod.rs:13-224, connect6.hpp:68-93 (host only, no GPU) */
+typedef struct c6_vec_int { int *vec; int len; } c6_vec_int;
+typedef struct c6_vec_float { float *vec; int len; } c6_vec_float;
+c6_path test_new_raw_path(void);                                                  /* ffi_test/mod.rs:13 */
+c6_path test_with_raw_path(void);                                                 /* :19 */
+c6_path test_echo_raw_path(int turn, int *board, int row, int col);               /* :38 */
+c6_play_result test_with_raw_play_result(c6_alloc_path allocator);                /* :61 */
+c6_play_result test_echo_raw_play_result(int winner, c6_path *path, int len, c6_alloc_path allocator); /* :90 */
+c6_vec_int test_with_raw_vec(c6_alloc_int allocator);                             /* :125 */
+c6_vec_int test_echo_raw_vec(int *ptr, int len, c6_alloc_int allocator);          /* :133 */
+c6_vec_float test_echo_cppeval(int turn, int *boards, int len, c6_callback callback, c6_alloc_float allocator); /* :149 */
+c6_vec_int test_cpp_policy(float *board, c6_policy_callback callback, c6_alloc_int allocator);                /* :201 */
+
+/* ======================================================================== */
+/* Part 2 -- extended engine API                                             */
+/* ======================================================================== */
+
+enum {
+    C6_OK = 0,
+    C6_ERR_NO_GPU = 1,        /* no gfx950 device / HIP runtime error */
+    C6_ERR_BAD_ARG = 2,
+    C6_ERR_OVERFLOW = 3,      /* a per-game record pool or path buffer overflowed */
+    C6_ERR_HIP = 4,
+    C6_ERR_INVALID_POSITION = 5, /* game/game_impl/mod.rs:151-153 "invalid position" */
+    C6_ERR_ALREADY_SET = 6       /* game/game_impl/mod.rs:155-157 "already set position" */
+};
+
+/* evaluator kinds (policy/alphazero_policy/mod.rs:128-134 `Evaluator`) */
+enum {
+    C6_EVAL_RANDOM = 1,   /* RandomEvaluator (mod.rs:137-169) on the seeded C6RNG stream, on device */
+    C6_EVAL_UNIFORM = 2,  /* value 0, policy 1/N^2 on device ("zero-cost evaluator", BASELINE config 5) */
+    C6_EVAL_NET = 3,      /* resident policy/value ResNet (AlphaZero/cpp_weighted/model.hpp:9-95) */
+    C6_EVAL_CALLBACK = 4  /* host callback with the reference's signature */
+};
+
+/* policy/alphazero_policy/mod.rs:91-96 HyperParameter + engine geometry */
+typedef struct c6_config {
+    int board_size;          /* 9, 15 or 19 */
+    int num_games;           /* concurrent games on this device */
+    int num_simulation;      /* HyperParameter.num_simulation */
+    float epsilon;           /* HyperParameter.epsilon */
+    double dirichlet_alpha;  /* HyperParameter.dirichlet_alpha */
+    float c_puct;            /* HyperParameter.c_puct */
+    uint64_t seed;           /* C6RNG seed */
+    uint32_t game_uid_base;  /* game slot i starts with uid = base + i (C6RNG key) */
+    uint32_t game_uid_stride;/* a recycled slot continues with uid += stride (0: num_games) */
+    int evaluator;           /* C6_EVAL_* */
+    int net_channels;        /* C (reference: 256) */
+    int net_blocks;          /* reference `num_block`: stem + (num_block-1) residual blocks */
+    int records_per_game;    /* 0: 4 * num_simulation + 64 */
+    int recycle;             /* 1: a finished game slot restarts at once (steady-state mode) */
+    int stagger;             /* 1: game i starts its first move with (i mod num_simulation) simulations
+                                already counted, so every round advances num_games/num_simulation games */
+    int device;              /* HIP device ordinal */
+    int net_chunk_boards;    /* 0: automatic; boards (dihedral images) per net pass */
+} c6_config;
+
+typedef struct c6_engine c6_engine;
+
+const char *c6_last_error(void);
+const char *c6_version(void);
+int c6_device_count(void);
+
+void c6_default_config(c6_config *cfg); /* HyperParameter::default (mod.rs:98-108), N = 15 */
+int c6_engine_create(const c6_config *cfg, c6_engine **out);
+void c6_engine_destroy(c6_engine *e);
+
+/* weight blob: flat f32 in PyTorch state order, see DESIGN.md "weight blob"; host pointer */
+size_t c6_net_blob_floats(int board_size, int channels, int blocks);
+int c6_engine_load_weights(c6_engine *e, const float *blob, size_t nfloats);
+int c6_engine_set_callback(c6_engine *e, c6_callback cb);
+
+/* Run `rounds` simulation rounds: every live game does one search() (mod.rs:411-426) per round;
+ * a game whose simulation count reaches num_simulation makes its move (mod.rs:464-489 +
+ * agent/agent_impl/mod.rs:131-171).  Asynchronous on the engine's stream unless noted. */
+int c6_engine_step(c6_engine *e, int rounds);
+/* step until every game has finished (recycle == 0) or max_rounds; synchronous */
+int c6_engine_run(c6_engine *e, long max_rounds);
+int c6_engine_sync(c6_engine *e);
+
+typedef struct c6_stats {
+    uint64_t rounds;          /* rounds stepped */
+    uint64_t simulations;     /* searches performed (all games) */
+    uint64_t select_steps;    /* PUCT evaluations (sum of select depths) */
+    uint64_t stones;          /* stones placed */
+    uint64_t games_finished;
+    uint64_t tuples;          /* training tuples emitted */
+    uint32_t live_games;
+    uint32_t overflow_games;
+    uint32_t max_records_used;
+    uint32_t max_depth;
+} c6_stats;
+int c6_engine_stats(c6_engine *e, c6_stats *out); /* synchronises */
+
+/* finished games (winner, moves): agent::PlayResult, agent/agent_impl/mod.rs:41-44.
+ * Copies up to `cap` finished, not yet fetched games: winners[i], lens[i], uids[i],
+ * moves[i*N*N + k] = cell of stone k.  Returns the number copied in *count. */
+int c6_engine_fetch_games(c6_engine *e, int cap, int *count, int *winners, int *lens, uint32_t *uids,
+                          int16_t *moves);
+
+/* training tuples (state, pi, turn, z): device buffer of fixed-size records
+ * [state int8 N*N | pi u16 N*N (root child visit counts, mod.rs:433-452) | turn int8 | z int8],
+ * padded to a multiple of 4 bytes.  The caller may supply the buffer (e.g. torch-owned memory
+ * handed to RCCL all-gather); count_dev is a device uint32. */
+size_t c6_tuple_stride(int board_size);
+int c6_engine_set_tuple_buffer(c6_engine *e, void *dev_buf, size_t capacity_records, uint32_t *count_dev);
+int c6_engine_enable_tuples(c6_engine *e, size_t capacity_records); /* engine-owned tuple buffer */
+int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, void *host_buf); /* copies + resets */
+
+/* inspection for parity tests: the root of game `g`, synchronises.
+ * visits[c] = child visit (-1 where the cell is occupied), q[c] = child q_value, prior[c] = child n_prob */
+typedef struct c6_root_info {
+    int turn, remain, stones, status, winner;
+    int root_visit;
+    float root_value, root_q_sum, root_q_value;
+    uint32_t nsearch;
+    int records_used;
+} c6_root_info;
+int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *board, int32_t *visits, float *q, float *prior);
+
+/* timing of the dominant kernel (3x3 conv) for the roofline: enables HIP-event timing on the
+ * engine's stream; totals since the last reset. */
+int c6_engine_profile(c6_engine *e, int enable);
+typedef struct c6_profile {
+    double conv_ms;        /* summed duration of conv3x3 launches */
+    uint64_t conv_launches;
+    double conv_flops;     /* algorithmic flops of those launches */
+    double select_ms, expand_ms, eval_other_ms, move_ms;
+    uint64_t select_launches, expand_launches;
+} c6_profile;
+int c6_engine_profile_read(c6_engine *e, c6_profile *out, int reset);
+
+/* ---- stand-alone batched operators (host buffers in/out; used by parity tests) ---- */
+
+/* K1 board kernel: boards SoA int8 [N*N][G] (cell-major, game minor), turn/remain int8 [G],
+ * pos int32 [G] = row*N+col, or <0 for "no move" ("row >= N" etc. must be passed as pos >= N*N).
+ * Game::set + is_game_end (game_impl/mod.rs:148-169,249-252).  Outputs winner int8 [G] and
+ * err int8 [G] (C6_OK / C6_ERR_INVALID_POSITION / C6_ERR_ALREADY_SET). */
+int c6_board_step(int board_size, int num_games, int8_t *boards_soa, int8_t *turn, int8_t *remain,
+                  const int32_t *pos, int8_t *winner, int8_t *err);
+/* search (search_winner/mod.rs:201-246) on `num` boards, SoA layout as above */
+int c6_search_winner(int board_size, int num, const int8_t *boards_soa, int8_t *winner);
+/* legal-move bitmask: mask[(c>>3)*G + g] bit (c&7) set iff cell c of game g is empty */
+int c6_legal_mask(int board_size, int num, const int8_t *boards_soa, uint8_t *mask);
+/* augment_way8 (augment.rs:60-73): boards int8 [num][N*N] -> out [num][8][N*N] */
+int c6_augment8(int board_size, int num, const int8_t *boards, int8_t *out);
+/* get_from tail (mod.rs:222-233): value = sum(values)/8, recover_way8, mask occupied */
+int c6_recover8(int board_size, int num, const int8_t *boards, const float *values8, const float *policies8,
+                float *value, float *prior);
+/* net forward (model.hpp:52-95) on `num` boards (int8, no augmentation) with per-board player */
+int c6_net_forward(int board_size, int channels, int blocks, const float *blob, size_t nfloats, int num,
+                   const int8_t *boards, const int8_t *player, float *policy, float *value);
+/* C6RNG Dirichlet noise of select step (search, depth) for `num` boards (keys k0/k1 per board) */
+int c6_dirichlet_noise(int board_size, int num, double alpha, const uint32_t *k0, const uint32_t *k1,
+                       const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+"""K4 resident net (FP32 MFMA conv + heads) against the oracle's FP32 net and the committed PyTorch
+golden vectors: |diff| <= 1e-5 on policy probabilities and value (BASELINE north_star tolerance)."""
+import os
+
+import numpy as np
+import pytest
+
+import c6oracle as o
+from gpu_common import need_gpu, pkg
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rand_blob(n, C, blocks, seed):
+    import __graft_entry__ as ge
+    return ge.make_random_blob(n, C, blocks, np.random.default_rng(seed))
+
+
+@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 64, 3, 5), (19, 128, 2, 4), (19, 256, 2, 3), (9, 256, 4, 8)])
+def test_net_forward_vs_oracle(n, C, blocks, num):
+    need_gpu()
+    rng = np.random.default_rng(n * 1000 + C)
+    blob = rand_blob(n, C, blocks, seed=n + C + blocks)
+    boards = rng.integers(-1, 2, size=(num, n * n)).astype(np.int8)
+    boards[0] = 0
+    player = rng.choice(np.array([-1, 1], np.int8), size=num)
+    pol, val = pkg.net_forward(n, C, blocks, blob, boards, player)
+    net = o.Net(n, C, blocks, blob)
+    for i in range(num):
+        rp, rv = net.forward(float(player[i]), boards[i].astype(np.float32))
+        assert np.abs(pol[i] - rp[0]).max() <= TOL, (i, np.abs(pol[i] - rp[0]).max())
+        assert abs(val[i] - rv[0]) <= TOL
+    assert np.allclose(pol.sum(axis=1), 1.0, atol=1e-5)
+    net.close()
+
+
+def test_net_forward_vs_torch_golden():
+    need_gpu()
+    z = np.load(os.path.join(GOLD, "net_golden_n9_c64_b3.npz"))
+    pol, val = pkg.net_forward(int(z["n"]), int(z["C"]), int(z["blocks"]), z["blob"], z["boards"], z["player"])
+    assert np.abs(pol - z["policy"]).max() <= TOL and np.abs(val - z["value"]).max() <= TOL
+
+
+def test_engine_net_evaluator_matches_oracle_priors():
+    """the evaluator path inside the engine (dihedral gather -> net -> recover -> mask) equals get_from
+    (mod.rs:218-234) computed by the oracle with its own FP32 net, to 1e-5"""
+    need_gpu()
+    n, C, blocks = 9, 64, 2
+    blob = rand_blob(n, C, blocks, seed=4)
+    eng = pkg.Engine(board_size=n, num_games=5, num_simulation=50, seed=1, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks)
+    eng.load_weights(blob)
+    eng.step(1)
+    net = o.Net(n, C, blocks, blob)
+    fn, ctx = net.eval_fn()
+    az = o.AlphaZero(n, eval_kind=o.EVAL_CUSTOM, eval_fn=fn, ctx=ctx, seed=1, game_uid=0)
+    s = o.sim_from_game(o.new_game(n))
+    az.init(s)
+    az.search(s)
+    want = az.node_prob(np.zeros((n, n), np.int8)).reshape(-1)
+    for g in range(5):
+        r = eng.root(g)
+        assert np.abs(r["prior"] - want).max() <= TOL
+        assert abs(r["root_value"] - az.node_info(np.zeros((n, n), np.int8)).value) <= TOL
+    eng.step(30)
+    st = eng.stats()
+    assert st["simulations"] == 31 * 5 and st["overflow_games"] == 0
+    eng.close()
+    net.close()
