@@ -88,10 +88,11 @@ class VecFloat(C.Structure):
 
 CALLBACK = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int)
 POLICY_CALLBACK = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.POINTER(C.c_int))
-ALLOC_PATH = C.CFUNCTYPE(C.POINTER(Path), C.c_int)
-ALLOC_RESULT = C.CFUNCTYPE(C.POINTER(PlayResult), C.c_int)
-ALLOC_INT = C.CFUNCTYPE(C.POINTER(C.c_int), C.c_int)
-ALLOC_FLOAT = C.CFUNCTYPE(C.POINTER(C.c_float), C.c_int)
+# ctypes callbacks cannot return POINTER(T): the allocators return the address as void*
+ALLOC_PATH = C.CFUNCTYPE(C.c_void_p, C.c_int)
+ALLOC_RESULT = C.CFUNCTYPE(C.c_void_p, C.c_int)
+ALLOC_INT = C.CFUNCTYPE(C.c_void_p, C.c_int)
+ALLOC_FLOAT = C.CFUNCTYPE(C.c_void_p, C.c_int)
 
 _lib = None
 
