@@ -1,0 +1,227 @@
+"""bench.py -- self-play games/sec of the MI355X engine (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload at every N (weak scaling: per-GPU work fixed): BASELINE.json configs[1] --
+4096 concurrent 19x19 games per GPU, 400 simulations/move, random-init policy/value net with
+"4 blocks" = stem + 3 residual blocks, C = 256, FP32 (parity tolerance 1e-5 forces FP32 MFMA).
+
+A "step" is one simulation ROUND: every live game performs one search() (select -> 8 dihedral
+net evaluations -> expand -> one-level backup); game phases are staggered, so each round
+G/400 games also make their move (policy -> board kernel -> prune / recycle), i.e. every step
+carries the steady-state share of all the work.  games/sec = rounds/sec * G / (400 * stones_per_game);
+stones_per_game cannot be measured inside a benchmark of minutes (one 19x19 game is ~83 000 rounds), the
+figure used is stated in config.stones_per_game (uniform-random 19x19 play, mean 208).
+Inputs (game state, trees, weights) are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (board, games/GPU, sims, net blocks (reference num_block), channels, evaluator, stones/game prior)
+    "config2": dict(n=19, games=4096, sims=400, blocks=4, channels=256, evaluator="net", stones=208.0),
+    "config3": dict(n=19, games=16384, sims=800, blocks=8, channels=256, evaluator="net", stones=208.0),
+    "config4": dict(n=19, games=8192, sims=400, blocks=4, channels=256, evaluator="net", stones=208.0),
+    "config5": dict(n=9, games=32768, sims=100, blocks=0, channels=0, evaluator="uniform", stones=68.0),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0
+
+
+def net_flops_per_board(n, C, blocks):
+    """F_net(N, k) = 2*9*2*C*N^2 + (k-1)*2*(2*9*C^2*N^2) + heads"""
+    n2 = n * n
+    heads = 2 * C * 2 * n2 + 2 * (2 * n2) * n2 + 2 * C * n2 + 2 * n2 * 256 + 2 * 256
+    return 2 * 9 * 2 * C * n2 + (blocks - 1) * 2 * (2 * 9 * C * C * n2) + heads
+
+
+def cpu_baseline(wl, seconds_budget=20.0):
+    """The CPU oracle (a port of the reference algorithm: the Rust path cannot be built, no rustc) on the
+    host cores, bounded sample: every core runs searches of the first move of one game of the same workload."""
+    import threading
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as ge
+    import c6oracle as o
+
+    cores = os.cpu_count() or 1
+    n = wl["n"]
+    net = None
+    if wl["evaluator"] == "net":
+        blob = ge.make_random_blob(n, wl["channels"], wl["blocks"], np.random.default_rng(0))
+        net = o.Net(n, wl["channels"], wl["blocks"], blob)
+        fn, ctx = net.eval_fn()
+        kind = o.EVAL_CUSTOM
+    else:
+        fn, ctx, kind = None, None, o.EVAL_UNIFORM
+    done = [0] * cores
+    stop = time.time() + seconds_budget
+
+    def work(i):
+        az = o.AlphaZero(n, num_simulation=wl["sims"], eval_kind=kind, eval_fn=fn, ctx=ctx, seed=0, game_uid=i)
+        s = o.sim_from_game(o.new_game(n))
+        az.init(s)
+        while time.time() < stop:
+            az.search(s)
+            done[i] += 1
+        az.close()
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    sims = sum(done)
+    if net:
+        net.close()
+    sims_s = sims / dt
+    return {"value": sims_s / (wl["sims"] * wl["stones"]), "unit": "games/s", "cores": cores, "kind": "port",
+            "sims_per_s": sims_s,
+            "sample": f"{sims} searches of the opening move ({cores} games, one per core, {dt:.1f} s) with the oracle's FP32 net; "
+                      f"games/s = searches/s / ({wl['sims']} * {wl['stones']:.0f})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--games", type=int, default=0, help="override games per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    if args.games:
+        wl["games"] = args.games
+
+    import torch
+    import torch.distributed as dist
+
+    from c6amd_loader import load_package
+    pkg = load_package()
+    from alphazero_connect6_amd import shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libconnect6_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n, G, S = wl["n"], wl["games"], wl["sims"]
+    uid_base, uid_stride = shard.uid_plan(G, world, rank)
+    ev = {"net": pkg.EVAL_NET, "uniform": pkg.EVAL_UNIFORM, "random": pkg.EVAL_RANDOM}[wl["evaluator"]]
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=2024, evaluator=ev, net_channels=max(wl["channels"], 64),
+                     net_blocks=max(wl["blocks"], 1), recycle=True, stagger=True, device=local_rank, game_uid_base=uid_base,
+                     game_uid_stride=uid_stride)
+    if ev == pkg.EVAL_NET:
+        import __graft_entry__ as ge
+        eng.load_weights(ge.make_random_blob(n, wl["channels"], wl["blocks"], np.random.default_rng(0)))
+    # training tuples go to a torch-owned device buffer that the all-gather reads in place
+    stride = pkg.lib().c6_tuple_stride(n)
+    cap = 4096
+    tbuf = torch.zeros((cap, stride), dtype=torch.uint8, device="cuda")
+    tcount = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.set_tuple_buffer(tbuf.data_ptr(), cap, tcount.data_ptr())
+    pooled_tuples = 0
+
+    def run_rounds(k):
+        nonlocal pooled_tuples
+        if world == 1:
+            eng.step(k)
+            eng.sync()
+            return
+        for _ in range(k):
+            eng.step(1)
+            eng.sync()
+            pooled, counts = shard.gather_tuples(tbuf, tcount, world)     # RCCL all-gather over xGMI
+            pooled_tuples += int(counts.clamp(max=cap).sum().item())
+            tcount.zero_()
+            torch.cuda.current_stream().synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_rounds(args.warmup)
+    eng.profile(True)
+    eng.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    run_rounds(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read(reset=True)
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.stats()
+
+    if rank == 0:
+        rounds_s = args.steps / dt
+        sims_s = rounds_s * G * world
+        games_s = sims_s / (S * wl["stones"])
+        out = {
+            "metric": "self-play games/sec at 400 sims/move, 19x19, 1/2/4/8 MI355X" if args.workload in ("config2", "config4")
+                      else f"self-play games/sec ({args.workload})",
+            "value": games_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (random-init weights, self-generated positions)",
+            "config": {"workload": f"{args.workload}: {G} concurrent {n}x{n} games per GPU, {S} sims/move, "
+                                   + (f"stem + {wl['blocks'] - 1} residual blocks, C={wl['channels']}, FP32" if ev == pkg.EVAL_NET else "on-device uniform evaluator"),
+                       "games_per_gpu": G, "board": n, "num_simulation": S, "net_blocks": wl["blocks"], "net_channels": wl["channels"],
+                       "stones_per_game": wl["stones"], "step": "one simulation round over all games (8 dihedral net evaluations per game), staggered move phases",
+                       "parallelism": f"games sharded over {world} GPU(s), RCCL all-gather of training tuples per round" if world > 1 else "1 GPU"},
+            "sims_per_s": sims_s, "boards_per_s": sims_s * 8,
+            "engine": {"select_steps_per_sim": st["select_steps"] / max(st["simulations"], 1), "max_records_used": st["max_records_used"],
+                       "overflow_games": st["overflow_games"], "stones": st["stones"], "tuples_pooled": pooled_tuples},
+        }
+        if ev == pkg.EVAL_NET and prof["conv_launches"]:
+            ach = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "c6_conv3x3_kernel<256,3> (FP32 MFMA implicit GEMM)", "achieved": ach,
+                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
+                               "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
+            fl = net_flops_per_board(n, wl["channels"], wl["blocks"]) * 8 * sims_s
+            out["net_tflops_end_to_end"] = fl / 1e12
+        else:
+            # tree-bound workload: algorithmic bytes per simulation, SURVEY 8d: (12*d + 13) * N^2
+            d = st["select_steps"] / max(st["simulations"], 1)
+            tree_ms = prof["select_ms"] + prof["expand_ms"]
+            bytes_sim = (12.0 * d + 13.0) * n * n
+            ach = bytes_sim * G * args.steps / max(tree_ms * 1e-3, 1e-9) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "c6_select_kernel + c6_expand_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_sim": bytes_sim}
+        out["phase_ms"] = {k: prof[k] for k in ("conv_ms", "select_ms", "expand_ms", "eval_other_ms", "move_ms")}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

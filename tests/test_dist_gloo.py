@@ -1,0 +1,104 @@
+"""N > 1 path on CPU: world_size 2, gloo.  The engine itself needs a GPU; what is distributed is the sharding
+plan and the tuple all-gather (alphazero-connect6_amd/shard.py), exercised here with oracle-made tuples."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _encode(n, games):
+    """oracle self-play results -> tuple records in the engine's layout (c6_tuple_stride)"""
+    cells = n * n
+    off = cells + (cells & 1)
+    stride = (off + 2 * cells + 2 + 3) & ~3
+    recs = []
+    for g in games:
+        for k, (turn, board, pos) in enumerate(g["path"]):
+            r = np.zeros(stride, np.uint8)
+            r[:cells] = board.reshape(-1).astype(np.int8).view(np.uint8)
+            r[off:off + 2 * cells] = g["pi"][k].astype(np.uint16).view(np.uint8)
+            r[-2] = np.int8(turn).view(np.uint8)
+            r[-1] = np.int8(g["winner"]).view(np.uint8)
+            recs.append(r)
+    return np.stack(recs), stride
+
+
+def _worker(rank, world, port, n, total_games, S, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from c6amd_loader import load_package
+    import c6oracle as o
+    pkg = load_package()
+    shard = __import__("importlib").import_module("alphazero_connect6_amd.shard")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine, first = shard.shard_games(total_games, world, rank)
+    base, stride_uid = shard.uid_plan(mine, world, rank)
+    assert base == first
+    games = o.self_play(n, num=mine, threads=1, num_simulation=S, seed=seed, uid_base=base, want_pi=True)
+    recs, stride = _encode(n, games)
+    cap = 4 * n * n
+    buf = torch.zeros((cap, stride), dtype=torch.uint8)
+    buf[: recs.shape[0]] = torch.from_numpy(recs)
+    count = torch.tensor([recs.shape[0]], dtype=torch.int32)
+    pooled, counts = shard.gather_tuples(buf, count, world)
+    allrec = shard.compact(pooled, counts)
+    dec = pkg.decode_tuples(allrec, n)
+    q.put((rank, int(counts.sum()), allrec.tobytes(), dec["z"].tolist(), base, stride_uid))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_pools_all_tuples():
+    import c6oracle as o
+    n, total, S, seed, world = 9, 4, 6, 13, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, total, S, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort()
+    # every rank holds the same pooled set, equal to the single-process run of all games in uid order
+    ref = o.self_play(n, num=total, threads=1, num_simulation=S, seed=seed, want_pi=True)
+    want, _ = _encode(n, ref)
+    assert out[0][2] == out[1][2] == want.tobytes()
+    assert out[0][1] == want.shape[0]
+    assert [o_[4] for o_ in out] == [0, 2] and out[0][5] == 4
+
+
+def test_shard_plan_is_a_partition():
+    from c6amd_loader import load_package
+    load_package()
+    from alphazero_connect6_amd import shard
+    for total, world in ((65536, 8), (10, 4), (7, 8)):
+        spans = [shard.shard_games(total, world, r) for r in range(world)]
+        assert sum(m for m, _ in spans) == total
+        pos = 0
+        for m, first in spans:
+            assert first == pos
+            pos += m
+    uids = set()
+    for r in range(8):
+        base, stride = shard.uid_plan(8192, 8, r)
+        assert stride == 65536
+        uids |= set(range(base, base + 8192))
+    assert uids == set(range(65536))
