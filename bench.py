@@ -45,6 +45,23 @@ def net_flops_per_board(n, C, blocks):
     return 2 * 9 * 2 * C * n2 + (blocks - 1) * 2 * (2 * 9 * C * C * n2) + heads
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc
+    passes of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d["kernels"].items():
+            if kernel_substr in k:
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(wl, seconds_budget=20.0):
     """The CPU oracle (a port of the reference algorithm: the Rust path cannot be built, no rustc) on the
     host cores, bounded sample: every core runs searches of the first move of one game of the same workload."""
@@ -200,7 +217,8 @@ def main():
         if ev == pkg.EVAL_NET and prof["conv_launches"]:
             ach = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "c6_conv3x3_kernel<256,3> (FP32 MFMA implicit GEMM)", "achieved": ach,
-                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": pmc_traffic("c6_conv3x3_kernel") if args.workload == "config2" and not args.games else None,
                                "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
                                "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
             fl = net_flops_per_board(n, wl["channels"], wl["blocks"]) * 8 * sims_s
