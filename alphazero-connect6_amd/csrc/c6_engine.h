@@ -87,7 +87,9 @@ struct C6Dev {
     const unsigned long long *zob; // [2][C6_MAXCELLS]
     const int16_t *aug_map;        // [8][cells] image k, cell c -> source cell of the board
     const int16_t *rec_map;        // [8][cells] image k, output cell c -> cell of image k's policy
-    unsigned long long *counters;  // [C6_CNT_N]
+    unsigned long long *counters;  // [C6_CNT_N] (rare events only: finished games, tuples, fetch queue)
+    unsigned long long *g_sims, *g_select, *g_stones;   // [G] per-game statistics, reduced on the host
+    uint32_t *g_maxdepth, *g_maxrec;                    // [G]
 };
 
 // tree_kernels.hip
@@ -117,7 +119,10 @@ struct C6NetDev {
     // packed weights (BatchNorm folded), see net_kernels.hip
     const float *stem_w;  // [9][2][C]
     const float *stem_b;  // [C]
+    int variant;          // 1: c6_conv3x3_kernel (NHWC), 2: c6_conv3x3_v2_kernel (slice-major S32 activations)
+    int num_cus;
     const float *conv_w;  // [(blocks-1)*2][packed 9*C*C]
+    const float *conv_w2; // same weights packed for conv v2
     const float *conv_b;  // [(blocks-1)*2][C]
     const float *pc_w;    // [2][C] folded
     const float *pc_b;    // [2]
@@ -138,4 +143,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                         const int8_t *player, const int16_t *aug_map, float *act0, float *act1, float *act2, float *ph,
                         float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers);
 size_t c6_conv_packed_floats(int C);
+void c6_pack_conv_weights_v2(int C, const float *w_oihw_folded, float *packed);
+bool c6_conv_v2_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
+                         int num_cus, hipStream_t s);
+#define C6_ACT_SLACK 1024   // floats of slack behind every activation buffer (conv v2's last DMA piece over-reads < 1 KiB)
 void c6_pack_conv_weights(int C, const float *w_oihw_folded, float *packed);

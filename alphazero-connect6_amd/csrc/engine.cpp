@@ -172,6 +172,17 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
     auto take = [&](size_t k) { const float *r = p; p += k; return r; };
     C6NetDev &d = nh.dev;
     d.N = n; d.cells = cells; d.C = C; d.blocks = nb;
+    {
+        // A/B switch.  1 = c6_conv3x3_kernel (32x32x2 tiles, NHWC; the faster one: 129 vs 119 TFLOP/s on MI355X),
+        // 2 = c6_conv3x3_v2_kernel (16x16x4 tiles, slice-major activations; experimental)
+        const char *v = std::getenv("C6_CONV_VARIANT");
+        d.variant = v ? std::atoi(v) : 1;
+        if (d.variant != 2) d.variant = 1;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        hipGetDevice(&dev);
+        d.num_cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
 
     {   // stem
         const float *w = take((size_t)C * 2 * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
@@ -188,7 +199,7 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
     {   // tower
         const int L = 2 * (nb - 1);
         const size_t wsz = c6_conv_packed_floats(C);
-        std::vector<float> cw((size_t)std::max(L, 1) * wsz), cb((size_t)std::max(L, 1) * C), folded((size_t)C * C * 9);
+        std::vector<float> cw((size_t)std::max(L, 1) * wsz), cw2((size_t)std::max(L, 1) * wsz), cb((size_t)std::max(L, 1) * C), folded((size_t)C * C * 9);
         for (int l = 0; l < L; l++) {
             const float *w = take((size_t)C * C * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
             for (int co = 0; co < C; co++) {
@@ -197,9 +208,10 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
                 for (size_t k = 0; k < (size_t)C * 9; k++) folded[(size_t)co * C * 9 + k] = w[(size_t)co * C * 9 + k] * s;
             }
             c6_pack_conv_weights(C, folded.data(), cw.data() + (size_t)l * wsz);
+            c6_pack_conv_weights_v2(C, folded.data(), cw2.data() + (size_t)l * wsz);
         }
         int rc;
-        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cb, &d.conv_b))) return rc;
+        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cb, &d.conv_b))) return rc;
     }
     {   // policy head
         const float *w = take((size_t)2 * C), *b = take(2), *bn = take(8);
@@ -351,6 +363,7 @@ static int engine_alloc(c6_engine *e) {
     ALLOC(d.fin_winner, d.finq_cap); ALLOC(d.fin_len, d.finq_cap); ALLOC(d.fin_uid, d.finq_cap);
     ALLOC(d.fin_moves, (size_t)d.finq_cap * cells);
     ALLOC(d.counters, C6_CNT_N);
+    ALLOC(d.g_sims, G); ALLOC(d.g_select, G); ALLOC(d.g_stones, G); ALLOC(d.g_maxdepth, G); ALLOC(d.g_maxrec, G);
     d.tuple_stride = (int)c6_tuple_stride(N);
 
     std::vector<unsigned long long> zob;
@@ -370,7 +383,7 @@ static int engine_alloc(c6_engine *e) {
         int chunk_leaves = std::max(1, chunk_boards / 8);
         chunk_leaves = std::min(chunk_leaves, G);
         e->chunk_leaves = chunk_leaves;
-        const size_t nb = (size_t)chunk_leaves * 8, act = nb * cells * c.net_channels;
+        const size_t nb = (size_t)chunk_leaves * 8, act = nb * cells * c.net_channels + C6_ACT_SLACK;
         ALLOC(e->act0, act); ALLOC(e->act1, act); ALLOC(e->act2, act);
         ALLOC(e->ph, nb * 2 * cells); ALLOC(e->vh, nb * cells);
     }
@@ -577,6 +590,20 @@ extern "C" int c6_engine_stats(c6_engine *e, c6_stats *out) {
     int live = 0, errs = 0;
     int rc = live_games(e, &live, &errs);
     if (rc != C6_OK) return rc;
+    const int G = e->d.G;
+    std::vector<unsigned long long> a(G), b(G), s(G);
+    std::vector<uint32_t> md(G), mr(G);
+    HIPCHK(hipMemcpy(a.data(), e->d.g_sims, (size_t)G * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b.data(), e->d.g_select, (size_t)G * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s.data(), e->d.g_stones, (size_t)G * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(md.data(), e->d.g_maxdepth, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mr.data(), e->d.g_maxrec, (size_t)G * 4, hipMemcpyDeviceToHost));
+    c[C6_CNT_SIMS] = c[C6_CNT_SELECT] = c[C6_CNT_STONES] = c[C6_CNT_MAXDEPTH] = c[C6_CNT_MAXREC] = 0;
+    for (int g = 0; g < G; g++) {
+        c[C6_CNT_SIMS] += a[g]; c[C6_CNT_SELECT] += b[g]; c[C6_CNT_STONES] += s[g];
+        c[C6_CNT_MAXDEPTH] = std::max<unsigned long long>(c[C6_CNT_MAXDEPTH], md[g]);
+        c[C6_CNT_MAXREC] = std::max<unsigned long long>(c[C6_CNT_MAXREC], mr[g]);
+    }
     out->rounds = e->rounds;
     out->simulations = c[C6_CNT_SIMS];
     out->select_steps = c[C6_CNT_SELECT];
@@ -866,7 +893,7 @@ extern "C" int c6_net_forward(int n, int C, int blocks, const float *blob, size_
     std::vector<int16_t> aug, rec;
     build_maps(n, aug, rec);
     TmpDev t;
-    const size_t act = (size_t)num * cells * C;
+    const size_t act = (size_t)num * cells * C + C6_ACT_SLACK;
     int8_t *db = t.get<int8_t>((size_t)num * cells, boards), *dpl = t.get<int8_t>(num, player);
     int16_t *dm = t.get<int16_t>(aug.size(), aug.data());
     float *a0 = t.get<float>(act), *a1 = t.get<float>(act), *a2 = t.get<float>(act), *ph = t.get<float>((size_t)num * 2 * cells),
@@ -878,5 +905,46 @@ extern "C" int c6_net_forward(int n, int C, int blocks, const float *blob, size_
     if (he == hipSuccess) he = hipMemcpy(value, dv, (size_t)num * 4, hipMemcpyDeviceToHost);
     nh.pool.release();
     if (he != hipSuccess) return fail(C6_ERR_HIP, hipGetErrorString(he));
+    return C6_OK;
+}
+
+// ---- conv micro-benchmark (development tool; also used to collect per-kernel profiles) ----------
+void c6_conv_bench_launch(int variant, int ablate, int C, int N, int nboards, const float *in, const float *w1, const float *w2,
+                          const float *bias, const float *res, float *out, int num_cus, hipStream_t s);
+__global__ void c6_fill_random_kernel(float *p, size_t n, uint32_t seed, float lo, float hi) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = lo + (hi - lo) * ((float)(x >> 8) * (1.0f / 16777216.0f));
+    }
+}
+extern "C" int c6_bench_conv(int n, int C, int nboards, int iters, int variant, int ablate, int with_res, double *avg_ms) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const size_t cells = (size_t)n * n, act = (size_t)nboards * cells * C + C6_ACT_SLACK, wsz = c6_conv_packed_floats(C);
+    float *in, *res, *out, *w, *bias;
+    HIPCHK(hipMalloc(&in, act * 4)); HIPCHK(hipMalloc(&res, act * 4)); HIPCHK(hipMalloc(&out, act * 4));
+    HIPCHK(hipMalloc(&w, wsz * 4)); HIPCHK(hipMalloc(&bias, C * 4));
+    hipLaunchKernelGGL(c6_fill_random_kernel, dim3(4096), dim3(256), 0, nullptr, in, act, 1u, 0.f, 1.f);
+    hipLaunchKernelGGL(c6_fill_random_kernel, dim3(4096), dim3(256), 0, nullptr, res, act, 2u, 0.f, 1.f);
+    hipLaunchKernelGGL(c6_fill_random_kernel, dim3(256), dim3(256), 0, nullptr, w, wsz, 3u, -0.02f, 0.02f);
+    hipLaunchKernelGGL(c6_fill_random_kernel, dim3(1), dim3(256), 0, nullptr, bias, (size_t)C, 4u, -0.1f, 0.1f);
+    hipDeviceProp_t prop;
+    const int cus = hipGetDeviceProperties(&prop, 0) == hipSuccess ? prop.multiProcessorCount : 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    c6_conv_bench_launch(variant, ablate, C, n, nboards, in, w, w, bias, with_res ? res : nullptr, out, cus, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; i++) c6_conv_bench_launch(variant, ablate, C, n, nboards, in, w, w, bias, with_res ? res : nullptr, out, cus, nullptr);
+    hipEventRecord(e1, nullptr);
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *avg_ms = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(in); hipFree(res); hipFree(out); hipFree(w); hipFree(bias);
     return C6_OK;
 }

@@ -40,7 +40,9 @@ struct C6NetTimers {
 // ----------------------------------------------------------------------------------------
 // conv3x3 C->C, pad 1, + bias (+ residual) + ReLU
 // ----------------------------------------------------------------------------------------
-template <int C, int MTW>
+// ABL: ablation switch used only by c6_bench_conv (0 = the product kernel):
+//   1 no weight staging, 2 no input staging, 3 neither and no barriers, 4 operands from registers (no LDS reads)
+template <int C, int MTW, int ABL = 0>
 __global__ __launch_bounds__(CONV_THREADS) void c6_conv3x3_kernel(const float *__restrict__ in, const float *__restrict__ wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ res,
                                                                  float *__restrict__ out, int N) {
@@ -77,31 +79,22 @@ __global__ __launch_bounds__(CONV_THREADS) void c6_conv3x3_kernel(const float *_
 
     for (int k = tid; k < in_floats; k += CONV_THREADS) lds_in[k] = 0.f;   // halo stays zero for the whole kernel
 
-    constexpr int WV = WSTAGE / 4 / CONV_THREADS;   // float4 per thread per weight stage (C=256: 4)
-    static_assert(WSTAGE / 4 % CONV_THREADS == 0 || WSTAGE / 4 < CONV_THREADS, "weight stage shape");
-    constexpr int WVR = WV > 0 ? WV : 1;
-    f32x4 wreg[WVR];
-    auto load_w = [&](int stage) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(wp + (size_t)stage * WSTAGE);
-#pragma unroll
-        for (int q = 0; q < WVR; q++) {
-            const int idx = tid + q * CONV_THREADS;
-            if (idx < WSTAGE / 4) wreg[q] = src[idx];
-        }
-    };
-    auto store_w = [&](int buf) {
-        f32x4 *dst = reinterpret_cast<f32x4 *>(lds_w + buf * WSTAGE);
-#pragma unroll
-        for (int q = 0; q < WVR; q++) {
-            const int idx = tid + q * CONV_THREADS;
-            if (idx < WSTAGE / 4) dst[idx] = wreg[q];
-        }
+    // weight stages (one contiguous 32*C-float block per (slice, tap)) stream into LDS by LDS-DMA
+    // (global_load_lds_dwordx4: no registers, no ds_write), one stage ahead of the MFMAs, double-buffered
+    constexpr int WPIECES = WSTAGE / 256;           // 1-KiB pieces per stage
+    auto dma_w = [&](int stage, int buf) {
+        const float *src = wp + (size_t)stage * WSTAGE;
+        float *dst = lds_w + buf * WSTAGE;
+        for (int pc = wave; pc < WPIECES; pc += CONV_THREADS / 64)
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)(src + pc * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(dst + pc * 256), 16, 0, 0);
     };
 
-    load_w(0);   // stage index = ks * 9 + tap
+    if (ABL != 1 && ABL != 3) dma_w(0, 0);   // stage index = ks * 9 + tap
     for (int ks = 0; ks < KS; ks++) {
-        __syncthreads();   // previous slice fully consumed (and the zero fill done)
+        if (ABL != 3) __syncthreads();   // previous slice fully consumed (and the zero fill done)
         // stage the 32-channel input slice: pixel p -> slot (y+1, x+1)
+        if (ABL != 2 && ABL != 3)
         for (int item = tid; item < cells * 8; item += CONV_THREADS) {
             const int p = item >> 3, q = item & 7;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(inb + (size_t)p * C + ks * 32 + q * 4);
@@ -110,19 +103,24 @@ __global__ __launch_bounds__(CONV_THREADS) void c6_conv3x3_kernel(const float *_
 #pragma unroll 1
         for (int tap = 0; tap < 9; tap++) {
             const int stage = ks * 9 + tap, buf = stage & 1;
-            store_w(buf);
-            __syncthreads();
-            if (stage + 1 < KS * 9) load_w(stage + 1);   // in flight behind the MFMAs below
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of `stage` have landed
+            if (ABL != 3) __syncthreads();                     // ... and everybody's; the other buffer is free again
+            if (ABL != 1 && ABL != 3) if (stage + 1 < KS * 9) dma_w(stage + 1, buf ^ 1);   // behind the MFMAs below
             const int toff = ((tap / 3 - 1) * P + (tap % 3 - 1)) * SLOT_F;
             const float *wb = lds_w + buf * WSTAGE;
 #pragma unroll
             for (int kq = 0; kq < 4; kq++) {
                 f32x4 a[MTW], bf[NTW];
 #pragma unroll
-                for (int mt = 0; mt < MTW; mt++) a[mt] = *reinterpret_cast<const f32x4 *>(lds_in + aoff[mt] + toff + kq * 8);
+                for (int mt = 0; mt < MTW; mt++) {
+                    if (ABL == 4) { a[mt] = f32x4{(float)tap, (float)kq, (float)mt, 1.f}; asm volatile("" : "+v"(a[mt])); }
+                    else a[mt] = *reinterpret_cast<const f32x4 *>(lds_in + aoff[mt] + toff + kq * 8);
+                }
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++)
-                    bf[nt] = *reinterpret_cast<const f32x4 *>(wb + ((kq * 2 + h) * C + (wn * NTW + nt) * 32 + i) * 4);
+                for (int nt = 0; nt < NTW; nt++) {
+                    if (ABL == 4) { bf[nt] = f32x4{(float)ks, 0.5f, (float)nt, 2.f}; asm volatile("" : "+v"(bf[nt])); }
+                    else bf[nt] = *reinterpret_cast<const f32x4 *>(wb + ((kq * 2 + h) * C + (wn * NTW + nt) * 32 + i) * 4);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -134,24 +132,39 @@ __global__ __launch_bounds__(CONV_THREADS) void c6_conv3x3_kernel(const float *_
         }
     }
 
-    // epilogue: C/D layout of 32x32: col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
+    // epilogue.  In the C/D layout a lane owns ONE channel (col = lane & 31) and 16 rows
+    // (row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)), which would make every residual load / output store a 4-byte
+    // access.  Each 32x32 tile is therefore transposed through a wave-private LDS patch so that a lane handles four
+    // consecutive channels of a pixel: residual and output move as 16-byte vectors, 1 KiB per wave-instruction.
+    __syncthreads();                                   // every wave is done with the staging buffers
+    constexpr int PSTR = 36;                           // patch row stride in floats (16-byte aligned rows)
+    float *patch = smem + wave * (32 * PSTR);          // 8 x 4.5 KiB; the launcher sizes LDS for it
     float *outb = out + b * (size_t)cells * C;
     const float *resb = res ? res + b * (size_t)cells * C : nullptr;
+    const int r8 = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
-        const int n = (wn * NTW + nt) * 32 + i;
-        const float bi = bias[n];
+        const int n4 = (wn * NTW + nt) * 32 + c4;
+        const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + n4);
 #pragma unroll
         for (int mt = 0; mt < MTW; mt++) {
 #pragma unroll
-            for (int v = 0; v < 16; v++) {
-                const int p = (wm * MTW + mt) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+            for (int v = 0; v < 16; v++) patch[((v & 3) + 8 * (v >> 2) + 4 * h) * PSTR + i] = acc[mt][nt][v];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = j * 8 + r8;
+                const int p = (wm * MTW + mt) * 32 + row;
+                f32x4 y = *reinterpret_cast<const f32x4 *>(patch + row * PSTR + c4);
                 if (p < cells) {
-                    float y = acc[mt][nt][v] + bi;
-                    if (resb) y += resb[(size_t)p * C + n];
-                    outb[(size_t)p * C + n] = y > 0.f ? y : 0.f;
+                    y = y + bi;
+                    if (resb) y = y + *reinterpret_cast<const f32x4 *>(resb + (size_t)p * C + n4);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) y[q] = y[q] > 0.f ? y[q] : 0.f;
+                    *reinterpret_cast<f32x4 *>(outb + (size_t)p * C + n4) = y;
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next tile overwrites it
         }
     }
 }
@@ -179,7 +192,8 @@ void c6_pack_conv_weights(int C, const float *w, float *packed) {
 __global__ __launch_bounds__(256) void c6_stem_kernel(const int8_t *__restrict__ boards, int board_stride,
                                                      const int8_t *__restrict__ player, const int16_t *__restrict__ aug_map,
                                                      int images, const float *__restrict__ w /*[9][2][C]*/,
-                                                     const float *__restrict__ bias, float *__restrict__ out, int N, int C) {
+                                                     const float *__restrict__ bias, float *__restrict__ out, int N, int C,
+                                                     int s32) {
     __shared__ float pl[21 * 21], bd[21 * 21];
     const int cells = N * N, P = N + 2;
     const size_t b = blockIdx.x;
@@ -210,7 +224,9 @@ __global__ __launch_bounds__(256) void c6_stem_kernel(const int8_t *__restrict__
             acc = __builtin_fmaf(w0[t], pl[o], acc);
             acc = __builtin_fmaf(w1[t], bd[o], acc);
         }
-        ob[(size_t)p * C + co] = acc > 0.f ? acc : 0.f;
+        // NHWC, or slice-major S32 = [C/32][pixel][32] (conv_v2.hip)
+        const size_t o = s32 ? ((size_t)(co >> 5) * cells + p) * 32 + (co & 31) : (size_t)p * C + co;
+        ob[o] = acc > 0.f ? acc : 0.f;
     }
 }
 
@@ -222,14 +238,15 @@ __global__ __launch_bounds__(256) void c6_head_conv_kernel(const float *__restri
                                                           const float *__restrict__ pc_b, const float *__restrict__ vc_w,
                                                           float vc_b, const float *__restrict__ vn_scale,
                                                           const float *__restrict__ vn_shift, float *__restrict__ ph,
-                                                          float *__restrict__ vh, int cells, int C) {
+                                                          float *__restrict__ vh, int cells, int C, int s32) {
     const size_t b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *ab = act + b * (size_t)cells * C;
     for (int p = wave; p < cells; p += 4) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(ab + (size_t)p * C + c);
+            const size_t o = s32 ? ((size_t)(c >> 5) * cells + p) * 32 + (c & 31) : (size_t)p * C + c;
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(ab + o);
             const f32x4 a = *reinterpret_cast<const f32x4 *>(pc_w + c);
             const f32x4 d = *reinterpret_cast<const f32x4 *>(pc_w + C + c);
             const f32x4 e = *reinterpret_cast<const f32x4 *>(vc_w + c);
@@ -370,7 +387,8 @@ static void launch_conv(int MTW, int nboards, size_t smem, const float *in, cons
 static void conv_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res,
                           float *out, hipStream_t s) {
     const int cells = N * N, MT = (cells + 31) / 32, MTW = (MT + 3) / 4, P = N + 2;
-    const size_t smem = ((size_t)((P * P * SLOT_F + 3) & ~3) + 2 * 32 * (size_t)C) * sizeof(float);
+    size_t smem = ((size_t)((P * P * SLOT_F + 3) & ~3) + 2 * 32 * (size_t)C) * sizeof(float);
+    if (smem < (size_t)8 * 32 * 36 * sizeof(float)) smem = (size_t)8 * 32 * 36 * sizeof(float);   // epilogue patches
     switch (C) {
     case 64: launch_conv<64>(MTW, nboards, smem, in, wp, bias, res, out, N, s); break;
     case 128: launch_conv<128>(MTW, nboards, smem, in, wp, bias, res, out, N, s); break;
@@ -391,8 +409,9 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                         float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers) {
     const int nb = nleaf * images, cells = net.cells, C = net.C;
     if (nb == 0) return;
+    const int v2 = net.variant == 2 ? 1 : 0;
     hipLaunchKernelGGL(c6_stem_kernel, dim3(nb), dim3(256), 0, s, boards, board_stride, player, aug_map, images, net.stem_w,
-                       net.stem_b, act0, net.N, C);
+                       net.stem_b, act0, net.N, C, v2);
     float *x = act0, *y = act1, *z = act2;
     const size_t wsz = c6_conv_packed_floats(C);
     const bool timed = timers && timers->enabled;
@@ -400,8 +419,11 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
         for (int half = 0; half < 2; half++) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (timed) { e0 = timer_event(timers); e1 = timer_event(timers); hipEventRecord(e0, s); }
-            if (half == 0) conv_dispatch(C, net.N, nb, x, net.conv_w + (size_t)(2 * i) * wsz, net.conv_b + (size_t)(2 * i) * C, nullptr, y, s);
-            else conv_dispatch(C, net.N, nb, y, net.conv_w + (size_t)(2 * i + 1) * wsz, net.conv_b + (size_t)(2 * i + 1) * C, x, z, s);
+            const int l = 2 * i + half;
+            const float *cin = half == 0 ? x : y, *cres = half == 0 ? nullptr : x;
+            float *cout = half == 0 ? y : z;
+            if (v2) c6_conv_v2_dispatch(C, net.N, nb, cin, net.conv_w2 + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
+            else conv_dispatch(C, net.N, nb, cin, net.conv_w + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, s);
             if (timed) {
                 hipEventRecord(e1, s);
                 timers->conv.emplace_back(e0, e1);
@@ -411,7 +433,7 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
         float *t = x; x = z; z = t;
     }
     hipLaunchKernelGGL(c6_head_conv_kernel, dim3(nb), dim3(256), 0, s, x, net.pc_w, net.pc_b, net.vc_w, net.vc_b, net.vn_scale,
-                       net.vn_shift, ph, vh, cells, C);
+                       net.vn_shift, ph, vh, cells, C, v2);
     const int hgrid = (nb + HB - 1) / HB;
     const size_t sm_p = (size_t)(HB * 2 * cells + HB * cells) * sizeof(float);
     hipLaunchKernelGGL(c6_head_policy_kernel, dim3(hgrid), dim3(256), sm_p, s, ph, net.pl_wT, net.pl_b, pol, cells, nb);
@@ -445,4 +467,17 @@ void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches,
     *launches = t->acc_n;
     *flops = t->conv_flops;
     if (reset) { t->acc_ms = 0; t->acc_n = 0; t->conv_flops = 0; }
+}
+
+// ---- micro-benchmark hook (c6_bench_conv in engine.cpp): one conv launch of a variant / ablation ----
+void c6_conv_bench_launch(int variant, int ablate, int C, int N, int nboards, const float *in, const float *w1, const float *w2,
+                          const float *bias, const float *res, float *out, int num_cus, hipStream_t s) {
+    if (variant == 2) { c6_conv_v2_dispatch(C, N, nboards, in, w2, bias, res, out, num_cus, s); return; }
+    if (C != 256 || N != 19 || ablate == 0) { conv_dispatch(C, N, nboards, in, w1, bias, res, out, s); return; }
+    const int P = N + 2;
+    const size_t smem = ((size_t)((P * P * SLOT_F + 3) & ~3) + 2 * 32 * (size_t)C) * sizeof(float);
+#define ABLCASE(A) case A: hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<256, 3, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((c6_conv3x3_kernel<256, 3, A>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, w1, bias, res, out, N); break;
+    switch (ablate) { ABLCASE(1) ABLCASE(2) ABLCASE(3) ABLCASE(4) default: break; }
+#undef ABLCASE
 }

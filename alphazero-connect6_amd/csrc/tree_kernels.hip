@@ -194,7 +194,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
         if (kind < 0) {   // overflow / NaN: stop this game, reported through status
             E.status[g] = C6_ST_ERROR;
             E.leaf_kind[g] = C6_LEAF_NONE;
-            atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull);
         } else {
             E.leaf_kind[g] = (int8_t)kind;
             E.leaf_turn[g] = (int8_t)turn;
@@ -202,8 +201,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
             E.leaf_sig[g * 4 + 0] = sg0; E.leaf_sig[g * 4 + 1] = sg1; E.leaf_sig[g * 4 + 2] = sg2; E.leaf_sig[g * 4 + 3] = sg3;
             E.leaf_level[g] = (int16_t)level;
             E.path_len[g] = d;
-            atomicAdd(&E.counters[C6_CNT_SELECT], (unsigned long long)d);
-            atomicMax(&E.counters[C6_CNT_MAXDEPTH], (unsigned long long)d);
+            E.g_select[g] += (unsigned long long)d;      // per-game statistics: no shared-address atomics
+            if ((uint32_t)d > E.g_maxdepth[g]) E.g_maxdepth[g] = (uint32_t)d;
         }
     }
 }
@@ -340,7 +339,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
         }
         idx = __shfl(idx, 0, 64);
         if (idx < 0) {
-            if (lane == 0) { E.status[g] = C6_ST_ERROR; atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull); }
+            if (lane == 0) E.status[g] = C6_ST_ERROR;
             return;
         }
         value = E.eval_value[g];
@@ -359,8 +358,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
             E.rec_sig[(rbase + idx) * 4 + 2] = q2; E.rec_sig[(rbase + idx) * 4 + 3] = q3;
             if (!ht_insert(E.ht + (size_t)g * E.H, E.H, key, idx)) E.status[g] = C6_ST_ERROR;
             if (len == 0) E.root_rec[g] = idx;
-            const unsigned long long used = (unsigned long long)(E.R - E.free_top[g]);
-            atomicMax(&E.counters[C6_CNT_MAXREC], used);
+            const uint32_t used = (uint32_t)(E.R - E.free_top[g]);
+            if (used > E.g_maxrec[g]) E.g_maxrec[g] = used;
         }
         // last-writer rule for transposed children (entry().or_insert + n_prob overwrite, mod.rs:366-370):
         // every expanded P on this level with P + i == Q + s sees its child i's prior become prob_Q[s]
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
         }
         E.nsearch[g] += 1;
         E.sim_in_move[g] += 1;
-        atomicAdd(&E.counters[C6_CNT_SIMS], 1ull);
+        E.g_sims[g] += 1ull;
     }
 }
 
@@ -546,7 +545,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
             E.moves[(size_t)g * cells + old_level] = (uint16_t)pos;
             E.nstones[g] = (int16_t)nst;
             E.sim_in_move[g] = 0;
-            atomicAdd(&E.counters[C6_CNT_STONES], 1ull);
+            E.g_stones[g] += 1ull;
         }
     }
     __builtin_amdgcn_wave_barrier();

@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--games", type=int, default=0, help="override games per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to "
+                    "exercise the N > 1 path on a 1-GPU box together with C6_BENCH_SHARE_GPU=1)")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
     if args.games:
@@ -139,9 +141,14 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libconnect6_amd has no CPU fallback)")
+    if os.environ.get("C6_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n, G, S = wl["n"], wl["games"], wl["sims"]
     uid_base, uid_stride = shard.uid_plan(G, world, rank)
@@ -169,7 +176,10 @@ def main():
         for _ in range(k):
             eng.step(1)
             eng.sync()
-            pooled, counts = shard.gather_tuples(tbuf, tcount, world)     # RCCL all-gather over xGMI
+            if args.backend == "nccl":
+                pooled, counts = shard.gather_tuples(tbuf, tcount, world)     # RCCL all-gather over xGMI
+            else:
+                pooled, counts = shard.gather_tuples(tbuf.cpu(), tcount.cpu(), world)
             pooled_tuples += int(counts.clamp(max=cap).sum().item())
             tcount.zero_()
             torch.cuda.current_stream().synchronize()
@@ -190,7 +200,7 @@ def main():
     prof = eng.profile_read(reset=True)
     eng.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = eng.stats()

@@ -1,0 +1,78 @@
+// mfma_calib.hip -- calibration of the FP32 matrix-core ceiling on this MI355X in the shapes the conv kernels use.
+// Not part of the library.  hipcc --offload-arch=gfx950 -O3 mfma_calib.hip -o mfma_calib
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC, bool RANDOM>
+__global__ __launch_bounds__(512) void k16(float *out, int iters, unsigned long long *clk) {
+    f32x4 acc[NACC];
+    for (int i = 0; i < NACC; i++) acc[i] = f32x4{0, 0, 0, 0};
+    float a = threadIdx.x * 0.001f + 0.5f, b = 1.0f + blockIdx.x * 1e-4f;
+    unsigned int lcg = threadIdx.x * 2654435761u + blockIdx.x;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+        if (RANDOM) {   // full-range random operands: the data the real kernel sees toggles every bit
+            lcg = lcg * 1664525u + 1013904223u;
+            a = __uint_as_float(0x3f800000u | (lcg >> 9)) - 1.5f;
+            b = __uint_as_float(0x3f800000u | ((lcg * 747796405u) >> 9)) - 1.5f;
+        }
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        if (!RANDOM) a += 1e-6f;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <int NACC>
+__global__ __launch_bounds__(512) void k32(float *out, int iters, unsigned long long *clk) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; i++) for (int j = 0; j < 16; j++) acc[i][j] = 0;
+    float a = threadIdx.x * 0.001f + 0.5f, b = 1.0f + blockIdx.x * 1e-4f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        a += 1e-6f;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int i = 0; i < NACC; i++) for (int j = 0; j < 16; j++) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <typename F> void run(const char *name, F launch, int threads, double flop_per_wave_iter, int iters) {
+    float *out; unsigned long long *clk;
+    hipMalloc(&out, 256 * 512 * 4); hipMalloc(&clk, 256 * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    launch(out, iters / 10, clk);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    launch(out, iters, clk);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(512); hipMemcpy(h.data(), clk, 256 * 16, hipMemcpyDeviceToHost);
+    double ghz = (double)h[0] / (double)h[1] * 0.1;   // s_memrealtime ticks at 100 MHz
+    double tf = flop_per_wave_iter * (threads / 64) * 256.0 * iters / (ms * 1e-3) / 1e12;
+    printf("%-28s threads=%d  %.2f ms  %.1f TFLOP/s  in-kernel clock %.2f GHz  (%.1f%% of 157.3)\n", name, threads, ms, tf, ghz, tf / 1.573);
+    hipFree(out); hipFree(clk);
+}
+
+int main(int argc, char **argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 20000;
+    run("16x16x4 46acc 8 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((k16<46, false>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 46 * 2048.0, iters);
+    run("16x16x4 46acc 8w RANDOM data", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((k16<46, true>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 46 * 2048.0, iters);
+    run("16x16x4 46acc 4 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((k16<46, false>), dim3(256), dim3(256), 0, 0, o, it, c); }, 256, 46 * 2048.0, iters);
+    run("32x32x2 12acc 8 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL(k32<12>, dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 12 * 4096.0, iters);
+    run("32x32x2 12acc 4 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL(k32<12>, dim3(256), dim3(256), 0, 0, o, it, c); }, 256, 12 * 4096.0, iters);
+    run("32x32x2 4acc 4 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL(k32<4>, dim3(256), dim3(256), 0, 0, o, it, c); }, 256, 4 * 4096.0, iters * 3);
+    return 0;
+}
