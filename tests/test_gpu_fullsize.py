@@ -1,0 +1,114 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties, plus exact oracle checks on samples.
+(configs: 4096 x 19x19 x 400 sims, 32768 x 9x9 x 100 sims.)"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import c6oracle as o
+from gpu_common import need_gpu, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_board_kernel_32768_games_9x9():
+    """config 5 shape: one stone on each of 32768 random mid-game boards: exactly one cell changes per game, turn/remain
+    follow the 1-then-2 rule, winners agree with the oracle on a sample, and winner == 0 wherever no six exists."""
+    need_gpu()
+    n, G = 9, 32768
+    rng = np.random.default_rng(5)
+    boards = np.zeros((G, n * n), np.int8)
+    stones = rng.integers(0, 60, G)
+    for g in range(G):
+        idx = rng.permutation(n * n)[: stones[g]]
+        boards[g, idx] = rng.choice(np.array([-1, 1], np.int8), stones[g])
+    turn = rng.choice(np.array([-1, 1], np.int8), G)
+    remain = rng.integers(1, 3, G).astype(np.int8)
+    pos = np.array([rng.choice(np.flatnonzero(boards[g] == 0)) for g in range(G)], np.int32)
+    soa2, t2, r2, win, err = pkg.board_step(n, pkg.to_soa(boards), turn, remain, pos)
+    after = soa2.T
+    assert (err == 0).all()
+    diff = after != boards
+    assert (diff.sum(axis=1) == 1).all() and (after[np.arange(G), pos] == turn).all()
+    assert ((r2 == 1) == (remain == 2)).all() and ((t2 == -turn) == (remain == 1)).all() and ((r2 == 2) == (remain == 1)).all()
+    sample = rng.choice(G, 600, replace=False)
+    for g in sample:
+        assert o.search(after[g].reshape(n, n)) == win[g]
+    # checksum of checksums: the full-scan kernel on the same boards gives the same winners
+    assert (pkg.search_winner(n, soa2) == win).all()
+
+
+def test_engine_4096_games_19x19_invariants_and_samples():
+    """config 2 shape with the on-device RandomEvaluator: after R rounds every one of the 4096 roots has visit R and
+    sum(child visits) == R - 1 (every search but the first passes through a child: alphazero_policy/tests.rs:90-136
+    generalised), nothing overflowed; sampled games equal the seeded oracle bit for bit."""
+    need_gpu()
+    n, G, S, R, seed = 19, 4096, 400, 24, 99
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_RANDOM)
+    eng.step(R)
+    st = eng.stats()
+    assert st["simulations"] == G * R and st["overflow_games"] == 0 and st["live_games"] == G
+    assert 0.5 < st["select_steps"] / st["simulations"] < 3.0
+    for g in list(range(0, G, 257)) + [G - 1]:
+        r = eng.root(g)
+        assert r["root_visit"] == R and r["visits"].sum() == R - 1 and r["stones"] == 0 and r["nsearch"] == R
+    for g in (0, 1, 4095):
+        az = o.AlphaZero(n, num_simulation=S, eval_kind=o.EVAL_RANDOM, seed=seed, game_uid=g)
+        s = o.sim_from_game(o.new_game(n))
+        az.init(s)
+        for _ in range(R):
+            az.search(s)
+        vis, q, p = az.children(np.zeros((n, n), np.int8))
+        r = eng.root(g)
+        assert (r["visits"] == vis).all() and (r["q"] == q).all() and (r["prior"] == p).all()
+    eng.close()
+
+
+def test_tuples_round_trip_4096_games():
+    """encode -> decode round trip of the training tuples at 4096 games: every emitted state is the replay of its game's
+    move list, z is the game's winner and turn follows the 1-then-2 rule."""
+    need_gpu()
+    n, G, S = 9, 4096, 3
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=1, evaluator=pkg.EVAL_UNIFORM)
+    eng.enable_tuples(G * n * n)
+    eng.run()
+    games = eng.fetch_games()
+    tup = eng.fetch_tuples(G * n * n)
+    st = eng.stats()
+    eng.close()
+    assert len(games) == G and st["games_finished"] == G and st["tuples"] == sum(len(g["moves"]) for g in games) == tup["state"].shape[0]
+    want = {}
+    for g in games:
+        for k, (turn, board, cell) in enumerate(pkg.replay_moves(n, g["moves"])):
+            want.setdefault(board.tobytes(), set()).add((turn, g["winner"]))
+    for i in range(0, tup["state"].shape[0], 7):
+        key = tup["state"][i].tobytes()
+        assert (int(tup["turn"][i]), int(tup["z"][i])) in want[key]
+    assert tup["pi"].max() <= 4 * S * n        # child visits accumulate over reused subtrees, bounded by the sims played
+    ws = np.array([g["winner"] for g in games])
+    assert set(np.unique(ws)) <= {-1, 0, 1}
+
+
+def test_net_batch_invariance_full_batch():
+    """the resident net at a 32768-board pass (config 2's leaf batch): every board's output is independent of the batch
+    it travels in (the conv kernel owns one board per workgroup), and the dihedral average of a constant policy is
+    that constant (recover_way8 of eight equal images)."""
+    need_gpu()
+    import __graft_entry__ as ge
+    n, C, blocks, G = 19, 256, 2, 4096
+    blob = ge.make_random_blob(n, C, blocks, np.random.default_rng(3))
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=400, seed=4, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks)
+    eng.load_weights(blob)
+    eng.step(1)                       # all 4096 leaves are the empty board: 32768 images in one pass
+    r0 = eng.root(0)
+    for g in (1, 777, 4095):
+        r = eng.root(g)
+        assert (r["prior"] == r0["prior"]).all() and r["root_value"] == r0["root_value"]
+    pol, val = pkg.net_forward(n, C, blocks, blob, np.zeros((1, n * n), np.int8), -1)
+    # the empty board is invariant under the 8 images, so the recovered prior is the dihedral average of ONE policy
+    p = pol[0].reshape(n, n).astype(np.float64)
+    avg = sum(np.rot90(q, k) for q in (p, np.fliplr(p)) for k in range(4)) / 8
+    assert np.abs(r0["prior"].reshape(n, n) - avg).max() < 2e-7
+    assert abs(r0["root_value"] - val[0]) < 1e-6
+    eng.close()
