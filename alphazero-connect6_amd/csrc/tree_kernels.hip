@@ -56,6 +56,7 @@ __device__ __forceinline__ void next_turn(int &turn, int &remain) {   // simulat
 // ------------------------------------------------------------------------------------------
 // select: walk from the root by PUCT + Dirichlet noise until a node without record (leaf)
 // ------------------------------------------------------------------------------------------
+template <int J>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -74,9 +75,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
     int turn = E.turn[g], remain = E.remain[g], level = E.nstones[g];
     const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.game_uid[g], t = E.nsearch[g];
 
-    int8_t st[C6_MAXJ];
+    int8_t st[J];
 #pragma unroll
-    for (int j = 0; j < C6_MAXJ; j++) {
+    for (int j = 0; j < J; j++) {
         const int c = lane + 64 * j;
         st[j] = c < cells ? E.root_board[(size_t)g * E.cellsP + c] : (int8_t)2;
     }
@@ -90,11 +91,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const float *prior = E.rec_prior + (rbase + p) * (size_t)cells;
 
-        int cidx[C6_MAXJ], cvis[C6_MAXJ];
-        float cq[C6_MAXJ], cpr[C6_MAXJ];
+        int cidx[J], cvis[J];
+        float cq[J], cpr[J];
         int vs = 0;
 #pragma unroll
-        for (int j = 0; j < C6_MAXJ; j++) {
+        for (int j = 0; j < J; j++) {
             const int c = lane + 64 * j;
             cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f; cpr[j] = 0.f;
             if (st[j] == 0) {
@@ -110,14 +111,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
         if (nchild == 1) {                       // heuristic, mod.rs:255-258
             int mine = -1;
 #pragma unroll
-            for (int j = 0; j < C6_MAXJ; j++) if (st[j] == 0) mine = lane + 64 * j;
+            for (int j = 0; j < J; j++) if (st[j] == 0) mine = lane + 64 * j;
             chosen = c6_wave_max_i32(mine);
         } else {
             const float visit_sum = (float)c6_wave_sum_i32(vs);
             // Dirichlet noise: Gamma draws normalised by their sum (C6RNG), mod.rs:260-262,283
-            double gam[C6_MAXJ], part = 0.0;
+            double gam[J], part = 0.0;
 #pragma unroll
-            for (int j = 0; j < C6_MAXJ; j++) {
+            for (int j = 0; j < J; j++) {
                 gam[j] = 0.0;
                 if (st[j] == 0) {
                     gam[j] = c6_gamma_draw(E.alpha, E.gam_d, E.gam_c, k0, k1, (uint32_t)(lane + 64 * j), t, (uint32_t)d);
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
                 }
             }
             const double gsum = c6_butterfly_sum(part);
-            float sc[C6_MAXJ], best = -INFINITY;
+            float sc[J], best = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < C6_MAXJ; j++) {
+            for (int j = 0; j < J; j++) {
                 sc[j] = -INFINITY;
                 if (st[j] == 0) {                // mod.rs:265-280
                     const float noise = (float)(gam[j] / gsum);
@@ -141,10 +142,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
             }
             best = c6_wave_max_f32(best);
             // exact ties -> uniform choice (mod.rs:287-295), C6RNG TIE draw
-            unsigned long long tie[C6_MAXJ];
+            unsigned long long tie[J];
             int cnt = 0;
 #pragma unroll
-            for (int j = 0; j < C6_MAXJ; j++) {
+            for (int j = 0; j < J; j++) {
                 tie[j] = __ballot(st[j] == 0 && sc[j] == best);
                 cnt += __popcll(tie[j]);
             }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
             }
             chosen = -1;
 #pragma unroll
-            for (int j = 0; j < C6_MAXJ; j++) {
+            for (int j = 0; j < J; j++) {
                 const int pc = __popcll(tie[j]);
                 if (chosen < 0) {
                     if (pick < pc) chosen = c6_nth_set_bit(tie[j], pick) + 64 * j;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
         const int cl = chosen & 63, cj = chosen >> 6;
         int child = -1;
 #pragma unroll
-        for (int j = 0; j < C6_MAXJ; j++) if (j == cj) child = cidx[j];
+        for (int j = 0; j < J; j++) if (j == cj) child = cidx[j];
         child = __shfl(child, cl, 64);
         if (lane == 0) E.path_rec[(size_t)g * C6_MAXD + d] = (uint16_t)p;
         d++;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
         const uint32_t c1 = (uint32_t)chosen + 1u;
         if (turn == C6_BLACK) { sg0 += c1; sg1 += c1 * c1; } else { sg2 += c1; sg3 += c1 * c1; }
 #pragma unroll
-        for (int j = 0; j < C6_MAXJ; j++) if (j == cj && lane == cl) st[j] = (int8_t)turn;
+        for (int j = 0; j < J; j++) if (j == cj && lane == cl) st[j] = (int8_t)turn;
         next_turn(turn, remain);
         level++;
         p = child;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
     if (kind == C6_LEAF_EVAL && level == cells) kind = C6_LEAF_TERMINAL;   // board full, mod.rs:338
 
 #pragma unroll
-    for (int j = 0; j < C6_MAXJ; j++) {
+    for (int j = 0; j < J; j++) {
         const int c = lane + 64 * j;
         if (c < cells) E.leaf_board[(size_t)g * E.cellsP + c] = st[j];
     }
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
 // ------------------------------------------------------------------------------------------
 // move: policy() (mod.rs:433-452) for games whose simulation budget is spent
 // ------------------------------------------------------------------------------------------
+template <int J>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_move_select_kernel(C6Dev E) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -426,10 +428,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_move_select_kernel(C6
         const unsigned long long key = E.root_key[g];
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const int8_t *board = E.root_board + (size_t)g * E.cellsP;
-        int cv[C6_MAXJ];
+        int cv[J];
         int vs = 0;
 #pragma unroll
-        for (int j = 0; j < C6_MAXJ; j++) {
+        for (int j = 0; j < J; j++) {
             const int c = lane + 64 * j;
             cv[j] = -1;
             if (c < cells && board[c] == 0) {
@@ -440,9 +442,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_move_select_kernel(C6
         }
         const float visit_sum = (float)c6_wave_sum_i32(vs);
         float best = -INFINITY;
-        float sc[C6_MAXJ];
+        float sc[J];
 #pragma unroll
-        for (int j = 0; j < C6_MAXJ; j++) {
+        for (int j = 0; j < J; j++) {
             sc[j] = -INFINITY;
             if (cv[j] >= 0) {
                 const float visit = (float)cv[j];
@@ -453,12 +455,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_move_select_kernel(C6
         best = c6_wave_max_f32(best);
         int mine = -1;   // Iterator::max_by returns the LAST maximum
 #pragma unroll
-        for (int j = 0; j < C6_MAXJ; j++) if (cv[j] >= 0 && sc[j] == best) mine = lane + 64 * j;
+        for (int j = 0; j < J; j++) if (cv[j] >= 0 && sc[j] == best) mine = lane + 64 * j;
         pos = c6_wave_max_i32(mine);
         // pi = root child visit counts (build-side extension)
         uint16_t *pi = E.hist_pi + ((size_t)g * cells + level) * cells;
 #pragma unroll
-        for (int j = 0; j < C6_MAXJ; j++) {
+        for (int j = 0; j < J; j++) {
             const int c = lane + 64 * j;
             if (c < cells) pi[c] = (uint16_t)(cv[j] > 0 ? (cv[j] > 65535 ? 65535 : cv[j]) : 0);
         }
@@ -509,6 +511,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_reset_kernel(C6Dev E)
 }
 
 // after K1 placed the stones: advance the root, prune (next(), mod.rs:473-487), finish / recycle games
+template <int J>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6Dev E) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -605,9 +608,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
     }
     if (E.tuple_buf) {
         // replay the game: record k holds the board BEFORE stone k (agent_impl/mod.rs:139-143)
-        int8_t st[C6_MAXJ];
+        int8_t st[J];
 #pragma unroll
-        for (int j = 0; j < C6_MAXJ; j++) st[j] = 0;
+        for (int j = 0; j < J; j++) st[j] = 0;
         int t = C6_BLACK, rem = 1;
         for (int k = 0; k < nst; k++) {
             const unsigned long long rec = tbase + (unsigned long long)k;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
                 uint8_t *out = E.tuple_buf + rec * (unsigned long long)E.tuple_stride;
                 const uint16_t *pi = E.hist_pi + ((size_t)g * cells + k) * cells;
 #pragma unroll
-                for (int j = 0; j < C6_MAXJ; j++) {
+                for (int j = 0; j < J; j++) {
                     const int c = lane + 64 * j;
                     if (c < cells) {
                         out[c] = (uint8_t)st[j];
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
                 }
             }
 #pragma unroll
-            for (int j = 0; j < C6_MAXJ; j++) if ((mv >> 6) == j && (mv & 63) == lane) st[j] = (int8_t)t;
+            for (int j = 0; j < J; j++) if ((mv >> 6) == j && (mv & 63) == lane) st[j] = (int8_t)t;
             next_turn(t, rem);
         }
         if (lane == 0) atomicAdd(&E.counters[C6_CNT_TUPLES], (unsigned long long)nst);
@@ -650,9 +653,16 @@ __global__ void c6_stagger_kernel(C6Dev E) {
 
 static inline int wave_grid(int G) { return (G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }
 
-void c6_launch_select(const C6Dev &d, hipStream_t s) {
-    hipLaunchKernelGGL(c6_select_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
-}
+// J = cells owned by one lane: 2 (9x9), 4 (15x15), 6 (19x19)
+#define C6_LAUNCH_J(KERNEL, d, s)                                                                                     \
+    do {                                                                                                              \
+        const int j_ = ((d).cells + 63) / 64;                                                                         \
+        if (j_ <= 2) hipLaunchKernelGGL((KERNEL<2>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);      \
+        else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d); \
+        else hipLaunchKernelGGL((KERNEL<6>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);             \
+    } while (0)
+
+void c6_launch_select(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_select_kernel, d, s); }
 void c6_launch_expand(const C6Dev &d, hipStream_t s) {
     hipLaunchKernelGGL(c6_expand_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
 }
@@ -665,12 +675,8 @@ void c6_launch_recover(const C6Dev &d, hipStream_t s) {
 void c6_launch_augment(const C6Dev &d, float *img, hipStream_t s) {
     hipLaunchKernelGGL(c6_augment_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d, img);
 }
-void c6_launch_move_select(const C6Dev &d, hipStream_t s) {
-    hipLaunchKernelGGL(c6_move_select_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
-}
-void c6_launch_post_move(const C6Dev &d, hipStream_t s) {
-    hipLaunchKernelGGL(c6_post_move_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
-}
+void c6_launch_move_select(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_move_select_kernel, d, s); }
+void c6_launch_post_move(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_post_move_kernel, d, s); }
 void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s) {
     hipLaunchKernelGGL(c6_reset_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
     if (stagger) hipLaunchKernelGGL(c6_stagger_kernel, dim3((d.G + 255) / 256), dim3(256), 0, s, d);
