@@ -124,10 +124,12 @@ static void conv3_bn(const convbn *cb, int n, int cin, int cout, const float *in
         shift[co] = cb->be[co] - cb->m[co] * scale[co];
     }
     enum { PX = 6 };
-    for (int y = 0; y < n; y++)
-        for (int x0 = 0; x0 < n; x0 += PX) {
-            const int npx = n - x0 < PX ? n - x0 : PX;
-            for (int co = 0; co < cout; co += 16) {
+    /* co outermost: the 9*cin*16 weight block of a channel group (147 KB at cin = 256) stays in the core's cache
+     * while every pixel tile of the board streams past it */
+    for (int co = 0; co < cout; co += 16)
+        for (int y = 0; y < n; y++) {
+            for (int x0 = 0; x0 < n; x0 += PX) {
+                const int npx = n - x0 < PX ? n - x0 : PX;
                 v8f acc[PX][2];
                 for (int q = 0; q < PX; q++) { acc[q][0] = *(const v8f *)(cb->b + co); acc[q][1] = *(const v8f *)(cb->b + co + 8); }
                 for (int t = 0; t < 9; t++) {
