@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libconnect6_amd.so")
 BLACK, NONE, WHITE = -1, 0, 1
 EVAL_RANDOM, EVAL_UNIFORM, EVAL_NET, EVAL_CALLBACK = 1, 2, 3, 4
 OK, ERR_NO_GPU, ERR_BAD_ARG, ERR_OVERFLOW, ERR_HIP, ERR_INVALID_POSITION, ERR_ALREADY_SET = range(7)
+PREC_DEFAULT, PREC_FP32, PREC_BF16X3 = 0, 1, 3
 REF_N = 15
 
 DROPIN_SYMBOLS = ["cpp_play", "cpp_self_play", "cpp_play_with", "test_new_raw_path", "test_with_raw_path",
@@ -33,7 +34,8 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_engine_step", "c6_engine_run", "c6_engine_sync", "c6_engine_stats", "c6_engine_fetch_games",
                   "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
-                  "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_dirichlet_noise"]
+                  "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
+                  "c6_bench_conv"]
 
 
 class C6Error(RuntimeError):
@@ -45,7 +47,7 @@ class Config(C.Structure):
                 ("dirichlet_alpha", C.c_double), ("c_puct", C.c_float), ("seed", C.c_uint64),
                 ("game_uid_base", C.c_uint32), ("game_uid_stride", C.c_uint32), ("evaluator", C.c_int),
                 ("net_channels", C.c_int), ("net_blocks", C.c_int), ("records_per_game", C.c_int), ("recycle", C.c_int),
-                ("stagger", C.c_int), ("device", C.c_int), ("net_chunk_boards", C.c_int)]
+                ("stagger", C.c_int), ("device", C.c_int), ("net_chunk_boards", C.c_int), ("net_precision", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -136,6 +138,8 @@ def lib():
     L.c6_recover8.argtypes = [C.c_int, C.c_int, i8p, f32p, f32p, f32p, f32p]
     L.c6_net_forward.argtypes = [C.c_int, C.c_int, C.c_int, f32p, C.c_size_t, C.c_int, i8p, i8p, f32p, f32p]
     L.c6_dirichlet_noise.argtypes = [C.c_int, C.c_int, C.c_double, u32p, u32p, u32p, u32p, i8p, f32p]
+    L.c6_net_forward_prec.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_size_t, C.c_int, i8p, i8p, f32p, f32p]
+    L.c6_bench_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)]
     L.cpp_self_play.restype = Vec
     L.cpp_self_play.argtypes = [CALLBACK, ALLOC_PATH, ALLOC_RESULT, C.c_int, C.c_float, C.c_double, C.c_float, C.c_bool, C.c_int]
     L.cpp_play.restype = Vec
@@ -255,7 +259,7 @@ class Engine:
 
     def __init__(self, board_size=15, num_games=1, num_simulation=800, epsilon=0.25, dirichlet_alpha=0.03, c_puct=1.0,
                  seed=0, evaluator=EVAL_RANDOM, net_channels=256, net_blocks=10, records_per_game=0, recycle=False,
-                 stagger=False, device=0, game_uid_base=0, game_uid_stride=0, net_chunk_boards=0):
+                 stagger=False, device=0, game_uid_base=0, game_uid_stride=0, net_chunk_boards=0, net_precision=PREC_DEFAULT):
         L = lib()
         cfg = Config()
         L.c6_default_config(C.byref(cfg))
@@ -264,6 +268,7 @@ class Engine:
         cfg.evaluator, cfg.net_channels, cfg.net_blocks = evaluator, net_channels, net_blocks
         cfg.records_per_game, cfg.recycle, cfg.stagger, cfg.device = records_per_game, int(recycle), int(stagger), device
         cfg.game_uid_base, cfg.game_uid_stride, cfg.net_chunk_boards = game_uid_base, game_uid_stride, net_chunk_boards
+        cfg.net_precision = net_precision
         self.cfg = cfg
         self.n, self.cells, self.G = board_size, board_size * board_size, num_games
         self.h = C.c_void_p()
@@ -436,15 +441,22 @@ def recover8(n, boards, values8, policies8):
     return val, pri
 
 
-def net_forward(n, channels, blocks, blob, boards, player):
+def net_forward(n, channels, blocks, blob, boards, player, precision=PREC_DEFAULT):
     blob = np.ascontiguousarray(blob, dtype=np.float32)
     b = np.ascontiguousarray(boards, dtype=np.int8).reshape(-1, n * n)
     pl = np.ascontiguousarray(np.broadcast_to(np.asarray(player, dtype=np.int8), (b.shape[0],)))
     pol = np.zeros((b.shape[0], n * n), np.float32)
     val = np.zeros(b.shape[0], np.float32)
-    _chk(lib().c6_net_forward(n, channels, blocks, _p(blob, C.c_float), blob.size, b.shape[0], _p(b, C.c_int8), _p(pl, C.c_int8),
-                              _p(pol, C.c_float), _p(val, C.c_float)))
+    _chk(lib().c6_net_forward_prec(n, channels, blocks, precision, _p(blob, C.c_float), blob.size, b.shape[0], _p(b, C.c_int8),
+                                   _p(pl, C.c_int8), _p(pol, C.c_float), _p(val, C.c_float)))
     return pol, val
+
+
+def bench_conv(n, channels, nboards, iters=3, variant=1, ablate=0, with_residual=0):
+    """average ms of one 3x3 conv launch on random data (development / profiling hook)"""
+    ms = C.c_double()
+    _chk(lib().c6_bench_conv(n, channels, nboards, iters, variant, ablate, with_residual, C.byref(ms)))
+    return ms.value
 
 
 def dirichlet_noise(n, alpha, k0, k1, search, depth, boards):

@@ -123,6 +123,7 @@ struct C6NetDev {
     int num_cus;
     const float *conv_w;  // [(blocks-1)*2][packed 9*C*C]
     const float *conv_w2; // same weights packed for conv v2
+    const unsigned short *conv_w3; // same weights split into bf16 hi/mid planes (conv_bf16x3.hip)
     const float *conv_b;  // [(blocks-1)*2][C]
     const float *pc_w;    // [2][C] folded
     const float *pc_b;    // [2]
@@ -146,5 +147,9 @@ size_t c6_conv_packed_floats(int C);
 void c6_pack_conv_weights_v2(int C, const float *w_oihw_folded, float *packed);
 bool c6_conv_v2_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                          int num_cus, hipStream_t s);
+size_t c6_conv_packed_b3_units(int C);
+void c6_pack_conv_weights_b3(int C, const float *w_oihw_folded, unsigned short *packed);
+bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
+                         float *out, hipStream_t s);
 #define C6_ACT_SLACK 1024   // floats of slack behind every activation buffer (conv v2's last DMA piece over-reads < 1 KiB)
 void c6_pack_conv_weights(int C, const float *w_oihw_folded, float *packed);

@@ -161,7 +161,7 @@ template <typename T> static int upload(DevPool &pool, const std::vector<T> &h, 
 }
 
 // blob layout: AlphaZero/cpp_weighted/model.hpp:10-50 registration order, PyTorch layouts
-static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t nfloats) {
+static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t nfloats, int precision = C6_PREC_DEFAULT) {
     if (C != 64 && C != 128 && C != 256) return fail(C6_ERR_BAD_ARG, "net_channels must be 64, 128 or 256");
     if (nb < 1) return fail(C6_ERR_BAD_ARG, "net_blocks must be >= 1");
     if (nfloats != c6_net_blob_floats(n, C, nb)) return fail(C6_ERR_BAD_ARG, "weight blob has the wrong size");
@@ -175,9 +175,10 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
     {
         // A/B switch.  1 = c6_conv3x3_kernel (32x32x2 tiles, NHWC; the faster one: 129 vs 119 TFLOP/s on MI355X),
         // 2 = c6_conv3x3_v2_kernel (16x16x4 tiles, slice-major activations; experimental)
+        // 3 = c6_conv3x3_bf16x3_kernel (split bf16 products, fp32 accumulate; 440 TFLOP/s algorithmic) -- the default
         const char *v = std::getenv("C6_CONV_VARIANT");
-        d.variant = v ? std::atoi(v) : 1;
-        if (d.variant != 2) d.variant = 1;
+        d.variant = precision == C6_PREC_FP32 ? 1 : precision == C6_PREC_BF16X3 ? 3 : (v ? std::atoi(v) : 3);
+        if (d.variant != 1 && d.variant != 2) d.variant = 3;
         hipDeviceProp_t prop;
         int dev = 0;
         hipGetDevice(&dev);
@@ -200,6 +201,8 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         const int L = 2 * (nb - 1);
         const size_t wsz = c6_conv_packed_floats(C);
         std::vector<float> cw((size_t)std::max(L, 1) * wsz), cw2((size_t)std::max(L, 1) * wsz), cb((size_t)std::max(L, 1) * C), folded((size_t)C * C * 9);
+        const size_t w3 = c6_conv_packed_b3_units(C);
+        std::vector<unsigned short> cw3((size_t)std::max(L, 1) * w3);
         for (int l = 0; l < L; l++) {
             const float *w = take((size_t)C * C * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
             for (int co = 0; co < C; co++) {
@@ -209,9 +212,12 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
             }
             c6_pack_conv_weights(C, folded.data(), cw.data() + (size_t)l * wsz);
             c6_pack_conv_weights_v2(C, folded.data(), cw2.data() + (size_t)l * wsz);
+            c6_pack_conv_weights_b3(C, folded.data(), cw3.data() + (size_t)l * w3);
         }
         int rc;
-        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cb, &d.conv_b))) return rc;
+        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) ||
+            (rc = upload(nh.pool, cb, &d.conv_b)))
+            return rc;
     }
     {   // policy head
         const float *w = take((size_t)2 * C), *b = take(2), *bn = take(8);
@@ -424,7 +430,7 @@ extern "C" void c6_engine_destroy(c6_engine *e) {
 extern "C" int c6_engine_load_weights(c6_engine *e, const float *blob, size_t nfloats) {
     if (!e || !blob) return fail(C6_ERR_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
-    return net_load(e->net, e->cfg.board_size, e->cfg.net_channels, e->cfg.net_blocks, blob, nfloats);
+    return net_load(e->net, e->cfg.board_size, e->cfg.net_channels, e->cfg.net_blocks, blob, nfloats, e->cfg.net_precision);
 }
 
 extern "C" int c6_engine_set_callback(c6_engine *e, c6_callback cb) {
@@ -882,13 +888,19 @@ extern "C" int c6_dirichlet_noise(int n, int num, double alpha, const uint32_t *
     return C6_OK;
 }
 
+extern "C" int c6_net_forward_prec(int n, int C, int blocks, int precision, const float *blob, size_t nfloats, int num,
+                                   const int8_t *boards, const int8_t *player, float *policy, float *value);
 extern "C" int c6_net_forward(int n, int C, int blocks, const float *blob, size_t nfloats, int num, const int8_t *boards,
                               const int8_t *player, float *policy, float *value) {
+    return c6_net_forward_prec(n, C, blocks, C6_PREC_DEFAULT, blob, nfloats, num, boards, player, policy, value);
+}
+extern "C" int c6_net_forward_prec(int n, int C, int blocks, int precision, const float *blob, size_t nfloats, int num,
+                                   const int8_t *boards, const int8_t *player, float *policy, float *value) {
     int rc = check_n(n); if (rc) return rc;
     rc = require_gpu(0); if (rc) return rc;
     const int cells = n * n;
     NetHost nh;
-    rc = net_load(nh, n, C, blocks, blob, nfloats);
+    rc = net_load(nh, n, C, blocks, blob, nfloats, precision);
     if (rc) { nh.pool.release(); return rc; }
     std::vector<int16_t> aug, rec;
     build_maps(n, aug, rec);

@@ -6,7 +6,10 @@
 
 Workload at every N (weak scaling: per-GPU work fixed): BASELINE.json configs[1] --
 4096 concurrent 19x19 games per GPU, 400 simulations/move, random-init policy/value net with
-"4 blocks" = stem + 3 residual blocks, C = 256, FP32 (parity tolerance 1e-5 forces FP32 MFMA).
+"4 blocks" = stem + 3 residual blocks, C = 256.  The 3x3 convolutions run either as exact-FP32 MFMAs or as the
+bf16x3 split (f32 operands split into bf16 hi+mid, three bf16 MFMAs per product, f32 accumulation); both paths
+hold the net outputs to the 1e-5 parity bar (tests/test_gpu_net.py).  The headline `value` is the split path
+(--precision bf16x3, default); the exact-FP32 path is measured in the same run and reported as `fp32_path`.
 
 A "step" is one simulation ROUND: every live game performs one search() (select -> 8 dihedral
 net evaluations -> expand -> one-level backup); game phases are staggered, so each round
@@ -35,6 +38,7 @@ WORKLOADS = {
     "config5": dict(n=9, games=32768, sims=100, blocks=0, channels=0, evaluator="uniform", stones=68.0),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -119,6 +123,10 @@ def main():
     ap.add_argument("--games", type=int, default=0, help="override games per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="arithmetic of the 3x3 convolutions for the headline value; the other one is measured too and reported "
+                         "beside it (fp32_path / bf16x3_path) unless --single-precision")
+    ap.add_argument("--single-precision", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to "
                     "exercise the N > 1 path on a 1-GPU box together with C6_BENCH_SHARE_GPU=1)")
     args = ap.parse_args()
@@ -153,70 +161,102 @@ def main():
     n, G, S = wl["n"], wl["games"], wl["sims"]
     uid_base, uid_stride = shard.uid_plan(G, world, rank)
     ev = {"net": pkg.EVAL_NET, "uniform": pkg.EVAL_UNIFORM, "random": pkg.EVAL_RANDOM}[wl["evaluator"]]
-    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=2024, evaluator=ev, net_channels=max(wl["channels"], 64),
-                     net_blocks=max(wl["blocks"], 1), recycle=True, stagger=True, device=local_rank, game_uid_base=uid_base,
-                     game_uid_stride=uid_stride)
-    if ev == pkg.EVAL_NET:
-        import __graft_entry__ as ge
-        eng.load_weights(ge.make_random_blob(n, wl["channels"], wl["blocks"], np.random.default_rng(0)))
-    # training tuples go to a torch-owned device buffer that the all-gather reads in place
     stride = pkg.lib().c6_tuple_stride(n)
     cap = 4096
-    tbuf = torch.zeros((cap, stride), dtype=torch.uint8, device="cuda")
-    tcount = torch.zeros(1, dtype=torch.int32, device="cuda")
-    eng.set_tuple_buffer(tbuf.data_ptr(), cap, tcount.data_ptr())
-    pooled_tuples = 0
-
-    def run_rounds(k):
-        nonlocal pooled_tuples
-        if world == 1:
-            eng.step(k)
-            eng.sync()
-            return
-        for _ in range(k):
-            eng.step(1)
-            eng.sync()
-            if args.backend == "nccl":
-                pooled, counts = shard.gather_tuples(tbuf, tcount, world)     # RCCL all-gather over xGMI
-            else:
-                pooled, counts = shard.gather_tuples(tbuf.cpu(), tcount.cpu(), world)
-            pooled_tuples += int(counts.clamp(max=cap).sum().item())
-            tcount.zero_()
-            torch.cuda.current_stream().synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_rounds(args.warmup)
-    eng.profile(True)
-    eng.profile_read(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    run_rounds(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_read(reset=True)
-    eng.profile(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    st = eng.stats()
+    def measure(precision, steps, warmup):
+        """one engine, `warmup` untimed + `steps` timed rounds; returns (seconds, profile, stats, pooled tuples)"""
+        eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=2024, evaluator=ev, net_channels=max(wl["channels"], 64),
+                         net_blocks=max(wl["blocks"], 1), recycle=True, stagger=True, device=local_rank, game_uid_base=uid_base,
+                         game_uid_stride=uid_stride, net_precision=precision)
+        if ev == pkg.EVAL_NET:
+            import __graft_entry__ as ge
+            eng.load_weights(ge.make_random_blob(n, wl["channels"], wl["blocks"], np.random.default_rng(0)))
+        # training tuples go to a torch-owned device buffer that the all-gather reads in place
+        tbuf = torch.zeros((cap, stride), dtype=torch.uint8, device="cuda")
+        tcount = torch.zeros(1, dtype=torch.int32, device="cuda")
+        eng.set_tuple_buffer(tbuf.data_ptr(), cap, tcount.data_ptr())
+        pooled_tuples = 0
+
+        def run_rounds(k):
+            nonlocal pooled_tuples
+            if world == 1:
+                eng.step(k)
+                eng.sync()
+                return
+            for _ in range(k):
+                eng.step(1)
+                eng.sync()
+                if args.backend == "nccl":
+                    pooled, counts = shard.gather_tuples(tbuf, tcount, world)     # RCCL all-gather over xGMI
+                else:
+                    pooled, counts = shard.gather_tuples(tbuf.cpu(), tcount.cpu(), world)
+                pooled_tuples += int(counts.clamp(max=cap).sum().item())
+                tcount.zero_()
+                torch.cuda.current_stream().synchronize()
+
+        run_rounds(warmup)
+        eng.profile(True)
+        eng.profile_read(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        run_rounds(steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read(reset=True)
+        eng.profile(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        st = eng.stats()
+        eng.close()
+        del tbuf, tcount
+        torch.cuda.empty_cache()
+        return dt, prof, st, pooled_tuples
+
+    def conv_roofline(prof, dt, precision):
+        ach = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
+        if precision == pkg.PREC_FP32:
+            name, peak, note = "c6_conv3x3_kernel<256,3> (FP32 MFMA implicit GEMM, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, {}
+        else:
+            name, peak = "c6_conv3x3_bf16x3_kernel<256,3> (split-bf16 implicit GEMM, v_mfma_f32_32x32x16_bf16)", PEAK_BF16_MFMA_TFLOPS
+            note = {"mfma_flops_per_algorithmic_flop": 3, "executed_mfma_tflops": 3 * ach, "frac_executed": 3 * ach / peak}
+        r = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+             "traffic": pmc_traffic("bf16x3" if precision != pkg.PREC_FP32 else "c6_conv3x3_kernel") if args.workload == "config2" and not args.games else None,
+             "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
+             "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
+        r.update(note)
+        return r
+
+    prec = {"bf16x3": pkg.PREC_BF16X3, "fp32": pkg.PREC_FP32}[args.precision]
+    dt, prof, st, pooled_tuples = measure(prec, args.steps, args.warmup)
+    second = None
+    if ev == pkg.EVAL_NET and not args.single_precision:
+        other = pkg.PREC_FP32 if prec == pkg.PREC_BF16X3 else pkg.PREC_BF16X3
+        second = (other,) + measure(other, args.steps, args.warmup)
 
     if rank == 0:
-        rounds_s = args.steps / dt
-        sims_s = rounds_s * G * world
-        games_s = sims_s / (S * wl["stones"])
+        def line(dt_):
+            rounds_s = args.steps / dt_
+            sims = rounds_s * G * world
+            return sims, sims / (S * wl["stones"])
+        sims_s, games_s = line(dt)
+        dtype = ("bf16x3 (f32 operands split hi+mid in bf16, 3 bf16 MFMAs per product, f32 accumulate; net outputs within 1e-5)"
+                 if prec == pkg.PREC_BF16X3 else "f32") if ev == pkg.EVAL_NET else "f32/f64 (tree arithmetic), int8 boards"
         out = {
             "metric": "self-play games/sec at 400 sims/move, 19x19, 1/2/4/8 MI355X" if args.workload in ("config2", "config4")
                       else f"self-play games/sec ({args.workload})",
             "value": games_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (random-init weights, self-generated positions)",
+            "dtype": dtype, "data": "synthetic (random-init weights, self-generated positions)",
             "config": {"workload": f"{args.workload}: {G} concurrent {n}x{n} games per GPU, {S} sims/move, "
-                                   + (f"stem + {wl['blocks'] - 1} residual blocks, C={wl['channels']}, FP32" if ev == pkg.EVAL_NET else "on-device uniform evaluator"),
+                                   + (f"stem + {wl['blocks'] - 1} residual blocks, C={wl['channels']}" if ev == pkg.EVAL_NET else "on-device uniform evaluator"),
                        "games_per_gpu": G, "board": n, "num_simulation": S, "net_blocks": wl["blocks"], "net_channels": wl["channels"],
                        "stones_per_game": wl["stones"], "step": "one simulation round over all games (8 dihedral net evaluations per game), staggered move phases",
                        "parallelism": f"games sharded over {world} GPU(s), RCCL all-gather of training tuples per round" if world > 1 else "1 GPU"},
@@ -225,14 +265,15 @@ def main():
                        "overflow_games": st["overflow_games"], "stones": st["stones"], "tuples_pooled": pooled_tuples},
         }
         if ev == pkg.EVAL_NET and prof["conv_launches"]:
-            ach = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "c6_conv3x3_kernel<256,3> (FP32 MFMA implicit GEMM)", "achieved": ach,
-                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                               "traffic": pmc_traffic("c6_conv3x3_kernel") if args.workload == "config2" and not args.games else None,
-                               "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
-                               "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
-            fl = net_flops_per_board(n, wl["channels"], wl["blocks"]) * 8 * sims_s
-            out["net_tflops_end_to_end"] = fl / 1e12
+            out["roofline"] = conv_roofline(prof, dt, prec)
+            out["net_tflops_end_to_end"] = net_flops_per_board(n, wl["channels"], wl["blocks"]) * 8 * sims_s / 1e12
+            if second:
+                o_prec, o_dt, o_prof, o_st, _ = second
+                o_sims, o_games = line(o_dt)
+                key = "fp32_path" if o_prec == pkg.PREC_FP32 else "bf16x3_path"
+                out[key] = {"value": o_games, "unit": "games/s", "ms_per_step": 1000.0 * o_dt / args.steps, "sims_per_s": o_sims,
+                            "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact f32 products)" if o_prec == pkg.PREC_FP32 else "bf16x3",
+                            "roofline": conv_roofline(o_prof, o_dt, o_prec)}
         else:
             # tree-bound workload: algorithmic bytes per simulation, SURVEY 8d: (12*d + 13) * N^2
             d = st["select_steps"] / max(st["simulations"], 1)
@@ -245,7 +286,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -128,6 +128,14 @@ enum {
     C6_EVAL_CALLBACK = 4  /* host callback with the reference's signature */
 };
 
+/* arithmetic of the net's 3x3 convolutions.  Both hold the net outputs to the 1e-5 parity bar of the tests. */
+enum {
+    C6_PREC_DEFAULT = 0,  /* = C6_PREC_BF16X3 unless the environment sets C6_CONV_VARIANT */
+    C6_PREC_FP32 = 1,     /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate */
+    C6_PREC_BF16X3 = 3    /* operands split hi+mid in bf16, x_hi*w_hi + x_hi*w_mid + x_mid*w_hi on v_mfma_f32_32x32x16_bf16,
+                             f32 accumulate: error <= 3*2^-16 per product, 16x the FP32 matrix rate at 3 MFMAs per product */
+};
+
 /* policy/alphazero_policy/mod.rs:91-96 HyperParameter + engine geometry */
 typedef struct c6_config {
     int board_size;          /* 9, 15 or 19 */
@@ -148,6 +156,7 @@ typedef struct c6_config {
                                 already counted, so every round advances num_games/num_simulation games */
     int device;              /* HIP device ordinal */
     int net_chunk_boards;    /* 0: automatic; boards (dihedral images) per net pass */
+    int net_precision;       /* C6_PREC_*: arithmetic of the 3x3 convolutions (everything else is FP32) */
 } c6_config;
 
 typedef struct c6_engine c6_engine;
@@ -245,6 +254,12 @@ int c6_recover8(int board_size, int num, const int8_t *boards, const float *valu
 /* net forward (model.hpp:52-95) on `num` boards (int8, no augmentation) with per-board player */
 int c6_net_forward(int board_size, int channels, int blocks, const float *blob, size_t nfloats, int num,
                    const int8_t *boards, const int8_t *player, float *policy, float *value);
+/* same with an explicit C6_PREC_* */
+int c6_net_forward_prec(int board_size, int channels, int blocks, int precision, const float *blob, size_t nfloats, int num,
+                        const int8_t *boards, const int8_t *player, float *policy, float *value);
+/* development / profiling hook: average duration (ms) of `iters` launches of one 3x3 conv variant on random data
+ * (variant 1 = FP32 MFMA, 2 = experimental 16x16x4 kernel, 3 = bf16x3; ablate != 0 only for variant 1) */
+int c6_bench_conv(int board_size, int channels, int nboards, int iters, int variant, int ablate, int with_residual, double *avg_ms);
 /* C6RNG Dirichlet noise of select step (search, depth) for `num` boards (keys k0/k1 per board) */
 int c6_dirichlet_noise(int board_size, int num, double alpha, const uint32_t *k0, const uint32_t *k1,
                        const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise);

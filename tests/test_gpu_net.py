@@ -18,15 +18,19 @@ def rand_blob(n, C, blocks, seed):
     return ge.make_random_blob(n, C, blocks, np.random.default_rng(seed))
 
 
-@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 64, 3, 5), (19, 128, 2, 4), (19, 256, 2, 3), (9, 256, 4, 8)])
-def test_net_forward_vs_oracle(n, C, blocks, num):
+PRECISIONS = [pytest.param(1, id="fp32-mfma"), pytest.param(3, id="bf16x3-split")]
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 64, 3, 5), (19, 128, 2, 4), (19, 256, 2, 3), (9, 256, 4, 8), (19, 256, 4, 2)])
+def test_net_forward_vs_oracle(n, C, blocks, num, prec):
     need_gpu()
     rng = np.random.default_rng(n * 1000 + C)
     blob = rand_blob(n, C, blocks, seed=n + C + blocks)
     boards = rng.integers(-1, 2, size=(num, n * n)).astype(np.int8)
     boards[0] = 0
     player = rng.choice(np.array([-1, 1], np.int8), size=num)
-    pol, val = pkg.net_forward(n, C, blocks, blob, boards, player)
+    pol, val = pkg.net_forward(n, C, blocks, blob, boards, player, precision=prec)
     net = o.Net(n, C, blocks, blob)
     for i in range(num):
         rp, rv = net.forward(float(player[i]), boards[i].astype(np.float32))
@@ -36,20 +40,36 @@ def test_net_forward_vs_oracle(n, C, blocks, num):
     net.close()
 
 
-def test_net_forward_vs_torch_golden():
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_net_forward_vs_torch_golden(prec):
     need_gpu()
     z = np.load(os.path.join(GOLD, "net_golden_n9_c64_b3.npz"))
-    pol, val = pkg.net_forward(int(z["n"]), int(z["C"]), int(z["blocks"]), z["blob"], z["boards"], z["player"])
+    pol, val = pkg.net_forward(int(z["n"]), int(z["C"]), int(z["blocks"]), z["blob"], z["boards"], z["player"], precision=prec)
     assert np.abs(pol - z["policy"]).max() <= TOL and np.abs(val - z["value"]).max() <= TOL
 
 
-def test_engine_net_evaluator_matches_oracle_priors():
+def test_split_path_agrees_with_fp32_path_at_benchmark_shape():
+    """19x19, C = 256: the bf16x3 split path and the exact-FP32 MFMA path agree to the 1e-5 bar (the split error is
+    relative, <= 3 * 2^-16 per product, and shrinks by 1/sqrt(K) in the 2304-term sums)"""
+    need_gpu()
+    n, C, blocks = 19, 256, 3
+    blob = rand_blob(n, C, blocks, seed=77)
+    rng = np.random.default_rng(5)
+    boards = rng.integers(-1, 2, size=(3, n * n)).astype(np.int8)
+    ref = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=1)
+    got = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=3)
+    assert np.abs(ref[0] - got[0]).max() <= TOL and np.abs(ref[1] - got[1]).max() <= TOL
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_engine_net_evaluator_matches_oracle_priors(prec):
     """the evaluator path inside the engine (dihedral gather -> net -> recover -> mask) equals get_from
     (mod.rs:218-234) computed by the oracle with its own FP32 net, to 1e-5"""
     need_gpu()
     n, C, blocks = 9, 64, 2
     blob = rand_blob(n, C, blocks, seed=4)
-    eng = pkg.Engine(board_size=n, num_games=5, num_simulation=50, seed=1, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks)
+    eng = pkg.Engine(board_size=n, num_games=5, num_simulation=50, seed=1, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks,
+                     net_precision=prec)
     eng.load_weights(blob)
     eng.step(1)
     net = o.Net(n, C, blocks, blob)
