@@ -112,10 +112,24 @@ void c6o_net_free(c6o_net *net) {
  * extensions) so that the CPU baseline is a fair one; the arithmetic is the plain convolution sum. */
 typedef float v8f __attribute__((vector_size(32), aligned(4)));
 
-static void conv3_bn(const convbn *cb, int n, int cin, int cout, const float *in, const float *res, float *out) {
+/* per-thread scratch: the CPU baseline runs one game per core, and malloc/calloc of ~0.5 MB blocks (mmap + page faults)
+ * in every call serialises hundreds of threads in the kernel */
+static __thread float *tl_buf;
+static __thread size_t tl_cap;
+static float *scratch(size_t floats) {
+    if (floats > tl_cap) {
+        free(tl_buf);
+        tl_buf = (float *)malloc(sizeof(float) * floats);
+        tl_cap = floats;
+    }
+    return tl_buf;
+}
+
+static void conv3_bn(const convbn *cb, int n, int cin, int cout, const float *in, const float *res, float *out, float *pad) {
     const int P = n + 2;
-    /* zero-haloed copy of the input: taps become constant offsets */
-    float *pad = (float *)calloc(((size_t)P * P + 8) * cin, sizeof(float));   /* + slack: the last micro-tile over-reads */
+    /* zero-haloed copy of the input: taps become constant offsets (pad has (P*P + 8) * cin floats: the last
+     * micro-tile over-reads a little) */
+    memset(pad, 0, sizeof(float) * ((size_t)P * P + 8) * (size_t)cin);
     for (int y = 0; y < n; y++)
         memcpy(pad + ((size_t)(y + 1) * P + 1) * cin, in + (size_t)y * n * cin, sizeof(float) * (size_t)n * cin);
     float scale[512], shift[512];
@@ -158,26 +172,23 @@ static void conv3_bn(const convbn *cb, int n, int cin, int cout, const float *in
                 }
             }
         }
-    free(pad);
 }
 
 void c6o_net_forward(const c6o_net *net, float player, const float *boards, int len, float *policy, float *value) {
     int n = net->n, cells = net->cells, C = net->C;
-    float *x = (float *)malloc(sizeof(float) * (size_t)cells * C);
-    float *y = (float *)malloc(sizeof(float) * (size_t)cells * C);
-    float *z = (float *)malloc(sizeof(float) * (size_t)cells * C);
-    float *in2 = (float *)malloc(sizeof(float) * (size_t)cells * 2);
-    float *ph = (float *)malloc(sizeof(float) * (size_t)cells * 2);
-    float *vh = (float *)malloc(sizeof(float) * (size_t)cells);
+    const size_t act = (size_t)cells * C, padf = ((size_t)(n + 2) * (n + 2) + 8) * (size_t)C;
+    float *base = scratch(3 * act + padf + (size_t)cells * 5 + 64);
+    float *x = base, *y = x + act, *z = y + act, *pad = z + act;
+    float *in2 = pad + padf, *ph = in2 + (size_t)cells * 2, *vh = ph + (size_t)cells * 2;
     float hid[VHID];
     for (int b = 0; b < len; b++) {
         const float *bd = boards + (size_t)b * cells;
         /* model.hpp:56-57: planes [player broadcast, board] */
         for (int i = 0; i < cells; i++) { in2[2 * i] = player; in2[2 * i + 1] = bd[i]; }
-        conv3_bn(&net->stem, n, 2, C, in2, NULL, x);
+        conv3_bn(&net->stem, n, 2, C, in2, NULL, x, pad);
         for (int i = 0; i < net->nb - 1; i++) { /* res_block :61-78 */
-            conv3_bn(&net->tower[2 * i], n, C, C, x, NULL, y);
-            conv3_bn(&net->tower[2 * i + 1], n, C, C, y, x, z);
+            conv3_bn(&net->tower[2 * i], n, C, C, x, NULL, y, pad);
+            conv3_bn(&net->tower[2 * i + 1], n, C, C, y, x, z, pad);
             float *t = x; x = z; z = t;
         }
         /* policy head :80-84 (flatten is channel-major: NCHW view) */
@@ -221,16 +232,17 @@ void c6o_net_forward(const c6o_net *net, float player, const float *boards, int 
         for (int h = 0; h < VHID; h++) a += hid[h] * net->v2_w[h];
         value[b] = tanhf(a);
     }
-    free(x); free(y); free(z); free(in2); free(ph); free(vh);
 }
 
 /* evaluator glue, AlphaZero/cpp_weighted/main.cpp:16-37 */
 int c6o_net_eval(void *ctx, int turn, int n, int len, const int8_t *boards, float *values, float *policies) {
     const c6o_net *net = (const c6o_net *)ctx;
     int cells = n * n;
-    float *bf = (float *)malloc(sizeof(float) * (size_t)len * cells);
-    for (int i = 0; i < len * cells; i++) bf[i] = (float)boards[i];
-    c6o_net_forward(net, (float)turn, bf, len, policies, values);
-    free(bf);
+    float bf[8 * C6O_MAXCELLS];
+    for (int done = 0; done < len; done += 8) {   /* the reference always evaluates 8 images (mod.rs:218-234) */
+        const int m = len - done < 8 ? len - done : 8;
+        for (int i = 0; i < m * cells; i++) bf[i] = (float)boards[(size_t)done * cells + i];
+        c6o_net_forward(net, (float)turn, bf, m, policies + (size_t)done * cells, values + done);
+    }
     return 0;
 }
