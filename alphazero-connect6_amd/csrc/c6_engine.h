@@ -151,5 +151,7 @@ size_t c6_conv_packed_b3_units(int C);
 void c6_pack_conv_weights_b3(int C, const float *w_oihw_folded, unsigned short *packed);
 bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                          float *out, hipStream_t s);
+void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
+                       float *out, hipStream_t s);
 #define C6_ACT_SLACK 1024   // floats of slack behind every activation buffer (conv v2's last DMA piece over-reads < 1 KiB)
 void c6_pack_conv_weights(int C, const float *w_oihw_folded, float *packed);

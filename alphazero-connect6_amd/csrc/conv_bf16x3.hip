@@ -22,7 +22,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define B3_THREADS 512
 #define B3_SLOT 72          // ushort (2-byte) units per LDS pixel slot: 32 hi + 32 mid + 8 pad  (144 bytes)
 
-template <int C, int MTW>
+// ABL: ablation switch used only by c6_bench_conv (0 = the product kernel): 1 no weight DMA, 2 no input staging,
+//      3 neither and no barriers, 5 no epilogue stores (accumulators kept alive)
+template <int C, int MTW, int ABL = 0>
 __global__ __launch_bounds__(B3_THREADS) void c6_conv3x3_bf16x3_kernel(const float *__restrict__ in, const unsigned short *__restrict__ wp,
                                                                        const float *__restrict__ bias, const float *__restrict__ res,
                                                                        float *__restrict__ out, int N) {
@@ -68,29 +70,47 @@ __global__ __launch_bounds__(B3_THREADS) void c6_conv3x3_bf16x3_kernel(const flo
                                              (__attribute__((address_space(3))) void *)(dst + pc * 512), 16, 0, 0);
     };
 
-    dma_w(0, 0);
+    if (ABL != 1 && ABL != 3) dma_w(0, 0);
     for (int ks = 0; ks < KS; ks++) {
-        __syncthreads();
-        // stage + split the 32-channel input slice: x -> hi = bf16(x), mid = bf16(x - hi)
-        for (int item = tid; item < cells * 8; item += B3_THREADS) {
-            const int p = item >> 3, q = item & 7;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(inb + (size_t)p * C + ks * 32 + q * 4);
-            bf16x4 hi, mid;
+        if (ABL != 3) __syncthreads();
+        // stage + split the 32-channel input slice: x -> hi = bf16(x), mid = bf16(x - hi).  The loads of a thread go out in
+        // batches of SB before the first conversion of the batch: ceil(6 / SB) HBM round trips per slice instead of 6.
+        if (ABL != 2 && ABL != 3) {
+            constexpr int SB = 3;
+#pragma unroll 1
+            for (int k0 = 0; k0 < 6; k0 += SB) {
+                f32x4 v[SB];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                hi[r] = (__bf16)v[r];
-                mid[r] = (__bf16)(v[r] - (float)hi[r]);
+                for (int k = 0; k < SB; k++) {
+                    // unconditional loads (clamped): a branch around each load would make hipcc wait vmcnt(0) per element
+                    int item = tid + (k0 + k) * B3_THREADS;
+                    item = item < cells * 8 ? item : cells * 8 - 1;
+                    v[k] = *reinterpret_cast<const f32x4 *>(inb + (size_t)(item >> 3) * C + ks * 32 + (item & 7) * 4);
+                }
+#pragma unroll
+                for (int k = 0; k < SB; k++) {
+                    const int item = tid + (k0 + k) * B3_THREADS;
+                    if (item < cells * 8) {
+                        const int p = item >> 3, q = item & 7;
+                        bf16x4 hi, mid;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            hi[r] = (__bf16)v[k][r];
+                            mid[r] = (__bf16)(v[k][r] - (float)hi[r]);
+                        }
+                        unsigned short *dst = lds_in + ((p / N + 1) * P + (p % N + 1)) * B3_SLOT + q * 4;
+                        *reinterpret_cast<bf16x4 *>(dst) = hi;
+                        *reinterpret_cast<bf16x4 *>(dst + 32) = mid;
+                    }
+                }
             }
-            unsigned short *dst = lds_in + ((p / N + 1) * P + (p % N + 1)) * B3_SLOT + q * 4;
-            *reinterpret_cast<bf16x4 *>(dst) = hi;
-            *reinterpret_cast<bf16x4 *>(dst + 32) = mid;
         }
 #pragma unroll 1
         for (int tap = 0; tap < 9; tap++) {
             const int stage = ks * 9 + tap, buf = stage & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (stage + 1 < KS * 9) dma_w(stage + 1, buf ^ 1);
+            if (ABL != 3) __syncthreads();
+            if (ABL != 1 && ABL != 3) if (stage + 1 < KS * 9) dma_w(stage + 1, buf ^ 1);
             const int toff = ((tap / 3 - 1) * P + (tap % 3 - 1)) * B3_SLOT;
             const unsigned short *wb = lds_w + buf * WSTAGE;
 #pragma unroll
@@ -118,6 +138,17 @@ __global__ __launch_bounds__(B3_THREADS) void c6_conv3x3_bf16x3_kernel(const flo
         }
     }
 
+    if (ABL == 5) {   // keep the accumulators alive without the store traffic
+        float sum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) sum += acc[mt][nt][v];
+        if (sum == 123.456f) out[tid] = sum;
+        return;
+    }
     // epilogue: transpose each 32x32 tile through a wave-private LDS patch -> 16-byte residual loads / stores
     __syncthreads();
     constexpr int PSTR = 36;
@@ -198,6 +229,16 @@ static void launch_b3(int MTW, int nboards, size_t smem, const float *in, const 
         break;
     switch (MTW) { B3CASE(1) B3CASE(2) default: B3CASE(3) }
 #undef B3CASE
+}
+
+void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
+                       float *out, hipStream_t s) {
+    const int N = 19, P = N + 2, C = 256;
+    const size_t smem = ((size_t)((P * P * B3_SLOT + 7) & ~7) + 2 * (size_t)(2 * 2 * 2 * C * 8)) * sizeof(unsigned short);
+#define B3ABL(A) case A: hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_bf16x3_kernel<256, 3, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((c6_conv3x3_bf16x3_kernel<256, 3, A>), dim3(nboards), dim3(B3_THREADS), smem, s, in, wp, bias, res, out, N); break;
+    switch (ablate) { B3ABL(1) B3ABL(2) B3ABL(3) B3ABL(5) default: break; }
+#undef B3ABL
 }
 
 bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,

@@ -209,24 +209,36 @@ __global__ __launch_bounds__(256) void c6_stem_kernel(const int8_t *__restrict__
         bd[s] = (float)board[aug_map[k * cells + c]];
     }
     __syncthreads();
-    const int co = threadIdx.x % C, psub = threadIdx.x / C, PP = 256 / C;
-    float w0[9], w1[9];
+    // a thread owns 4 consecutive output channels (16-byte stores, 1 KiB per wave-instruction) and strides over pixels
+    const int CQ = C / 4;
+    const int cq = threadIdx.x % CQ, psub = threadIdx.x / CQ, PP = 256 / CQ;
+    const int co = cq * 4;
+    f32x4 w0[9], w1[9];
 #pragma unroll
-    for (int t = 0; t < 9; t++) { w0[t] = w[(t * 2 + 0) * C + co]; w1[t] = w[(t * 2 + 1) * C + co]; }
-    const float bi = bias[co];
+    for (int t = 0; t < 9; t++) {
+        w0[t] = *reinterpret_cast<const f32x4 *>(w + (t * 2 + 0) * C + co);
+        w1[t] = *reinterpret_cast<const f32x4 *>(w + (t * 2 + 1) * C + co);
+    }
+    const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + co);
     float *ob = out + b * (size_t)cells * C;
     for (int p = psub; p < cells; p += PP) {
         const int s = (p / N + 1) * P + (p % N + 1);
-        float acc = bi;
+        f32x4 acc = bi;
 #pragma unroll
         for (int t = 0; t < 9; t++) {
             const int o = s + (t / 3 - 1) * P + (t % 3 - 1);
-            acc = __builtin_fmaf(w0[t], pl[o], acc);
-            acc = __builtin_fmaf(w1[t], bd[o], acc);
+            const float pv2 = pl[o], bv = bd[o];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[r] = __builtin_fmaf(w0[t][r], pv2, acc[r]);
+                acc[r] = __builtin_fmaf(w1[t][r], bv, acc[r]);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
         // NHWC, or slice-major S32 = [C/32][pixel][32] (conv_v2.hip)
         const size_t o = s32 ? ((size_t)(co >> 5) * cells + p) * 32 + (co & 31) : (size_t)p * C + co;
-        ob[o] = acc > 0.f ? acc : 0.f;
+        *reinterpret_cast<f32x4 *>(ob + o) = acc;
     }
 }
 
@@ -474,6 +486,7 @@ void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches,
 void c6_conv_bench_launch(int variant, int ablate, int C, int N, int nboards, const float *in, const float *w1, const float *w2,
                           const float *bias, const float *res, float *out, int num_cus, hipStream_t s) {
     if (variant == 2) { c6_conv_v2_dispatch(C, N, nboards, in, w2, bias, res, out, num_cus, s); return; }
+    if (variant == 3 && ablate != 0 && C == 256 && N == 19) { c6_conv_b3_ablate(ablate, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, s); return; }
     if (variant == 3) { c6_conv_b3_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, s); return; }
     if (C != 256 || N != 19 || ablate == 0) { conv_dispatch(C, N, nboards, in, w1, bias, res, out, s); return; }
     const int P = N + 2;
