@@ -124,6 +124,7 @@ struct C6NetDev {
     const float *conv_w;  // [(blocks-1)*2][packed 9*C*C]
     const float *conv_w2; // same weights packed for conv v2
     const unsigned short *conv_w3; // same weights split into bf16 hi/mid planes (conv_bf16x3.hip)
+    const unsigned short *conv_w6; // split planes packed per wave (c6_conv3x3_b3n_kernel)
     const float *conv_b;  // [(blocks-1)*2][C]
     const float *pc_w;    // [2][C] folded
     const float *pc_b;    // [2]
@@ -151,6 +152,10 @@ size_t c6_conv_packed_b3_units(int C);
 void c6_pack_conv_weights_b3(int C, const float *w_oihw_folded, unsigned short *packed);
 bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                          float *out, hipStream_t s);
+size_t c6_conv_packed_b3n_units(int C);
+void c6_pack_conv_weights_b3n(int C, const float *w_oihw_folded, unsigned short *packed);
+bool c6_conv_b3n_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
+                          float *out, int num_cus, hipStream_t s);
 void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                        float *out, hipStream_t s);
 #define C6_ACT_SLACK 1024   // floats of slack behind every activation buffer (conv v2's last DMA piece over-reads < 1 KiB)

@@ -183,6 +183,195 @@ __global__ __launch_bounds__(B3_THREADS) void c6_conv3x3_bf16x3_kernel(const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "N-split" variant (c6_conv3x3_b3n_kernel): wave w owns output channels [32w, 32w+32) for EVERY pixel of the board.
+//  * its weights are private -> they stream L2 -> VGPR (one 16-byte load per 16-deep step and plane, prefetched one step
+//    ahead); no weight staging in LDS, hence NO per-tap barrier: one barrier per 32-channel slice (8 per board, not 72);
+//  * the LDS that the weight stages occupied holds a second input buffer: the next slice is loaded, split and written in
+//    small portions behind the MFMAs of the current one (no synchronous staging phase);
+//  * M runs over a 20-wide row grid (x = 19 is the zero column shared with the next row's x = -1), so that a pixel's LDS
+//    slot is linear in m: every A address is  base(lane) + immediate(m-tile, tap, k).  19*20 = 380 -> 12 tiles of 32
+//    rows, the same 384 rows the other kernels pad to.
+// ------------------------------------------------------------------------------------------------------------------
+template <int C, int N>
+struct B3NGeom {
+    static constexpr int W = N + 1;                        // row stride in slots
+    static constexpr int MROWS = N * W;                    // m = y*W + x, x == N is junk
+    static constexpr int MT = (MROWS + 31) / 32;
+    static constexpr int SLOTS = ((MT * 32 + 2 * W + 2 + 1) + 7) & ~7;   // every tap of every (junk) row stays inside
+    static constexpr int IN_UNITS = SLOTS * B3_SLOT;       // ushorts per input buffer
+    static constexpr int WAVES = C / 32;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr size_t LDS_BYTES = (size_t)2 * IN_UNITS * 2 + (size_t)WAVES * 32 * 36 * 4;   // + epilogue patches
+};
+
+template <int C, int N>
+__global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3n_kernel(const float *__restrict__ in, const unsigned short *__restrict__ wp,
+                                                                       const float *__restrict__ bias, const float *__restrict__ res,
+                                                                       float *__restrict__ out, int nboards) {
+    using G = B3NGeom<C, N>;
+    constexpr int W = G::W, MT = G::MT, KS = C / 32, THREADS = G::THREADS, WAVES = G::WAVES, CELLS = N * N;
+    constexpr int MG = 1;                                  // m-tiles whose A fragments are live at once (x2: double-buffered)
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short *lds0 = smem16;                         // two input buffers, then the epilogue patches
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    // persistent: this workgroup walks boards b0, b0 + grid, ...; no workgroup turnover (whose store drain and relaunch
+    // left the CU's wave slots empty ~20 % of the time), and the next board's first slice streams in behind the last
+    // slice of the current one.  Slices are numbered gs = local_board * KS + ks; slice gs lives in buffer gs & 1.
+    const int b0 = blockIdx.x, bstep = gridDim.x;
+    const int nlocal = b0 < nboards ? (nboards - b0 + bstep - 1) / bstep : 0;
+    const int total = nlocal * KS;
+
+    for (int k = tid; k < G::IN_UNITS; k += THREADS) reinterpret_cast<uint32_t *>(lds0)[k] = 0u;   // both buffers, halo = 0
+
+    auto item_load = [&](const float *slice /* board base + ks*32 */, int k) -> f32x4 {
+        int item = tid + k * THREADS;
+        item = item < CELLS * 8 ? item : CELLS * 8 - 1;
+        return *reinterpret_cast<const f32x4 *>(slice + (size_t)(item >> 3) * C + (item & 7) * 4);
+    };
+    auto item_store = [&](unsigned short *buf, int k, f32x4 v) {
+        const int item = tid + k * THREADS;
+        if (item < CELLS * 8) {
+            const int p = item >> 3, q = item & 7;
+            bf16x4 hi, mid;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                hi[r] = (__bf16)v[r];
+                mid[r] = (__bf16)(v[r] - (float)hi[r]);
+            }
+            unsigned short *dst = buf + ((p / N + 1) * W + (p % N + 1)) * B3_SLOT + q * 4;
+            *reinterpret_cast<bf16x4 *>(dst) = hi;
+            *reinterpret_cast<bf16x4 *>(dst + 32) = mid;
+        }
+    };
+    constexpr int NITEM = (CELLS * 8 + THREADS - 1) / THREADS;   // staging items per thread and slice
+    constexpr int IPS = (NITEM + 5) / 6;                         // items per trickle step (6 steps of 3 sub-stages per slice)
+
+    // weights of this wave: [stage = ks*9 + tap][wave][g][plane][lane][8]
+    auto wptr = [&](int stage, int g, int plane) -> const bf16x8 * {
+        return reinterpret_cast<const bf16x8 *>(wp + ((((size_t)stage * WAVES + wave) * 2 + g) * 2 + plane) * 512) + lane;
+    };
+
+    if (total == 0) return;
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < NITEM; k++) item_store(lds0, k, item_load(in + (size_t)b0 * (size_t)(CELLS * C), k));   // very first slice
+    bf16x8 bhi = *wptr(0, 0, 0), bmid = *wptr(0, 0, 1);
+    f32x4 pend[IPS];
+#pragma unroll
+    for (int q = 0; q < IPS; q++) pend[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int lb = 0; lb < nlocal; lb++) {
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[mt][v] = 0.f;
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks++) {
+        const int gs = lb * KS + ks;
+        __syncthreads();   // slice gs complete in its buffer; everybody has left the other buffer
+        const unsigned short *lds_in = lds0 + (gs & 1) * G::IN_UNITS;
+        unsigned short *lds_nx = lds0 + ((gs + 1) & 1) * G::IN_UNITS;
+        const bool more = gs + 1 < total;
+        // where the next slice comes from: same board, next 32 channels -- or the next board's first slice
+        const float *nslice = in + (size_t)(b0 + (ks + 1 < KS ? lb : lb + 1) * bstep) * (size_t)(CELLS * C) + (ks + 1 < KS ? (ks + 1) * 32 : 0);
+        int abase = i * B3_SLOT + 8 * h;                     // tap 0 = top-left neighbour of row m = i
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                // prefetch the weights of the next 16-deep step (of the next board's first slice at a board boundary)
+                bf16x8 nhi = bhi, nmid = bmid;
+                {
+                    int ng = g + 1, ntap = tap, nks = ks;
+                    if (ng == 2) { ng = 0; ntap++; }
+                    if (ntap == 9) { ntap = 0; nks++; }
+                    if (nks == KS) nks = 0;      // wraps to the next board's first stage (one harmless extra load at the very end)
+                    nhi = *wptr(nks * 9 + ntap, ng, 0);
+                    nmid = *wptr(nks * 9 + ntap, ng, 1);
+                }
+                // the next input slice trickles in: item k is loaded at sub-stage 3k and split + written at 3k + 1
+                if (more) {
+                    const int sidx = tap * 2 + g, k = sidx / 3, ph = sidx % 3;
+                    if (ph == 0) {
+#pragma unroll
+                        for (int q = 0; q < IPS; q++) if (k * IPS + q < NITEM) pend[q] = item_load(nslice, k * IPS + q);
+                    } else if (ph == 1) {
+#pragma unroll
+                        for (int q = 0; q < IPS; q++) if (k * IPS + q < NITEM) item_store(lds_nx, k * IPS + q, pend[q]);
+                    }
+                }
+                // A fragments are double-buffered by hand: the reads of the next MG m-tiles are issued before the MFMAs of
+                // the current ones (sched_barrier keeps hipcc from serialising read -> wait -> MFMA on one register set)
+                bf16x8 ahi[2][MG], amid[2][MG];
+                auto load_a = [&](int slot, int m0) {
+#pragma unroll
+                    for (int q = 0; q < MG; q++)
+                        if (m0 + q < MT) {
+                            const unsigned short *ap = lds_in + abase + ((m0 + q) * 32) * B3_SLOT + g * 16;
+                            ahi[slot][q] = *reinterpret_cast<const bf16x8 *>(ap);
+                            amid[slot][q] = *reinterpret_cast<const bf16x8 *>(ap + 32);
+                        }
+                };
+                load_a(0, 0);
+#pragma unroll
+                for (int m0 = 0, sl = 0; m0 < MT; m0 += MG, sl ^= 1) {
+                    if (m0 + MG < MT) load_a(sl ^ 1, m0 + MG);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < MG; q++)
+                        if (m0 + q < MT) {
+                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid[sl][q], bhi, acc[m0 + q], 0, 0, 0);
+                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[sl][q], bmid, acc[m0 + q], 0, 0, 0);
+                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[sl][q], bhi, acc[m0 + q], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                bhi = nhi;
+                bmid = nmid;
+            }
+            abase += (tap % 3 == 2 ? W - 2 : 1) * B3_SLOT;   // next tap: +1 slot, or the start of the next row
+        }
+    }   // ks
+
+        // epilogue of this board: wave-private LDS patch (behind the input buffers) -> 16-byte residual loads / stores;
+        // rows are m = y*W + x, x == N is junk.  The stores drain behind the next board's first slice.
+        const size_t b = (size_t)(b0 + lb * bstep);
+        constexpr int PSTR = 36;
+        float *patch = reinterpret_cast<float *>(smem16 + 2 * G::IN_UNITS) + wave * (32 * PSTR);
+        float *outb = out + b * (size_t)CELLS * C;
+        const float *resb = res ? res + b * (size_t)CELLS * C : nullptr;
+        const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+        const int n4 = wave * 32 + c4;
+        const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + n4);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+            for (int v = 0; v < 16; v++) patch[((v & 3) + 8 * (v >> 2) + 4 * h) * PSTR + i] = acc[mt][v];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = j * 8 + r8;
+                const int m = mt * 32 + row, y = m / W, x = m % W;
+                f32x4 yv = *reinterpret_cast<const f32x4 *>(patch + row * PSTR + c4);
+                if (x < N && y < N) {
+                    const size_t o = (size_t)(y * N + x) * C + n4;
+                    yv = yv + bi;
+                    if (resb) yv = yv + *reinterpret_cast<const f32x4 *>(resb + o);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) yv[q] = yv[q] > 0.f ? yv[q] : 0.f;
+                    *reinterpret_cast<f32x4 *>(outb + o) = yv;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
 static inline unsigned short f32_to_bf16_rne(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -252,4 +441,49 @@ bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsig
     case 256: launch_b3<256>(MTW, nboards, smem, in, wp, bias, res, out, N, s); return true;
     default: return false;
     }
+}
+
+size_t c6_conv_packed_b3n_units(int C) { return (size_t)9 * (C / 32) * (C / 32) * 2 * 2 * 512; }
+
+// w: folded OIHW [C][C][3][3] -> [stage = ks*9 + tap][wave][g][plane][lane][j]
+//    value = split(W[n = wave*32 + (lane & 31)][k = ks*32 + g*16 + (lane >> 5)*8 + j][tap]), bf16 bits
+void c6_pack_conv_weights_b3n(int C, const float *w, unsigned short *packed) {
+    const int KS = C / 32, WAVES = C / 32;
+    for (int ks = 0; ks < KS; ks++)
+        for (int t = 0; t < 9; t++)
+            for (int wv = 0; wv < WAVES; wv++)
+                for (int g = 0; g < 2; g++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const int n = wv * 32 + (lane & 31), k = ks * 32 + g * 16 + (lane >> 5) * 8 + j;
+                            const float x = w[((size_t)n * C + k) * 9 + t];
+                            const unsigned short hi = f32_to_bf16_rne(x);
+                            const unsigned short mid = f32_to_bf16_rne(x - bf16_to_f32(hi));
+                            const size_t base = ((((size_t)(ks * 9 + t) * WAVES + wv) * 2 + g) * 2) * 512;
+                            packed[base + 0 * 512 + lane * 8 + j] = hi;
+                            packed[base + 1 * 512 + lane * 8 + j] = mid;
+                        }
+}
+
+template <int C, int N>
+static void launch_b3n(int nboards, int grid, const float *in, const unsigned short *wp, const float *bias, const float *res, float *out,
+                       hipStream_t s) {
+    using G = B3NGeom<C, N>;
+    const size_t smem = G::LDS_BYTES;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3n_kernel<C, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((c6_conv3x3_b3n_kernel<C, N>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards);
+}
+
+bool c6_conv_b3n_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
+                          float *out, int num_cus, hipStream_t s) {
+    if (nboards <= 0) return true;
+    // persistent grid: one workgroup per CU (small-C workgroups are narrow: several fit a CU)
+    const int per_cu = C == 256 ? 1 : (C == 128 ? 2 : 4);
+    const int grid = nboards < num_cus * per_cu ? nboards : num_cus * per_cu;
+#define B3NCASE(CC, NN) if (C == CC && N == NN) { launch_b3n<CC, NN>(nboards, grid, in, wp, bias, res, out, s); return true; }
+    B3NCASE(256, 19) B3NCASE(256, 15) B3NCASE(256, 9)
+    B3NCASE(128, 19) B3NCASE(128, 15) B3NCASE(128, 9)
+    B3NCASE(64, 19) B3NCASE(64, 15) B3NCASE(64, 9)
+#undef B3NCASE
+    return false;
 }

@@ -175,10 +175,11 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
     {
         // A/B switch.  1 = c6_conv3x3_kernel (32x32x2 tiles, NHWC; the faster one: 129 vs 119 TFLOP/s on MI355X),
         // 2 = c6_conv3x3_v2_kernel (16x16x4 tiles, slice-major activations; experimental)
-        // 3 = c6_conv3x3_bf16x3_kernel (split bf16 products, fp32 accumulate; 440 TFLOP/s algorithmic) -- the default
+        // 6 = c6_conv3x3_b3n_kernel (split bf16 products, fp32 accumulate, persistent N-split schedule) -- the default;
+        // 3 = c6_conv3x3_bf16x3_kernel (same arithmetic, M x N wave grid with weight stages in LDS)
         const char *v = std::getenv("C6_CONV_VARIANT");
-        d.variant = precision == C6_PREC_FP32 ? 1 : precision == C6_PREC_BF16X3 ? 3 : (v ? std::atoi(v) : 3);
-        if (d.variant != 1 && d.variant != 2) d.variant = 3;
+        d.variant = precision == C6_PREC_FP32 ? 1 : precision == C6_PREC_BF16X3 ? 6 : (v ? std::atoi(v) : 6);
+        if (d.variant != 1 && d.variant != 2 && d.variant != 3) d.variant = 6;
         hipDeviceProp_t prop;
         int dev = 0;
         hipGetDevice(&dev);
@@ -203,6 +204,8 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         std::vector<float> cw((size_t)std::max(L, 1) * wsz), cw2((size_t)std::max(L, 1) * wsz), cb((size_t)std::max(L, 1) * C), folded((size_t)C * C * 9);
         const size_t w3 = c6_conv_packed_b3_units(C);
         std::vector<unsigned short> cw3((size_t)std::max(L, 1) * w3);
+        const size_t w6 = c6_conv_packed_b3n_units(C);
+        std::vector<unsigned short> cw6((size_t)std::max(L, 1) * w6);
         for (int l = 0; l < L; l++) {
             const float *w = take((size_t)C * C * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
             for (int co = 0; co < C; co++) {
@@ -213,9 +216,10 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
             c6_pack_conv_weights(C, folded.data(), cw.data() + (size_t)l * wsz);
             c6_pack_conv_weights_v2(C, folded.data(), cw2.data() + (size_t)l * wsz);
             c6_pack_conv_weights_b3(C, folded.data(), cw3.data() + (size_t)l * w3);
+            c6_pack_conv_weights_b3n(C, folded.data(), cw6.data() + (size_t)l * w6);
         }
         int rc;
-        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) ||
+        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) || (rc = upload(nh.pool, cw6, &d.conv_w6)) ||
             (rc = upload(nh.pool, cb, &d.conv_b)))
             return rc;
     }

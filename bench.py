@@ -225,10 +225,10 @@ def main():
         if precision == pkg.PREC_FP32:
             name, peak, note = "c6_conv3x3_kernel<256,3> (FP32 MFMA implicit GEMM, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, {}
         else:
-            name, peak = "c6_conv3x3_bf16x3_kernel<256,3> (split-bf16 implicit GEMM, v_mfma_f32_32x32x16_bf16)", PEAK_BF16_MFMA_TFLOPS
+            name, peak = "c6_conv3x3_b3n_kernel<256,19> (split-bf16 implicit GEMM, v_mfma_f32_32x32x16_bf16)", PEAK_BF16_MFMA_TFLOPS
             note = {"mfma_flops_per_algorithmic_flop": 3, "executed_mfma_tflops": 3 * ach, "frac_executed": 3 * ach / peak}
         r = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-             "traffic": pmc_traffic("bf16x3" if precision != pkg.PREC_FP32 else "c6_conv3x3_kernel") if args.workload == "config2" and not args.games else None,
+             "traffic": pmc_traffic("b3n" if precision != pkg.PREC_FP32 else "c6_conv3x3_kernel") if args.workload == "config2" and not args.games else None,
              "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
              "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
         r.update(note)
