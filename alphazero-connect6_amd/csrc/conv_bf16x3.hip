@@ -300,7 +300,9 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3n_kernel(const flo
                     if (ph == 0) {
 #pragma unroll
                         for (int q = 0; q < IPS; q++) if (k * IPS + q < NITEM) pend[q] = item_load(nslice, k * IPS + q);
-                    } else if (ph == 1) {
+                    } else if (ph == 2) {
+                        // two steps later: vmcnt completes in order, so this (HBM-latency) load must not be needed --
+                        // directly or through a wait on a younger weight load -- any earlier
 #pragma unroll
                         for (int q = 0; q < IPS; q++) if (k * IPS + q < NITEM) item_store(lds_nx, k * IPS + q, pend[q]);
                     }

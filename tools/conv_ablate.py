@@ -7,7 +7,7 @@ pkg = load_package()
 L = pkg.lib()
 L.c6_bench_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)]
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-cases = [(3, 0), (6, 0)]
+cases = [(6, 0)]
 flops = 2 * 9 * 256 * 256 * 361 * nb
 for rnd in range(2):
     for variant, abl in cases:
