@@ -35,7 +35,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
                   "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
-                  "c6_bench_conv"]
+                  "c6_bench_conv", "c6_bench_board"]
 
 
 class C6Error(RuntimeError):
@@ -140,6 +140,7 @@ def lib():
     L.c6_dirichlet_noise.argtypes = [C.c_int, C.c_int, C.c_double, u32p, u32p, u32p, u32p, i8p, f32p]
     L.c6_net_forward_prec.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_size_t, C.c_int, i8p, i8p, f32p, f32p]
     L.c6_bench_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)]
+    L.c6_bench_board.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.cpp_self_play.restype = Vec
     L.cpp_self_play.argtypes = [CALLBACK, ALLOC_PATH, ALLOC_RESULT, C.c_int, C.c_float, C.c_double, C.c_float, C.c_bool, C.c_int]
     L.cpp_play.restype = Vec
@@ -456,6 +457,13 @@ def bench_conv(n, channels, nboards, iters=3, variant=1, ablate=0, with_residual
     """average ms of one 3x3 conv launch on random data (development / profiling hook)"""
     ms = C.c_double()
     _chk(lib().c6_bench_conv(n, channels, nboards, iters, variant, ablate, with_residual, C.byref(ms)))
+    return ms.value
+
+
+def bench_board(n, num_games, iters=20):
+    """average ms of one K1 board-step launch over `num_games` resident games"""
+    ms = C.c_double()
+    _chk(lib().c6_bench_board(n, num_games, iters, C.byref(ms)))
     return ms.value
 
 

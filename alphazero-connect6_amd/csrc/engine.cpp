@@ -964,3 +964,37 @@ extern "C" int c6_bench_conv(int n, int C, int nboards, int iters, int variant, 
     hipFree(in); hipFree(res); hipFree(out); hipFree(w); hipFree(bias);
     return C6_OK;
 }
+
+// ---- K1 micro-benchmark: G games resident in HBM, every game places one stone per launch -------------------------------
+__global__ void c6_bench_pos_kernel(int cells, int G, int step, int32_t *pos) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) pos[g] = (int)(((unsigned)g * 2654435761u + (unsigned)step * 40503u) % (unsigned)cells);
+}
+extern "C" int c6_bench_board(int n, int G, int iters, double *avg_ms) {
+    int rc = check_n(n); if (rc) return rc;
+    rc = require_gpu(0); if (rc) return rc;
+    const int cells = n * n, Gpad = (G + 3) & ~3;
+    TmpDev t;
+    int8_t *db = t.get<int8_t>((size_t)cells * Gpad), *dt = t.get<int8_t>(Gpad), *dr = t.get<int8_t>(Gpad), *dw = t.get<int8_t>(Gpad),
+           *de = t.get<int8_t>(Gpad);
+    int32_t *dp = t.get<int32_t>(Gpad);
+    if (!db || !dt || !dr || !dw || !de || !dp) return fail(C6_ERR_HIP, "hipMalloc failed");
+    HIPCHK(hipMemset(dt, 0xff, Gpad));   // black to move
+    HIPCHK(hipMemset(dr, 1, Gpad));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float total = 0;
+    for (int i = -1; i < iters; i++) {   // occupied cells are rejected by the kernel ("already set position"): still a full board read
+        hipLaunchKernelGGL(c6_bench_pos_kernel, dim3((Gpad + 255) / 256), dim3(256), 0, nullptr, cells, Gpad, i + 1, dp);
+        hipEventRecord(e0, nullptr);
+        c6_launch_board_step(n, Gpad, db, dt, dr, dp, dw, de, nullptr);
+        hipEventRecord(e1, nullptr);
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (i >= 0) total += ms;
+    }
+    *avg_ms = total / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return C6_OK;
+}

@@ -260,6 +260,8 @@ int c6_net_forward_prec(int board_size, int channels, int blocks, int precision,
 /* development / profiling hook: average duration (ms) of `iters` launches of one 3x3 conv variant on random data
  * (variant 1 = FP32 MFMA, 2 = experimental 16x16x4 kernel, 3 = bf16x3; ablate != 0 only for variant 1) */
 int c6_bench_conv(int board_size, int channels, int nboards, int iters, int variant, int ablate, int with_residual, double *avg_ms);
+/* K1 alone: `num_games` resident games, one stone per game per launch (average ms over `iters` launches) */
+int c6_bench_board(int board_size, int num_games, int iters, double *avg_ms);
 /* C6RNG Dirichlet noise of select step (search, depth) for `num` boards (keys k0/k1 per board) */
 int c6_dirichlet_noise(int board_size, int num, double alpha, const uint32_t *k0, const uint32_t *k1,
                        const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise);
