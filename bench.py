@@ -66,6 +66,22 @@ def pmc_traffic(kernel_substr):
     return None
 
 
+def usable_cores():
+    """host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants cpu.max = 16 CPUs of time; more threads than that only fight over the quota)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(wl, seconds_budget=20.0):
     """The CPU oracle (a port of the reference algorithm: the Rust path cannot be built, no rustc) on the
     host cores, bounded sample: every core runs searches of the first move of one game of the same workload."""
@@ -75,7 +91,7 @@ def cpu_baseline(wl, seconds_budget=20.0):
     import __graft_entry__ as ge
     import c6oracle as o
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = wl["n"]
     net = None
     if wl["evaluator"] == "net":
