@@ -112,3 +112,26 @@ def test_net_batch_invariance_full_batch():
     assert np.abs(r0["prior"].reshape(n, n) - avg).max() < 2e-7
     assert abs(r0["root_value"] - val[0]) < 1e-6
     eng.close()
+
+
+def test_config1_full_game_19x19_400_sims():
+    """BASELINE config 1 (1 game, 19x19, num_simulation = 400, RandomEvaluator, seed 0): the whole game -- every one of
+    its ~200 stones chosen after 400 searches with tree reuse -- is bit-identical on the GPU engine and the CPU oracle."""
+    need_gpu()
+    import time
+    n, S, seed = 19, 400, 0
+    t0 = time.time()
+    eng = pkg.Engine(board_size=n, num_games=1, num_simulation=S, seed=seed, evaluator=pkg.EVAL_RANDOM)
+    eng.run()
+    st = eng.stats()
+    game = eng.fetch_games()[0]
+    eng.close()
+    t_gpu = time.time() - t0
+    t0 = time.time()
+    ref = o.self_play(n, num=1, threads=1, num_simulation=S, seed=seed)[0]
+    t_cpu = time.time() - t0
+    mv = [r * n + c for _, _, (r, c) in ref["path"]]
+    assert list(game["moves"]) == mv and game["winner"] == ref["winner"]
+    assert st["overflow_games"] == 0 and st["simulations"] == S * len(mv)
+    print(f"config1: winner {ref['winner']}, {len(mv)} stones, oracle {t_cpu:.1f} s, engine (1 game) {t_gpu:.1f} s, "
+          f"max records {st['max_records_used']}, max depth {st['max_depth']}")
