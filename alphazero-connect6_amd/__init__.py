@@ -35,7 +35,8 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
                   "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
-                  "c6_bench_conv", "c6_bench_board"]
+                  "c6_bench_conv", "c6_bench_board", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
+                  "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples"]
 
 
 class C6Error(RuntimeError):
@@ -141,6 +142,14 @@ def lib():
     L.c6_net_forward_prec.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_size_t, C.c_int, i8p, i8p, f32p, f32p]
     L.c6_bench_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)]
     L.c6_bench_board.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.c6_replay_create.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.c6_replay_destroy.argtypes = [C.c_void_p]
+    L.c6_replay_push_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.c6_replay_push_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.c6_replay_clear.argtypes = [C.c_void_p]
+    L.c6_engine_push_tuples.argtypes = [C.c_void_p, C.c_void_p]
+    L.c6_replay_size.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.c6_replay_sample.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, f32p, f32p, f32p, f32p, f32p]
     L.cpp_self_play.restype = Vec
     L.cpp_self_play.argtypes = [CALLBACK, ALLOC_PATH, ALLOC_RESULT, C.c_int, C.c_float, C.c_double, C.c_float, C.c_bool, C.c_int]
     L.cpp_play.restype = Vec
@@ -212,6 +221,20 @@ def _vec_to_py(v):
 def default_param():
     """pyconnect6.default_param (Connect6/pybind/pyconnect6/__init__.py:47-56)"""
     return {"num_simulation": 800, "epsilon": 0.25, "dirichlet_alpha": 0.03, "c_puct": 1.0, "debug": False, "num_game_thread": 1}
+
+
+def dump_param(path, param):
+    """pyconnect6.dump_param (pybind/pyconnect6/__init__.py:58-67): MCTS hyper-parameters as `<path>_mcts.json`"""
+    import json
+    with open(path + "_mcts.json", "w") as f:
+        json.dump(param, f)
+
+
+def load_param(path):
+    """pyconnect6.load_param (pybind/pyconnect6/__init__.py:69-79)"""
+    import json
+    with open(path + "_mcts.json") as f:
+        return json.load(f)
 
 
 def self_play(policy, param=None):
@@ -334,6 +357,10 @@ class Engine:
     def set_tuple_buffer(self, dev_ptr, capacity, count_dev_ptr):
         _chk(lib().c6_engine_set_tuple_buffer(self.h, C.c_void_p(dev_ptr), capacity, C.c_void_p(count_dev_ptr)))
 
+    def push_tuples(self, replay):
+        """device-to-device hand-off of the emitted tuples to a ReplayBuffer"""
+        _chk(lib().c6_engine_push_tuples(self.h, replay.h))
+
     def fetch_tuples(self, cap):
         stride = lib().c6_tuple_stride(self.n)
         buf = np.zeros((cap, stride), np.uint8)
@@ -372,7 +399,76 @@ def decode_tuples(buf, n):
     pi = buf[:, off:off + 2 * cells].copy().view(np.uint16).reshape(k, cells)
     turn = buf[:, -2].view(np.int8)
     z = buf[:, -1].view(np.int8)
-    return dict(state=state.copy(), pi=pi, turn=turn.copy(), z=z.copy())
+    pos = buf[:, -4:-2].copy().view(np.uint16).reshape(k)
+    return dict(state=state.copy(), pi=pi, turn=turn.copy(), z=z.copy(), pos=pos)
+
+
+def encode_tuples(n, games):
+    """[(winner, [(turn, board[n,n], (row, col)), ...], pi[len, n*n] or None), ...] -> records in the engine's tuple layout
+    (what the engine emits for a finished game; used to feed a ReplayBuffer from host-side game records)"""
+    cells = n * n
+    off = cells + (cells & 1)
+    stride = lib().c6_tuple_stride(n)
+    recs = []
+    for winner, path, pi in games:
+        for k, (turn, board, (row, col)) in enumerate(path):
+            r = np.zeros(stride, np.uint8)
+            r[:cells] = np.asarray(board, dtype=np.int8).reshape(-1).view(np.uint8)
+            if pi is not None:
+                r[off:off + 2 * cells] = np.asarray(pi[k]).astype(np.uint16).view(np.uint8)
+            r[-4:-2] = np.array([row * n + col], np.uint16).view(np.uint8)
+            r[-2] = np.int8(turn).view(np.uint8)
+            r[-1] = np.int8(winner).view(np.uint8)
+            recs.append(r)
+    return np.stack(recs) if recs else np.zeros((0, stride), np.uint8)
+
+
+class ReplayBuffer:
+    """device-resident ReplayBuffer (AlphaZero/cpp_weighted/ReplayBuffer.hpp:10-73) over engine tuple records"""
+
+    def __init__(self, board_size, max_size):
+        self.n, self.cells, self.max_size = board_size, board_size * board_size, max_size
+        self.h = C.c_void_p()
+        _chk(lib().c6_replay_create(board_size, max_size, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().c6_replay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def push_records(self, records):
+        rec = np.ascontiguousarray(records, dtype=np.uint8)
+        _chk(lib().c6_replay_push_host(self.h, rec.ctypes.data_as(C.c_void_p), rec.shape[0]))
+
+    def push_game(self, result, pi=None):
+        """pyconnect6-shaped game result (winner, [(turn, board, (row, col)), ...]), py_weighted/buffer.py:22-32"""
+        winner, path = result
+        self.push_records(encode_tuples(self.n, [(winner, path, pi)]))
+
+    def push_device(self, tuples_dev_ptr, count_dev_ptr, cap):
+        _chk(lib().c6_replay_push_dev(self.h, C.c_void_p(tuples_dev_ptr), C.c_void_p(count_dev_ptr), cap))
+
+    def clear(self):
+        _chk(lib().c6_replay_clear(self.h))
+
+    def size(self):
+        nd, tail = C.c_size_t(), C.c_size_t()
+        _chk(lib().c6_replay_size(self.h, C.byref(nd), C.byref(tail)))
+        return nd.value, tail.value
+
+    def __len__(self):
+        return self.size()[0]
+
+    def sample(self, num_sample, seed=0, draw_id=0, want_pi=False):
+        w = np.zeros(num_sample, np.float32); p = np.zeros(num_sample, np.float32)
+        b = np.zeros((num_sample, self.cells), np.float32); q = np.zeros(num_sample, np.float32)
+        pi = np.zeros((num_sample, self.cells), np.float32) if want_pi else None
+        _chk(lib().c6_replay_sample(self.h, num_sample, seed, draw_id, _p(w, C.c_float), _p(p, C.c_float), _p(b, C.c_float),
+                                    _p(q, C.c_float), _p(pi, C.c_float) if want_pi else None))
+        return (w, p, b, q, pi) if want_pi else (w, p, b, q)
 
 
 def replay_moves(n, moves):

@@ -333,7 +333,7 @@ extern "C" void c6_default_config(c6_config *cfg) {
 
 extern "C" size_t c6_tuple_stride(int n) {
     const size_t cells = (size_t)n * n;
-    return (cells + (cells & 1) + 2 * cells + 2 + 3) & ~(size_t)3;
+    return (cells + (cells & 1) + 2 * cells + 2 + 2 + 3) & ~(size_t)3;   // state | pad | pi u16 | pos u16 | turn | z
 }
 
 static int engine_alloc(c6_engine *e) {
@@ -658,6 +658,19 @@ extern "C" int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, v
     if (m && host_buf) HIPCHK(hipMemcpy(host_buf, d.tuple_buf, m * d.tuple_stride, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(d.tuple_count, 0, sizeof(uint32_t)));
     *count = m;
+    return C6_OK;
+}
+
+// hand the tuples emitted so far to a replay buffer, device to device (no host round trip), and reset the counter
+extern "C" int c6_engine_push_tuples(c6_engine *e, c6_replay *r) {
+    if (!e || !r) return fail(C6_ERR_BAD_ARG, "null argument");
+    C6Dev &d = e->d;
+    if (!d.tuple_buf) return fail(C6_ERR_BAD_ARG, "no tuple buffer: call c6_engine_enable_tuples / c6_engine_set_tuple_buffer first");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = c6_replay_push_dev(r, d.tuple_buf, d.tuple_count, (size_t)d.tuple_cap);
+    if (rc != C6_OK) return fail(rc, "c6_replay_push_dev failed");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(d.tuple_count, 0, sizeof(uint32_t)));
     return C6_OK;
 }
 

@@ -627,6 +627,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
                     }
                 }
                 if (lane == 0) {
+                    *reinterpret_cast<uint16_t *>(out + E.tuple_stride - 4) = (uint16_t)mv;   // the stone played (Path.pos)
                     out[E.tuple_stride - 2] = (uint8_t)(int8_t)t;
                     out[E.tuple_stride - 1] = (uint8_t)(int8_t)win;
                 }

@@ -203,7 +203,8 @@ int c6_engine_fetch_games(c6_engine *e, int cap, int *count, int *winners, int *
                           int16_t *moves);
 
 /* training tuples (state, pi, turn, z): device buffer of fixed-size records
- * [state int8 N*N | pi u16 N*N (root child visit counts, mod.rs:433-452) | turn int8 | z int8],
+ * [state int8 N*N | pad to even | pi u16 N*N (root child visit counts, mod.rs:433-452) | ... | pos u16 | turn int8 | z int8]
+ * (pos = row*N+col of the stone played, agent::Path.pos; the last four bytes of a record are pos, turn, z),
  * padded to a multiple of 4 bytes.  The caller may supply the buffer (e.g. torch-owned memory
  * handed to RCCL all-gather); count_dev is a device uint32. */
 size_t c6_tuple_stride(int board_size);
@@ -265,6 +266,25 @@ int c6_bench_board(int board_size, int num_games, int iters, double *avg_ms);
 /* C6RNG Dirichlet noise of select step (search, depth) for `num` boards (keys k0/k1 per board) */
 int c6_dirichlet_noise(int board_size, int num, double alpha, const uint32_t *k0, const uint32_t *k1,
                        const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise);
+
+/* ---- replay buffer: device-resident restatement of AlphaZero/cpp_weighted/ReplayBuffer.hpp ---- */
+typedef struct c6_replay c6_replay;
+int c6_replay_create(int board_size, size_t max_size, c6_replay **out);      /* ReplayBuffer(max_size, .), :12-20 */
+void c6_replay_destroy(c6_replay *r);
+/* push_game (:22-29) for every record of a tuple buffer.  _dev: records and their count live on the device (e.g. the
+ * all-gathered tuple buffer), count clamped to `cap`; no host synchronisation. */
+int c6_replay_push_dev(c6_replay *r, const void *tuples_dev, const uint32_t *count_dev, size_t cap);
+int c6_replay_push_host(c6_replay *r, const void *tuples_host, size_t count);
+/* everything the engine has emitted since the last fetch/push goes device-to-device into the ring; the engine's tuple
+ * counter is reset */
+int c6_engine_push_tuples(c6_engine *e, c6_replay *r);
+int c6_replay_clear(c6_replay *r);                                           /* :31-33 */
+int c6_replay_size(c6_replay *r, size_t *num_data, size_t *tail);             /* :35-37 */
+/* sample (:39-65): num_sample draws WITH replacement, index_i = C6RNG(seed; i, draw_id) % num_data.  Host outputs:
+ * winners[n], players[n], boards[n*N*N] (f32 -1/0/1), poses[n] (row*N+col) as the reference; pi[n*N*N] optional
+ * (visit counts as f32, build-side extension). */
+int c6_replay_sample(c6_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
+                     float *boards, float *poses, float *pi);
 
 #ifdef __cplusplus
 }

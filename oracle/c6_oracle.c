@@ -917,3 +917,58 @@ void c6o_self_play(int n, const c6o_hyper *hp, int eval_kind, c6o_eval_fn fn, vo
     for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
     free(th);
 }
+
+/* ===================================================================== */
+/* replay buffer (AlphaZero/cpp_weighted/ReplayBuffer.hpp)                */
+/* ===================================================================== */
+
+typedef struct { int winner; c6o_path path; } replay_entry;
+struct c6o_replay {
+    int n;
+    size_t max_size, tail, num_data;
+    replay_entry *paths;
+};
+
+c6o_replay *c6o_replay_new(int n, size_t max_size) {
+    c6o_replay *r = (c6o_replay *)calloc(1, sizeof *r);
+    r->n = n;
+    r->max_size = max_size;
+    r->paths = (replay_entry *)calloc(max_size, sizeof(replay_entry));
+    return r;
+}
+
+void c6o_replay_free(c6o_replay *r) {
+    if (!r) return;
+    free(r->paths);
+    free(r);
+}
+
+/* ReplayBuffer.hpp:22-29 */
+void c6o_replay_push_game(c6o_replay *r, int winner, const c6o_path *path, int len) {
+    r->num_data = r->num_data + (size_t)len < r->max_size ? r->num_data + (size_t)len : r->max_size;
+    for (int i = 0; i < len; i++) {
+        r->paths[r->tail].winner = winner;
+        r->paths[r->tail].path = path[i];
+        r->tail = (r->tail + 1) % r->max_size;
+    }
+}
+
+void c6o_replay_clear(c6o_replay *r) { r->num_data = r->tail = 0; }
+size_t c6o_replay_size(const c6o_replay *r) { return r->num_data; }
+size_t c6o_replay_tail(const c6o_replay *r) { return r->tail; }
+
+/* ReplayBuffer.hpp:39-65 */
+void c6o_replay_sample(const c6o_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
+                       float *boards, float *poses) {
+    const int cells = r->n * r->n;
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int i = 0; i < num_sample; i++) {
+        uint32_t ctr[4] = {(uint32_t)i, draw_id, 0, 5}, w[4];
+        c6o_philox4x32_10(ctr, key, w);
+        const replay_entry *e = &r->paths[w[0] % r->num_data];   /* gen() % num_data */
+        winners[i] = (float)e->winner;
+        players[i] = (float)e->path.turn;
+        for (int c = 0; c < cells; c++) boards[(size_t)i * cells + c] = (float)e->path.board[c];
+        poses[i] = (float)(e->path.row * r->n + e->path.col);
+    }
+}

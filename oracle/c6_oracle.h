@@ -200,6 +200,19 @@ void c6o_play_result_free(c6o_play_result *r);
 void c6o_self_play(int n, const c6o_hyper *hp, int eval_kind, c6o_eval_fn fn, void *ctx, uint64_t seed,
                    uint32_t uid_base, int num, int threads, int want_pi, c6o_play_result *out /* num */);
 
+/* ---- replay buffer (AlphaZero/cpp_weighted/ReplayBuffer.hpp:10-73) ---- */
+typedef struct c6o_replay c6o_replay;
+c6o_replay *c6o_replay_new(int n, size_t max_size);                                         /* :12-20 */
+void c6o_replay_free(c6o_replay *r);
+void c6o_replay_push_game(c6o_replay *r, int winner, const c6o_path *path, int len);         /* :22-29 */
+void c6o_replay_clear(c6o_replay *r);                                                        /* :31-33 */
+size_t c6o_replay_size(const c6o_replay *r);                                                 /* :35-37 */
+size_t c6o_replay_tail(const c6o_replay *r);
+/* :39-65; the reference draws gen() % num_data from a random_device-seeded engine (unpinned): here the index of
+ * draw i is Philox(seed; i, draw_id, 0, tag 5).x % num_data (C6RNG) */
+void c6o_replay_sample(const c6o_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
+                       float *boards, float *poses);
+
 /* ---- policy/value net (AlphaZero/cpp_weighted/model.hpp:9-95) -------- */
 
 typedef struct c6o_net c6o_net;

@@ -128,6 +128,16 @@ def lib():
     L.c6o_play_result_free.argtypes = [C.POINTER(PlayResult)]
     L.c6o_self_play.argtypes = [C.c_int, C.POINTER(Hyper), C.c_int, EVAL_FN, C.c_void_p, C.c_uint64, C.c_uint32,
                                 C.c_int, C.c_int, C.c_int, C.POINTER(PlayResult)]
+    L.c6o_replay_new.restype = C.c_void_p
+    L.c6o_replay_new.argtypes = [C.c_int, C.c_size_t]
+    L.c6o_replay_free.argtypes = [C.c_void_p]
+    L.c6o_replay_push_game.argtypes = [C.c_void_p, C.c_int, C.POINTER(Path), C.c_int]
+    L.c6o_replay_clear.argtypes = [C.c_void_p]
+    L.c6o_replay_size.restype = C.c_size_t
+    L.c6o_replay_size.argtypes = [C.c_void_p]
+    L.c6o_replay_tail.restype = C.c_size_t
+    L.c6o_replay_tail.argtypes = [C.c_void_p]
+    L.c6o_replay_sample.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, f32p, f32p, f32p, f32p]
     L.c6o_net_blob_floats.restype = C.c_size_t
     L.c6o_net_blob_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     L.c6o_net_new.restype = C.c_void_p
@@ -343,4 +353,38 @@ class Net:
     def close(self):
         if self.h:
             lib().c6o_net_free(self.h)
+            self.h = None
+
+
+class Replay:
+    """oracle replay buffer (AlphaZero/cpp_weighted/ReplayBuffer.hpp)"""
+
+    def __init__(self, n, max_size):
+        self.n, self.h = n, lib().c6o_replay_new(n, max_size)
+
+    def push_game(self, winner, path):
+        """path: [(turn, board[n,n], (row, col)), ...]"""
+        arr = (Path * max(1, len(path)))()
+        for i, (turn, board, (row, col)) in enumerate(path):
+            arr[i].turn, arr[i].row, arr[i].col = int(turn), int(row), int(col)
+            flat = np.ascontiguousarray(board, dtype=np.int8).reshape(-1)
+            C.memmove(arr[i].board, flat.ctypes.data, flat.size)
+        lib().c6o_replay_push_game(self.h, int(winner), arr, len(path))
+
+    def clear(self):
+        lib().c6o_replay_clear(self.h)
+
+    def size(self):
+        return lib().c6o_replay_size(self.h), lib().c6o_replay_tail(self.h)
+
+    def sample(self, num_sample, seed, draw_id=0):
+        cells = self.n * self.n
+        w = np.zeros(num_sample, np.float32); p = np.zeros(num_sample, np.float32)
+        b = np.zeros((num_sample, cells), np.float32); q = np.zeros(num_sample, np.float32)
+        lib().c6o_replay_sample(self.h, num_sample, seed, draw_id, f32(w), f32(p), f32(b), f32(q))
+        return w, p, b, q
+
+    def close(self):
+        if self.h:
+            lib().c6o_replay_free(self.h)
             self.h = None

@@ -26,13 +26,14 @@ def _encode(n, games):
     """oracle self-play results -> tuple records in the engine's layout (c6_tuple_stride)"""
     cells = n * n
     off = cells + (cells & 1)
-    stride = (off + 2 * cells + 2 + 3) & ~3
+    stride = (off + 2 * cells + 2 + 2 + 3) & ~3
     recs = []
     for g in games:
         for k, (turn, board, pos) in enumerate(g["path"]):
             r = np.zeros(stride, np.uint8)
             r[:cells] = board.reshape(-1).astype(np.int8).view(np.uint8)
             r[off:off + 2 * cells] = g["pi"][k].astype(np.uint16).view(np.uint8)
+            r[-4:-2] = np.array([pos[0] * n + pos[1]], np.uint16).view(np.uint8)
             r[-2] = np.int8(turn).view(np.uint8)
             r[-1] = np.int8(g["winner"]).view(np.uint8)
             recs.append(r)
