@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libconnect6_amd.so")
+LIB_PATH = os.environ.get("C6_LIB_PATH") or os.path.join(_HERE, "libconnect6_amd.so")   # override: A/B builds (tools/)
 
 BLACK, NONE, WHITE = -1, 0, 1
 EVAL_RANDOM, EVAL_UNIFORM, EVAL_NET, EVAL_CALLBACK = 1, 2, 3, 4

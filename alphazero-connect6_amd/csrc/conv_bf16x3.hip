@@ -202,7 +202,7 @@ struct B3NGeom {
     static constexpr int IN_UNITS = SLOTS * B3_SLOT;       // ushorts per input buffer
     static constexpr int WAVES = C / 32;
     static constexpr int THREADS = 64 * WAVES;
-    static constexpr size_t LDS_BYTES = (size_t)2 * IN_UNITS * 2 + (size_t)WAVES * 32 * 36 * 4;   // + epilogue patches
+    static constexpr size_t LDS_BYTES = (size_t)2 * IN_UNITS * 2;
 };
 
 template <int C, int N>
@@ -265,11 +265,41 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3n_kernel(const flo
 
 #pragma unroll 1
     for (int lb = 0; lb < nlocal; lb++) {
+    // opaque per board: otherwise LICM hoists the row offsets of the unrolled tile loops out of the board loop and
+    // they sit in (spilled) registers across the whole MFMA loop
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int pi = lane_o & 31, n4 = wave * 32 + 4 * (lane_o >> 5);
+    auto row_off = [&](int mt, bool &ok) -> size_t {
+        const int m = mt * 32 + pi, y = m / W, x = m % W;
+        ok = x < N && y < N;
+        return (size_t)((ok ? y : 0) * N + (ok ? x : 0)) * C + n4;      // clamped: loads stay unconditional
+    };
+    const size_t b = (size_t)(b0 + lb * bstep);
+    // acc[mt][4g + r] = channel 32 wave + 8g + 4h + r of pixel row m = 32 mt + i (weights are the MFMA "A" operand), i.e.
+    // four 16-byte runs of the NHWC tensors.  The residual is therefore loaded STRAIGHT INTO the accumulators: all 4 MT
+    // loads are in flight at once (one HBM latency per board; read tile by tile in the epilogue they were twelve
+    // dependent round trips, 10 % of a residual launch).
     f32x16 acc[MT];
+    if (res) {
+        const float *resb = res + b * (size_t)CELLS * C;
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+        for (int mt = 0; mt < MT; mt++) {
+            bool ok;
+            const float *rp = resb + row_off(mt, ok);
 #pragma unroll
-        for (int v = 0; v < 16; v++) acc[mt][v] = 0.f;
+            for (int g = 0; g < 4; g++) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(rp + 8 * g);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[mt][4 * g + r] = t[r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[mt][v] = 0.f;
+    }
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks++) {
         const int gs = lb * KS + ks;
@@ -327,9 +357,11 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3n_kernel(const flo
 #pragma unroll
                     for (int q = 0; q < MG; q++)
                         if (m0 + q < MT) {
-                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid[sl][q], bhi, acc[m0 + q], 0, 0, 0);
-                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[sl][q], bmid, acc[m0 + q], 0, 0, 0);
-                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[sl][q], bhi, acc[m0 + q], 0, 0, 0);
+                            // weights are the MFMA "A" operand, pixels the "B": D = W x X^T, so a lane ends up holding
+                            // 4 x 4 CONSECUTIVE channels of one pixel and the epilogue needs no transposition
+                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bhi, amid[sl][q], acc[m0 + q], 0, 0, 0);
+                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bmid, ahi[sl][q], acc[m0 + q], 0, 0, 0);
+                            acc[m0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bhi, ahi[sl][q], acc[m0 + q], 0, 0, 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -340,36 +372,28 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3n_kernel(const flo
         }
     }   // ks
 
-        // epilogue of this board: wave-private LDS patch (behind the input buffers) -> 16-byte residual loads / stores;
-        // rows are m = y*W + x, x == N is junk.  The stores drain behind the next board's first slice.
-        const size_t b = (size_t)(b0 + lb * bstep);
-        constexpr int PSTR = 36;
-        float *patch = reinterpret_cast<float *>(smem16 + 2 * G::IN_UNITS) + wave * (32 * PSTR);
+        // epilogue of this board: + bias, ReLU, four 16-byte stores per tile straight from the accumulators (lanes i / i+32
+        // complete 32-byte sectors; rows with x == N are junk).  The stores drain behind the next board's first slice.
         float *outb = out + b * (size_t)CELLS * C;
-        const float *resb = res ? res + b * (size_t)CELLS * C : nullptr;
-        const int r8 = lane >> 3, c4 = (lane & 7) * 4;
-        const int n4 = wave * 32 + c4;
-        const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + n4);
+        f32x4 bi[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) bi[g] = *reinterpret_cast<const f32x4 *>(bias + n4 + 8 * g);
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
+            bool ok;
+            float *op = outb + row_off(mt, ok);
+            if (ok) {
 #pragma unroll
-            for (int v = 0; v < 16; v++) patch[((v & 3) + 8 * (v >> 2) + 4 * h) * PSTR + i] = acc[mt][v];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int g = 0; g < 4; g++) {
+                    f32x4 yv;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = j * 8 + r8;
-                const int m = mt * 32 + row, y = m / W, x = m % W;
-                f32x4 yv = *reinterpret_cast<const f32x4 *>(patch + row * PSTR + c4);
-                if (x < N && y < N) {
-                    const size_t o = (size_t)(y * N + x) * C + n4;
-                    yv = yv + bi;
-                    if (resb) yv = yv + *reinterpret_cast<const f32x4 *>(resb + o);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) yv[q] = yv[q] > 0.f ? yv[q] : 0.f;
-                    *reinterpret_cast<f32x4 *>(outb + o) = yv;
+                    for (int r = 0; r < 4; r++) {
+                        const float t = acc[mt][4 * g + r] + bi[g][r];
+                        yv[r] = t > 0.f ? t : 0.f;
+                    }
+                    *reinterpret_cast<f32x4 *>(op + 8 * g) = yv;
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
 }
