@@ -49,21 +49,26 @@ def net_flops_per_board(n, C, blocks):
     return 2 * 9 * 2 * C * n2 + (blocks - 1) * 2 * (2 * 9 * C * C * n2) + heads
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc
-    passes of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+def pmc_record(kernel_substr):
+    """The dominant kernel's row of the committed rocprofv3 PMC summary (separate --pmc passes of this same command,
+    tools/profile_round.sh): HBM bytes per launch (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
+    matrix-core busy fraction and effective clock."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
-        return None
+        return {}
     try:
         d = json.load(open(files[-1]))
         for k, v in d["kernels"].items():
             if kernel_substr in k:
-                return v.get("hbm_bytes_per_launch")
+                return v
     except Exception:
-        return None
-    return None
+        return {}
+    return {}
+
+
+def pmc_traffic(kernel_substr):
+    return pmc_record(kernel_substr).get("hbm_bytes_per_launch")
 
 
 def usable_cores():
@@ -247,6 +252,11 @@ def main():
              "traffic": pmc_traffic("b3n" if precision != pkg.PREC_FP32 else "c6_conv3x3_kernel") if args.workload == "config2" and not args.games else None,
              "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
              "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
+        if args.workload == "config2" and not args.games:
+            rec = pmc_record("b3n" if precision != pkg.PREC_FP32 else "c6_conv3x3_kernel")
+            if "mfma_util" in rec:      # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (profiles/)
+                r["pmc_mfma_busy_frac"] = rec["mfma_util"]
+                r["pmc_effective_clock_ghz"] = rec.get("effective_clock_ghz")
         r.update(note)
         return r
 

@@ -32,7 +32,36 @@ for k, d in out["kernels"].items():
     rd = 2.0 * d.get("FETCH_SIZE_avg_KiB", 0.0) * 1024
     wr = d.get("WRITE_SIZE_avg_KiB", 0.0) * 1024
     d["hbm_bytes_per_launch"] = rd + wr
+# optional third pass: SQ / GRBM counters (matrix-core utilisation, effective clock, LDS conflicts)
+sq = glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"), recursive=True)
+if sq:
+    f = max(sq, key=os.path.getmtime)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "c6_" not in k:
+            continue
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            dur[k][r.get("Dispatch_Id", len(dur[k]))] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    out["sq_note"] = ("SQ_* are sums over all SIMDs of the device; GRBM_GUI_ACTIVE is the sum over the 8 XCDs, so device cycles = "
+                      "GRBM_GUI_ACTIVE / 8 (MI355X_MICROARCH.md, DVFS give-back). mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / "
+                      "(device cycles * 1024 SIMDs); effective_clock_ghz = device cycles / profiled duration")
+    for k, ctrs in agg.items():
+        d = out["kernels"].setdefault(k, {})
+        for c, v in ctrs.items():
+            d[c + "_avg"] = sum(v) / len(v)
+        cyc = d.get("GRBM_GUI_ACTIVE_avg", 0.0) / 8.0
+        if cyc > 0:
+            d["mfma_util"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES_avg", 0.0) / (cyc * 1024.0)
+            if dur[k]:
+                ns = sum(dur[k].values()) / len(dur[k])
+                d["profiled_avg_ns"] = ns
+                d["effective_clock_ghz"] = cyc / ns
+        if d.get("SQ_LDS_IDX_ACTIVE_avg"):
+            d["lds_bank_conflict_frac"] = d.get("SQ_LDS_BANK_CONFLICT_avg", 0.0) / d["SQ_LDS_IDX_ACTIVE_avg"]
 for f in glob.glob(os.path.join(src, "bench_*.json")):
     shutil.copy(f, os.path.join(here, f"{tag}_{os.path.basename(f)}"))
 json.dump(out, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
-print(json.dumps(out["kernels"], indent=1)[:1500])
+print(json.dumps(out["kernels"], indent=1)[:3000])

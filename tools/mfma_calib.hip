@@ -1,4 +1,4 @@
-// mfma_calib.hip -- calibration of the FP32 matrix-core ceiling on this MI355X in the shapes the conv kernels use.
+// mfma_calib.hip -- calibration of the FP32 and bf16 matrix-core ceilings on this MI355X in the shapes the conv kernels use.
 // Not part of the library.  hipcc --offload-arch=gfx950 -O3 mfma_calib.hip -o mfma_calib
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -49,7 +49,44 @@ __global__ __launch_bounds__(512) void k32(float *out, int iters, unsigned long 
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <typename F> void run(const char *name, F launch, int threads, double flop_per_wave_iter, int iters) {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// the split-bf16 conv's instruction: v_mfma_f32_32x32x16_bf16, 12 independent accumulator tiles, 3 MFMAs per tile and
+// operand pair like the kernel (hi*hi, hi*mid, mid*hi); RANDOM toggles every operand bit each iteration
+template <int NACC, bool RANDOM>
+__global__ __launch_bounds__(512) void kb16(float *out, int iters, unsigned long long *clk) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; i++) for (int j = 0; j < 16; j++) acc[i][j] = 0;
+    union U { bf16x8 v; unsigned u[4]; } a0, a1, b0, b1;
+    unsigned int lcg = threadIdx.x * 2654435761u + blockIdx.x;
+    for (int q = 0; q < 4; q++) { a0.u[q] = 0x3f803f80u + q; a1.u[q] = 0x3c003c00u + q; b0.u[q] = 0x3f003f00u; b1.u[q] = 0x3b803b80u; }
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+        if (RANDOM) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                lcg = lcg * 1664525u + 1013904223u;
+                a0.u[q] = (lcg & 0x807f807fu) | 0x3f003f00u;            // random sign + mantissa, exponent ~1
+                a1.u[q] = ((lcg >> 3) & 0x807f807fu) | 0x3b003b00u;
+                b0.u[q] = ((lcg >> 5) & 0x807f807fu) | 0x3e803e80u;
+                b1.u[q] = ((lcg >> 7) & 0x807f807fu) | 0x3a803a80u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NACC; i++) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0.v, a1.v, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1.v, a0.v, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0.v, a0.v, acc[i], 0, 0, 0);
+        }
+        if (!RANDOM) a0.u[0] ^= it & 1;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int i = 0; i < NACC; i++) for (int j = 0; j < 16; j++) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <typename F> void run(const char *name, F launch, int threads, double flop_per_wave_iter, int iters, double peak = 157.3) {
     float *out; unsigned long long *clk;
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&clk, 256 * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -62,7 +99,7 @@ template <typename F> void run(const char *name, F launch, int threads, double f
     std::vector<unsigned long long> h(512); hipMemcpy(h.data(), clk, 256 * 16, hipMemcpyDeviceToHost);
     double ghz = (double)h[0] / (double)h[1] * 0.1;   // s_memrealtime ticks at 100 MHz
     double tf = flop_per_wave_iter * (threads / 64) * 256.0 * iters / (ms * 1e-3) / 1e12;
-    printf("%-28s threads=%d  %.2f ms  %.1f TFLOP/s  in-kernel clock %.2f GHz  (%.1f%% of 157.3)\n", name, threads, ms, tf, ghz, tf / 1.573);
+    printf("%-28s threads=%d  %.2f ms  %.1f TFLOP/s  in-kernel clock %.2f GHz  (%.1f%% of %.1f)\n", name, threads, ms, tf, ghz, tf / peak * 100.0, peak);
     hipFree(out); hipFree(clk);
 }
 
@@ -74,5 +111,7 @@ int main(int argc, char **argv) {
     run("32x32x2 12acc 8 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL(k32<12>, dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 12 * 4096.0, iters);
     run("32x32x2 12acc 4 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL(k32<12>, dim3(256), dim3(256), 0, 0, o, it, c); }, 256, 12 * 4096.0, iters);
     run("32x32x2 4acc 4 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL(k32<4>, dim3(256), dim3(256), 0, 0, o, it, c); }, 256, 4 * 4096.0, iters * 3);
+    run("bf16 32x32x16 12acc x3 8 waves", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((kb16<12, false>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 36 * 32768.0, iters / 4, 2500.0);
+    run("bf16 32x32x16 12acc x3 8w RANDOM", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((kb16<12, true>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 36 * 32768.0, iters / 4, 2500.0);
     return 0;
 }
