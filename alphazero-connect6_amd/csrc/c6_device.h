@@ -98,26 +98,36 @@ __device__ __forceinline__ double c6_det_exp(double x) {
 
 // Gamma(alpha, 1), alpha < 1: Marsaglia-Tsang at shape alpha+1 times U^(1/alpha) (rand 0.6 GammaSmallShape),
 // normal deviates by the polar method.  d and c are the per-kernel constants of the sampler.
+// One ATTEMPT of the C6RNG spec (counter words 2*att and 2*att+1 of this cell): true and the variate if it is accepted.
+// A cell's variate is that of its first accepted attempt; attempts are independent of one another, so who evaluates
+// them, and in which order, is free (c6_wave_gamma below spreads the retries over the wave).
+__device__ __forceinline__ bool c6_gamma_try(double alpha, double d, double c, uint32_t k0, uint32_t k1, uint32_t cell,
+                                             uint32_t search, uint32_t depth, uint32_t att, double &out) {
+    const uint32_t tag = C6_TAG_NOISE | (depth << 8);
+    c6_u4 w = c6_philox(cell, 2 * att, search, tag, k0, k1);
+    double v1 = 2.0 * c6_open01(w.x, w.y) - 1.0, v2 = 2.0 * c6_open01(w.z, w.w) - 1.0;
+    double s = v1 * v1 + v2 * v2;
+    if (s >= 1.0 || s == 0.0) return false;
+    double x = v1 * sqrt(-2.0 * c6_det_log(s) / s);
+    double vc = 1.0 + c * x;
+    if (vc <= 0.0) return false;
+    double v = vc * vc * vc;
+    w = c6_philox(cell, 2 * att + 1, search, tag, k0, k1);
+    double u = c6_open01(w.x, w.y), u2 = c6_open01(w.z, w.w);
+    double x2 = x * x;
+    if (u < 1.0 - 0.0331 * x2 * x2 || c6_det_log(u) < 0.5 * x2 + d * (1.0 - v + c6_det_log(v))) {
+        double g = d * v;
+        out = g * c6_det_exp(c6_det_log(u2) / alpha);
+        return true;
+    }
+    return false;
+}
+
 __device__ __forceinline__ double c6_gamma_draw(double alpha, double d, double c, uint32_t k0, uint32_t k1, uint32_t cell,
                                                 uint32_t search, uint32_t depth) {
-    const uint32_t tag = C6_TAG_NOISE | (depth << 8);
-    for (uint32_t att = 0;; att++) {
-        c6_u4 w = c6_philox(cell, 2 * att, search, tag, k0, k1);
-        double v1 = 2.0 * c6_open01(w.x, w.y) - 1.0, v2 = 2.0 * c6_open01(w.z, w.w) - 1.0;
-        double s = v1 * v1 + v2 * v2;
-        if (s >= 1.0 || s == 0.0) continue;
-        double x = v1 * sqrt(-2.0 * c6_det_log(s) / s);
-        double vc = 1.0 + c * x;
-        if (vc <= 0.0) continue;
-        double v = vc * vc * vc;
-        w = c6_philox(cell, 2 * att + 1, search, tag, k0, k1);
-        double u = c6_open01(w.x, w.y), u2 = c6_open01(w.z, w.w);
-        double x2 = x * x;
-        if (u < 1.0 - 0.0331 * x2 * x2 || c6_det_log(u) < 0.5 * x2 + d * (1.0 - v + c6_det_log(v))) {
-            double g = d * v;
-            return g * c6_det_exp(c6_det_log(u2) / alpha);
-        }
-    }
+    double g;
+    for (uint32_t att = 0;; att++)
+        if (c6_gamma_try(alpha, d, c, k0, k1, cell, search, depth, att, g)) return g;
 }
 
 // ---- wave64 helpers ---------------------------------------------------------
@@ -164,4 +174,83 @@ __device__ __forceinline__ float c6_wave_max_f32(float v) {
 __device__ __forceinline__ int c6_nth_set_bit(unsigned long long m, int n) {
     for (int i = 0; i < n; i++) m &= m - 1;
     return __ffsll((long long)m) - 1;
+}
+
+// position of the n-th (0-based) set bit of m by halving (n < popcount(m)); per-lane n without a data-dependent loop
+__device__ __forceinline__ int c6_select_bit(unsigned long long m, int n) {
+    int pos = 0;
+    uint32_t w = (uint32_t)m;
+    int c = __popc(w);
+    if (n >= c) { n -= c; pos = 32; w = (uint32_t)(m >> 32); }
+#pragma unroll
+    for (int width = 16; width >= 1; width >>= 1) {
+        const uint32_t low = w & ((1u << width) - 1u);
+        c = __popc(low);
+        if (n >= c) { n -= c; pos += width; w >>= width; } else w = low;
+    }
+    return pos;
+}
+
+// Gamma variates for the cells a wave owns (lane owns cells lane + 64 j where need[j]).  Same values as calling
+// c6_gamma_draw per cell -- the attempt that is accepted for a cell does not depend on who evaluates it -- but the
+// rejection loops are not run in lockstep: with one loop per lane the wave pays max-over-64-lanes attempts per j
+// (~4.3 for the 21 % polar rejection, 26 evaluations at N = 19), here attempt 0 is one dense pass and the rejected
+// cells of each later attempt are packed onto lanes 0..k-1 (~11 evaluations at N = 19, ~5 instead of ~9 at N = 9).
+// `scratch` = cells doubles of wave-private LDS: workers hand the variates (or -1 = rejected) back to the owners.
+template <int J>
+__device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], double (&gam)[J], double *scratch, int lane, double alpha,
+                                              double d, double c, uint32_t k0, uint32_t k1, uint32_t search, uint32_t depth) {
+    unsigned long long pend[J];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        bool ok = true;
+        gam[j] = 0.0;
+        if (need[j]) ok = c6_gamma_try(alpha, d, c, k0, k1, (uint32_t)(lane + 64 * j), search, depth, 0u, gam[j]);
+        pend[j] = __ballot(!ok);
+        any |= pend[j] != 0ull;
+    }
+    for (uint32_t att = 1; any;) {
+        int tot = 0;
+#pragma unroll
+        for (int j = 0; j < J; j++) tot += __popcll(pend[j]);
+        // k speculative attempts (att .. att+k-1) per pending cell while they fit on the 64 lanes; the lowest accepted
+        // attempt of a cell wins, exactly as if they had been tried one after the other
+        const int k = tot >= 64 ? 1 : 64 / tot;
+        for (int base = 0; base < tot * k; base += 64) {
+            const int item = base + lane;
+            const bool active = item < tot * k;
+            const int idx = item / k, sub = item - idx * k;
+            int rem = idx, cell = -1;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int pc = __popcll(pend[j]);
+                if (active && cell < 0) {
+                    if (rem < pc) cell = c6_select_bit(pend[j], rem) + 64 * j;
+                    else rem -= pc;
+                }
+            }
+            double v = 0.0;
+            const bool ok = active && c6_gamma_try(alpha, d, c, k0, k1, (uint32_t)cell, search, depth, att + (uint32_t)sub, v);
+            // lanes of one cell are consecutive (sub = 0..k-1, one batch whenever k > 1): the first accepted one writes
+            const unsigned long long okm = __ballot(ok);
+            const unsigned long long mine = (okm >> (lane - sub)) & (k >= 64 ? ~0ull : ((1ull << k) - 1ull));
+            if (active && sub == 0 && mine == 0ull) scratch[cell] = -1.0;
+            if (ok && (mine & ((1ull << sub) - 1ull)) == 0ull) scratch[cell] = v;
+        }
+        att += (uint32_t)k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS is in order within a wave; this binds the compiler
+        any = false;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            bool still = false;
+            if ((pend[j] >> lane) & 1ull) {
+                const double v = scratch[lane + 64 * j];
+                if (v < 0.0) still = true; else gam[j] = v;
+            }
+            pend[j] = __ballot(still);
+            any |= pend[j] != 0ull;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
 }

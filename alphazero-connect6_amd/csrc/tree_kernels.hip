@@ -57,7 +57,8 @@ __device__ __forceinline__ void next_turn(int &turn, int &remain) {   // simulat
 // select: walk from the root by PUCT + Dirichlet noise until a node without record (leaf)
 // ------------------------------------------------------------------------------------------
 template <int J>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)) void c6_select_kernel(C6Dev E) {
+    __shared__ double gscratch[WAVES_PER_BLOCK][64 * J];    // c6_wave_gamma hand-back, wave-private
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= E.G) return;
@@ -117,14 +118,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_select_kernel(C6Dev E
             const float visit_sum = (float)c6_wave_sum_i32(vs);
             // Dirichlet noise: Gamma draws normalised by their sum (C6RNG), mod.rs:260-262,283
             double gam[J], part = 0.0;
+            bool need[J];
 #pragma unroll
-            for (int j = 0; j < J; j++) {
-                gam[j] = 0.0;
-                if (st[j] == 0) {
-                    gam[j] = c6_gamma_draw(E.alpha, E.gam_d, E.gam_c, k0, k1, (uint32_t)(lane + 64 * j), t, (uint32_t)d);
-                    part = part + gam[j];
-                }
-            }
+            for (int j = 0; j < J; j++) need[j] = st[j] == 0;
+            c6_wave_gamma<J>(need, gam, gscratch[threadIdx.x >> 6], lane, E.alpha, E.gam_d, E.gam_c, k0, k1, t, (uint32_t)d);
+#pragma unroll
+            for (int j = 0; j < J; j++) part = part + gam[j];     // cells that need none hold 0.0 (+ 0.0 is exact)
             const double gsum = c6_butterfly_sum(part);
             float sc[J], best = -INFINITY;
 #pragma unroll
@@ -694,16 +693,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_noise_op_kernel(int N
     if (b >= num) return;
     const int cells = N * N;
     const int8_t *board = boards + (size_t)b * cells;
+    __shared__ double gscratch[WAVES_PER_BLOCK][64 * C6_MAXJ];
     double gam[C6_MAXJ], part = 0.0;
+    bool need[C6_MAXJ];
 #pragma unroll
     for (int j = 0; j < C6_MAXJ; j++) {
         const int c = lane + 64 * j;
-        gam[j] = 0.0;
-        if (c < cells && board[c] == 0) {
-            gam[j] = c6_gamma_draw(alpha, gd, gc, k0[b], k1[b], (uint32_t)c, search[b], depth[b]);
-            part = part + gam[j];
-        }
+        need[j] = c < cells && board[c] == 0;
     }
+    // the same wave-cooperative sampler as c6_select_kernel (the oracle draws cell by cell with its own loop)
+    c6_wave_gamma<C6_MAXJ>(need, gam, gscratch[threadIdx.x >> 6], lane, alpha, gd, gc, k0[b], k1[b], search[b], depth[b]);
+#pragma unroll
+    for (int j = 0; j < C6_MAXJ; j++) part = part + gam[j];
     const double gsum = c6_butterfly_sum(part);
 #pragma unroll
     for (int j = 0; j < C6_MAXJ; j++) {
