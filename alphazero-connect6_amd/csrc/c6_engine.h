@@ -125,6 +125,7 @@ struct C6NetDev {
     const float *conv_w2; // same weights packed for conv v2
     const unsigned short *conv_w3; // same weights split into bf16 hi/mid planes (conv_bf16x3.hip)
     const unsigned short *conv_w6; // split planes packed per wave (c6_conv3x3_b3n_kernel)
+    const unsigned short *conv_w7; // the same for the 16x16x32 tiling (c6_conv3x3_b3s_kernel)
     const float *conv_b;  // [(blocks-1)*2][C]
     const float *pc_w;    // [2][C] folded
     const float *pc_b;    // [2]
@@ -154,6 +155,9 @@ bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsig
                          float *out, hipStream_t s);
 size_t c6_conv_packed_b3n_units(int C);
 void c6_pack_conv_weights_b3n(int C, const float *w_oihw_folded, unsigned short *packed);
+void c6_pack_conv_weights_b3s(int C, const float *w_oihw_folded, unsigned short *packed);
+bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
+                          float *out, int num_cus, hipStream_t s);
 bool c6_conv_b3n_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                           float *out, int num_cus, hipStream_t s);
 void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,

@@ -398,6 +398,199 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3n_kernel(const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "small-tile" N-split variant (c6_conv3x3_b3s_kernel): the b3n kernel on v_mfma_f32_16x16x32_bf16.
+//  Under a bf16-MFMA load on real data the chip is clock-limited (DVFS), and the clock it holds depends on the MFMA
+//  shape: tools/mfma_calib.hip measures the SAME instruction mix from registers at 1.82-1.90 PFLOP/s (1.84-1.88 GHz) in
+//  the 32x32x16 shape and 2.15-2.28 PFLOP/s (2.09-2.28 GHz) in 16x16x32.  Same data movement as b3n: a wave still owns 32
+//  output channels x all pixels (2 x PT accumulator tiles of 4 registers = the same 192 VGPRs at N = 19), one K step is a
+//  whole 32-channel slice of one tap, a pixel fragment pair (hi, mid) read from LDS feeds 6 MFMAs (96 cycles, as before),
+//  the weights of a step are 2 tiles x 2 planes = 16 VGPRs, prefetched one step ahead.
+//  LDS slot = 160 bytes: with lane = (pixel j = l & 15, k-block l >> 4) reading 16 bytes at slot(j) + 16 kb, 160 is the
+//  stride below 256 for which all four 16-lane groups of ds_read_b128 hit 16 distinct 4-bank groups (144 gives 2-way).
+//  D = W x X^T as in b3n: lane (j, q = l >> 4) of tile (ct, pt) holds channels 32 wave + 16 ct + 4 q + 0..3 of pixel row
+//  16 pt + j -> 16-byte NHWC runs, lanes q = 0..3 completing 64 bytes; residual = initial accumulator value.
+// ------------------------------------------------------------------------------------------------------------------
+#define B3S_SLOT 80
+template <int C, int N>
+struct B3SGeom {
+    static constexpr int W = N + 1;
+    static constexpr int MROWS = N * W;
+    static constexpr int PT = (MROWS + 15) / 16;           // 24 @19 (384 rows), 15 @15 (240 rows: no padding), 6 @9
+    static constexpr int SLOTS = ((PT * 16 + 2 * W + 2 + 1) + 7) & ~7;
+    static constexpr int IN_UNITS = SLOTS * B3S_SLOT;
+    static constexpr int WAVES = C / 32;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr size_t LDS_BYTES = (size_t)2 * IN_UNITS * 2;
+};
+
+template <int C, int N>
+__global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const float *__restrict__ in, const unsigned short *__restrict__ wp,
+                                                                       const float *__restrict__ bias, const float *__restrict__ res,
+                                                                       float *__restrict__ out, int nboards) {
+    using G = B3SGeom<C, N>;
+    constexpr int W = G::W, PT = G::PT, KS = C / 32, THREADS = G::THREADS, WAVES = G::WAVES, CELLS = N * N;
+    constexpr int PH0 = (PT + 1) / 2;                      // a tap's pixel tiles run in two halves (trickle sub-stages)
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short *lds0 = smem16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x, bstep = gridDim.x;
+    const int nlocal = b0 < nboards ? (nboards - b0 + bstep - 1) / bstep : 0;
+    const int total = nlocal * KS;
+
+    for (int k = tid; k < G::IN_UNITS; k += THREADS) reinterpret_cast<uint32_t *>(lds0)[k] = 0u;   // both buffers, halo = 0
+
+    auto item_load = [&](const float *slice, int k) -> f32x4 {
+        int item = tid + k * THREADS;
+        item = item < CELLS * 8 ? item : CELLS * 8 - 1;
+        return *reinterpret_cast<const f32x4 *>(slice + (size_t)(item >> 3) * C + (item & 7) * 4);
+    };
+    auto item_store = [&](unsigned short *buf, int k, f32x4 v) {
+        const int item = tid + k * THREADS;
+        if (item < CELLS * 8) {
+            const int p = item >> 3, q = item & 7;
+            bf16x4 hi, mid;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                hi[r] = (__bf16)v[r];
+                mid[r] = (__bf16)(v[r] - (float)hi[r]);
+            }
+            unsigned short *dst = buf + ((p / N + 1) * W + (p % N + 1)) * B3S_SLOT + q * 4;
+            *reinterpret_cast<bf16x4 *>(dst) = hi;
+            *reinterpret_cast<bf16x4 *>(dst + 32) = mid;
+        }
+    };
+    constexpr int NITEM = (CELLS * 8 + THREADS - 1) / THREADS;
+    constexpr int IPS = (NITEM + 5) / 6;
+
+    // weights of this wave: [stage = ks*9 + tap][wave][ct][plane][lane][8]
+    auto wptr = [&](int stage, int ct, int plane) -> const bf16x8 * {
+        return reinterpret_cast<const bf16x8 *>(wp + ((((size_t)stage * WAVES + wave) * 2 + ct) * 2 + plane) * 512) + lane;
+    };
+
+    if (total == 0) return;
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < NITEM; k++) item_store(lds0, k, item_load(in + (size_t)b0 * (size_t)(CELLS * C), k));   // very first slice
+    bf16x8 whi[2], wmid[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) { whi[ct] = *wptr(0, ct, 0); wmid[ct] = *wptr(0, ct, 1); }
+    f32x4 pend[IPS];
+#pragma unroll
+    for (int q = 0; q < IPS; q++) pend[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int lb = 0; lb < nlocal; lb++) {
+    // opaque per board: otherwise LICM hoists the row offsets of the unrolled tile loops out of the board loop
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int pj = lane_o & 15, n4 = wave * 32 + 4 * (lane_o >> 4);
+    auto row_off = [&](int pt, bool &ok) -> size_t {
+        const int m = pt * 16 + pj, y = m / W, x = m % W;
+        ok = x < N && y < N;
+        return (size_t)((ok ? y : 0) * N + (ok ? x : 0)) * C + n4;      // clamped: loads stay unconditional
+    };
+    const size_t b = (size_t)(b0 + lb * bstep);
+    f32x4 acc[2][PT];
+    if (res) {      // the residual is the accumulators' initial value: all loads in flight at once
+        const float *resb = res + b * (size_t)CELLS * C;
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
+            bool ok;
+            const float *rp = resb + row_off(pt, ok);
+            acc[0][pt] = *reinterpret_cast<const f32x4 *>(rp);
+            acc[1][pt] = *reinterpret_cast<const f32x4 *>(rp + 16);
+        }
+    } else {
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) acc[0][pt] = acc[1][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks++) {
+        const int gs = lb * KS + ks;
+        __syncthreads();   // slice gs complete in its buffer; everybody has left the other buffer
+        const unsigned short *lds_in = lds0 + (gs & 1) * G::IN_UNITS;
+        unsigned short *lds_nx = lds0 + ((gs + 1) & 1) * G::IN_UNITS;
+        const bool more = gs + 1 < total;
+        const float *nslice = in + (size_t)(b0 + (ks + 1 < KS ? lb : lb + 1) * bstep) * (size_t)(CELLS * C) + (ks + 1 < KS ? (ks + 1) * 32 : 0);
+        int abase = (lane & 15) * B3S_SLOT + 8 * (lane >> 4);   // tap 0 = top-left neighbour of row m = j; k-block l >> 4
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+            // prefetch the weights of the next step (of the next board's first slice at a board boundary)
+            bf16x8 nhi[2], nmid[2];
+            {
+                int ntap = tap + 1, nks = ks;
+                if (ntap == 9) { ntap = 0; nks++; }
+                if (nks == KS) nks = 0;      // wraps to the next board's first stage (one harmless extra load at the very end)
+#pragma unroll
+                for (int ct = 0; ct < 2; ct++) { nhi[ct] = *wptr(nks * 9 + ntap, ct, 0); nmid[ct] = *wptr(nks * 9 + ntap, ct, 1); }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                // the next input slice trickles in: item group k is loaded at sub-stage 3k and split + written at 3k + 2
+                // (vmcnt completes in order: the HBM load must not be needed -- directly or through a wait on a younger
+                // weight load -- any earlier)
+                if (more) {
+                    const int sidx = tap * 2 + half, k = sidx / 3, ph = sidx % 3;
+                    if (ph == 0) {
+#pragma unroll
+                        for (int q = 0; q < IPS; q++) if (k * IPS + q < NITEM) pend[q] = item_load(nslice, k * IPS + q);
+                    } else if (ph == 2) {
+#pragma unroll
+                        for (int q = 0; q < IPS; q++) if (k * IPS + q < NITEM) item_store(lds_nx, k * IPS + q, pend[q]);
+                    }
+                }
+                // pixel fragments double-buffered by hand (sched_barrier keeps hipcc from serialising read -> wait -> MFMA)
+                bf16x8 phi[2], pmid[2];
+                auto load_p = [&](int slot, int pt) {
+                    const unsigned short *ap = lds_in + abase + (pt * 16) * B3S_SLOT;
+                    phi[slot] = *reinterpret_cast<const bf16x8 *>(ap);
+                    pmid[slot] = *reinterpret_cast<const bf16x8 *>(ap + 32);
+                };
+                const int p_lo = half == 0 ? 0 : PH0, p_hi = half == 0 ? PH0 : PT;
+                load_p(0, p_lo);
+#pragma unroll
+                for (int pt = p_lo, sl = 0; pt < p_hi; pt++, sl ^= 1) {
+                    if (pt + 1 < p_hi) load_p(sl ^ 1, pt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ct++) {
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ct], pmid[sl], acc[ct][pt], 0, 0, 0);
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid[ct], phi[sl], acc[ct][pt], 0, 0, 0);
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ct], phi[sl], acc[ct][pt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) { whi[ct] = nhi[ct]; wmid[ct] = nmid[ct]; }
+            abase += (tap % 3 == 2 ? W - 2 : 1) * B3S_SLOT;   // next tap: +1 slot, or the start of the next row
+        }
+    }   // ks
+
+        // epilogue: + bias, ReLU, 16-byte stores straight from the accumulators (rows with x == N are junk); the stores
+        // drain behind the next board's first slice
+        float *outb = out + b * (size_t)CELLS * C;
+        const f32x4 bi0 = *reinterpret_cast<const f32x4 *>(bias + n4), bi1 = *reinterpret_cast<const f32x4 *>(bias + n4 + 16);
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
+            bool ok;
+            float *op = outb + row_off(pt, ok);
+            if (ok) {
+                f32x4 y0 = acc[0][pt] + bi0, y1 = acc[1][pt] + bi1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    y0[r] = y0[r] > 0.f ? y0[r] : 0.f;
+                    y1[r] = y1[r] > 0.f ? y1[r] : 0.f;
+                }
+                *reinterpret_cast<f32x4 *>(op) = y0;
+                *reinterpret_cast<f32x4 *>(op + 16) = y1;
+            }
+        }
+    }
+}
+
 static inline unsigned short f32_to_bf16_rne(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -489,6 +682,48 @@ void c6_pack_conv_weights_b3n(int C, const float *w, unsigned short *packed) {
                             packed[base + 0 * 512 + lane * 8 + j] = hi;
                             packed[base + 1 * 512 + lane * 8 + j] = mid;
                         }
+}
+
+// w: folded OIHW [C][C][3][3] -> [stage = ks*9 + tap][wave][ct][plane][lane][j]
+//    value = split(W[n = wave*32 + ct*16 + (lane & 15)][k = ks*32 + (lane >> 4)*8 + j][tap]), bf16 bits (same size as b3n)
+void c6_pack_conv_weights_b3s(int C, const float *w, unsigned short *packed) {
+    const int KS = C / 32, WAVES = C / 32;
+    for (int ks = 0; ks < KS; ks++)
+        for (int t = 0; t < 9; t++)
+            for (int wv = 0; wv < WAVES; wv++)
+                for (int ct = 0; ct < 2; ct++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const int n = wv * 32 + ct * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
+                            const float x = w[((size_t)n * C + k) * 9 + t];
+                            const unsigned short hi = f32_to_bf16_rne(x);
+                            const unsigned short mid = f32_to_bf16_rne(x - bf16_to_f32(hi));
+                            const size_t base = ((((size_t)(ks * 9 + t) * WAVES + wv) * 2 + ct) * 2) * 512;
+                            packed[base + 0 * 512 + lane * 8 + j] = hi;
+                            packed[base + 1 * 512 + lane * 8 + j] = mid;
+                        }
+}
+
+template <int C, int N>
+static void launch_b3s(int nboards, int grid, const float *in, const unsigned short *wp, const float *bias, const float *res, float *out,
+                       hipStream_t s) {
+    using G = B3SGeom<C, N>;
+    const size_t smem = G::LDS_BYTES;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3s_kernel<C, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards);
+}
+
+bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
+                          float *out, int num_cus, hipStream_t s) {
+    if (nboards <= 0) return true;
+    const int per_cu = C == 256 ? 1 : (C == 128 ? 2 : 4);
+    const int grid = nboards < num_cus * per_cu ? nboards : num_cus * per_cu;
+#define B3SCASE(CC, NN) if (C == CC && N == NN) { launch_b3s<CC, NN>(nboards, grid, in, wp, bias, res, out, s); return true; }
+    B3SCASE(256, 19) B3SCASE(256, 15) B3SCASE(256, 9)
+    B3SCASE(128, 19) B3SCASE(128, 15) B3SCASE(128, 9)
+    B3SCASE(64, 19) B3SCASE(64, 15) B3SCASE(64, 9)
+#undef B3SCASE
+    return false;
 }
 
 template <int C, int N>

@@ -173,13 +173,16 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
     C6NetDev &d = nh.dev;
     d.N = n; d.cells = cells; d.C = C; d.blocks = nb;
     {
-        // A/B switch.  1 = c6_conv3x3_kernel (32x32x2 tiles, NHWC; the faster one: 129 vs 119 TFLOP/s on MI355X),
-        // 2 = c6_conv3x3_v2_kernel (16x16x4 tiles, slice-major activations; experimental)
-        // 6 = c6_conv3x3_b3n_kernel (split bf16 products, fp32 accumulate, persistent N-split schedule) -- the default;
-        // 3 = c6_conv3x3_bf16x3_kernel (same arithmetic, M x N wave grid with weight stages in LDS)
+        // A/B switch (C6_CONV_VARIANT).  FP32 precision: 1 = c6_conv3x3_kernel (32x32x2 tiles, NHWC; 129 TFLOP/s),
+        // 2 = c6_conv3x3_v2_kernel (16x16x4 tiles, slice-major activations; experimental, 119 TFLOP/s).
+        // Split-bf16 precision (the default): 7 = c6_conv3x3_b3s_kernel (persistent N-split schedule on 16x16x32 MFMAs,
+        // the default: the chip holds a higher clock on that shape), 6 = c6_conv3x3_b3n_kernel (same schedule on
+        // 32x32x16), 3 = c6_conv3x3_bf16x3_kernel (M x N wave grid with weight stages in LDS)
         const char *v = std::getenv("C6_CONV_VARIANT");
-        d.variant = precision == C6_PREC_FP32 ? 1 : precision == C6_PREC_BF16X3 ? 6 : (v ? std::atoi(v) : 6);
-        if (d.variant != 1 && d.variant != 2 && d.variant != 3) d.variant = 6;
+        const int ev = v ? std::atoi(v) : 0;
+        if (precision == C6_PREC_FP32) d.variant = ev == 2 ? 2 : 1;
+        else if (precision == C6_PREC_BF16X3) d.variant = (ev == 3 || ev == 6) ? ev : 7;
+        else d.variant = (ev == 1 || ev == 2 || ev == 3 || ev == 6) ? ev : 7;
         hipDeviceProp_t prop;
         int dev = 0;
         hipGetDevice(&dev);
@@ -205,7 +208,7 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         const size_t w3 = c6_conv_packed_b3_units(C);
         std::vector<unsigned short> cw3((size_t)std::max(L, 1) * w3);
         const size_t w6 = c6_conv_packed_b3n_units(C);
-        std::vector<unsigned short> cw6((size_t)std::max(L, 1) * w6);
+        std::vector<unsigned short> cw6((size_t)std::max(L, 1) * w6), cw7((size_t)std::max(L, 1) * w6);
         for (int l = 0; l < L; l++) {
             const float *w = take((size_t)C * C * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
             for (int co = 0; co < C; co++) {
@@ -217,9 +220,10 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
             c6_pack_conv_weights_v2(C, folded.data(), cw2.data() + (size_t)l * wsz);
             c6_pack_conv_weights_b3(C, folded.data(), cw3.data() + (size_t)l * w3);
             c6_pack_conv_weights_b3n(C, folded.data(), cw6.data() + (size_t)l * w6);
+            c6_pack_conv_weights_b3s(C, folded.data(), cw7.data() + (size_t)l * w6);
         }
         int rc;
-        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) || (rc = upload(nh.pool, cw6, &d.conv_w6)) ||
+        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) || (rc = upload(nh.pool, cw6, &d.conv_w6)) || (rc = upload(nh.pool, cw7, &d.conv_w7)) ||
             (rc = upload(nh.pool, cb, &d.conv_b)))
             return rc;
     }

@@ -40,6 +40,26 @@ def test_net_forward_vs_oracle(n, C, blocks, num, prec):
     net.close()
 
 
+@pytest.mark.parametrize("variant", ["7", "6", "3"])
+@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 128, 3, 5), (19, 256, 2, 300), (15, 256, 2, 7)])
+def test_split_conv_variants_vs_oracle(n, C, blocks, num, variant, monkeypatch):
+    """every split-bf16 conv kernel (C6_CONV_VARIANT: 7 = 16x16x32 N-split, the default; 6 = 32x32x16 N-split; 3 = M x N
+    grid) against the oracle; num = 300 > 256 CUs makes the persistent workgroups walk over more than one board"""
+    need_gpu()
+    monkeypatch.setenv("C6_CONV_VARIANT", variant)
+    rng = np.random.default_rng(n * 77 + C)
+    blob = rand_blob(n, C, blocks, seed=n + C + blocks + 1)
+    boards = rng.integers(-1, 2, size=(num, n * n)).astype(np.int8)
+    player = rng.choice(np.array([-1, 1], np.int8), size=num)
+    pol, val = pkg.net_forward(n, C, blocks, blob, boards, player, precision=3)
+    net = o.Net(n, C, blocks, blob)
+    for i in list(range(min(num, 4))) + ([num - 1, num // 2, 257] if num > 257 else []):
+        rp, rv = net.forward(float(player[i]), boards[i].astype(np.float32))
+        assert np.abs(pol[i] - rp[0]).max() <= TOL, (i, np.abs(pol[i] - rp[0]).max())
+        assert abs(val[i] - rv[0]) <= TOL
+    net.close()
+
+
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_net_forward_vs_torch_golden(prec):
     need_gpu()
