@@ -36,7 +36,10 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
                   "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
                   "c6_bench_conv", "c6_bench_board", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
-                  "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples"]
+                  "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
+                  "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
+                  "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
+                  "c6_trainer_last_error", "c6_trainer_set_precision"]
 
 
 class C6Error(RuntimeError):
@@ -150,6 +153,17 @@ def lib():
     L.c6_engine_push_tuples.argtypes = [C.c_void_p, C.c_void_p]
     L.c6_replay_size.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.c6_replay_sample.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, f32p, f32p, f32p, f32p, f32p]
+    L.c6_trainer_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_void_p)]
+    L.c6_trainer_destroy.argtypes = [C.c_void_p]
+    L.c6_trainer_set_lr.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    L.c6_trainer_set_precision.argtypes = [C.c_void_p, C.c_int]
+    L.c6_trainer_load_weights.argtypes = [C.c_void_p, f32p, C.c_size_t]
+    L.c6_trainer_export_weights.argtypes = [C.c_void_p, f32p, C.c_size_t]
+    L.c6_trainer_gradients.argtypes = [C.c_void_p, f32p, C.c_size_t]
+    L.c6_trainer_step.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, f32p]
+    L.c6_trainer_loss.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, f32p]
+    L.c6_trainer_step_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, f32p]
+    L.c6_trainer_last_error.restype = C.c_char_p
     L.cpp_self_play.restype = Vec
     L.cpp_self_play.argtypes = [CALLBACK, ALLOC_PATH, ALLOC_RESULT, C.c_int, C.c_float, C.c_double, C.c_float, C.c_bool, C.c_int]
     L.cpp_play.restype = Vec
@@ -176,7 +190,8 @@ def lib():
 
 def _chk(rc):
     if rc != OK:
-        raise C6Error(f"libconnect6_amd error {rc}: {lib().c6_last_error().decode()}")
+        msg = lib().c6_last_error().decode() or lib().c6_trainer_last_error().decode()
+        raise C6Error(f"libconnect6_amd error {rc}: {msg}")
 
 
 def _p(a, t):
@@ -469,6 +484,68 @@ class ReplayBuffer:
         _chk(lib().c6_replay_sample(self.h, num_sample, seed, draw_id, _p(w, C.c_float), _p(p, C.c_float), _p(b, C.c_float),
                                     _p(q, C.c_float), _p(pi, C.c_float) if want_pi else None))
         return (w, p, b, q, pi) if want_pi else (w, p, b, q)
+
+
+class Trainer:
+    """The train-loop body of AlphaZero/cpp_weighted/main.cpp:148-160 on the GPU: `step` = zero_grad + model->loss +
+    backward + SGD step (WeightedPolicy in train mode, model.hpp:52-108).  Weights are the engine's blob."""
+
+    def __init__(self, board_size, channels, blocks, batch, lr=1e-3, momentum=0.9, device=0, precision=PREC_BF16X3):
+        self.n, self.cells, self.C, self.blocks, self.batch = board_size, board_size * board_size, channels, blocks, batch
+        self.nfloats = lib().c6_net_blob_floats(board_size, channels, blocks)
+        self.h = C.c_void_p()
+        _chk(lib().c6_trainer_create(board_size, channels, blocks, batch, lr, momentum, device, C.byref(self.h)))
+        _chk(lib().c6_trainer_set_precision(self.h, precision))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().c6_trainer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def load_weights(self, blob):
+        b = np.ascontiguousarray(blob, dtype=np.float32)
+        _chk(lib().c6_trainer_load_weights(self.h, _p(b, C.c_float), b.size))
+
+    def export_weights(self):
+        b = np.zeros(self.nfloats, np.float32)
+        _chk(lib().c6_trainer_export_weights(self.h, _p(b, C.c_float), b.size))
+        return b
+
+    def gradients(self):
+        b = np.zeros(self.nfloats, np.float32)
+        _chk(lib().c6_trainer_gradients(self.h, _p(b, C.c_float), b.size))
+        return b
+
+    def _batch(self, winners, players, boards, poses):
+        w = np.ascontiguousarray(winners, dtype=np.float32).reshape(-1)
+        p = np.ascontiguousarray(players, dtype=np.float32).reshape(-1)
+        b = np.ascontiguousarray(boards, dtype=np.float32).reshape(-1)
+        q = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1)
+        if not (w.size == p.size == q.size == self.batch and b.size == self.batch * self.cells):
+            raise C6Error("batch shapes do not match the trainer's mini-batch size")
+        return w, p, b, q
+
+    def step(self, winners, players, boards, poses):
+        """one SGD step; returns the loss before the step"""
+        w, p, b, q = self._batch(winners, players, boards, poses)
+        loss = C.c_float()
+        _chk(lib().c6_trainer_step(self.h, _p(w, C.c_float), _p(p, C.c_float), _p(b, C.c_float), _p(q, C.c_float), 0, C.byref(loss)))
+        return loss.value
+
+    def loss(self, winners, players, boards, poses):
+        w, p, b, q = self._batch(winners, players, boards, poses)
+        loss = C.c_float()
+        _chk(lib().c6_trainer_loss(self.h, _p(w, C.c_float), _p(p, C.c_float), _p(b, C.c_float), _p(q, C.c_float), 0, C.byref(loss)))
+        return loss.value
+
+    def step_replay(self, replay, seed=0, draw_id=0):
+        """buffer.sample() + step without leaving the device"""
+        loss = C.c_float()
+        _chk(lib().c6_trainer_step_replay(self.h, replay.h, seed, draw_id, C.byref(loss)))
+        return loss.value
 
 
 def replay_moves(n, moves):

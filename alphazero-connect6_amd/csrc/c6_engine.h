@@ -156,8 +156,10 @@ bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsig
 size_t c6_conv_packed_b3n_units(int C);
 void c6_pack_conv_weights_b3n(int C, const float *w_oihw_folded, unsigned short *packed);
 void c6_pack_conv_weights_b3s(int C, const float *w_oihw_folded, unsigned short *packed);
+bool c6_conv_fp32_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
+                           hipStream_t s, int relu);
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                          float *out, int num_cus, hipStream_t s);
+                          float *out, int num_cus, hipStream_t s, int relu = 1);
 bool c6_conv_b3n_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                           float *out, int num_cus, hipStream_t s);
 void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,

@@ -427,7 +427,7 @@ struct B3SGeom {
 template <int C, int N>
 __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const float *__restrict__ in, const unsigned short *__restrict__ wp,
                                                                        const float *__restrict__ bias, const float *__restrict__ res,
-                                                                       float *__restrict__ out, int nboards) {
+                                                                       float *__restrict__ out, int nboards, int relu) {
     using G = B3SGeom<C, N>;
     constexpr int W = G::W, PT = G::PT, KS = C / 32, THREADS = G::THREADS, WAVES = G::WAVES, CELLS = N * N;
     constexpr int PH0 = (PT + 1) / 2;                      // a tap's pixel tiles run in two halves (trickle sub-stages)
@@ -572,7 +572,10 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
         // epilogue: + bias, ReLU, 16-byte stores straight from the accumulators (rows with x == N are junk); the stores
         // drain behind the next board's first slice
         float *outb = out + b * (size_t)CELLS * C;
-        const f32x4 bi0 = *reinterpret_cast<const f32x4 *>(bias + n4), bi1 = *reinterpret_cast<const f32x4 *>(bias + n4 + 16);
+        // bias == nullptr and relu == 0: the training path (plain convolution: pre-BatchNorm output, input gradient)
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bi0 = bias ? *reinterpret_cast<const f32x4 *>(bias + n4) : zero4, bi1 = bias ? *reinterpret_cast<const f32x4 *>(bias + n4 + 16) : zero4;
+        const float floor_ = relu ? 0.f : -INFINITY;
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
             bool ok;
@@ -581,8 +584,8 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
                 f32x4 y0 = acc[0][pt] + bi0, y1 = acc[1][pt] + bi1;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    y0[r] = y0[r] > 0.f ? y0[r] : 0.f;
-                    y1[r] = y1[r] > 0.f ? y1[r] : 0.f;
+                    y0[r] = y0[r] > floor_ ? y0[r] : floor_;
+                    y1[r] = y1[r] > floor_ ? y1[r] : floor_;
                 }
                 *reinterpret_cast<f32x4 *>(op) = y0;
                 *reinterpret_cast<f32x4 *>(op + 16) = y1;
@@ -706,19 +709,19 @@ void c6_pack_conv_weights_b3s(int C, const float *w, unsigned short *packed) {
 
 template <int C, int N>
 static void launch_b3s(int nboards, int grid, const float *in, const unsigned short *wp, const float *bias, const float *res, float *out,
-                       hipStream_t s) {
+                       int relu, hipStream_t s) {
     using G = B3SGeom<C, N>;
     const size_t smem = G::LDS_BYTES;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3s_kernel<C, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards);
+    hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu);
 }
 
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                          float *out, int num_cus, hipStream_t s) {
+                          float *out, int num_cus, hipStream_t s, int relu) {
     if (nboards <= 0) return true;
     const int per_cu = C == 256 ? 1 : (C == 128 ? 2 : 4);
     const int grid = nboards < num_cus * per_cu ? nboards : num_cus * per_cu;
-#define B3SCASE(CC, NN) if (C == CC && N == NN) { launch_b3s<CC, NN>(nboards, grid, in, wp, bias, res, out, s); return true; }
+#define B3SCASE(CC, NN) if (C == CC && N == NN) { launch_b3s<CC, NN>(nboards, grid, in, wp, bias, res, out, relu, s); return true; }
     B3SCASE(256, 19) B3SCASE(256, 15) B3SCASE(256, 9)
     B3SCASE(128, 19) B3SCASE(128, 15) B3SCASE(128, 9)
     B3SCASE(64, 19) B3SCASE(64, 15) B3SCASE(64, 9)

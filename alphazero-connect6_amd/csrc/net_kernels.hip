@@ -45,7 +45,7 @@ struct C6NetTimers {
 template <int C, int MTW, int ABL = 0>
 __global__ __launch_bounds__(CONV_THREADS) void c6_conv3x3_kernel(const float *__restrict__ in, const float *__restrict__ wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ res,
-                                                                 float *__restrict__ out, int N) {
+                                                                 float *__restrict__ out, int N, int relu) {
     constexpr int NTW = C / 64;          // 32-wide n-tiles per wave (2 waves along N)
     constexpr int KS = C / 32;           // 32-channel k-slices
     constexpr int WSTAGE = 32 * C;       // floats per weight stage
@@ -145,7 +145,9 @@ __global__ __launch_bounds__(CONV_THREADS) void c6_conv3x3_kernel(const float *_
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
         const int n4 = (wn * NTW + nt) * 32 + c4;
-        const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + n4);
+        // bias == nullptr / relu == 0: the training path (plain convolution)
+        const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + n4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float floor_ = relu ? 0.f : -INFINITY;
 #pragma unroll
         for (int mt = 0; mt < MTW; mt++) {
 #pragma unroll
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(CONV_THREADS) void c6_conv3x3_kernel(const float *_
                     y = y + bi;
                     if (resb) y = y + *reinterpret_cast<const f32x4 *>(resb + (size_t)p * C + n4);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) y[q] = y[q] > 0.f ? y[q] : 0.f;
+                    for (int q = 0; q < 4; q++) y[q] = y[q] > floor_ ? y[q] : floor_;
                     *reinterpret_cast<f32x4 *>(outb + (size_t)p * C + n4) = y;
                 }
             }
@@ -379,34 +381,42 @@ __global__ __launch_bounds__(256) void c6_head_value_kernel(const float *__restr
 // ----------------------------------------------------------------------------------------
 template <int C>
 static void launch_conv(int MTW, int nboards, size_t smem, const float *in, const float *wp, const float *bias, const float *res,
-                        float *out, int N, hipStream_t s) {
+                        float *out, int N, hipStream_t s, int relu) {
     switch (MTW) {
     case 1:
         hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 1>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N);
+        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 1>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N, relu);
         break;
     case 2:
         hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<C, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 2>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N);
+        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 2>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N, relu);
         break;
     default:
         hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<C, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 3>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N);
+        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 3>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N, relu);
         break;
     }
 }
 
 static void conv_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res,
-                          float *out, hipStream_t s) {
+                          float *out, hipStream_t s, int relu = 1) {
     const int cells = N * N, MT = (cells + 31) / 32, MTW = (MT + 3) / 4, P = N + 2;
     size_t smem = ((size_t)((P * P * SLOT_F + 3) & ~3) + 2 * 32 * (size_t)C) * sizeof(float);
     if (smem < (size_t)8 * 32 * 36 * sizeof(float)) smem = (size_t)8 * 32 * 36 * sizeof(float);   // epilogue patches
     switch (C) {
-    case 64: launch_conv<64>(MTW, nboards, smem, in, wp, bias, res, out, N, s); break;
-    case 128: launch_conv<128>(MTW, nboards, smem, in, wp, bias, res, out, N, s); break;
-    case 256: launch_conv<256>(MTW, nboards, smem, in, wp, bias, res, out, N, s); break;
+    case 64: launch_conv<64>(MTW, nboards, smem, in, wp, bias, res, out, N, s, relu); break;
+    case 128: launch_conv<128>(MTW, nboards, smem, in, wp, bias, res, out, N, s, relu); break;
+    case 256: launch_conv<256>(MTW, nboards, smem, in, wp, bias, res, out, N, s, relu); break;
     default: break;
     }
+}
+
+// exact-FP32 convolution for the trainer (csrc/trainer.cpp): plain conv (bias nullable, relu selectable) + residual
+bool c6_conv_fp32_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
+                           hipStream_t s, int relu) {
+    if (C != 64 && C != 128 && C != 256) return false;
+    conv_dispatch(C, N, nboards, in, wp, bias, res, out, s, relu);
+    return true;
 }
 
 static hipEvent_t timer_event(C6NetTimers *t) {
@@ -496,7 +506,7 @@ void c6_conv_bench_launch(int variant, int ablate, int C, int N, int nboards, co
     const int P = N + 2;
     const size_t smem = ((size_t)((P * P * SLOT_F + 3) & ~3) + 2 * 32 * (size_t)C) * sizeof(float);
 #define ABLCASE(A) case A: hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<256, 3, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((c6_conv3x3_kernel<256, 3, A>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, w1, bias, res, out, N); break;
+        hipLaunchKernelGGL((c6_conv3x3_kernel<256, 3, A>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, w1, bias, res, out, N, 1); break;
     switch (ablate) { ABLCASE(1) ABLCASE(2) ABLCASE(3) ABLCASE(4) default: break; }
 #undef ABLCASE
 }

@@ -140,6 +140,19 @@ extern "C" int c6_replay_size(c6_replay *r, size_t *num_data, size_t *tail) {
     return C6_OK;
 }
 
+// ReplayBuffer::sample into DEVICE buffers on a caller's stream (the trainer's mini-batch, no host round trip)
+extern "C" int c6_replay_sample_device(c6_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
+                                       float *boards, float *poses, void *stream) {
+    if (!r || num_sample < 1 || !winners || !players || !boards || !poses) return rfail(C6_ERR_BAD_ARG, "c6_replay_sample_device: bad argument");
+    unsigned long long st[2] = {0, 0};
+    RCHK(hipMemcpy(st, r->state, sizeof(st), hipMemcpyDeviceToHost));
+    if (st[1] == 0) return rfail(C6_ERR_BAD_ARG, "c6_replay_sample_device: the buffer is empty");
+    hipLaunchKernelGGL(c6_replay_sample_kernel, dim3(num_sample), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), r->ring, r->state, r->cells,
+                       r->stride, num_sample, (uint32_t)seed, (uint32_t)(seed >> 32), draw_id, winners, players, boards, poses, (float *)nullptr);
+    return C6_OK;
+}
+extern "C" int c6_replay_board_size(const c6_replay *r) { return r ? r->n : 0; }
+
 extern "C" int c6_replay_sample(c6_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
                                 float *boards, float *poses, float *pi) {
     if (!r || num_sample < 1 || !winners || !players || !boards || !poses) return rfail(C6_ERR_BAD_ARG, "c6_replay_sample: bad argument");

@@ -286,6 +286,46 @@ int c6_replay_size(c6_replay *r, size_t *num_data, size_t *tail);             /*
 int c6_replay_sample(c6_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
                      float *boards, float *poses, float *pi);
 
+/* the same draw into DEVICE buffers on a caller's HIP stream (hipStream_t passed as void*): the trainer's mini-batch */
+int c6_replay_sample_device(c6_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
+                            float *boards, float *poses, void *stream);
+int c6_replay_board_size(const c6_replay *r);
+
+/* =====================================================================================================================
+ * Part 4 -- training step: the body of the reference's train loop,
+ *     optimizer.zero_grad(); loss = model->loss(winners, players, boards, poses); loss.backward(); optimizer.step();
+ * (AlphaZero/cpp_weighted/main.cpp:151-157) with model = WeightedPolicy in train() mode (model.hpp:52-108: BatchNorm on
+ * batch statistics, running statistics updated with momentum 0.1; loss = mean((winner - value)^2) with the reference's
+ * [B] - [B,1] broadcast + mean(-log(policy[pos] + 1e-7))) and torch::optim::SGD(lr).momentum(m) (main.cpp:107-109).
+ * Weights use the blob of c6_engine_load_weights, so c6_trainer_export_weights -> c6_engine_load_weights closes the
+ * self-play / train loop.  FP32; every reduction has a fixed order (a step is bit-reproducible).
+ * ===================================================================================================================== */
+typedef struct c6_trainer c6_trainer;
+
+/* batch = mini_batch (ReplayBuffer::num_sample, main.cpp:111); lr / momentum as torch::optim::SGDOptions */
+int c6_trainer_create(int board_size, int channels, int blocks, int batch, float lr, float momentum, int device, c6_trainer **out);
+void c6_trainer_destroy(c6_trainer *t);
+int c6_trainer_set_lr(c6_trainer *t, float lr, float momentum);
+/* precision of the 3x3 convolutions of the forward pass and of the input gradient: C6_PREC_BF16X3 (default, the evaluator's
+ * split-bf16 kernel) or C6_PREC_FP32 (exact-FP32 MFMA, 3x slower; gradient parity with an FP32 framework to ~1e-5).  The
+ * weight gradient is exact FP32 in both. */
+int c6_trainer_set_precision(c6_trainer *t, int precision);
+/* torch::load / torch::save (main.cpp:100,163) in blob form; load resets the momentum buffers */
+int c6_trainer_load_weights(c6_trainer *t, const float *blob, size_t nfloats);
+int c6_trainer_export_weights(c6_trainer *t, float *blob, size_t nfloats);
+/* one optimisation step on the batch (winners[B], players[B], boards[B*N*N], poses[B] as ReplayBuffer::sample returns
+ * them; on_device != 0: the pointers are device memory).  *loss_out = the loss before the step (may be NULL). */
+int c6_trainer_step(c6_trainer *t, const float *winners, const float *players, const float *boards, const float *poses, int on_device,
+                    float *loss_out);
+/* model->loss(...) alone, in train mode like main.cpp:159-160 (running statistics move, parameters do not) */
+int c6_trainer_loss(c6_trainer *t, const float *winners, const float *players, const float *boards, const float *poses, int on_device,
+                    float *loss_out);
+/* buffer.sample() + step on the device-resident replay buffer, no host round trip */
+int c6_trainer_step_replay(c6_trainer *t, c6_replay *r, uint64_t seed, uint32_t draw_id, float *loss_out);
+/* gradients of the last step in blob layout (zeros at the BatchNorm running statistics) -- for the parity tests */
+int c6_trainer_gradients(c6_trainer *t, float *blob, size_t nfloats);
+const char *c6_trainer_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif
