@@ -182,7 +182,7 @@ size_t c6t_stem_bwd_partial_floats(int C, int B) { return (size_t)((B + STEM_BWD
 //   mode 2 (plain column sum):   s0 = sum x
 // partial[chunk][2][C]; finalize sums the chunks in order (double accumulators).
 // ------------------------------------------------------------------------------------------------------------------
-#define CS_ROWS 64
+#define CS_ROWS 256
 __global__ __launch_bounds__(256) void c6t_colstats_kernel(int mode, size_t R, int C, const float *__restrict__ x, const float *__restrict__ aout,
                                                            const float *__restrict__ y, const float *__restrict__ mean,
                                                            const float *__restrict__ var, float *__restrict__ partial) {
@@ -207,13 +207,22 @@ __global__ __launch_bounds__(256) void c6t_colstats_kernel(int mode, size_t R, i
         partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
     }
 }
-// mode 0: out0 = mean, out1 = biased variance; otherwise out0 = s0, out1 = s1
-__global__ void c6t_colstats_finalize_kernel(int mode, size_t R, int C, int nchunk, const float *__restrict__ partial, float *__restrict__ out0,
-                                             float *__restrict__ out1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// mode 0: out0 = mean, out1 = biased variance; otherwise out0 = s0, out1 = s1.  32 columns x 8 chunk lanes per
+// workgroup: lane ky sums chunks ky, ky + 8, ... in order, the eight lane sums are then added in lane order (fixed order,
+// double accumulators).
+__global__ __launch_bounds__(256) void c6t_colstats_finalize_kernel(int mode, size_t R, int C, int nchunk, const float *__restrict__ partial,
+                                                                    float *__restrict__ out0, float *__restrict__ out1) {
+    __shared__ double l0[8][32], l1[8][32];
+    const int cx = threadIdx.x & 31, ky = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < nchunk; k++) { s0 += (double)partial[((size_t)k * 2 + 0) * C + c]; s1 += (double)partial[((size_t)k * 2 + 1) * C + c]; }
+    if (c < C)
+        for (int k = ky; k < nchunk; k += 8) { s0 += (double)partial[((size_t)k * 2 + 0) * C + c]; s1 += (double)partial[((size_t)k * 2 + 1) * C + c]; }
+    l0[ky][cx] = s0; l1[ky][cx] = s1;
+    __syncthreads();
+    if (ky != 0 || c >= C) return;
+    s0 = 0.0; s1 = 0.0;
+    for (int q = 0; q < 8; q++) { s0 += l0[q][cx]; s1 += l1[q][cx]; }
     if (mode == 0) {
         const double m = s0 / (double)R;
         double v = s1 / (double)R - m * m;
@@ -230,7 +239,7 @@ void c6t_colstats(int mode, size_t R, int C, const float *x, const float *aout, 
                   float *partial, float *out0, float *out1, hipStream_t s) {
     const int nchunk = (int)((R + CS_ROWS - 1) / CS_ROWS);
     hipLaunchKernelGGL(c6t_colstats_kernel, dim3(nchunk), dim3(256), 0, s, mode, R, C, x, aout, y, mean, var, partial);
-    hipLaunchKernelGGL(c6t_colstats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, mode, R, C, nchunk, partial, out0, out1);
+    hipLaunchKernelGGL(c6t_colstats_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, mode, R, C, nchunk, partial, out0, out1);
 }
 
 // a = relu?( (y - mean) * invstd * gamma + beta (+ res) )      (train-mode BatchNorm with the batch statistics)
@@ -498,12 +507,20 @@ __global__ __launch_bounds__(256) void c6t_head_conv_bwd_w_kernel(size_t R, int 
         partial[((size_t)blockIdx.x * 3 + 2) * C + c] = s2;
     }
 }
-__global__ void c6t_head_conv_bwd_w_finalize_kernel(int C, int nchunk, const float *__restrict__ partial, float *__restrict__ dwp, float *__restrict__ dwv) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 3 * C) return;
+__global__ __launch_bounds__(256) void c6t_head_conv_bwd_w_finalize_kernel(int C, int nchunk, const float *__restrict__ partial,
+                                                                           float *__restrict__ dwp, float *__restrict__ dwv) {
+    __shared__ double l0[8][32];
+    const int cx = threadIdx.x & 31, ky = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + cx;        // (q, c) flattened
     const int q = idx / C, c = idx % C;
     double s = 0.0;
-    for (int k = 0; k < nchunk; k++) s += (double)partial[((size_t)k * 3 + q) * C + c];
+    if (idx < 3 * C)
+        for (int k = ky; k < nchunk; k += 8) s += (double)partial[((size_t)k * 3 + q) * C + c];
+    l0[ky][cx] = s;
+    __syncthreads();
+    if (ky != 0 || idx >= 3 * C) return;
+    s = 0.0;
+    for (int j = 0; j < 8; j++) s += l0[j][cx];
     if (q < 2) dwp[q * C + c] = (float)s; else dwv[c] = (float)s;
 }
 // da[r][c] = dyp[r][0] wp[0][c] + dyp[r][1] wp[1][c] + dyv[r] wv[c]
@@ -520,7 +537,7 @@ void c6t_head_conv_bwd(size_t R, int C, const float *a, const float *dyp, const 
                        float *dwp, float *dwv, float *da, hipStream_t s) {
     const int nchunk = (int)((R + CS_ROWS - 1) / CS_ROWS);
     hipLaunchKernelGGL(c6t_head_conv_bwd_w_kernel, dim3(nchunk), dim3(256), 0, s, R, C, a, dyp, dyv, partial);
-    hipLaunchKernelGGL(c6t_head_conv_bwd_w_finalize_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, s, C, nchunk, partial, dwp, dwv);
+    hipLaunchKernelGGL(c6t_head_conv_bwd_w_finalize_kernel, dim3((3 * C + 31) / 32), dim3(256), 0, s, C, nchunk, partial, dwp, dwv);
     hipLaunchKernelGGL(c6t_head_conv_bwd_x_kernel, dim3(2048), dim3(256), 0, s, R, C, dyp, dyv, wp, wv, da);
 }
 
@@ -550,12 +567,14 @@ void c6t_sgd(size_t n, float lr, float momentum, int first, const unsigned char 
 //    linear in k -- A = dy[k][co] (zero in the halo columns, so the padding positions add nothing), B_tap = x[k + off];
 //    a 32x32x2 MFMA eats two consecutive k; lane (i, kb) reads element [k + kb][base + i]: 32 consecutive floats;
 //  * per K step one A read and nine B reads from LDS feed nine MFMAs;
+//  * two workgroups per CU (LDS <= 80 KB each): staging is synchronous inside a workgroup, the partner's MFMAs cover it;
 //  * partial[split][tap][co][ci]; c6t_wgrad_reduce_kernel sums the splits in order into OIHW.
 // ------------------------------------------------------------------------------------------------------------------
 template <int N>
 struct WGradGeom {
     static constexpr int P = N + 2;
-    static constexpr int RB = N <= 15 ? N : (N + 1) / 2;           // output rows per band (LDS budget)
+    static constexpr int RB = N <= 9 ? N : (N <= 15 ? 8 : 5);      // output rows per band: LDS <= 80 KB, two workgroups per CU
+                                                                    // (one stages its next band while the other runs MFMAs)
     static constexpr int BANDS = (N + RB - 1) / RB;
     static constexpr int KPAD = ((RB * P + 1) / 2) * 2;             // k positions per band (even)
     static constexpr int DY_ROWS = KPAD + 2;
@@ -564,7 +583,7 @@ struct WGradGeom {
 };
 
 template <int N>
-__global__ __launch_bounds__(256) void c6_wgrad_kernel(int C, int B, int boards_per_split, const float *__restrict__ dy, const float *__restrict__ x,
+__global__ __launch_bounds__(256, 2) void c6_wgrad_kernel(int C, int B, int boards_per_split, const float *__restrict__ dy, const float *__restrict__ x,
                                                        float *__restrict__ partial) {
     using G = WGradGeom<N>;
     constexpr int P = G::P, RB = G::RB;
@@ -585,23 +604,62 @@ __global__ __launch_bounds__(256) void c6_wgrad_kernel(int C, int B, int boards_
         for (int v = 0; v < 16; v++) acc[t][v] = 0.f;
 
     const int b_lo = split * boards_per_split, b_hi = (b_lo + boards_per_split < B) ? b_lo + boards_per_split : B;
+    // the halo cells are written once: the fills below only touch interior cells (and, with several bands per board, the
+    // rows a shorter last band leaves over are cleared again)
+    for (int e = tid; e < (G::DY_ROWS + G::X_ROWS) * 16; e += 256) reinterpret_cast<f32x4 *>(wsm)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int b = b_lo; b < b_hi; b++) {
         for (int band = 0; band < G::BANDS; band++) {
             const int y0 = band * RB, rows = (y0 + RB <= N) ? RB : N - y0;
             __syncthreads();
-            // zero + fill: 16 threads (f32x4 each) per 64-channel row
-            for (int e = tid; e < (G::DY_ROWS + G::X_ROWS) * 16; e += 256) reinterpret_cast<f32x4 *>(wsm)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-            __syncthreads();
-            for (int e = tid; e < rows * N * 16; e += 256) {
-                const int pix = e / 16, q = e % 16, yy = pix / N, xx = pix % N;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(dy + ((size_t)b * N * N + (size_t)(y0 + yy) * N + xx) * C + co0 + q * 4);
-                *reinterpret_cast<f32x4 *>(dyL + (yy * P + xx + 1) * 64 + q * 4) = v;     // k = yy*P + (xx+1)
+            if (G::BANDS > 1 && rows < RB) {      // stale rows of the previous (full) band
+                for (int e = tid; e < (RB - rows) * P * 16; e += 256) {
+                    reinterpret_cast<f32x4 *>(dyL + rows * P * 64)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    reinterpret_cast<f32x4 *>(xL + (rows + 2) * P * 64)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
-            for (int e = tid; e < (rows + 2) * N * 16; e += 256) {
-                const int pix = e / 16, q = e % 16, yy = pix / N, xx = pix % N, gy = y0 - 1 + yy;
-                if (gy >= 0 && gy < N) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((size_t)b * N * N + (size_t)gy * N + xx) * C + ci0 + q * 4);
-                    *reinterpret_cast<f32x4 *>(xL + (yy * P + xx + 1) * 64 + q * 4) = v;
+            // staging in batches of 8 loads in flight per thread (one workgroup per CU: nothing else hides the latency)
+            {
+                const int cnt = rows * N * 16;
+                for (int base = 0; base < cnt; base += 8 * 256) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        int e = base + u * 256 + tid;
+                        e = e < cnt ? e : cnt - 1;
+                        const int pix = e / 16, q = e % 16;
+                        v[u] = *reinterpret_cast<const f32x4 *>(dy + ((size_t)b * N * N + (size_t)y0 * N + pix) * C + co0 + q * 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = base + u * 256 + tid;
+                        if (e < cnt) {
+                            const int pix = e / 16, q = e % 16, yy = pix / N, xx = pix % N;
+                            *reinterpret_cast<f32x4 *>(dyL + (yy * P + xx + 1) * 64 + q * 4) = v[u];     // k = yy*P + (xx+1)
+                        }
+                    }
+                }
+            }
+            {
+                const int cnt = (rows + 2) * N * 16;
+                for (int base = 0; base < cnt; base += 8 * 256) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        int e = base + u * 256 + tid;
+                        e = e < cnt ? e : cnt - 1;
+                        const int pix = e / 16, q = e % 16, yy = pix / N, xx = pix % N, gy = y0 - 1 + yy;
+                        const int cy = gy < 0 ? 0 : (gy >= N ? N - 1 : gy);                    // clamped: unconditional load
+                        v[u] = *reinterpret_cast<const f32x4 *>(x + ((size_t)b * N * N + (size_t)cy * N + xx) * C + ci0 + q * 4);
+                        if (gy < 0 || gy >= N) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};               // rows outside the board: zero
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = base + u * 256 + tid;
+                        if (e < cnt) {
+                            const int pix = e / 16, q = e % 16, yy = pix / N, xx = pix % N;
+                            *reinterpret_cast<f32x4 *>(xL + (yy * P + xx + 1) * 64 + q * 4) = v[u];
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -610,15 +668,24 @@ __global__ __launch_bounds__(256) void c6_wgrad_kernel(int C, int B, int boards_
             const float *ap = dyL + kb * 64 + wco + i;
             const float *bp = xL + kb * 64 + wci + i;
             const int ksteps = (rows * P + 1) / 2;
-#pragma unroll 2
-            for (int ks = 0; ks < ksteps; ks++) {
-                const float av = ap[(2 * ks) * 64];
+            // operands of step ks + 1 are read before the MFMAs of step ks (one wave per SIMD: nothing else hides the LDS latency)
+            float av = ap[0], bv[9];
 #pragma unroll
-                for (int t = 0; t < 9; t++) {
-                    const int off = (t / 3) * P + (t % 3) - 1;
-                    const float bv = bp[(2 * ks + off) * 64];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < 9; t++) bv[t] = bp[((t / 3) * P + (t % 3) - 1) * 64];
+#pragma unroll 1
+            for (int ks = 0; ks < ksteps; ks++) {
+                const int kn = ks + 1 < ksteps ? ks + 1 : ks;
+                const float an = ap[(2 * kn) * 64];
+                float bn[9];
+#pragma unroll
+                for (int t = 0; t < 9; t++) bn[t] = bp[(2 * kn + (t / 3) * P + (t % 3) - 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 9; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                av = an;
+#pragma unroll
+                for (int t = 0; t < 9; t++) bv[t] = bn[t];
             }
         }
     }

@@ -43,6 +43,8 @@ def test_no_gpu_fails_loudly():
         pkg.Engine(board_size=9)
     with pytest.raises(pkg.C6Error):
         pkg.search_winner(9, np.zeros((81, 4), np.int8))
+    with pytest.raises(pkg.C6Error, match="no HIP device"):       # the trainer has no CPU fallback either
+        pkg.Trainer(9, 64, 2, 8)
 
 
 def test_raw_path_hooks():  # rawobj.cpp:5-65

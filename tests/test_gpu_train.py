@@ -107,6 +107,22 @@ def test_train_step_loose_random_batchnorm(n, C, blocks, B, prec):
     assert np.linalg.norm(grads - ref_grads) <= 5e-2 * np.linalg.norm(ref_grads)
 
 
+def test_train_step_vs_committed_golden():
+    """tests/golden/train_golden_n9_c64_b2.npz (gen_train_golden.py: PyTorch autograd, float64): no torch needed here"""
+    need_gpu()
+    z = np.load(os.path.join(GOLD, "train_golden_n9_c64_b2.npz"))
+    n, C, blocks, B = int(z["n"]), int(z["C"]), int(z["blocks"]), int(z["B"])
+    t = pkg.Trainer(n, C, blocks, B, lr=float(z["lr"]), momentum=float(z["momentum"]), precision=pkg.PREC_FP32)
+    t.load_weights(z["blob"])
+    loss = t.step(z["winners"], z["players"], z["boards"].astype(np.float32), z["poses"])
+    grads, after = t.gradients(), t.export_weights()
+    t.close()
+    assert abs(loss - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    assert np.linalg.norm(grads - z["grads"]) <= 1e-5 * np.linalg.norm(z["grads"])
+    assert np.abs(after - z["after"]).max() <= 1e-5
+    assert np.all(grads[z["param_mask"] == 0] == 0)          # BatchNorm running statistics carry no gradient
+
+
 def test_three_steps_with_momentum_and_running_statistics():
     need_gpu()
     n, C, blocks, B = 9, 64, 2, 8
