@@ -438,6 +438,7 @@ extern "C" void c6_engine_destroy(c6_engine *e) {
 extern "C" int c6_engine_load_weights(c6_engine *e, const float *blob, size_t nfloats) {
     if (!e || !blob) return fail(C6_ERR_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));      // rounds in flight still read the weights that are about to be replaced
     return net_load(e->net, e->cfg.board_size, e->cfg.net_channels, e->cfg.net_blocks, blob, nfloats, e->cfg.net_precision);
 }
 
