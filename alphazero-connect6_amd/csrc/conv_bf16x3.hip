@@ -421,7 +421,9 @@ struct B3SGeom {
     static constexpr int IN_UNITS = SLOTS * B3S_SLOT;
     static constexpr int WAVES = C / 32;
     static constexpr int THREADS = 64 * WAVES;
-    static constexpr size_t LDS_BYTES = (size_t)2 * IN_UNITS * 2;
+    static constexpr int NITEM = (N * N * 8 + THREADS - 1) / THREADS;   // 16-byte staging items per thread and slice
+    static constexpr int IPS = (NITEM + 5) / 6;                         // items per trickle step
+    static constexpr size_t LDS_BYTES = (size_t)2 * IN_UNITS * 2 + (size_t)THREADS * IPS * 16;   // + LDS-DMA landing area
 };
 
 template <int C, int N>
@@ -461,8 +463,9 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
             *reinterpret_cast<bf16x4 *>(dst + 32) = mid;
         }
     };
-    constexpr int NITEM = (CELLS * 8 + THREADS - 1) / THREADS;
-    constexpr int IPS = (NITEM + 5) / 6;
+    constexpr int NITEM = G::NITEM, IPS = G::IPS;
+    // landing area of the trickle's LDS-DMA: [wave][item slot][lane] x 16 bytes, behind the two input buffers
+    float *stg = reinterpret_cast<float *>(smem16 + 2 * G::IN_UNITS) + (size_t)wave * IPS * 256;
 
     // weights of this wave: [stage = ks*9 + tap][wave][ct][plane][lane][8]
     auto wptr = [&](int stage, int ct, int plane) -> const bf16x8 * {
@@ -476,9 +479,6 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
     bf16x8 whi[2], wmid[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) { whi[ct] = *wptr(0, ct, 0); wmid[ct] = *wptr(0, ct, 1); }
-    f32x4 pend[IPS];
-#pragma unroll
-    for (int q = 0; q < IPS; q++) pend[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
     for (int lb = 0; lb < nlocal; lb++) {
@@ -528,17 +528,26 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
             }
 #pragma unroll
             for (int half = 0; half < 2; half++) {
-                // the next input slice trickles in: item group k is loaded at sub-stage 3k and split + written at 3k + 2
-                // (vmcnt completes in order: the HBM load must not be needed -- directly or through a wait on a younger
-                // weight load -- any earlier)
+                // the next input slice trickles in: item group k leaves global memory at sub-stage 3k by LDS-DMA
+                // (global_load_lds_dwordx4: per-lane gather, no VGPRs -- a register-held copy was being spilled across the
+                // MFMAs, and that scratch traffic showed up as +30 % HBM bytes) and is split + written to its slots at 3k + 2.
+                // vmcnt completes in order: exactly the four weight loads of one step are younger than the DMA by then.
                 if (more) {
                     const int sidx = tap * 2 + half, k = sidx / 3, ph = sidx % 3;
                     if (ph == 0) {
 #pragma unroll
-                        for (int q = 0; q < IPS; q++) if (k * IPS + q < NITEM) pend[q] = item_load(nslice, k * IPS + q);
+                        for (int q = 0; q < IPS; q++)
+                            if (k * IPS + q < NITEM) {
+                                int item = tid + (k * IPS + q) * THREADS;
+                                item = item < CELLS * 8 ? item : CELLS * 8 - 1;
+                                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)(nslice + (size_t)(item >> 3) * C + (item & 7) * 4),
+                                                                 (__attribute__((address_space(3))) void *)(stg + q * 256), 16, 0, 0);
+                            }
                     } else if (ph == 2) {
+                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #pragma unroll
-                        for (int q = 0; q < IPS; q++) if (k * IPS + q < NITEM) item_store(lds_nx, k * IPS + q, pend[q]);
+                        for (int q = 0; q < IPS; q++)
+                            if (k * IPS + q < NITEM) item_store(lds_nx, k * IPS + q, *reinterpret_cast<const f32x4 *>(stg + q * 256 + lane * 4));
                     }
                 }
                 // pixel fragments double-buffered by hand (sched_barrier keeps hipcc from serialising read -> wait -> MFMA)

@@ -8,5 +8,5 @@ mkdir -p tools/ab
 cp "$src" alphazero-connect6_amd/csrc/_ab_tmp.hip
 (cd alphazero-connect6_amd/csrc && hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include -Wno-unused-value -x hip -c _ab_tmp.hip -o /tmp/ab_$name.o; rm -f _ab_tmp.hip)
 B=alphazero-connect6_amd/_build
-hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/lib$name.so $B/board_kernel.hip.o $B/tree_kernels.hip.o $B/net_kernels.hip.o $B/conv_v2.hip.o /tmp/ab_$name.o $B/replay.hip.o $B/engine.cpp.o $B/abi_dropin.cpp.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/lib$name.so $(ls $B/*.o | grep -v conv_bf16x3) /tmp/ab_$name.o
 echo built tools/ab/lib$name.so
