@@ -540,8 +540,14 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
                             if (k * IPS + q < NITEM) {
                                 int item = tid + (k * IPS + q) * THREADS;
                                 item = item < CELLS * 8 ? item : CELLS * 8 - 1;
-                                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)(nslice + (size_t)(item >> 3) * C + (item & 7) * 4),
-                                                                 (__attribute__((address_space(3))) void *)(stg + q * 256), 16, 0, 0);
+                                // Written as asm: through the builtin hipcc treats every later ds_read as a possible reader of
+                                // the DMA's LDS bytes and puts s_waitcnt vmcnt(0) in front of the next pixel-fragment reads --
+                                // the "asynchronous" copy was waited for on the spot (HBM latency, 6 times per slice).  The
+                                // landing area is read only at ph == 2, behind the explicit vmcnt wait below.
+                                const float *gp = nslice + (size_t)(item >> 3) * C + (item & 7) * 4;
+                                // LDS byte address of this wave's landing slot (the dynamic segment starts at 0: no static LDS here)
+                                const int lds_off = __builtin_amdgcn_readfirstlane((int)((2 * G::IN_UNITS) * 2 + (wave * IPS + q) * 1024));
+                                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_off) : "memory", "m0");
                             }
                     } else if (ph == 2) {
                         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
