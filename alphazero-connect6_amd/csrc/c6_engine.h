@@ -119,7 +119,8 @@ struct C6NetDev {
     // packed weights (BatchNorm folded), see net_kernels.hip
     const float *stem_w;  // [9][2][C]
     const float *stem_b;  // [C]
-    int variant;          // 1: c6_conv3x3_kernel (NHWC), 2: c6_conv3x3_v2_kernel (slice-major S32 activations)
+    int variant;          // 1: c6_conv3x3_kernel (NHWC), 2: c6_conv3x3_v2_kernel (slice-major S32 activations), 3/6/7: split bf16,
+                          // 8: c6_conv3x3_b3s_kernel without the split (plain bf16 products, relaxed tolerance)
     int num_cus;
     const float *conv_w;  // [(blocks-1)*2][packed 9*C*C]
     const float *conv_w2; // same weights packed for conv v2
@@ -159,7 +160,7 @@ void c6_pack_conv_weights_b3s(int C, const float *w_oihw_folded, unsigned short 
 bool c6_conv_fp32_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            hipStream_t s, int relu);
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                          float *out, int num_cus, hipStream_t s, int relu = 1);
+                          float *out, int num_cus, hipStream_t s, int relu = 1, int split = 1);
 bool c6_conv_b3n_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                           float *out, int num_cus, hipStream_t s);
 void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,

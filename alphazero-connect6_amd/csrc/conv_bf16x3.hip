@@ -426,7 +426,9 @@ struct B3SGeom {
     static constexpr size_t LDS_BYTES = (size_t)2 * IN_UNITS * 2 + (size_t)THREADS * IPS * 16;   // + LDS-DMA landing area
 };
 
-template <int C, int N>
+// SPLIT = false: plain bf16 products (x_hi * w_hi only, one MFMA instead of three) -- C6_PREC_BF16, a RELAXED-tolerance
+// evaluator (net outputs ~1e-3, not the 1e-5 parity grade), SURVEY 8f rank 4
+template <int C, int N, bool SPLIT = true>
 __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const float *__restrict__ in, const unsigned short *__restrict__ wp,
                                                                        const float *__restrict__ bias, const float *__restrict__ res,
                                                                        float *__restrict__ out, int nboards, int relu) {
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
             }
             unsigned short *dst = buf + ((p / N + 1) * W + (p % N + 1)) * B3S_SLOT + q * 4;
             *reinterpret_cast<bf16x4 *>(dst) = hi;
-            *reinterpret_cast<bf16x4 *>(dst + 32) = mid;
+            if (SPLIT) *reinterpret_cast<bf16x4 *>(dst + 32) = mid;
         }
     };
     constexpr int NITEM = G::NITEM, IPS = G::IPS;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
     for (int k = 0; k < NITEM; k++) item_store(lds0, k, item_load(in + (size_t)b0 * (size_t)(CELLS * C), k));   // very first slice
     bf16x8 whi[2], wmid[2];
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) { whi[ct] = *wptr(0, ct, 0); wmid[ct] = *wptr(0, ct, 1); }
+    for (int ct = 0; ct < 2; ct++) { whi[ct] = *wptr(0, ct, 0); wmid[ct] = SPLIT ? *wptr(0, ct, 1) : whi[ct]; }
 
 #pragma unroll 1
     for (int lb = 0; lb < nlocal; lb++) {
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
                 if (ntap == 9) { ntap = 0; nks++; }
                 if (nks == KS) nks = 0;      // wraps to the next board's first stage (one harmless extra load at the very end)
 #pragma unroll
-                for (int ct = 0; ct < 2; ct++) { nhi[ct] = *wptr(nks * 9 + ntap, ct, 0); nmid[ct] = *wptr(nks * 9 + ntap, ct, 1); }
+                for (int ct = 0; ct < 2; ct++) { nhi[ct] = *wptr(nks * 9 + ntap, ct, 0); nmid[ct] = SPLIT ? *wptr(nks * 9 + ntap, ct, 1) : nhi[ct]; }
             }
 #pragma unroll
             for (int half = 0; half < 2; half++) {
@@ -550,7 +552,8 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
                                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_off) : "memory", "m0");
                             }
                     } else if (ph == 2) {
-                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        if (SPLIT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // four weight loads per step are younger ...
+                        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");             // ... two without the mid planes
 #pragma unroll
                         for (int q = 0; q < IPS; q++)
                             if (k * IPS + q < NITEM) item_store(lds_nx, k * IPS + q, *reinterpret_cast<const f32x4 *>(stg + q * 256 + lane * 4));
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
                 auto load_p = [&](int slot, int pt) {
                     const unsigned short *ap = lds_in + abase + (pt * 16) * B3S_SLOT;
                     phi[slot] = *reinterpret_cast<const bf16x8 *>(ap);
-                    pmid[slot] = *reinterpret_cast<const bf16x8 *>(ap + 32);
+                    if (SPLIT) pmid[slot] = *reinterpret_cast<const bf16x8 *>(ap + 32);
                 };
                 const int p_lo = half == 0 ? 0 : PH0, p_hi = half == 0 ? PH0 : PT;
                 load_p(0, p_lo);
@@ -571,8 +574,10 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int ct = 0; ct < 2; ct++) {
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ct], pmid[sl], acc[ct][pt], 0, 0, 0);
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid[ct], phi[sl], acc[ct][pt], 0, 0, 0);
+                        if (SPLIT) {
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ct], pmid[sl], acc[ct][pt], 0, 0, 0);
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid[ct], phi[sl], acc[ct][pt], 0, 0, 0);
+                        }
                         acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ct], phi[sl], acc[ct][pt], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -724,19 +729,24 @@ void c6_pack_conv_weights_b3s(int C, const float *w, unsigned short *packed) {
 
 template <int C, int N>
 static void launch_b3s(int nboards, int grid, const float *in, const unsigned short *wp, const float *bias, const float *res, float *out,
-                       int relu, hipStream_t s) {
+                       int relu, int split, hipStream_t s) {
     using G = B3SGeom<C, N>;
     const size_t smem = G::LDS_BYTES;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3s_kernel<C, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu);
+    if (split) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3s_kernel<C, N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N, true>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3s_kernel<C, N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N, false>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu);
+    }
 }
 
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                          float *out, int num_cus, hipStream_t s, int relu) {
+                          float *out, int num_cus, hipStream_t s, int relu, int split) {
     if (nboards <= 0) return true;
     const int per_cu = C == 256 ? 1 : (C == 128 ? 2 : 4);
     const int grid = nboards < num_cus * per_cu ? nboards : num_cus * per_cu;
-#define B3SCASE(CC, NN) if (C == CC && N == NN) { launch_b3s<CC, NN>(nboards, grid, in, wp, bias, res, out, relu, s); return true; }
+#define B3SCASE(CC, NN) if (C == CC && N == NN) { launch_b3s<CC, NN>(nboards, grid, in, wp, bias, res, out, relu, split, s); return true; }
     B3SCASE(256, 19) B3SCASE(256, 15) B3SCASE(256, 9)
     B3SCASE(128, 19) B3SCASE(128, 15) B3SCASE(128, 9)
     B3SCASE(64, 19) B3SCASE(64, 15) B3SCASE(64, 9)

@@ -264,9 +264,11 @@ def main():
     prec = {"bf16x3": pkg.PREC_BF16X3, "fp32": pkg.PREC_FP32}[args.precision]
     dt, prof, st, pooled_tuples = measure(prec, args.steps, args.warmup)
     second = None
+    relaxed = None
     if ev == pkg.EVAL_NET and not args.single_precision:
         other = pkg.PREC_FP32 if prec == pkg.PREC_BF16X3 else pkg.PREC_BF16X3
         second = (other,) + measure(other, args.steps, args.warmup)
+        relaxed = measure(pkg.PREC_BF16, args.steps, args.warmup)      # side report only, never `value`
 
     if rank == 0:
         def line(dt_):
@@ -301,6 +303,12 @@ def main():
                 out[key] = {"value": o_games, "unit": "games/s", "ms_per_step": 1000.0 * o_dt / args.steps, "sims_per_s": o_sims,
                             "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact f32 products)" if o_prec == pkg.PREC_FP32 else "bf16x3",
                             "roofline": conv_roofline(o_prof, o_dt, o_prec)}
+            if relaxed:      # C6_PREC_BF16: NOT parity grade (value error ~1e-4..1e-3 > the 1e-5 bar) -- a side report, never `value`
+                r_dt, r_prof, _, _ = relaxed
+                r_sims, r_games = line(r_dt)
+                out["relaxed_bf16_path"] = {"value": r_games, "unit": "games/s", "ms_per_step": 1000.0 * r_dt / args.steps, "sims_per_s": r_sims,
+                                            "dtype": "bf16 (one MFMA per product; net outputs within ~1e-3 of FP32: below the parity bar, reported for headroom only)",
+                                            "conv_tflops_algorithmic": r_prof["conv_flops"] / (r_prof["conv_ms"] * 1e-3) / 1e12}
         else:
             # tree-bound workload: algorithmic bytes per simulation, SURVEY 8d: (12*d + 13) * N^2
             d = st["select_steps"] / max(st["simulations"], 1)
