@@ -90,6 +90,8 @@ struct C6Dev {
     unsigned long long *counters;  // [C6_CNT_N] (rare events only: finished games, tuples, fetch queue)
     unsigned long long *g_sims, *g_select, *g_stones;   // [G] per-game statistics, reduced on the host
     uint32_t *g_maxdepth, *g_maxrec;                    // [G]
+    int *rec_hi;                                        // [G] 1 + highest record index ever handed out since the game's reset:
+                                                        // every scan over a game's records stops there (R = 4S + 64 is a bound, not the use)
 };
 
 // tree_kernels.hip

@@ -378,7 +378,7 @@ static int engine_alloc(c6_engine *e) {
     ALLOC(d.fin_winner, d.finq_cap); ALLOC(d.fin_len, d.finq_cap); ALLOC(d.fin_uid, d.finq_cap);
     ALLOC(d.fin_moves, (size_t)d.finq_cap * cells);
     ALLOC(d.counters, C6_CNT_N);
-    ALLOC(d.g_sims, G); ALLOC(d.g_select, G); ALLOC(d.g_stones, G); ALLOC(d.g_maxdepth, G); ALLOC(d.g_maxrec, G);
+    ALLOC(d.g_sims, G); ALLOC(d.g_select, G); ALLOC(d.g_stones, G); ALLOC(d.g_maxdepth, G); ALLOC(d.g_maxrec, G); ALLOC(d.rec_hi, G);
     d.tuple_stride = (int)c6_tuple_stride(N);
 
     std::vector<unsigned long long> zob;

@@ -338,6 +338,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
             if (top > 0) { idx = E.free_stack[rbase + top - 1]; E.free_top[g] = top - 1; }
         }
         idx = __shfl(idx, 0, 64);
+        int hi = E.rec_hi[g];
+        if (idx + 1 > hi) { hi = idx + 1; if (lane == 0) E.rec_hi[g] = hi; }
         if (idx < 0) {
             if (lane == 0) E.status[g] = C6_ST_ERROR;
             return;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const uint32_t ms = turn == C6_BLACK ? q0 : q2, mq = turn == C6_BLACK ? q1 : q3;   // mover colour sums of Q
         const uint32_t os = turn == C6_BLACK ? q2 : q0, oq = turn == C6_BLACK ? q3 : q1;
-        for (int r = lane; r < E.R; r += 64) {
+        for (int r = lane; r < hi; r += 64) {      // records at or above hi were never used: level -1
             if (r == idx || E.rec_level[rbase + r] != level) continue;
             const uint32_t *sg = E.rec_sig + (rbase + r) * 4;
             const uint32_t pms = turn == C6_BLACK ? sg[0] : sg[2], pmq = turn == C6_BLACK ? sg[1] : sg[3];
@@ -497,6 +499,7 @@ __device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane,
         E.root_sig[g * 4 + 0] = 0; E.root_sig[g * 4 + 1] = 0; E.root_sig[g * 4 + 2] = 0; E.root_sig[g * 4 + 3] = 0;
         E.root_rec[g] = -1;
         E.free_top[g] = E.R;
+        E.rec_hi[g] = 0;
         E.leaf_kind[g] = C6_LEAF_NONE;
         E.move_pos[g] = -2;
     }
@@ -556,10 +559,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
         // prune: nodes of the old root's level are dropped (mod.rs:473-484).  The re-inserted old root
         // (:486) and older levels can never be reached again, so they are dropped too.
         int top = E.free_top[g];
-        for (int r0 = 0; r0 < E.R; r0 += 64) {
+        const int hi = E.rec_hi[g];
+        for (int r0 = 0; r0 < hi; r0 += 64) {
             const int r = r0 + lane;
             bool kill = false;
-            if (r < E.R) {
+            if (r < hi) {
                 const int lv = E.rec_level[rbase + r];
                 kill = lv >= 0 && lv <= old_level;
             }
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
         for (int i = lane; i < E.H; i += 64) { ht[i].key = 0ull; ht[i].idx1 = 0; }
         __threadfence_block();
         int rr = -1;   // record of the new root, if that child was expanded (tree reuse)
-        for (int r = lane; r < E.R; r += 64)
+        for (int r = lane; r < hi; r += 64)
             if (E.rec_level[rbase + r] >= 0) {
                 const unsigned long long k = E.rec_key[rbase + r];
                 ht_insert(ht, E.H, k, r);
