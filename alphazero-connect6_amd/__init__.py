@@ -39,7 +39,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
-                  "c6_trainer_last_error", "c6_trainer_set_precision"]
+                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_engine_apply_moves"]
 
 
 class C6Error(RuntimeError):
@@ -125,6 +125,7 @@ def lib():
     L.c6_engine_step.argtypes = [C.c_void_p, C.c_int]
     L.c6_engine_run.argtypes = [C.c_void_p, C.c_long]
     L.c6_engine_sync.argtypes = [C.c_void_p]
+    L.c6_engine_apply_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.c6_engine_fetch_games.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), i32p, i32p, u32p, i16p]
     L.c6_tuple_stride.restype = C.c_size_t
@@ -290,6 +291,32 @@ def play(policy, debug=False, num_game_thread=1):
     return _vec_to_py(v)
 
 
+def play_with(policy, param=None):
+    """Connect6::play_with (connect6.hpp:340-354) through cpp_play_with: AlphaZero over `policy` (the evaluator callback of
+    self_play) plays Black, a human on stdin/stdout plays White ("aB" = row a, column B).  Returns (winner, path)."""
+    prm = default_param()
+    prm.update(param or {})
+
+    def tramp(player, values, policies, n):
+        pol = np.ctypeslib.as_array(policies, shape=(n, REF_N * REF_N))
+        val = np.ctypeslib.as_array(values, shape=(n,))
+        v, p = policy(player, pol.astype(np.int8))
+        val[:] = np.asarray(v, dtype=np.float32).reshape(n)
+        pol[:] = np.asarray(p, dtype=np.float32).reshape(n, REF_N * REF_N)
+
+    cb = CALLBACK(tramp)
+    arena = _Arena()
+    L = lib()
+    L.cpp_play_with.restype = PlayResult
+    L.cpp_play_with.argtypes = [CALLBACK, ALLOC_PATH, C.c_int, C.c_float, C.c_double, C.c_float]
+    r = L.cpp_play_with(cb, arena.alloc_path, prm["num_simulation"], prm["epsilon"], prm["dirichlet_alpha"], prm["c_puct"])
+    paths = []
+    for k in range(r.len):
+        pth = r.paths[k]
+        paths.append((pth.turn, np.ctypeslib.as_array(pth.board).astype(np.int8).reshape(REF_N, REF_N).copy(), (pth.row, pth.col)))
+    return r.winner, paths
+
+
 # ---------------------------------------------------------------------------------------------
 # engine
 # ---------------------------------------------------------------------------------------------
@@ -348,6 +375,13 @@ class Engine:
 
     def sync(self):
         _chk(lib().c6_engine_sync(self.h))
+
+    def apply_moves(self, pos):
+        """stones from outside the engine's policy (MultiPolicy / the human of play_with): pos[g] = cell or -2 for none"""
+        p = np.ascontiguousarray(pos, dtype=np.int32).reshape(-1)
+        if p.size != self.G:
+            raise C6Error("apply_moves needs one entry per game")
+        _chk(lib().c6_engine_apply_moves(self.h, _p(p, C.c_int32)))
 
     def stats(self):
         s = Stats()

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -132,13 +133,102 @@ extern "C" c6_vec cpp_play(c6_policy_callback callback, c6_alloc_path alloc_path
     return v;
 }
 
-extern "C" c6_play_result cpp_play_with(c6_callback, c6_alloc_path alloc_path, int, float, double, float) {
-    std::fprintf(stderr, "libconnect6_amd: cpp_play_with (stdin human play, lib.rs:140-169) is out of scope of the self-play engine\n");
-    c6_play_result r;
-    r.winner = 0;
-    r.len = 0;
-    r.paths = alloc_path(0);
-    return r;
+// Game::print, game_impl/mod.rs:217-237
+static void print_board(const int8_t *board) {
+    std::printf("0 A B C D E F G H I J K L M N O\n");
+    for (int i = 0; i < N; i++) {
+        std::printf("%c ", 'a' + i);
+        for (int j = 0; j < N; j++) std::printf("%s", board[i * N + j] == -1 ? "X " : (board[i * N + j] == 1 ? "O " : "_ "));
+        std::printf("\n");
+    }
+    std::fflush(stdout);
+}
+
+// IoPolicy::next, policy/io_policy/mod.rs:70-107: up to 10 bytes per read, the alphabetic characters must be exactly a
+// lower-case row and an upper-case column inside the board; otherwise "invalid input, retry".  EOF ends the game (the
+// reference would spin on empty reads).
+static bool read_human_move(int *row, int *col) {
+    for (;;) {
+        char buf[10];
+        const size_t got = std::fread(buf, 1, 1, stdin);        // line-wise below: a terminal delivers whole lines
+        if (got == 0) return false;
+        size_t n = 1;
+        while (n < sizeof buf && buf[n - 1] != '\n') {
+            if (std::fread(buf + n, 1, 1, stdin) != 1) break;
+            n++;
+        }
+        char q[10];
+        int k = 0;
+        for (size_t i = 0; i < n; i++)
+            if ((buf[i] >= 'a' && buf[i] <= 'z') || (buf[i] >= 'A' && buf[i] <= 'Z')) q[k++] = buf[i];
+        if (k == 2) {
+            const unsigned r = (unsigned)(unsigned char)q[0] - 0x61u, c = (unsigned)(unsigned char)q[1] - 0x41u;   // usize arithmetic: wraps
+            if (r < (unsigned)N && c < (unsigned)N) { *row = (int)r; *col = (int)c; return true; }
+        }
+        std::printf("invalid input, retry\n");
+        std::fflush(stdout);
+    }
+}
+
+// cpp_play_with, lib.rs:140-169: MultiPolicy(black = AlphaZero over the callback evaluator, white = IoPolicy on
+// stdin/stdout), Agent::debug(...).play(): the board is printed before every stone and each stone is logged as
+// "{player:?} ({row}, {col}), remain {n}, {s}.{ms} elapsed" (agent_impl/mod.rs:121-178).
+extern "C" c6_play_result cpp_play_with(c6_callback callback, c6_alloc_path alloc_path, int num_simulation, float epsilon, double dirichlet_alpha,
+                                        float c_puct) {
+    c6_config cfg;
+    c6_default_config(&cfg);
+    cfg.board_size = N;
+    cfg.num_games = 1;
+    cfg.num_simulation = num_simulation;
+    cfg.epsilon = epsilon;
+    cfg.dirichlet_alpha = dirichlet_alpha;
+    cfg.c_puct = c_puct;
+    cfg.seed = pick_seed();
+    cfg.evaluator = C6_EVAL_CALLBACK;
+    c6_engine *e = nullptr;
+    if (c6_engine_create(&cfg, &e) != C6_OK) die("cpp_play_with: engine");
+    c6_engine_set_callback(e, callback);
+    std::vector<int8_t> board(CELLS, 0);
+    std::vector<int16_t> hist;
+    int winner = 0;
+    for (;;) {
+        c6_root_info info;
+        if (c6_engine_root(e, 0, &info, board.data(), nullptr, nullptr, nullptr) != C6_OK) die("cpp_play_with: root");
+        if (info.status != 0 /* not playing any more */) { winner = info.winner; break; }
+        print_board(board.data());
+        const auto t0 = std::chrono::steady_clock::now();
+        int pos = -1;
+        if (info.turn == -1) {                                   // Black: AlphaZero::next = num_simulation searches + policy()
+            if (c6_engine_step(e, num_simulation) != C6_OK) die("cpp_play_with: search");
+            std::vector<int8_t> after(CELLS);
+            c6_root_info ai;
+            if (c6_engine_root(e, 0, &ai, after.data(), nullptr, nullptr, nullptr) != C6_OK) die("cpp_play_with: root");
+            for (int c = 0; c < CELLS; c++) if (after[c] != board[c]) pos = c;
+            if (pos < 0) { winner = ai.winner; break; }         // the policy had no move: the game ends (agent_impl/mod.rs:135-137)
+        } else {                                                 // White: the human
+            int row, col;
+            if (!read_human_move(&row, &col)) break;
+            pos = row * N + col;
+            const int32_t p = pos;
+            if (c6_engine_apply_moves(e, &p) != C6_OK) die("cpp_play_with: move");
+            c6_root_info ai;
+            if (c6_engine_root(e, 0, &ai, nullptr, nullptr, nullptr, nullptr) != C6_OK) die("cpp_play_with: root");
+            if (ai.status == 2 /* error: already set position */) {
+                std::fprintf(stderr, "libconnect6_amd: cpp_play_with: already set position\n");   // Err -> unwrap() panic, lib.rs:167
+                std::abort();
+            }
+        }
+        hist.push_back((int16_t)pos);
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        const int remain_after = info.remain - 1;                // SetResult::num_remain: after the decrement, before the reset
+        std::printf("%s (%c, %c), remain %d, %lld.%lld elapsed\n", info.turn == -1 ? "Black" : "White", 'a' + pos / N, 'A' + pos % N, remain_after,
+                    (long long)(ms / 1000), (long long)(ms % 1000));
+        std::fflush(stdout);
+    }
+    c6_engine_root(e, 0, nullptr, board.data(), nullptr, nullptr, nullptr);
+    print_board(board.data());
+    c6_engine_destroy(e);
+    return make_result(winner, (int)hist.size(), hist.data(), alloc_path);
 }
 
 // ---- FFI echo hooks (ffi_test/mod.rs), host only ---------------------------------------------

@@ -563,6 +563,27 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
     return C6_OK;
 }
 
+// Stones placed from OUTSIDE the engine's policy (MultiPolicy: another policy plays one colour, multi_policy/mod.rs:61-71;
+// cpp_play_with: the human's stones, lib.rs:140-169): pos[g] = cell of game g, or -2 for "no move for this game".  Game::set
+// + is_game_end on the GPU, then the same re-rooting as after the engine's own move -- the AlphaZero tree of the other
+// colour keeps every node below the new position (the reference's policy is simply not consulted for this stone and
+// finds its old nodes again at its next turn).
+extern "C" int c6_engine_apply_moves(c6_engine *e, const int32_t *pos) {
+    if (!e || !pos) return fail(C6_ERR_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    C6Dev &d = e->d;
+    std::vector<int32_t> h((size_t)d.Gpad, -2);
+    for (int g = 0; g < d.G; g++) h[g] = pos[g];
+    HIPCHK(hipMemcpyAsync(d.move_pos, h.data(), (size_t)d.Gpad * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.move_turn, d.turn, (size_t)d.G, hipMemcpyDeviceToDevice, e->stream));   // the mover = the side to move now
+    HIPCHK(hipStreamSynchronize(e->stream));       // h goes out of scope
+    c6_launch_board_step(d.N, d.Gpad, d.board_soa, d.turn, d.remain, d.move_pos, d.winner, d.err, e->stream);
+    c6_launch_post_move(d, e->stream);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    return C6_OK;
+}
+
 extern "C" int c6_engine_sync(c6_engine *e) {
     if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
     HIPCHK(hipStreamSynchronize(e->stream));

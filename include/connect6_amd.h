@@ -226,6 +226,13 @@ typedef struct c6_root_info {
 } c6_root_info;
 int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *board, int32_t *visits, float *q, float *prior);
 
+/* stones from outside the engine's policy: MultiPolicy (policy/multi_policy/mod.rs:61-71: another policy plays one
+ * colour) and the human side of cpp_play_with (lib.rs:140-169).  pos[g] = cell (row*N + col) or -2 = none for game g.
+ * Runs Game::set / is_game_end and re-roots the engine's tree below the new position (tree reuse as in
+ * AlphaZero::next, alphazero_policy/mod.rs:464-489).  An occupied or out-of-range cell makes the game's status an error
+ * (the reference: Err -> unwrap() panic). */
+int c6_engine_apply_moves(c6_engine *e, const int32_t *pos);
+
 /* timing of the dominant kernel (3x3 conv) for the roofline: enables HIP-event timing on the
  * engine's stream; totals since the last reset. */
 int c6_engine_profile(c6_engine *e, int enable);

@@ -1,5 +1,6 @@
 """The reference's C ABI (cpp_self_play / cpp_play, N = 15) served by the GPU engine.
 Reference tests mirrored: test_cppbind/main.cpp:46-57 (K-11) and the deterministic cpp_play vectors."""
+import os
 import numpy as np
 import pytest
 
@@ -93,3 +94,77 @@ def test_callback_evaluator_matches_oracle_with_same_callback():
     for uid in range(G):
         mv = [r * n + c for _, _, (r, c) in ref[uid]["path"]]
         assert list(games[uid]["moves"]) == mv and games[uid]["winner"] == ref[uid]["winner"]
+
+
+def test_apply_moves_engine_black_vs_outside_white():
+    """c6_engine_apply_moves (MultiPolicy / cpp_play_with's human side): the engine searches and moves for Black, White's
+    stones come from outside (first empty cell).  Bookkeeping (stone count, turn order 1-2-2, winner) must follow
+    Game::set / is_game_end, and the first Black stone equals plain self-play's (same searches, same seed)."""
+    need_gpu()
+    import os
+    n, S, seed = 9, 24, 11
+    ref = pkg.Engine(board_size=n, num_games=1, num_simulation=S, seed=seed, evaluator=pkg.EVAL_RANDOM)
+    ref.run()
+    first = int(ref.fetch_games()[0]["moves"][0])
+    ref.close()
+    e = pkg.Engine(board_size=n, num_games=1, num_simulation=S, seed=seed, evaluator=pkg.EVAL_RANDOM)
+    stones, mirror = 0, np.zeros(n * n, np.int8)
+    turn, remain = -1, 1
+    while True:
+        r = e.root(0)
+        assert r["turn"] == turn and r["remain"] == remain and r["stones"] == stones
+        if turn == -1:
+            e.step(S)                                   # Black: S searches + the engine's own move
+        else:
+            e.apply_moves([int(np.flatnonzero(mirror == 0)[0])])
+        r = e.root(0)
+        board = r["board"].reshape(-1)
+        new = np.flatnonzero(board != mirror)
+        if r["status"] == 0 or r["winner"] != 0:
+            assert new.size == 1 and board[new[0]] == turn
+            if stones == 0:
+                assert new[0] == first
+            mirror = board.copy()
+            stones += 1
+        remain -= 1
+        if remain <= 0:
+            remain, turn = 2, -turn
+        if r["status"] != 0:
+            break
+    assert r["status"] == 1 and r["winner"] == o.search(mirror.reshape(n, n))
+    assert e.stats()["overflow_games"] == 0
+    e.close()
+
+
+def test_cpp_play_with_scripted_human(tmp_path):
+    """cpp_play_with (lib.rs:140-169): AlphaZero(Black, host callback) against scripted stdin moves; run in a subprocess
+    because the human side reads the process's stdin.  White walks along a row; a collision with a Black stone makes the
+    library abort like the reference's unwrap(), so a few rows are tried."""
+    need_gpu()
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {root!r})
+        from c6amd_loader import load_package
+        pkg = load_package()
+        def policy(turn, boards):
+            k = boards.shape[0]
+            return np.zeros(k, np.float32), np.full((k, 225), 1 / 225, np.float32)
+        winner, path = pkg.play_with(policy, dict(num_simulation=8))
+        print("RESULT", winner, len(path), path[-1][0])
+    """)
+    ok = False
+    for row in "onmlk":
+        script = "xx\n" + "".join(f"{row}{c}\n" for c in "ABCDEFGH")       # first line: invalid input, retried
+        r = subprocess.run([sys.executable, "-c", prog], input=script, capture_output=True, text=True, timeout=300, env=dict(os.environ, C6_SEED="7"))
+        if r.returncode != 0:
+            assert "already set position" in r.stderr, r.stderr[-500:]
+            continue
+        out = r.stdout
+        assert "invalid input, retry" in out and "0 A B C D E F G H I J K L M N O" in out and "White (" in out and "Black (" in out
+        line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+        assert int(line[1]) == 1 and int(line[3]) == 1 and int(line[2]) >= 11          # White wins with its sixth stone in the row
+        ok = True
+        break
+    assert ok
