@@ -87,9 +87,11 @@ c6_vec cpp_self_play(c6_callback callback, c6_alloc_path alloc_path, c6_alloc_re
                      int num_simulation, float epsilon, double dirichlet_alpha, float c_puct, bool debug,
                      int num_game_thread);
 
-/* cppbind/libcppconnect6/src/lib.rs:140-169, connect6.hpp:60-65: human-vs-net play on stdin.
- * Out of scope: exported so that connect6.hpp links; prints a message and returns
- * an empty result. */
+/* cppbind/libcppconnect6/src/lib.rs:140-169, connect6.hpp:60-65: MultiPolicy(black = AlphaZero over `callback`,
+ * white = IoPolicy on stdin / stdout, policy/io_policy/mod.rs:70-107: "aB" = row a, column B; "invalid input, retry"),
+ * Agent::debug(...).play(): the board is printed before every stone and each stone is logged as
+ * "{player:?} ({row}, {col}), remain {n}, {s}.{ms} elapsed" (agent/agent_impl/mod.rs:121-178).  An occupied cell aborts
+ * with "already set position" like the reference's unwrap(); end of input ends the game. */
 c6_play_result cpp_play_with(c6_callback callback, c6_alloc_path alloc_path, int num_simulation, float epsilon,
                              double dirichlet_alpha, float c_puct);
 
