@@ -39,7 +39,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
-                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_engine_apply_moves"]
+                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_engine_apply_moves", "c6_engine_last_moves"]
 
 
 class C6Error(RuntimeError):
@@ -126,6 +126,7 @@ def lib():
     L.c6_engine_run.argtypes = [C.c_void_p, C.c_long]
     L.c6_engine_sync.argtypes = [C.c_void_p]
     L.c6_engine_apply_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.c6_engine_last_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.c6_engine_fetch_games.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), i32p, i32p, u32p, i16p]
     L.c6_tuple_stride.restype = C.c_size_t
@@ -375,6 +376,12 @@ class Engine:
 
     def sync(self):
         _chk(lib().c6_engine_sync(self.h))
+
+    def last_moves(self):
+        """cells chosen in the last move phase: cell, -1 = no move (draw), -2 = the game did not move"""
+        p = np.zeros(self.G, np.int32)
+        _chk(lib().c6_engine_last_moves(self.h, _p(p, C.c_int32)))
+        return p
 
     def apply_moves(self, pos):
         """stones from outside the engine's policy (MultiPolicy / the human of play_with): pos[g] = cell or -2 for none"""

@@ -584,6 +584,17 @@ extern "C" int c6_engine_apply_moves(c6_engine *e, const int32_t *pos) {
     return C6_OK;
 }
 
+// the cells chosen by the engine's last move phase (c6_engine_step): pos[g] = cell, -1 = the policy had no move (the game
+// ended as a draw), -2 = game g did not move.  With c6_engine_apply_moves on a second engine this is MultiPolicy for two
+// resident nets (net-vs-net evaluation games, policy/multi_policy/mod.rs:61-71).
+extern "C" int c6_engine_last_moves(c6_engine *e, int32_t *pos) {
+    if (!e || !pos) return fail(C6_ERR_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(pos, e->d.move_pos, (size_t)e->d.G * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return C6_OK;
+}
+
 extern "C" int c6_engine_sync(c6_engine *e) {
     if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
     HIPCHK(hipStreamSynchronize(e->stream));

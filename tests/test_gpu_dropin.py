@@ -168,3 +168,26 @@ def test_cpp_play_with_scripted_human(tmp_path):
         ok = True
         break
     assert ok
+
+
+def test_net_vs_net_two_engines_stay_in_step():
+    """MultiPolicy with two resident nets (tools/net_vs_net.py): both engines must record the same games -- every stone
+    searched by one side and applied from outside on the other -- and every game must end like the oracle's
+    search says."""
+    need_gpu()
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import net_vs_net
+    import __graft_entry__ as ge
+    n, C, nb, G, S = 9, 64, 2, 24, 6
+    ba = ge.make_random_blob(n, C, nb, np.random.default_rng(1))
+    bb = ge.make_random_blob(n, C, nb, np.random.default_rng(2))
+    ga, gb = net_vs_net.play_match(pkg, n, G, S, ba, bb, C, nb, seed=5)
+    assert len(ga) == len(gb) == G
+    key = lambda g: g["uid"]
+    for a, b in zip(sorted(ga, key=key), sorted(gb, key=key)):
+        assert list(a["moves"]) == list(b["moves"]) and a["winner"] == b["winner"]
+        board = np.zeros(n * n, np.int8)
+        for turn, _, cell in pkg.replay_moves(n, a["moves"]):
+            board[cell] = turn
+        assert o.search(board.reshape(n, n)) == a["winner"]
