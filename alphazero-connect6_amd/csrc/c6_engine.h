@@ -129,6 +129,7 @@ struct C6NetDev {
     const unsigned short *conv_w3; // same weights split into bf16 hi/mid planes (conv_bf16x3.hip)
     const unsigned short *conv_w6; // split planes packed per wave (c6_conv3x3_b3n_kernel)
     const unsigned short *conv_w7; // the same for the 16x16x32 tiling (c6_conv3x3_b3s_kernel)
+    const float *conv_w5;          // FP32 weights packed per wave (c6_conv3x3_f32n_kernel)
     const float *conv_b;  // [(blocks-1)*2][C]
     const float *pc_w;    // [2][C] folded
     const float *pc_b;    // [2]
@@ -159,6 +160,10 @@ bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsig
 size_t c6_conv_packed_b3n_units(int C);
 void c6_pack_conv_weights_b3n(int C, const float *w_oihw_folded, unsigned short *packed);
 void c6_pack_conv_weights_b3s(int C, const float *w_oihw_folded, unsigned short *packed);
+size_t c6_conv_packed_f32n_floats(int C);
+void c6_pack_conv_weights_f32n(int C, const float *w_oihw_folded, float *packed);
+bool c6_conv_f32n_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
+                           int num_cus, hipStream_t s, int relu = 1);
 bool c6_conv_fp32_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            hipStream_t s, int relu);
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,

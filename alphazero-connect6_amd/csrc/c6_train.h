@@ -5,6 +5,7 @@
 
 void c6t_pack_b3s(int C, const float *w_oihw, unsigned short *packed, int transpose_flip, hipStream_t s);
 void c6t_pack_fp32(int C, const float *w_oihw, float *packed, int transpose_flip, hipStream_t s);
+void c6t_pack_f32n(int C, const float *w_oihw, float *packed, int transpose_flip, hipStream_t s);
 
 void c6t_stem_fwd(int N, int C, int B, const float *boards, const float *players, const float *w, const float *bias, float *y, hipStream_t s);
 size_t c6t_stem_bwd_partial_floats(int C, int B);

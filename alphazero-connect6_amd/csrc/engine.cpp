@@ -173,7 +173,8 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
     C6NetDev &d = nh.dev;
     d.N = n; d.cells = cells; d.C = C; d.blocks = nb;
     {
-        // A/B switch (C6_CONV_VARIANT).  FP32 precision: 1 = c6_conv3x3_kernel (32x32x2 tiles, NHWC; 129 TFLOP/s),
+        // A/B switch (C6_CONV_VARIANT).  FP32 precision: 5 = c6_conv3x3_f32n_kernel (N-split persistent schedule, the default:
+        // 137-139 TFLOP/s), 1 = c6_conv3x3_kernel (M x N wave grid, weight stages in LDS by LDS-DMA, barrier per tap; 127-132),
         // 2 = c6_conv3x3_v2_kernel (16x16x4 tiles, slice-major activations; experimental, 119 TFLOP/s).
         // Split-bf16 precision (the default): 7 = c6_conv3x3_b3s_kernel (persistent N-split schedule on 16x16x32 MFMAs,
         // the default: the chip holds a higher clock on that shape), 6 = c6_conv3x3_b3n_kernel (same schedule on
@@ -181,9 +182,9 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         const char *v = std::getenv("C6_CONV_VARIANT");
         const int ev = v ? std::atoi(v) : 0;
         if (precision == C6_PREC_BF16) d.variant = 8;      // plain bf16 products: relaxed tolerance, not parity grade
-        else if (precision == C6_PREC_FP32) d.variant = ev == 2 ? 2 : 1;
+        else if (precision == C6_PREC_FP32) d.variant = (ev == 1 || ev == 2) ? ev : 5;   // 5 = c6_conv3x3_f32n_kernel (N-split persistent FP32), the default
         else if (precision == C6_PREC_BF16X3) d.variant = (ev == 3 || ev == 6) ? ev : 7;
-        else d.variant = (ev == 1 || ev == 2 || ev == 3 || ev == 6) ? ev : 7;
+        else d.variant = (ev == 1 || ev == 2 || ev == 3 || ev == 5 || ev == 6) ? ev : 7;
         hipDeviceProp_t prop;
         int dev = 0;
         hipGetDevice(&dev);
@@ -210,6 +211,7 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         std::vector<unsigned short> cw3((size_t)std::max(L, 1) * w3);
         const size_t w6 = c6_conv_packed_b3n_units(C);
         std::vector<unsigned short> cw6((size_t)std::max(L, 1) * w6), cw7((size_t)std::max(L, 1) * w6);
+        std::vector<float> cw5((size_t)std::max(L, 1) * wsz);
         for (int l = 0; l < L; l++) {
             const float *w = take((size_t)C * C * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
             for (int co = 0; co < C; co++) {
@@ -222,9 +224,10 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
             c6_pack_conv_weights_b3(C, folded.data(), cw3.data() + (size_t)l * w3);
             c6_pack_conv_weights_b3n(C, folded.data(), cw6.data() + (size_t)l * w6);
             c6_pack_conv_weights_b3s(C, folded.data(), cw7.data() + (size_t)l * w6);
+            c6_pack_conv_weights_f32n(C, folded.data(), cw5.data() + (size_t)l * wsz);
         }
         int rc;
-        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) || (rc = upload(nh.pool, cw6, &d.conv_w6)) || (rc = upload(nh.pool, cw7, &d.conv_w7)) ||
+        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) || (rc = upload(nh.pool, cw6, &d.conv_w6)) || (rc = upload(nh.pool, cw7, &d.conv_w7)) || (rc = upload(nh.pool, cw5, &d.conv_w5)) ||
             (rc = upload(nh.pool, cb, &d.conv_b)))
             return rc;
     }

@@ -444,7 +444,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
             const int l = 2 * i + half;
             const float *cin = half == 0 ? x : y, *cres = half == 0 ? nullptr : x;
             float *cout = half == 0 ? y : z;
-            if (net.variant == 7 || net.variant == 8) c6_conv_b3s_dispatch(C, net.N, nb, cin, net.conv_w7 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s, 1, net.variant == 7);
+            if (net.variant == 5) c6_conv_f32n_dispatch(C, net.N, nb, cin, net.conv_w5 + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
+            else if (net.variant == 7 || net.variant == 8) c6_conv_b3s_dispatch(C, net.N, nb, cin, net.conv_w7 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s, 1, net.variant == 7);
             else if (net.variant == 6) c6_conv_b3n_dispatch(C, net.N, nb, cin, net.conv_w6 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
             else if (net.variant == 3) c6_conv_b3_dispatch(C, net.N, nb, cin, net.conv_w3 + (size_t)l * c6_conv_packed_b3_units(C), net.conv_b + (size_t)l * C, cres, cout, s);
             else if (v2) c6_conv_v2_dispatch(C, net.N, nb, cin, net.conv_w2 + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
@@ -498,6 +499,7 @@ void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches,
 void c6_conv_bench_launch(int variant, int ablate, int C, int N, int nboards, const float *in, const float *w1, const float *w2,
                           const float *bias, const float *res, float *out, int num_cus, hipStream_t s) {
     if (variant == 2) { c6_conv_v2_dispatch(C, N, nboards, in, w2, bias, res, out, num_cus, s); return; }
+    if (variant == 5) { c6_conv_f32n_dispatch(C, N, nboards, in, w2, bias, res, out, num_cus, s); return; }
     if (variant == 6) { c6_conv_b3n_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, num_cus, s); return; }
     if (variant == 7 || variant == 8) { c6_conv_b3s_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, num_cus, s, 1, variant == 7); return; }
     if (variant == 3 && ablate != 0 && C == 256 && N == 19) { c6_conv_b3_ablate(ablate, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, s); return; }

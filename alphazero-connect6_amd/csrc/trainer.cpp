@@ -188,8 +188,8 @@ extern "C" int c6_trainer_gradients(c6_trainer *t, float *blob, size_t nfloats) 
 static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const float *in, const float *bias, const float *res, float *out) {
     bool ok;
     if (t->precision == C6_PREC_FP32) {
-        c6t_pack_fp32(t->C, w_oihw, t->wpack32, transpose_flip, t->stream);
-        ok = c6_conv_fp32_dispatch(t->C, t->n, t->B, in, t->wpack32, bias, res, out, t->stream, /*relu=*/0);
+        c6t_pack_f32n(t->C, w_oihw, t->wpack32, transpose_flip, t->stream);
+        ok = c6_conv_f32n_dispatch(t->C, t->n, t->B, in, t->wpack32, bias, res, out, t->num_cus, t->stream, /*relu=*/0);
     } else {
         c6t_pack_b3s(t->C, w_oihw, t->wpack, transpose_flip, t->stream);
         ok = c6_conv_b3s_dispatch(t->C, t->n, t->B, in, t->wpack, bias, res, out, t->num_cus, t->stream, /*relu=*/0);

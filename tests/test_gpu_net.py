@@ -60,18 +60,20 @@ def test_split_conv_variants_vs_oracle(n, C, blocks, num, variant, monkeypatch):
     net.close()
 
 
-@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (19, 256, 2, 5), (15, 128, 3, 6)])
-def test_fp32_conv_v2_variant_vs_oracle(n, C, blocks, num, monkeypatch):
-    """the experimental FP32 kernel (C6_CONV_VARIANT=2: 16x16x4 tiles, slice-major activations, conv_v2.hip)"""
+@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (19, 256, 2, 300), (15, 128, 3, 6), (15, 256, 2, 7)])
+@pytest.mark.parametrize("variant", ["2", "5"])
+def test_fp32_conv_variants_vs_oracle(n, C, blocks, num, variant, monkeypatch):
+    """the other FP32 kernels: C6_CONV_VARIANT=2 (experimental: 16x16x4 tiles, slice-major activations, conv_v2.hip) and
+    5 (N-split persistent schedule, conv_f32n.hip)"""
     need_gpu()
-    monkeypatch.setenv("C6_CONV_VARIANT", "2")
+    monkeypatch.setenv("C6_CONV_VARIANT", variant)
     rng = np.random.default_rng(n + C)
     blob = rand_blob(n, C, blocks, seed=n + C + blocks + 2)
     boards = rng.integers(-1, 2, size=(num, n * n)).astype(np.int8)
     player = rng.choice(np.array([-1, 1], np.int8), size=num)
     pol, val = pkg.net_forward(n, C, blocks, blob, boards, player, precision=1)
     net = o.Net(n, C, blocks, blob)
-    for i in range(num):
+    for i in list(range(min(num, 6))) + ([num - 1, 257] if num > 257 else []):
         rp, rv = net.forward(float(player[i]), boards[i].astype(np.float32))
         assert np.abs(pol[i] - rp[0]).max() <= TOL and abs(val[i] - rv[0]) <= TOL
     net.close()
