@@ -688,18 +688,22 @@ __global__ __launch_bounds__(256, 2) void c6_wgrad_kernel(int C, int B, int boar
             // (ty, tx) is xL row (kk / P + ty) , column (kk % P + tx - 1)  ->  xL index kk + ty * P + tx - 1
             const float *ap = dyL + kb * 64 + wco + i;
             const float *bp = xL + kb * 64 + wci + i;
-            const int ksteps = (rows * P + 1) / 2;
-            // operands of step ks + 1 are read before the MFMAs of step ks (one wave per SIMD: nothing else hides the LDS latency)
-            float av = ap[0], bv[9];
+            // K steps of two grid cells; a row's steps start at its first real cell (column 1), so only the right halo
+            // cell (N odd: paired with the last pixel) is multiplied in vain -- not both halo columns of every row
+            constexpr int SPR = (N + 1) / 2;                 // steps per row
+            const int ksteps = rows * SPR;
+            auto kpos = [&](int ks) -> int { return (ks / SPR) * P + 1 + 2 * (ks % SPR); };
+            // operands of step ks + 1 are read before the MFMAs of step ks (the partner workgroup's waves aside, nothing else hides the LDS latency)
+            float av = ap[kpos(0) * 64], bv[9];
 #pragma unroll
-            for (int t = 0; t < 9; t++) bv[t] = bp[((t / 3) * P + (t % 3) - 1) * 64];
+            for (int t = 0; t < 9; t++) bv[t] = bp[(kpos(0) + (t / 3) * P + (t % 3) - 1) * 64];
 #pragma unroll 1
             for (int ks = 0; ks < ksteps; ks++) {
-                const int kn = ks + 1 < ksteps ? ks + 1 : ks;
-                const float an = ap[(2 * kn) * 64];
+                const int kn = kpos(ks + 1 < ksteps ? ks + 1 : ks);
+                const float an = ap[kn * 64];
                 float bn[9];
 #pragma unroll
-                for (int t = 0; t < 9; t++) bn[t] = bp[(2 * kn + (t / 3) * P + (t % 3) - 1) * 64];
+                for (int t = 0; t < 9; t++) bn[t] = bp[(kn + (t / 3) * P + (t % 3) - 1) * 64];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 9; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
