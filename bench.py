@@ -251,11 +251,11 @@ def main():
             name, peak = ("c6_conv3x3_%s_kernel<256,19> (split-bf16 implicit GEMM, v_mfma_f32_%s_bf16)" % (b3, "32x32x16" if b3 == "b3n" else "16x16x32")), PEAK_BF16_MFMA_TFLOPS
             note = {"mfma_flops_per_algorithmic_flop": 3, "executed_mfma_tflops": 3 * ach, "frac_executed": 3 * ach / peak}
         r = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-             "traffic": pmc_traffic("b3s" if precision != pkg.PREC_FP32 else "f32n") if args.workload == "config2" and not args.games else None,
+             "traffic": pmc_traffic("true>" if precision != pkg.PREC_FP32 else "f32n") if args.workload == "config2" and not args.games else None,
              "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
              "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
         if args.workload == "config2" and not args.games:
-            rec = pmc_record("b3s" if precision != pkg.PREC_FP32 else "f32n")
+            rec = pmc_record("true>" if precision != pkg.PREC_FP32 else "f32n")      # c6_conv3x3_b3s_kernel<256, 19, true>: the split (parity-grade) instantiation
             if "mfma_util" in rec:      # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (profiles/)
                 r["pmc_mfma_busy_frac"] = rec["mfma_util"]
                 r["pmc_effective_clock_ghz"] = rec.get("effective_clock_ghz")
