@@ -221,6 +221,12 @@ def main():
                 tcount.zero_()
                 torch.cuda.current_stream().synchronize()
 
+        if ev != pkg.EVAL_NET and world == 1:
+            # tree-only workload: a round costs more in the middle game (deeper selects, fuller record pools) than in the
+            # opening all games start in -- settle into the steady state (one full game length of rounds, a few seconds)
+            # before the warm-up; the net workloads are conv-bound and phase-independent
+            eng.step(int(S * wl["stones"]))
+            eng.sync()
         run_rounds(warmup)
         eng.profile(True)
         eng.profile_read(reset=True)
@@ -288,7 +294,8 @@ def main():
             "config": {"workload": f"{args.workload}: {G} concurrent {n}x{n} games per GPU, {S} sims/move, "
                                    + (f"stem + {wl['blocks'] - 1} residual blocks, C={wl['channels']}" if ev == pkg.EVAL_NET else "on-device uniform evaluator"),
                        "games_per_gpu": G, "board": n, "num_simulation": S, "net_blocks": wl["blocks"], "net_channels": wl["channels"],
-                       "stones_per_game": wl["stones"], "step": "one simulation round over all games (8 dihedral net evaluations per game), staggered move phases",
+                       "stones_per_game": wl["stones"], "step": ("one simulation round over all games (8 dihedral net evaluations per game), staggered move phases" if ev == pkg.EVAL_NET else
+                                "one simulation round over all games, staggered move phases, measured in the steady state (after one game length of rounds)"),
                        "parallelism": f"games sharded over {world} GPU(s), RCCL all-gather of training tuples per round" if world > 1 else "1 GPU"},
             "sims_per_s": sims_s, "boards_per_s": sims_s * 8,
             "engine": {"select_steps_per_sim": st["select_steps"] / max(st["simulations"], 1), "max_records_used": st["max_records_used"],
