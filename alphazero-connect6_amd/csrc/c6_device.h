@@ -194,8 +194,8 @@ __device__ __forceinline__ int c6_select_bit(unsigned long long m, int n) {
 // Gamma variates for the cells a wave owns (lane owns cells lane + 64 j where need[j]).  Same values as calling
 // c6_gamma_draw per cell -- the attempt that is accepted for a cell does not depend on who evaluates it -- but the
 // rejection loops are not run in lockstep: with one loop per lane the wave pays max-over-64-lanes attempts per j
-// (~4.3 for the 21 % polar rejection, 26 evaluations at N = 19), here attempt 0 is one dense pass and the rejected
-// cells of each later attempt are packed onto lanes 0..k-1 (~11 evaluations at N = 19, ~5 instead of ~9 at N = 9).
+// (~4.3 for the 21 % polar rejection, 26 evaluations at N = 19), here the cells still without a variate are packed
+// onto lanes 0..k-1 in every round (~11 evaluations on an empty 19x19 board, ~4 instead of ~9 in a 9x9 middle game).
 // `scratch` = cells doubles of wave-private LDS: workers hand the variates (or -1 = rejected) back to the owners.
 template <int J>
 __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], double (&gam)[J], double *scratch, int lane, double alpha,
@@ -204,13 +204,13 @@ __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], double (&ga
     bool any = false;
 #pragma unroll
     for (int j = 0; j < J; j++) {
-        bool ok = true;
         gam[j] = 0.0;
-        if (need[j]) ok = c6_gamma_try(alpha, d, c, k0, k1, (uint32_t)(lane + 64 * j), search, depth, 0u, gam[j]);
-        pend[j] = __ballot(!ok);
+        pend[j] = __ballot(need[j]);
         any |= pend[j] != 0ull;
     }
-    for (uint32_t att = 1; any;) {
+    // every round -- the first included -- packs the pending cells onto the lanes: occupied cells cost nothing (in the
+    // middle of a 9x9 game the 2 x 64 owned slots hold ~47 empty cells: one pass instead of two)
+    for (uint32_t att = 0; any;) {
         int tot = 0;
 #pragma unroll
         for (int j = 0; j < J; j++) tot += __popcll(pend[j]);
