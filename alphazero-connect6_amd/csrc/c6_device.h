@@ -5,7 +5,8 @@
 //    Gamma(alpha < 1) sampler that replaces rand 0.6's `Dirichlet::sample`
 //    (reference call sites: policy/alphazero_policy/mod.rs:262,283,294,145,163).
 //    Only IEEE +,-,*,/ and sqrt are used (no fma contraction: this translation unit
-//    is compiled with -ffp-contract=off), so the stream is bit-reproducible.
+//    is compiled with -ffp-contract=off), so the stream is bit-reproducible.  The Gamma
+//    variates are single precision (C6RNG v2), their normaliser double.
 //  * wave64 reductions used by the tree kernels.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -48,76 +49,75 @@ __device__ __forceinline__ double c6_open01(uint32_t hi, uint32_t lo) {
 // U[-1,1) with 24 bits, RandomEvaluator (policy/alphazero_policy/mod.rs:141-168)
 __device__ __forceinline__ float c6_u11(uint32_t w) { return 2.0f * ((float)(w >> 8) * (1.0f / 16777216.0f)) - 1.0f; }
 
-__device__ __forceinline__ double c6_det_log(double x) {
-    uint64_t b = (uint64_t)__double_as_longlong(x);
-    int e = (int)((b >> 52) & 0x7ff) - 1023;
-    double m = __longlong_as_double((long long)((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    double f = (m - 1.0) / (m + 1.0), f2 = f * f;
-    double p = 1.0 / 23.0;
-    p = p * f2 + 1.0 / 21.0;
-    p = p * f2 + 1.0 / 19.0;
-    p = p * f2 + 1.0 / 17.0;
-    p = p * f2 + 1.0 / 15.0;
-    p = p * f2 + 1.0 / 13.0;
-    p = p * f2 + 1.0 / 11.0;
-    p = p * f2 + 1.0 / 9.0;
-    p = p * f2 + 1.0 / 7.0;
-    p = p * f2 + 1.0 / 5.0;
-    p = p * f2 + 1.0 / 3.0;
-    p = p * f2 + 1.0;
-    double lm = 2.0 * f * p;
-    double de = (double)e;
-    return de * 6.93147180369123816490e-01 + (lm + de * 1.90821492927058770002e-10);
+// single-precision log / exp of the Gamma sampler: explicit polynomials on IEEE + - * / (no contraction) -> the same
+// bits on the CPU oracle (c6o_det_logf / c6o_det_expf_parts).  logf: x > 0 normal.
+__device__ __forceinline__ float c6_det_logf(float x) {
+    uint32_t b = __float_as_uint(x);
+    int e = (int)((b >> 23) & 0xff) - 127;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float f = (m - 1.0f) / (m + 1.0f), f2 = f * f;
+    float p = 1.0f / 11.0f;
+    p = p * f2 + 1.0f / 9.0f;
+    p = p * f2 + 1.0f / 7.0f;
+    p = p * f2 + 1.0f / 5.0f;
+    p = p * f2 + 1.0f / 3.0f;
+    p = p * f2 + 1.0f;
+    float lm = 2.0f * f * p;
+    float de = (float)e;
+    return de * 0.693145751953125f + (lm + de * 1.42860677e-6f);
 }
 
-__device__ __forceinline__ double c6_det_exp(double x) {
-    if (x < -746.0) return 0.0;
-    double t = x * 1.44269504088896338700e+00;
-    long long k = (long long)(t + (t >= 0 ? 0.5 : -0.5));
-    double dk = (double)k;
-    double r = (x - dk * 6.93147180369123816490e-01) - dk * 1.90821492927058770002e-10;
-    double p = 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
-    long long k1 = k / 2, k2 = k - k1;
-    double s1 = __longlong_as_double((k1 + 1023) << 52), s2 = __longlong_as_double((k2 + 1023) << 52);
-    return (p * s1) * s2;
+// exp(x) = p * 2^k with p in about [0.7, 1.42]: the polynomial part in float, the exponent returned separately -- the
+// sampler's U^(1/alpha) reaches 1e-250 at alpha = 0.03 and must not underflow (an all-zero noise vector would be NaN
+// after normalisation), so the scaling is applied in double
+__device__ __forceinline__ float c6_det_expf_parts(float x, int &k) {
+    float t = x * 1.44269504f;
+    k = (int)(t + (t >= 0.0f ? 0.5f : -0.5f));
+    float dk = (float)k;
+    float r = (x - dk * 0.693145751953125f) - dk * 1.42860677e-6f;
+    float p = 1.0f / 40320.0f;
+    p = p * r + 1.0f / 5040.0f;
+    p = p * r + 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    return p;
 }
 
-// Gamma(alpha, 1), alpha < 1: Marsaglia-Tsang at shape alpha+1 times U^(1/alpha) (rand 0.6 GammaSmallShape),
-// normal deviates by the polar method.  d and c are the per-kernel constants of the sampler.
-// One ATTEMPT of the C6RNG spec (counter words 2*att and 2*att+1 of this cell): true and the variate if it is accepted.
-// A cell's variate is that of its first accepted attempt; attempts are independent of one another, so who evaluates
-// them, and in which order, is free (c6_wave_gamma below spreads the retries over the wave).
-__device__ __forceinline__ bool c6_gamma_try(double alpha, double d, double c, uint32_t k0, uint32_t k1, uint32_t cell,
+// 24-bit uniform strictly inside (0,1)
+__device__ __forceinline__ float c6_open01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// Gamma(alpha, 1), alpha < 1: Marsaglia-Tsang at shape alpha+1 times U^(1/alpha) (rand 0.6 GammaSmallShape /
+// GammaLargeShape), normal deviates by the polar method.  C6RNG v2: the variate is computed in SINGLE precision -- the
+// reference casts the noise to f32 before it is used (alphazero_policy/mod.rs:283) and f64 vector arithmetic runs at half
+// the f32 rate on gfx950 -- and one Philox block serves an attempt (words: polar v1, polar v2, squeeze u, power u).
+// d and c are the sampler's constants (double, rounded to float here).
+// One ATTEMPT of the spec (counter word c1 = att of this cell): true and the variate if it is accepted.  A cell's
+// variate is that of its first accepted attempt; attempts are independent of one another, so who evaluates them, and in
+// which order, is free (c6_wave_gamma below spreads them over the wave).
+__device__ __forceinline__ bool c6_gamma_try(double alpha, double d_, double c_, uint32_t k0, uint32_t k1, uint32_t cell,
                                              uint32_t search, uint32_t depth, uint32_t att, double &out) {
     const uint32_t tag = C6_TAG_NOISE | (depth << 8);
-    c6_u4 w = c6_philox(cell, 2 * att, search, tag, k0, k1);
-    double v1 = 2.0 * c6_open01(w.x, w.y) - 1.0, v2 = 2.0 * c6_open01(w.z, w.w) - 1.0;
-    double s = v1 * v1 + v2 * v2;
-    if (s >= 1.0 || s == 0.0) return false;
-    double x = v1 * sqrt(-2.0 * c6_det_log(s) / s);
-    double vc = 1.0 + c * x;
-    if (vc <= 0.0) return false;
-    double v = vc * vc * vc;
-    w = c6_philox(cell, 2 * att + 1, search, tag, k0, k1);
-    double u = c6_open01(w.x, w.y), u2 = c6_open01(w.z, w.w);
-    double x2 = x * x;
-    if (u < 1.0 - 0.0331 * x2 * x2 || c6_det_log(u) < 0.5 * x2 + d * (1.0 - v + c6_det_log(v))) {
-        double g = d * v;
-        out = g * c6_det_exp(c6_det_log(u2) / alpha);
+    const float d = (float)d_, c = (float)c_, inv_alpha = 1.0f / (float)alpha;
+    const c6_u4 w = c6_philox(cell, att, search, tag, k0, k1);
+    const float v1 = 2.0f * c6_open01f(w.x) - 1.0f, v2 = 2.0f * c6_open01f(w.y) - 1.0f;
+    const float s = v1 * v1 + v2 * v2;
+    if (s >= 1.0f || s == 0.0f) return false;
+    const float x = v1 * sqrtf(-2.0f * c6_det_logf(s) / s);
+    const float vc = 1.0f + c * x;
+    if (vc <= 0.0f) return false;
+    const float v = vc * vc * vc;
+    const float u = c6_open01f(w.z), u2 = c6_open01f(w.w);
+    const float x2 = x * x;
+    if (u < 1.0f - 0.0331f * x2 * x2 || c6_det_logf(u) < 0.5f * x2 + d * (1.0f - v + c6_det_logf(v))) {
+        int k;
+        const float g = (d * v) * c6_det_expf_parts(c6_det_logf(u2) * inv_alpha, k);      // in [~1e-30, ~50]: a normal float
+        // 2^k exactly, in double (k >= -1000: far inside the normal range; smaller variates are 0)
+        out = k < -1000 ? 0.0 : (double)g * __longlong_as_double((long long)(k + 1023) << 52);
         return true;
     }
     return false;

@@ -259,92 +259,88 @@ void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 static inline double bits2d(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 static inline uint64_t d2bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
 
-/* natural log, x > 0 normal; only + - * / and bit operations (bit-identical on every IEEE machine) */
-double c6o_det_log(double x) {
-    uint64_t b = d2bits(x);
-    int e = (int)((b >> 52) & 0x7ff) - 1023;
-    double m = bits2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1,2) */
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    double f = (m - 1.0) / (m + 1.0), f2 = f * f;
-    double p = 1.0 / 23.0;
-    p = p * f2 + 1.0 / 21.0;
-    p = p * f2 + 1.0 / 19.0;
-    p = p * f2 + 1.0 / 17.0;
-    p = p * f2 + 1.0 / 15.0;
-    p = p * f2 + 1.0 / 13.0;
-    p = p * f2 + 1.0 / 11.0;
-    p = p * f2 + 1.0 / 9.0;
-    p = p * f2 + 1.0 / 7.0;
-    p = p * f2 + 1.0 / 5.0;
-    p = p * f2 + 1.0 / 3.0;
-    p = p * f2 + 1.0;
-    double lm = 2.0 * f * p;
-    double de = (double)e;
-    return de * 6.93147180369123816490e-01 + (lm + de * 1.90821492927058770002e-10);
-}
-
-/* exp, same rules; x <= ~709 */
-double c6o_det_exp(double x) {
-    if (x < -746.0) return 0.0;
-    double t = x * 1.44269504088896338700e+00;
-    long long k = (long long)(t + (t >= 0 ? 0.5 : -0.5));
-    double dk = (double)k;
-    double r = (x - dk * 6.93147180369123816490e-01) - dk * 1.90821492927058770002e-10;
-    double p = 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
-    /* scale by 2^k in two exact-power steps so that gradual underflow rounds once */
-    long long k1 = k / 2, k2 = k - k1;
-    double s1 = bits2d((uint64_t)(k1 + 1023) << 52), s2 = bits2d((uint64_t)(k2 + 1023) << 52);
-    return (p * s1) * s2;
-}
-
 /* 53-bit uniform strictly inside (0,1) */
 static inline double open01(uint32_t hi, uint32_t lo) {
     uint64_t v = ((uint64_t)hi << 21) | (uint64_t)(lo >> 11);
     return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
 }
 
+static inline float bits2f(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+static inline uint32_t f2bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
+
+/* single-precision log / exp of the Gamma sampler (C6RNG v2): explicit polynomials on IEEE + - * / -- this file is
+ * compiled with -ffp-contract=off and x86-64 evaluates float expressions in float, so the bits equal the GPU's */
+float c6o_det_logf(float x) {
+    uint32_t b = f2bits(x);
+    int e = (int)((b >> 23) & 0xff) - 127;
+    float m = bits2f((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float f = (m - 1.0f) / (m + 1.0f), f2 = f * f;
+    float p = 1.0f / 11.0f;
+    p = p * f2 + 1.0f / 9.0f;
+    p = p * f2 + 1.0f / 7.0f;
+    p = p * f2 + 1.0f / 5.0f;
+    p = p * f2 + 1.0f / 3.0f;
+    p = p * f2 + 1.0f;
+    float lm = 2.0f * f * p;
+    float de = (float)e;
+    return de * 0.693145751953125f + (lm + de * 1.42860677e-6f);
+}
+
+/* exp(x) = p * 2^k, p in about [0.7, 1.42]: polynomial part in float, exponent returned separately (the sampler applies it
+ * in double: U^(1/alpha) reaches 1e-250 at alpha = 0.03 and must not underflow) */
+float c6o_det_expf_parts(float x, int *kout) {
+    float t = x * 1.44269504f;
+    int k = (int)(t + (t >= 0.0f ? 0.5f : -0.5f));
+    float dk = (float)k;
+    float r = (x - dk * 0.693145751953125f) - dk * 1.42860677e-6f;
+    float p = 1.0f / 40320.0f;
+    p = p * r + 1.0f / 5040.0f;
+    p = p * r + 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    *kout = k;
+    return p;
+}
+
+/* 24-bit uniform strictly inside (0,1) */
+static inline float open01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
 /*
  * Gamma(alpha, 1), alpha < 1 -- the algorithm of rand 0.6 `Gamma` (GammaSmallShape:
  * Marsaglia-Tsang for shape alpha+1 times U^(1/alpha)), which is what
  * `Dirichlet::new_with_param(alpha, n).sample` draws per component
  * (called from alphazero_policy/mod.rs:262,283).  Normal deviates come from the
- * polar method so that only log/sqrt are needed.
+ * polar method so that only log/sqrt are needed.  C6RNG v2: the variate is computed in
+ * single precision (the reference casts the noise to f32 before use, mod.rs:283) and one
+ * Philox block serves an attempt: words = polar v1, polar v2, squeeze u, power u.
  */
 double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth) {
     const double shape = alpha + 1.0;
-    const double d = shape - 1.0 / 3.0;
-    const double c = 1.0 / sqrt(9.0 * d);
+    const double dd = shape - 1.0 / 3.0;
+    const double cd = 1.0 / sqrt(9.0 * dd);
+    const float d = (float)dd, c = (float)cd, inv_alpha = 1.0f / (float)alpha;
     uint32_t key[2] = {k0, k1};
     for (uint32_t att = 0;; att++) {
-        uint32_t ctr[4] = {cell, 2 * att, search, (uint32_t)C6O_TAG_NOISE | (depth << 8)}, w[4];
+        uint32_t ctr[4] = {cell, att, search, (uint32_t)C6O_TAG_NOISE | (depth << 8)}, w[4];
         c6o_philox4x32_10(ctr, key, w);
-        double v1 = 2.0 * open01(w[0], w[1]) - 1.0, v2 = 2.0 * open01(w[2], w[3]) - 1.0;
-        double s = v1 * v1 + v2 * v2;
-        if (s >= 1.0 || s == 0.0) continue;
-        double x = v1 * sqrt(-2.0 * c6o_det_log(s) / s);
-        double vc = 1.0 + c * x;
-        if (vc <= 0.0) continue;
-        double v = vc * vc * vc;
-        ctr[1] = 2 * att + 1;
-        c6o_philox4x32_10(ctr, key, w);
-        double u = open01(w[0], w[1]), u2 = open01(w[2], w[3]);
-        double x2 = x * x;
-        if (u < 1.0 - 0.0331 * x2 * x2 || c6o_det_log(u) < 0.5 * x2 + d * (1.0 - v + c6o_det_log(v))) {
-            double g = d * v;
-            return g * c6o_det_exp(c6o_det_log(u2) / alpha);
+        const float v1 = 2.0f * open01f(w[0]) - 1.0f, v2 = 2.0f * open01f(w[1]) - 1.0f;
+        const float s = v1 * v1 + v2 * v2;
+        if (s >= 1.0f || s == 0.0f) continue;
+        const float x = v1 * sqrtf(-2.0f * c6o_det_logf(s) / s);
+        const float vc = 1.0f + c * x;
+        if (vc <= 0.0f) continue;
+        const float v = vc * vc * vc;
+        const float u = open01f(w[2]), u2 = open01f(w[3]);
+        const float x2 = x * x;
+        if (u < 1.0f - 0.0331f * x2 * x2 || c6o_det_logf(u) < 0.5f * x2 + d * (1.0f - v + c6o_det_logf(v))) {
+            int k;
+            const float g = (d * v) * c6o_det_expf_parts(c6o_det_logf(u2) * inv_alpha, &k);
+            return k < -1000 ? 0.0 : (double)g * bits2d((uint64_t)(k + 1023) << 52);   /* 2^k exactly, in double */
         }
     }
 }

@@ -106,8 +106,8 @@ enum {
     C6O_TAG_EVAL_P = 4 /* RandomEvaluator policy,  ctr = (cell>>2, image, search, tag) word cell&3 */
 };
 void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-double c6o_det_log(double x);
-double c6o_det_exp(double x);
+float c6o_det_logf(float x);   /* single-precision pair used by the Gamma sampler (C6RNG v2) */
+float c6o_det_expf_parts(float x, int *k);   /* exp(x) = return value * 2^k */
 /* Gamma(alpha<1,1) draw number `cell` of select step (search, depth) of a game */
 double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth);
 /* sum of 64 lane-partials with the xor-butterfly order of the spec */

@@ -17,15 +17,20 @@ def test_philox_known_answers():
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def test_det_log_exp_accuracy():
+def test_det_logf_expf_accuracy():
+    """the single-precision pair of the Gamma sampler (C6RNG v2): a few ulp of float over the ranges the sampler uses"""
     L = o.lib()
     rng = np.random.default_rng(0)
-    for x in np.concatenate([rng.uniform(1e-300, 1, 2000), rng.uniform(1, 1e6, 500), 10.0 ** rng.uniform(-30, 0, 500)]):
-        assert abs(L.c6o_det_log(x) - math.log(x)) <= 4e-16 * max(1.0, abs(math.log(x)))
-    for x in rng.uniform(-700, 50, 3000):
-        assert abs(L.c6o_det_exp(x) - math.exp(x)) <= 1e-14 * math.exp(x)
-    assert L.c6o_det_exp(-800.0) == 0.0
-    assert 0 < L.c6o_det_exp(-740.0) < 1e-300  # gradual underflow
+    xs = np.concatenate([rng.uniform(2.0 ** -25, 1, 3000), rng.uniform(1, 64, 500), 10.0 ** rng.uniform(-7, 0, 500)]).astype(np.float32)
+    for x in xs:
+        assert abs(L.c6o_det_logf(float(x)) - math.log(float(x))) <= 6e-7 * max(1.0, abs(math.log(float(x))))
+    import ctypes as C
+    k = C.c_int()
+    for x in rng.uniform(-600, 10, 3000).astype(np.float32):
+        p = L.c6o_det_expf_parts(float(x), C.byref(k))
+        assert 0.70 < p < 1.42
+        # the argument is a float: at |x| ~ 600 its own resolution (2^-24 |x|) bounds the accuracy of exp
+        assert abs(math.ldexp(p, k.value) - math.exp(float(x))) <= (1e-6 + 1.5e-7 * abs(float(x))) * math.exp(float(x))
 
 
 def test_gamma_moments():
