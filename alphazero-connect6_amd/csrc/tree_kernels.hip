@@ -369,8 +369,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
         const uint32_t ms = turn == C6_BLACK ? q0 : q2, mq = turn == C6_BLACK ? q1 : q3;   // mover colour sums of Q
         const uint32_t os = turn == C6_BLACK ? q2 : q0, oq = turn == C6_BLACK ? q3 : q1;
         for (int r = lane; r < hi; r += 64) {      // records at or above hi were never used: level -1
-            if (r == idx || E.rec_level[rbase + r] != level) continue;
-            const uint32_t *sg = E.rec_sig + (rbase + r) * 4;
+            // level, signature and key are fetched together (three independent loads in flight: one memory round trip per
+            // 64 records instead of up to three dependent ones -- this scan is most of the kernel's latency chain)
+            const int lv = E.rec_level[rbase + r];
+            const uint4 sgv = *reinterpret_cast<const uint4 *>(E.rec_sig + (rbase + r) * 4);
+            const unsigned long long rk = E.rec_key[rbase + r];
+            if (r == idx || lv != level) continue;
+            const uint32_t sg[4] = {sgv.x, sgv.y, sgv.z, sgv.w};
             const uint32_t pms = turn == C6_BLACK ? sg[0] : sg[2], pmq = turn == C6_BLACK ? sg[1] : sg[3];
             const uint32_t pos_ = turn == C6_BLACK ? sg[2] : sg[0], poq = turn == C6_BLACK ? sg[3] : sg[1];
             if (pos_ != os || poq != oq) continue;
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
             const long long s1 = (T + D1) / 2, i1 = (T - D1) / 2;
             if (s1 < 1 || i1 < 1 || s1 > cells || i1 > cells) continue;
             const int s = (int)s1 - 1, i = (int)i1 - 1;
-            if (E.rec_key[rbase + r] != (key ^ zk[i] ^ zk[s])) continue;
+            if (rk != (key ^ zk[i] ^ zk[s])) continue;
             E.rec_prior[(rbase + r) * (size_t)cells + i] = prob[s];
         }
         if (lane == 0) E.rec_level[rbase + idx] = (int16_t)level;   // after the scan: Q never matches itself
