@@ -414,6 +414,7 @@ extern "C" int c6_engine_create(const c6_config *cfg, c6_engine **out) {
     if (N != 9 && N != 15 && N != 19) return fail(C6_ERR_BAD_ARG, "board_size must be 9, 15 or 19");
     if (cfg->num_games < 1 || cfg->num_simulation < 1) return fail(C6_ERR_BAD_ARG, "num_games and num_simulation must be >= 1");
     if (cfg->evaluator < C6_EVAL_RANDOM || cfg->evaluator > C6_EVAL_CALLBACK) return fail(C6_ERR_BAD_ARG, "bad evaluator kind");
+    if (!(cfg->dirichlet_alpha > 0.0)) return fail(C6_ERR_BAD_ARG, "dirichlet_alpha must be > 0 (Dirichlet::new_with_param asserts it)");
     int rc = require_gpu(cfg->device);
     if (rc != C6_OK) return rc;
     c6_engine *e = new c6_engine();
