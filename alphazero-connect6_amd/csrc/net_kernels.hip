@@ -303,17 +303,38 @@ __global__ __launch_bounds__(256) void c6_head_policy_kernel(const float *__rest
         x[idx] = bb < (size_t)nboards ? ph[bb * K + idx % K] : 0.f;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < cells; o += 256) {
-        float acc[HB];
+    {
+        // a thread owns outputs o1 = tid and (19x19: 361 > 256) o2 = tid + 256 and walks k ONCE for both: the LDS reads of x
+        // are shared, and the second pass that ran with 105 of 256 threads active is gone (same k order per output:
+        // bit-identical results)
+        const int o1 = threadIdx.x, o2 = threadIdx.x + 256;
+        const bool h1 = o1 < cells, h2 = o2 < cells;
+        const int c1 = h1 ? o1 : 0, c2 = h2 ? o2 : c1;      // clamped: loads stay unconditional
+        float acc1[HB], acc2[HB];
 #pragma unroll
-        for (int q = 0; q < HB; q++) acc[q] = bias[o];
-        for (int k = 0; k < K; k++) {
-            const float w = wT[(size_t)k * cells + o];
+        for (int q = 0; q < HB; q++) { acc1[q] = bias[c1]; acc2[q] = bias[c2]; }
+        if (cells > 256) {
+            for (int k = 0; k < K; k++) {
+                const float w1 = wT[(size_t)k * cells + c1], w2 = wT[(size_t)k * cells + c2];
 #pragma unroll
-            for (int q = 0; q < HB; q++) acc[q] = __builtin_fmaf(w, x[q * K + k], acc[q]);
+                for (int q = 0; q < HB; q++) {
+                    const float xv = x[q * K + k];
+                    acc1[q] = __builtin_fmaf(w1, xv, acc1[q]);
+                    acc2[q] = __builtin_fmaf(w2, xv, acc2[q]);
+                }
+            }
+        } else {
+            for (int k = 0; k < K; k++) {
+                const float w1 = wT[(size_t)k * cells + c1];
+#pragma unroll
+                for (int q = 0; q < HB; q++) acc1[q] = __builtin_fmaf(w1, x[q * K + k], acc1[q]);
+            }
         }
 #pragma unroll
-        for (int q = 0; q < HB; q++) lg[q * cells + o] = acc[q];
+        for (int q = 0; q < HB; q++) {
+            if (h1) lg[q * cells + o1] = acc1[q];
+            if (h2) lg[q * cells + o2] = acc2[q];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
