@@ -40,4 +40,4 @@ void c6t_sgd(size_t n, float lr, float momentum, int first, const unsigned char 
 
 int c6t_wgrad_splits(int C, int B);
 size_t c6t_wgrad_partial_floats(int C, int B);
-bool c6t_wgrad(int N, int C, int B, const float *dy, const float *x, float *partial, float *dw, hipStream_t s);
+bool c6t_wgrad(int N, int C, int B, const float *dy, const float *x, float *partial, float *dw, hipStream_t s, int split_bf16 = 0);

@@ -736,6 +736,188 @@ __global__ void c6t_wgrad_reduce_kernel(int C, int nsplit, const float *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix cores with split operands (dy = hi + mid, x = hi + mid,
+// dy.x = hi.hi + hi.mid + mid.hi, FP32 accumulate): c6_wgrad_b3_kernel, v_mfma_f32_16x16x32_bf16.
+//  * K = grid cells (pixels), 32 per MFMA: both operands must be K-CONTIGUOUS per lane although memory (NHWC) and the LDS
+//    image are channel-contiguous -> the fragments are fetched with ds_read_b64_tr_b16 (a 4-row x 16-column block of
+//    16-bit elements per 16-lane group, delivered column-major: lane i gets channel i of four consecutive cells).
+//  * LDS image: one 256-byte row per grid cell = 16 chunks of 16 bytes: chunks 0-7 the hi plane of the block's 64
+//    channels, 8-15 the mid plane; chunk ch of row r lives at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) -- the
+//    guide's image (b), conflict-free for the transposed reads at ANY row offset (the nine taps shift the x rows).
+//    The swizzle depends on r mod 16 only and K steps advance by 32 rows: per lane two base addresses for dy and two per
+//    tap for x; tile (+16 channels) and plane (+64 channels) are XORs of the address with 32 and 128.
+//  * workgroup = 64 x 64 block of dW x 9 taps x one K split as in the FP32 kernel; wave = 32 x 32 = 2 x 2 tiles of
+//    16 x 16 x 9 taps = 36 accumulator tiles (144 VGPRs); row bands sized for two workgroups per CU.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+template <int N>
+struct WGradB3Geom {
+    static constexpr int P = N + 2;
+    static constexpr int RB = N <= 9 ? N : (N <= 15 ? 5 : 4);         // output rows per band
+    static constexpr int BANDS = (N + RB - 1) / RB;
+    static constexpr int KSTEPS = (RB * P + 31) / 32;
+    static constexpr int DY_ROWS = KSTEPS * 32;
+    static constexpr int X_ROWS = ((DY_ROWS + 2 * P + 3) + 3) & ~3;     // x image row j = grid cell j - 1 of the haloed band
+    static constexpr size_t LDS_BYTES = (size_t)(DY_ROWS + X_ROWS) * 256;
+};
+
+__device__ __forceinline__ int wg_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <int N>
+__global__ __launch_bounds__(256, 2) void c6_wgrad_b3_kernel(int C, int B, int boards_per_split, const float *__restrict__ dy,
+                                                             const float *__restrict__ x, float *__restrict__ partial) {
+    using G = WGradB3Geom<N>;
+    constexpr int P = G::P, RB = G::RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wb[];
+    unsigned char *dyL = wb, *xL = wb + (size_t)G::DY_ROWS * 256;
+
+    const int nblk = C / 64;
+    const int co0 = (blockIdx.x / nblk) * 64, ci0 = (blockIdx.x % nblk) * 64, split = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const int g = lane >> 4, i = lane & 15, q = (lane >> 2) & 3, p = lane & 3;
+
+    f32x4 acc[2][2][9];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int tp = 0; tp < 9; tp++) acc[t][u][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane bases of the transposed reads: lane 4q+p of group g supplies row (8g + q [+4]) , chunk c0 + (p >> 1), half p & 1
+    int baseA[2], baseB[9][2];
+#pragma unroll
+    for (int ex = 0; ex < 2; ex++) {
+        const int row = 8 * g + q + 4 * ex;
+        baseA[ex] = wg_off(row, (wco >> 3) + (p >> 1)) + 8 * (p & 1);
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) baseB[tp][ex] = wg_off(row + (tp / 3) * P + (tp % 3), (wci >> 3) + (p >> 1)) + 8 * (p & 1);
+    }
+
+    for (int e = tid; e < (int)(G::LDS_BYTES / 16); e += 256) reinterpret_cast<f32x4 *>(wb)[e] = f32x4{0.f, 0.f, 0.f, 0.f};   // halo cells: once
+
+    auto put = [&](unsigned char *img, int row, int qq, f32x4 v) {      // 4 channels (qq-th quad of the block's 64) of one cell
+        bf16x4_t hi, mid;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { hi[r] = (__bf16)v[r]; mid[r] = (__bf16)(v[r] - (float)hi[r]); }
+        *reinterpret_cast<bf16x4_t *>(img + wg_off(row, qq >> 1) + 8 * (qq & 1)) = hi;
+        *reinterpret_cast<bf16x4_t *>(img + wg_off(row, 8 + (qq >> 1)) + 8 * (qq & 1)) = mid;
+    };
+
+    const int b_lo = split * boards_per_split, b_hi = (b_lo + boards_per_split < B) ? b_lo + boards_per_split : B;
+    for (int b = b_lo; b < b_hi; b++) {
+        for (int band = 0; band < G::BANDS; band++) {
+            const int y0 = band * RB, rows = (y0 + RB <= N) ? RB : N - y0;
+            __syncthreads();
+            if (G::BANDS > 1 && rows < RB) {      // rows a shorter last band leaves over from the previous full band
+                for (int e = tid; e < (RB - rows) * P * 16; e += 256) {
+                    reinterpret_cast<f32x4 *>(dyL + (size_t)rows * P * 256)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    reinterpret_cast<f32x4 *>(xL + (size_t)((rows + 2) * P + 1) * 256)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __syncthreads();
+            }
+            {   // dy rows of the band: cell (yy, xx) -> image row yy*P + xx + 1
+                const int cnt = rows * N * 16;
+                for (int base = 0; base < cnt; base += 8 * 256) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        int e = base + u * 256 + tid;
+                        e = e < cnt ? e : cnt - 1;
+                        v[u] = *reinterpret_cast<const f32x4 *>(dy + ((size_t)b * N * N + (size_t)y0 * N + e / 16) * C + co0 + (e % 16) * 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = base + u * 256 + tid;
+                        if (e < cnt) { const int pix = e / 16; put(dyL, (pix / N) * P + pix % N + 1, e % 16, v[u]); }
+                    }
+                }
+            }
+            {   // x rows y0-1 .. y0+rows: cell (yy, xx) -> image row yy*P + xx + 2 (grid cell + 1)
+                const int cnt = (rows + 2) * N * 16;
+                for (int base = 0; base < cnt; base += 8 * 256) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        int e = base + u * 256 + tid;
+                        e = e < cnt ? e : cnt - 1;
+                        const int pix = e / 16, yy = pix / N, xx = pix % N, gy = y0 - 1 + yy;
+                        const int cy = gy < 0 ? 0 : (gy >= N ? N - 1 : gy);
+                        v[u] = *reinterpret_cast<const f32x4 *>(x + ((size_t)b * N * N + (size_t)cy * N + xx) * C + ci0 + (e % 16) * 4);
+                        if (gy < 0 || gy >= N) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = base + u * 256 + tid;
+                        if (e < cnt) { const int pix = e / 16; put(xL, (pix / N) * P + pix % N + 2, e % 16, v[u]); }
+                    }
+                }
+            }
+            __syncthreads();
+            const int ksteps = (rows * P + 31) / 32;
+            auto frag = [&](const unsigned char *img, int base0, int base1, int kofs, int x_or) -> bf16x8_t {
+                // opaque: otherwise LICM hoists the 40 (base ^ constant) addresses out of the K loop -> spills
+                asm volatile("" : "+v"(base0), "+v"(base1));
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(img + ((base0 ^ x_or) + kofs)));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(img + ((base1 ^ x_or) + kofs)));
+                union { s16x4_t s[2]; bf16x8_t v; } uu;
+                uu.s[0] = lo; uu.s[1] = hi;
+                return uu.v;
+            };
+#pragma unroll 1
+            for (int ks = 0; ks < ksteps; ks++) {
+                const int kofs = ks * 32 * 256;
+                bf16x8_t ah[2], am[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) { ah[t] = frag(dyL, baseA[0], baseA[1], kofs, 32 * t); am[t] = frag(dyL, baseA[0], baseA[1], kofs, 32 * t + 128); }
+                // x fragments of tap tp + 1 are read before the MFMAs of tap tp (double-buffered by hand; sched_barrier keeps
+                // hipcc from hoisting all nine taps' reads to the top: 72 fragment registers -> spills)
+                bf16x8_t bh[2][2], bm[2][2];
+                auto load_b = [&](int slot, int tp) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        bh[slot][u] = frag(xL, baseB[tp][0], baseB[tp][1], kofs, 32 * u);
+                        bm[slot][u] = frag(xL, baseB[tp][0], baseB[tp][1], kofs, 32 * u + 128);
+                    }
+                };
+                load_b(0, 0);
+#pragma unroll
+                for (int tp = 0, sl = 0; tp < 9; tp++, sl ^= 1) {
+                    if (tp + 1 < 9) load_b(sl ^ 1, tp + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int t = 0; t < 2; t++) {
+                            acc[t][u][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bh[sl][u], acc[t][u][tp], 0, 0, 0);
+                            acc[t][u][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bm[sl][u], acc[t][u][tp], 0, 0, 0);
+                            acc[t][u][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh[sl][u], acc[t][u][tp], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // D tile (t, u): lane (column i = ci, g) holds rows co = 4g + r
+    float *pp = partial + (size_t)split * 9 * C * C;
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int co = co0 + wco + 16 * t + 4 * g + r, ci = ci0 + wci + 16 * u + i;
+                    pp[((size_t)tp * C + co) * C + ci] = acc[t][u][tp][r];
+                }
+}
+
 int c6t_wgrad_splits(int C, int B) {
     const int blocks = (C / 64) * (C / 64);
     int splits = (512 + blocks - 1) / blocks;      // about two workgroups per CU
@@ -746,19 +928,26 @@ int c6t_wgrad_splits(int C, int B) {
 size_t c6t_wgrad_partial_floats(int C, int B) { return (size_t)c6t_wgrad_splits(C, B) * 9 * C * C; }
 
 template <int N>
-static void launch_wgrad(int C, int B, const float *dy, const float *x, float *partial, float *dw, hipStream_t s) {
-    using G = WGradGeom<N>;
+static void launch_wgrad(int C, int B, const float *dy, const float *x, float *partial, float *dw, int split_bf16, hipStream_t s) {
     const int splits = c6t_wgrad_splits(C, B), per = (B + splits - 1) / splits;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wgrad_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-    hipLaunchKernelGGL(c6_wgrad_kernel<N>, dim3((C / 64) * (C / 64), splits), dim3(256), G::LDS_BYTES, s, C, B, per, dy, x, partial);
+    if (split_bf16) {
+        using G = WGradB3Geom<N>;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wgrad_b3_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        hipLaunchKernelGGL(c6_wgrad_b3_kernel<N>, dim3((C / 64) * (C / 64), splits), dim3(256), G::LDS_BYTES, s, C, B, per, dy, x, partial);
+    } else {
+        using G = WGradGeom<N>;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wgrad_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        hipLaunchKernelGGL(c6_wgrad_kernel<N>, dim3((C / 64) * (C / 64), splits), dim3(256), G::LDS_BYTES, s, C, B, per, dy, x, partial);
+    }
     hipLaunchKernelGGL(c6t_wgrad_reduce_kernel, dim3(1024), dim3(256), 0, s, C, splits, partial, dw);
 }
-bool c6t_wgrad(int N, int C, int B, const float *dy, const float *x, float *partial, float *dw, hipStream_t s) {
+// split_bf16 = 0: exact FP32 MFMA; 1: split-bf16 products (3 bf16 MFMAs per product), the trainer's default precision
+bool c6t_wgrad(int N, int C, int B, const float *dy, const float *x, float *partial, float *dw, hipStream_t s, int split_bf16) {
     if (C % 64) return false;
     switch (N) {
-    case 9: launch_wgrad<9>(C, B, dy, x, partial, dw, s); return true;
-    case 15: launch_wgrad<15>(C, B, dy, x, partial, dw, s); return true;
-    case 19: launch_wgrad<19>(C, B, dy, x, partial, dw, s); return true;
+    case 9: launch_wgrad<9>(C, B, dy, x, partial, dw, split_bf16, s); return true;
+    case 15: launch_wgrad<15>(C, B, dy, x, partial, dw, split_bf16, s); return true;
+    case 19: launch_wgrad<19>(C, B, dy, x, partial, dw, split_bf16, s); return true;
     default: return false;
     }
 }

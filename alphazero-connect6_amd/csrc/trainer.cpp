@@ -272,7 +272,7 @@ static int backward(c6_trainer *t) {
             c6t_colstats(1, R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, t->partial, G + u.be, G + u.g, s);
             c6t_bn_bwd_apply(R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, dz, s);
             c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, t->partial, G + u.b, nullptr, s);
-            if (!c6t_wgrad(t->n, C, B, dy, t->a[l1], t->partial, G + u.w, s)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
+            if (!c6t_wgrad(t->n, C, B, dy, t->a[l1], t->partial, G + u.w, s, t->precision != C6_PREC_FP32)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
             int rc = conv3x3(t, P + u.w, 1, dy, nullptr, nullptr, dmid);
             if (rc) return rc;
         }
@@ -282,7 +282,7 @@ static int backward(c6_trainer *t) {
             c6t_colstats(1, R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, t->partial, G + u.be, G + u.g, s);
             c6t_bn_bwd_apply(R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, nullptr, s);
             c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, t->partial, G + u.b, nullptr, s);
-            if (!c6t_wgrad(t->n, C, B, dy, t->a[l0], t->partial, G + u.w, s)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
+            if (!c6t_wgrad(t->n, C, B, dy, t->a[l0], t->partial, G + u.w, s, t->precision != C6_PREC_FP32)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
             int rc = conv3x3(t, P + u.w, 1, dy, nullptr, dz /* + the skip connection's gradient */, cur);
             if (rc) return rc;
         }
