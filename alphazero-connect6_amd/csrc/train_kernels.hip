@@ -11,7 +11,8 @@
 //
 // 3x3 convolutions: the forward pass and the input gradient run on the evaluator's split-bf16 kernel
 // (c6_conv3x3_b3s_kernel with relu = 0, bias folded out, weights packed on the device each step by c6_pack_b3s_kernel --
-// transposed and flipped for the input gradient); the weight gradient is c6_wgrad_kernel below (exact FP32 MFMA).
+// transposed and flipped for the input gradient); the weight gradient is c6_wgrad_b3_kernel below (split bf16) or, with
+// C6_PREC_FP32, c6_wgrad_kernel (exact FP32 MFMA) next to the exact-FP32 convolution c6_conv3x3_f32n_kernel.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -821,41 +822,36 @@ __global__ __launch_bounds__(256, 2) void c6_wgrad_b3_kernel(int C, int B, int b
                 }
                 __syncthreads();
             }
-            {   // dy rows of the band: cell (yy, xx) -> image row yy*P + xx + 1
-                const int cnt = rows * N * 16;
-                for (int base = 0; base < cnt; base += 8 * 256) {
-                    f32x4 v[8];
+            {   // dy rows of the band: cell (yy, xx) -> image row yy*P + xx + 1;  x rows y0-1 .. y0+rows: cell (yy, xx) ->
+                // image row yy*P + xx + 2 (grid cell + 1).  All loads of the band are issued before the first conversion
+                // (one HBM round trip per band instead of two or more: the kernel waits on exactly this)
+                constexpr int DYI = (RB * N * 16 + 255) / 256, XI = ((RB + 2) * N * 16 + 255) / 256;
+                const int cnt_d = rows * N * 16, cnt_x = (rows + 2) * N * 16;
+                f32x4 vd[DYI], vx[XI];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        int e = base + u * 256 + tid;
-                        e = e < cnt ? e : cnt - 1;
-                        v[u] = *reinterpret_cast<const f32x4 *>(dy + ((size_t)b * N * N + (size_t)y0 * N + e / 16) * C + co0 + (e % 16) * 4);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int e = base + u * 256 + tid;
-                        if (e < cnt) { const int pix = e / 16; put(dyL, (pix / N) * P + pix % N + 1, e % 16, v[u]); }
-                    }
+                for (int u = 0; u < DYI; u++) {
+                    int e = u * 256 + tid;
+                    e = e < cnt_d ? e : cnt_d - 1;
+                    vd[u] = *reinterpret_cast<const f32x4 *>(dy + ((size_t)b * N * N + (size_t)y0 * N + e / 16) * C + co0 + (e % 16) * 4);
                 }
-            }
-            {   // x rows y0-1 .. y0+rows: cell (yy, xx) -> image row yy*P + xx + 2 (grid cell + 1)
-                const int cnt = (rows + 2) * N * 16;
-                for (int base = 0; base < cnt; base += 8 * 256) {
-                    f32x4 v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        int e = base + u * 256 + tid;
-                        e = e < cnt ? e : cnt - 1;
-                        const int pix = e / 16, yy = pix / N, xx = pix % N, gy = y0 - 1 + yy;
-                        const int cy = gy < 0 ? 0 : (gy >= N ? N - 1 : gy);
-                        v[u] = *reinterpret_cast<const f32x4 *>(x + ((size_t)b * N * N + (size_t)cy * N + xx) * C + ci0 + (e % 16) * 4);
-                        if (gy < 0 || gy >= N) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
+                for (int u = 0; u < XI; u++) {
+                    int e = u * 256 + tid;
+                    e = e < cnt_x ? e : cnt_x - 1;
+                    const int pix = e / 16, yy = pix / N, xx = pix % N, gy = y0 - 1 + yy;
+                    const int cy = gy < 0 ? 0 : (gy >= N ? N - 1 : gy);
+                    vx[u] = *reinterpret_cast<const f32x4 *>(x + ((size_t)b * N * N + (size_t)cy * N + xx) * C + ci0 + (e % 16) * 4);
+                    if (gy < 0 || gy >= N) vx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int e = base + u * 256 + tid;
-                        if (e < cnt) { const int pix = e / 16; put(xL, (pix / N) * P + pix % N + 2, e % 16, v[u]); }
-                    }
+                for (int u = 0; u < DYI; u++) {
+                    const int e = u * 256 + tid;
+                    if (e < cnt_d) { const int pix = e / 16; put(dyL, (pix / N) * P + pix % N + 1, e % 16, vd[u]); }
+                }
+#pragma unroll
+                for (int u = 0; u < XI; u++) {
+                    const int e = u * 256 + tid;
+                    if (e < cnt_x) { const int pix = e / 16; put(xL, (pix / N) * P + pix % N + 2, e % 16, vx[u]); }
                 }
             }
             __syncthreads();

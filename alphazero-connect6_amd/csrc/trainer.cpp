@@ -33,7 +33,7 @@ struct Bn { size_t g, be, rm, rv; };
 struct c6_trainer {
     int n = 0, cells = 0, C = 0, nb = 0, L = 0, B = 0, device = 0, num_cus = 256;
     float lr = 1e-3f, momentum = 0.9f;
-    int precision = C6_PREC_BF16X3;     // of the 3x3 convolutions (forward + input gradient); the weight gradient is always FP32
+    int precision = C6_PREC_BF16X3;     // of the 3x3 convolutions: forward, input gradient and weight gradient
     long steps = 0;
     size_t nfloats = 0, act = 0;
     hipStream_t stream = nullptr;

@@ -10,8 +10,8 @@ percents at these batch sizes (PyTorch float32 vs float64 shows the same).  So
     <= 1e-5: summation order only) and every tensor within 1e-3 of its largest reference entry -- the per-tensor bound
     is that wide because BatchNorm backward over a mini-batch cancels heavily (value head: statistics over B samples)
     and amplifies a 1e-7 difference of its INPUT by up to 1e4; well-conditioned tensors agree to ~1e-6.
-    precision = BF16X3 (the evaluator's split-bf16 kernel for the forward pass and the input gradient; weight gradient
-    exact FP32): L2 2e-3, per tensor 4e-3 (products carry ~2^-16 relative error);
+    precision = BF16X3 (split-bf16 products in the forward pass, the input gradient and the weight gradient): L2 2e-3,
+    per tensor 4e-3 (products carry ~2^-16 relative error);
   * LOOSE cases (ordinary random BatchNorm parameters, large nets) bound the L2 error of the whole gradient by 5e-2.
 The loss agrees to 1e-4 everywhere."""
 import os
