@@ -229,6 +229,53 @@ __global__ __launch_bounds__(256) void c6t_colstats_kernel(int mode, size_t R, i
         partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
     }
 }
+// the same for the tower's shapes (C = 64 / 128 / 256): a thread owns FOUR channels (16-byte loads: 1 KiB per wave
+// instruction) and every RL-th row of the chunk, RL = 256 / (C / 4) row lanes; the row lanes' sums are added in lane order
+__global__ __launch_bounds__(256) void c6t_colstats4_kernel(int mode, size_t R, int C, const float *__restrict__ x, const float *__restrict__ aout,
+                                                            const float *__restrict__ y, const float *__restrict__ mean,
+                                                            const float *__restrict__ var, float *__restrict__ partial) {
+    __shared__ f32x4 red[2][256];
+    const int CQ = C / 4, RL = 256 / CQ;
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ, c = cq * 4;
+    const size_t r0 = (size_t)blockIdx.x * CS_ROWS;
+    const size_t r1 = r0 + CS_ROWS < R ? r0 + CS_ROWS : R;
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (mode == 0) {
+        for (size_t r = r0 + rl; r < r1; r += RL) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * C + c);
+            s0 = s0 + v;
+#pragma unroll
+            for (int q = 0; q < 4; q++) s1[q] = __builtin_fmaf(v[q], v[q], s1[q]);
+        }
+    } else if (mode == 1) {
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(mean + c), vv = *reinterpret_cast<const f32x4 *>(var + c);
+        f32x4 is;
+#pragma unroll
+        for (int q = 0; q < 4; q++) is[q] = 1.0f / sqrtf(vv[q] + BN_EPS);
+        for (size_t r = r0 + rl; r < r1; r += RL) {
+            f32x4 dz = *reinterpret_cast<const f32x4 *>(x + r * C + c);
+            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * C + c);
+            if (aout) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(aout + r * C + c);
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (!(a[q] > 0.f)) dz[q] = 0.f;
+            }
+            s0 = s0 + dz;
+#pragma unroll
+            for (int q = 0; q < 4; q++) s1[q] = __builtin_fmaf(dz[q], (yv[q] - m[q]) * is[q], s1[q]);
+        }
+    } else {
+        for (size_t r = r0 + rl; r < r1; r += RL) s0 = s0 + *reinterpret_cast<const f32x4 *>(x + r * C + c);
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < RL; l++) { s0 = s0 + red[0][l * CQ + cq]; s1 = s1 + red[1][l * CQ + cq]; }
+        *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 0) * C + c) = s0;
+        *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 1) * C + c) = s1;
+    }
+}
 // mode 0: out0 = mean, out1 = biased variance; otherwise out0 = s0, out1 = s1.  32 columns x 8 chunk lanes per
 // workgroup: lane ky sums chunks ky, ky + 8, ... in order, the eight lane sums are then added in lane order (fixed order,
 // double accumulators).
@@ -260,7 +307,8 @@ size_t c6t_colstats_partial_floats(size_t R, int C) { return ((R + CS_ROWS - 1) 
 void c6t_colstats(int mode, size_t R, int C, const float *x, const float *aout, const float *y, const float *mean, const float *var,
                   float *partial, float *out0, float *out1, hipStream_t s) {
     const int nchunk = (int)((R + CS_ROWS - 1) / CS_ROWS);
-    hipLaunchKernelGGL(c6t_colstats_kernel, dim3(nchunk), dim3(256), 0, s, mode, R, C, x, aout, y, mean, var, partial);
+    if (C == 64 || C == 128 || C == 256) hipLaunchKernelGGL(c6t_colstats4_kernel, dim3(nchunk), dim3(256), 0, s, mode, R, C, x, aout, y, mean, var, partial);
+    else hipLaunchKernelGGL(c6t_colstats_kernel, dim3(nchunk), dim3(256), 0, s, mode, R, C, x, aout, y, mean, var, partial);
     hipLaunchKernelGGL(c6t_colstats_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, mode, R, C, nchunk, partial, out0, out1);
 }
 
