@@ -277,6 +277,22 @@ def self_play(policy, param=None):
     return _vec_to_py(v)
 
 
+class RandomPolicy:
+    """policy/random_policy/mod.rs:39-47 as a `play()` policy: a uniformly random empty cell, None on a full board
+    (`possible.choose(&mut thread_rng())`; the reference's generator is unseeded, this one takes a seed)"""
+
+    def __init__(self, seed=None):
+        self.rng = np.random.default_rng(seed)
+
+    def __call__(self, board):
+        empty = np.flatnonzero(np.asarray(board).reshape(-1) == 0)
+        if empty.size == 0:
+            return None
+        c = int(self.rng.choice(empty))
+        n = int(round(np.sqrt(np.asarray(board).size)))
+        return c // n, c % n
+
+
 def play(policy, debug=False, num_game_thread=1):
     """Connect6::play (connect6.hpp:311-323) through cpp_play: policy(board[15,15] float) -> (row, col) or None"""
 

@@ -191,3 +191,21 @@ def test_net_vs_net_two_engines_stay_in_step():
         for turn, _, cell in pkg.replay_moves(n, a["moves"]):
             board[cell] = turn
         assert o.search(board.reshape(n, n)) == a["winner"]
+
+
+def test_cpp_play_with_random_policy():
+    """RandomPolicy (policy/random_policy/mod.rs:39-47) behind cpp_play: complete legal games, winner = the oracle's
+    search on the final position, last mover = winner (agent_impl/tests.rs invariant)"""
+    need_gpu()
+    res = pkg.play(pkg.RandomPolicy(seed=3), num_game_thread=16)
+    assert len(res) == 16
+    for winner, path in res:
+        board = path[-1][1].copy()
+        turn, _, (r, c) = path[-1]
+        assert board[r, c] == 0
+        board[r, c] = turn
+        assert o.search(board) == winner
+        if winner != 0:
+            assert turn == winner
+        turns = [t for t, _, _ in path]
+        assert turns[0] == -1 and turns[1:3] == [1, 1]          # 1 stone, then 2 per turn
