@@ -39,7 +39,9 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
-                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_engine_apply_moves", "c6_engine_last_moves"]
+                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_engine_apply_moves", "c6_engine_last_moves",
+                  "c6_rollout_create", "c6_rollout_destroy", "c6_rollout_reset", "c6_rollout_next", "c6_rollout_slot_info",
+                  "c6_rollout_node", "c6_rollout_bench_playouts"]
 
 
 class C6Error(RuntimeError):
@@ -70,6 +72,10 @@ class Profile(C.Structure):
     _fields_ = [("conv_ms", C.c_double), ("conv_launches", C.c_uint64), ("conv_flops", C.c_double), ("select_ms", C.c_double),
                 ("expand_ms", C.c_double), ("eval_other_ms", C.c_double), ("move_ms", C.c_double),
                 ("select_launches", C.c_uint64), ("expand_launches", C.c_uint64)]
+
+
+class RolloutInfo(C.Structure):
+    _fields_ = [("nodes", C.c_uint32), ("edges", C.c_uint32), ("searches", C.c_uint32), ("uid", C.c_uint32)]
 
 
 class Path(C.Structure):  # cppbind/.../rawobj/mod.rs:29-36
@@ -128,6 +134,14 @@ def lib():
     L.c6_engine_apply_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_last_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.c6_rollout_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+    L.c6_rollout_destroy.argtypes = [C.c_void_p]
+    L.c6_rollout_reset.argtypes = [C.c_void_p, u8p]
+    L.c6_rollout_next.argtypes = [C.c_void_p, i8p, u8p, i32p, C.c_int]
+    L.c6_rollout_slot_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(RolloutInfo)]
+    L.c6_rollout_node.argtypes = [C.c_void_p, C.c_int, i8p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.c_int, i32p, i32p, i32p]
+    L.c6_rollout_bench_playouts.argtypes = [C.c_void_p, i8p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), i8p]
     L.c6_engine_fetch_games.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), i32p, i32p, u32p, i16p]
     L.c6_tuple_stride.restype = C.c_size_t
     L.c6_tuple_stride.argtypes = [C.c_int]
@@ -603,6 +617,71 @@ class Trainer:
         loss = C.c_float()
         _chk(lib().c6_trainer_step_replay(self.h, replay.h, seed, draw_id, C.byref(loss)))
         return loss.value
+
+
+class DefaultPolicy:
+    """policy/default_policy/mod.rs:84-275, pure MCTS with random playouts, for `num_games` independent policies on the GPU
+    (include/connect6_amd.h part 5).  next(boards) is Policy::next for every slot at once; with num_games == 1 the object is
+    also a `play()` policy (board[N,N] -> (row, col))."""
+
+    def __init__(self, board_size=15, num_games=1, num_iter=50, seed=0, max_nodes=0, device=0):
+        self.n, self.G, self.num_iter = board_size, num_games, num_iter
+        h = C.c_void_p()
+        _chk(lib().c6_rollout_create(board_size, num_games, num_iter, seed, max_nodes, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().c6_rollout_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def reset(self, mask=None):
+        """DefaultPolicy::new for the masked slots (all by default)"""
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        _chk(lib().c6_rollout_reset(self.h, None if m is None else _p(m, C.c_uint8)))
+
+    def next(self, boards, active=None):
+        """boards int8 [G, N*N] (or [G, N, N]) -> int32 [G] cells (row * N + col), -1 for inactive slots / full boards"""
+        b = np.ascontiguousarray(boards, np.int8).reshape(self.G, self.n * self.n)
+        a = None if active is None else np.ascontiguousarray(active, np.uint8)
+        pos = np.empty(self.G, np.int32)
+        _chk(lib().c6_rollout_next(self.h, _p(b, C.c_int8), None if a is None else _p(a, C.c_uint8), _p(pos, C.c_int32), 0))
+        return pos
+
+    def __call__(self, board):
+        if self.G != 1:
+            raise C6Error("DefaultPolicy as a play() policy needs num_games == 1")
+        b = np.rint(np.asarray(board)).astype(np.int8)
+        c = int(self.next(b.reshape(1, -1))[0])
+        return None if c < 0 else (c // self.n, c % self.n)
+
+    def info(self, g=0):
+        i = RolloutInfo()
+        _chk(lib().c6_rollout_slot_info(self.h, g, C.byref(i)))
+        return dict(nodes=i.nodes, edges=i.edges, searches=i.searches, uid=i.uid)
+
+    def node(self, g, board, cap=1024):
+        """None, or (visit, black_win, [(cell, visit, black_win) of the children in push order])"""
+        b = np.ascontiguousarray(board, np.int8).reshape(-1)
+        f, v, w, k = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        cc, cv, cw = (np.zeros(cap, np.int32) for _ in range(3))
+        _chk(lib().c6_rollout_node(self.h, g, _p(b, C.c_int8), C.byref(f), C.byref(v), C.byref(w), C.byref(k), cap, _p(cc, C.c_int32),
+                                   _p(cv, C.c_int32), _p(cw, C.c_int32)))
+        if not f.value:
+            return None
+        m = min(k.value, cap)
+        return v.value, w.value, [(int(cc[i]), int(cv[i]), int(cw[i])) for i in range(m)]
+
+    def bench_playouts(self, boards, iters=5):
+        """(ms per launch, stones placed per launch, winners int8 [G]) of uniformly random playouts from `boards`"""
+        b = np.ascontiguousarray(boards, np.int8).reshape(self.G, self.n * self.n)
+        ms, steps = C.c_double(), C.c_double()
+        win = np.zeros(self.G, np.int8)
+        _chk(lib().c6_rollout_bench_playouts(self.h, _p(b, C.c_int8), iters, C.byref(ms), C.byref(steps), _p(win, C.c_int8)))
+        return ms.value, steps.value, win
 
 
 def replay_moves(n, moves):

@@ -31,6 +31,7 @@ static int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess) return fail(C6_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
+int c6_set_error(int code, const char *msg) { return fail(code, msg); }   // for the other translation units (c6_engine.h)
 extern "C" const char *c6_last_error(void) { return g_err.c_str(); }
 extern "C" const char *c6_version(void) { return "connect6_amd 0.1 (gfx950)"; }
 extern "C" int c6_device_count(void) {

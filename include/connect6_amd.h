@@ -342,6 +342,43 @@ int c6_trainer_step_replay(c6_trainer *t, c6_replay *r, uint64_t seed, uint32_t 
 int c6_trainer_gradients(c6_trainer *t, float *blob, size_t nfloats);
 const char *c6_trainer_last_error(void);
 
+/* =====================================================================================================================
+ * Part 5 -- DefaultPolicy, pure MCTS with random playouts: policy/default_policy/mod.rs:84-275 for
+ * `num_games` independent policies at once, one GPU thread per policy, trees resident in HBM.  c6_rollout_next is
+ * Policy::next (:262-273): num_iter x search (:213-236: select :119-148, expand :150-170, playout + update :172-211), then
+ * policy (:238-258).  The reference's quirks are kept (the map is never pruned, max_by takes the last of equal children,
+ * White stops at a child Black never won, expand resets a node that already exists and pushes duplicates); its
+ * `thread_rng` picks become the k-th empty cell in row-major order with k = (w * len) >> 32, w = the next word of
+ * C6RNG Philox(key = (seed_lo, seed_hi + uid); ctr = (draw >> 2, 0, search, 6)), the fallback of `policy` word 0 of
+ * ctr = (0, 0, searches so far, 7); uid = slot + num_games * (resets of the slot).  The board key is a 64-bit Zobrist hash
+ * (the reference: 64-bit SipHash).  tests/test_gpu_rollout.py holds it bit-exact to oracle/c6_default.c.
+ * Turn and stones-left are derived from the stone count (Black 1, then 2 each: game/game_impl/mod.rs:125-169).
+ * ===================================================================================================================== */
+typedef struct c6_rollout c6_rollout;
+
+/* num_iter: DefaultPolicy::with_num_iter (:103-108; new() = 50).  max_nodes = nodes (and edges) per tree, 0 = enough for a
+ * whole game with both sides on this policy (num_iter * N*N + N*N + 1).  C6_ERR_OVERFLOW from next() when a tree fills up. */
+int c6_rollout_create(int board_size, int num_games, int num_iter, uint64_t seed, size_t max_nodes, int device, c6_rollout **out);
+void c6_rollout_destroy(c6_rollout *r);
+/* DefaultPolicy::new for the slots with mask[g] != 0 (all when NULL): an empty map and the next uid of the slot */
+int c6_rollout_reset(c6_rollout *r, const uint8_t *mask);
+/* boards int8 [num_games][N*N] (-1 Black / 0 / 1 White), active uint8 [num_games] or NULL = all, pos int32 [num_games] out:
+ * row * N + col, or -1 (inactive slot / no empty cell).  on_device != 0: the three pointers are device memory. */
+int c6_rollout_next(c6_rollout *r, const int8_t *boards, const uint8_t *active, int32_t *pos, int on_device);
+typedef struct c6_rollout_info {
+    uint32_t nodes, edges;   /* map.len() and the sum of next_node.len() ever pushed */
+    uint32_t searches;       /* search() calls since the reset */
+    uint32_t uid;
+} c6_rollout_info;
+int c6_rollout_slot_info(c6_rollout *r, int g, c6_rollout_info *out);
+/* the Node of `board` in slot g (test access): *found, its visit / black_win, and up to cap children in push order
+ * (cell, visit, black_win); *n_children = next_node.len() */
+int c6_rollout_node(c6_rollout *r, int g, const int8_t *board, int *found, int *visit, int *black_win, int *n_children, int cap,
+                    int32_t *child_cell, int32_t *child_visit, int32_t *child_black_win);
+/* playouts only, for the bench: `iters` x (uniformly random playout from every board to the end); *avg_ms per launch,
+ * *steps = stones placed per launch, winners int8 [num_games] of the last launch (may be NULL) */
+int c6_rollout_bench_playouts(c6_rollout *r, const int8_t *boards, int iters, double *avg_ms, double *steps, int8_t *winners);
+
 #ifdef __cplusplus
 }
 #endif

@@ -959,7 +959,7 @@ void c6o_replay_sample(const c6o_replay *r, int num_sample, uint64_t seed, uint3
     const int cells = r->n * r->n;
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     for (int i = 0; i < num_sample; i++) {
-        uint32_t ctr[4] = {(uint32_t)i, draw_id, 0, 5}, w[4];
+        uint32_t ctr[4] = {(uint32_t)i, draw_id, 0, C6O_TAG_SAMPLE}, w[4];
         c6o_philox4x32_10(ctr, key, w);
         const replay_entry *e = &r->paths[w[0] % r->num_data];   /* gen() % num_data */
         winners[i] = (float)e->winner;

@@ -103,7 +103,10 @@ enum {
     C6O_TAG_NOISE = 1, /* Dirichlet noise, ctr = (cell, attempt*2+{0,1}, search, tag | depth<<8) */
     C6O_TAG_TIE = 2,   /* tie-break,       ctr = (0, 0, search, tag | depth<<8) */
     C6O_TAG_EVAL_V = 3,/* RandomEvaluator value,   ctr = (image, 0, search, tag) word 0 */
-    C6O_TAG_EVAL_P = 4 /* RandomEvaluator policy,  ctr = (cell>>2, image, search, tag) word cell&3 */
+    C6O_TAG_EVAL_P = 4,/* RandomEvaluator policy,  ctr = (cell>>2, image, search, tag) word cell&3 */
+    C6O_TAG_SAMPLE = 5,/* replay sampling,         ctr = (i, draw_id, 0, tag) word 0 */
+    C6O_TAG_ROLL = 6,  /* DefaultPolicy expand + playout picks, ctr = (draw>>2, 0, search, tag) word draw&3 */
+    C6O_TAG_ROLL_POLICY = 7 /* DefaultPolicy::policy fallback,  ctr = (0, 0, searches so far, tag) word 0 */
 };
 void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 float c6o_det_logf(float x);   /* single-precision pair used by the Gamma sampler (C6RNG v2) */
@@ -226,6 +229,23 @@ void c6o_net_forward(const c6o_net *net, float player, const float *boards, int 
                      float *value);
 /* c6o_eval_fn adaptor: ctx = c6o_net* */
 int c6o_net_eval(void *ctx, int turn, int n, int len, const int8_t *boards, float *values, float *policies);
+
+/* ---- DefaultPolicy: pure MCTS with random playouts (c6_default.c) ----- */
+
+typedef struct c6o_default c6o_default;
+c6o_default *c6o_default_new(int n, int num_iter, uint64_t seed, uint32_t uid); /* default_policy/mod.rs:95-108 */
+void c6o_default_free(c6o_default *dp);
+void c6o_default_init(c6o_default *dp, const c6o_sim *s);                       /* :110-113 */
+int c6o_default_select(const c6o_default *dp, const c6o_sim *s);                /* :119-148, cell or -1 */
+int c6o_default_expand(c6o_default *dp, const c6o_sim *s);                      /* :150-170, cell */
+void c6o_default_update(c6o_default *dp, const c6o_sim *s, const int16_t *path, int len); /* :172-211 */
+void c6o_default_search(c6o_default *dp, const c6o_game *g);                    /* :213-236 */
+int c6o_default_policy(c6o_default *dp, const c6o_sim *s);                      /* :238-258, cell or -1 */
+int c6o_default_next(c6o_default *dp, const c6o_game *g);                       /* :262-273, cell or -1 */
+size_t c6o_default_map_len(const c6o_default *dp);
+uint32_t c6o_default_search_count(const c6o_default *dp);
+int c6o_default_node(const c6o_default *dp, const int8_t *board, int *visit, int *black_win, int *n_next, int cap,
+                     int32_t *child_cell, int32_t *child_visit, int32_t *child_black_win);
 
 #ifdef __cplusplus
 }

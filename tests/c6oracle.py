@@ -20,7 +20,7 @@ EVAL_CUSTOM, EVAL_RANDOM, EVAL_UNIFORM = 0, 1, 2
 
 
 def build(force=False):
-    srcs = [os.path.join(ODIR, f) for f in ("c6_oracle.c", "c6_oracle_net.c", "c6_oracle.h", "Makefile")]
+    srcs = [os.path.join(ODIR, f) for f in ("c6_oracle.c", "c6_oracle_net.c", "c6_default.c", "c6_oracle.h", "Makefile")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
         subprocess.check_call(["make", "-C", ODIR], stdout=subprocess.DEVNULL)
     return SO
@@ -146,6 +146,19 @@ def lib():
     L.c6o_net_forward.argtypes = [C.c_void_p, C.c_float, f32p, C.c_int, f32p, f32p]
     L.c6o_net_eval.restype = C.c_int
     L.c6o_net_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i8p, f32p, f32p]
+    L.c6o_default_new.restype = C.c_void_p
+    L.c6o_default_new.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32]
+    L.c6o_default_free.argtypes = [C.c_void_p]
+    for nm in ("init", "select", "expand", "policy"):
+        getattr(L, f"c6o_default_{nm}").argtypes = [C.c_void_p, C.POINTER(Sim)]
+    L.c6o_default_update.argtypes = [C.c_void_p, C.POINTER(Sim), C.POINTER(C.c_int16), C.c_int]
+    L.c6o_default_search.argtypes = [C.c_void_p, C.POINTER(Game)]
+    L.c6o_default_next.argtypes = [C.c_void_p, C.POINTER(Game)]
+    L.c6o_default_map_len.restype = C.c_size_t
+    L.c6o_default_map_len.argtypes = [C.c_void_p]
+    L.c6o_default_search_count.restype = C.c_uint32
+    L.c6o_default_search_count.argtypes = [C.c_void_p]
+    L.c6o_default_node.argtypes = [C.c_void_p, i8p, i32p, i32p, i32p, C.c_int, i32p, i32p, i32p]
     _lib = L
     return L
 
@@ -286,6 +299,63 @@ class AlphaZero:
         p = np.zeros(cells, np.float32)
         lib().c6o_az_children(self.h, i8(b), vis.ctypes.data_as(C.POINTER(C.c_int)), f32(q), f32(p))
         return vis, q, p
+
+
+class DefaultPolicy:
+    """policy/default_policy/mod.rs:84-275 (pure MCTS with random playouts) on the C6RNG stream."""
+
+    def __init__(self, n, num_iter=50, seed=0, uid=0):
+        self.n, self.L = n, lib()
+        self.h = self.L.c6o_default_new(n, num_iter, seed, uid)
+
+    def close(self):
+        if self.h:
+            self.L.c6o_default_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def next(self, g):
+        """cell (row * n + col) or -1"""
+        return self.L.c6o_default_next(self.h, C.byref(g))
+
+    def init(self, s):
+        self.L.c6o_default_init(self.h, C.byref(s))
+
+    def select(self, s):
+        return self.L.c6o_default_select(self.h, C.byref(s))
+
+    def expand(self, s):
+        return self.L.c6o_default_expand(self.h, C.byref(s))
+
+    def update(self, s, path):
+        arr = (C.c_int16 * max(len(path), 1))(*path)
+        self.L.c6o_default_update(self.h, C.byref(s), arr, len(path))
+
+    def search(self, g):
+        self.L.c6o_default_search(self.h, C.byref(g))
+
+    def policy(self, s):
+        return self.L.c6o_default_policy(self.h, C.byref(s))
+
+    def map_len(self):
+        return self.L.c6o_default_map_len(self.h)
+
+    def search_count(self):
+        return self.L.c6o_default_search_count(self.h)
+
+    def node(self, board, cap=1024):
+        """None, or (visit, black_win, [(cell, visit, black_win) of the children in push order])"""
+        b = np.ascontiguousarray(board, dtype=np.int8).reshape(-1)
+        v, w, k = C.c_int(), C.c_int(), C.c_int()
+        cc, cv, cw = (np.zeros(cap, np.int32) for _ in range(3))
+        i32p = C.POINTER(C.c_int)
+        if not self.L.c6o_default_node(self.h, i8(b), C.byref(v), C.byref(w), C.byref(k), cap, cc.ctypes.data_as(i32p),
+                                       cv.ctypes.data_as(i32p), cw.ctypes.data_as(i32p)):
+            return None
+        m = min(k.value, cap)
+        return v.value, w.value, [(int(cc[i]), int(cv[i]), int(cw[i])) for i in range(m)]
 
 
 def _result_to_py(r, n, want_pi=False):
