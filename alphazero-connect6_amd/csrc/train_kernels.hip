@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 
 #include "c6_train.h"
 
@@ -962,6 +964,222 @@ __global__ __launch_bounds__(256, 2) void c6_wgrad_b3_kernel(int C, int B, int b
                 }
 }
 
+// Wave-specialised weight gradient (the trainer's default): the arithmetic of c6_wgrad_b3_kernel (same split, same three
+// products per accumulator in the same order), restructured around what the kernel above waits for.
+//  * Roles.  Above, a workgroup stages a band (global -> split -> LDS) and then multiplies it, two workgroups per CU taking
+//    turns; a staging phase is an HBM round trip plus ~50 VALU/LDS instructions per thread and the matrix pipes idled 63 %.
+//    Here a workgroup is 8 waves: waves 0-3 own the 64 x 64 x 9-tap accumulators and only read fragments and issue MFMAs;
+//    waves 4-7 (no accumulators: two whole bands fit in their registers) load band i + 2, split and store band i + 1 into the
+//    other half of a double-buffered image while band i is multiplied.  One barrier per band, reached by both roles.
+//  * Fragment addressing.  A lone compute wave per SIMD has nobody to hide its address arithmetic behind, and the XOR-swizzled
+//    image above costs 2-3 VALU instructions per transposed read.  This image is LINEAR with a 288-byte row (256 + 32 pad):
+//    tile, plane, tap and read-half are immediate offsets of ONE base register per operand.  Conflict-free because the K
+//    slots of an MFMA are permuted (the same way for dy and x, so every product still meets its partner): lane group g reads
+//    rows 4g + q and 16 + 4g + q of a 32-row K step instead of 8g + q and 8g + 4 + q, so the 32 lanes LDS serves together
+//    touch 8 consecutive rows = 8 distinct 32-byte bank groups, at any tap shift.  (The K permutation reorders the f32 sums
+//    inside an MFMA: last-bit differences from the kernel above, still bit-reproducible run to run.)
+//  * Issue order.  Every MFMA is followed by at most one ds_read_tr of the fragments two taps ahead (three B slots), which
+//    issues in that MFMA's shadow; consecutive MFMAs never share an accumulator; the K loop is unrolled by two so that every
+//    register index is static.
+//  * XCD-aware 1-D grid: all blocks of one K split (they read the same bands, each band C/64 times) get workgroup ids of one
+//    residue mod 8 = one XCD = one L2.
+template <int N>
+struct WGradWSGeom {
+    static constexpr int P = N + 2;
+    static constexpr int RS = 288;                                     // image row stride in bytes
+    static constexpr int RB = N <= 9 ? 5 : (N <= 15 ? 5 : 4);          // output rows per band (two images of a band must fit 160 KB)
+    static constexpr int BANDS = (N + RB - 1) / RB;
+    static constexpr int KSTEPS = (RB * P + 31) / 32;
+    static constexpr int DY_ROWS = KSTEPS * 32;
+    static constexpr int X_ROWS = ((DY_ROWS + 2 * P + 3) + 3) & ~3;     // x image row j = grid cell j - 1 of the haloed band
+    static constexpr size_t IMG_BYTES = (size_t)(DY_ROWS + X_ROWS) * RS;
+    static constexpr size_t LDS_BYTES = 2 * IMG_BYTES;
+};
+
+template <int N>
+__global__ __launch_bounds__(512, 1) void c6_wgrad_b3w_kernel(int C, int B, int boards_per_split, const float *__restrict__ dy,
+                                                              const float *__restrict__ x, float *__restrict__ partial) {
+    using G = WGradWSGeom<N>;
+    constexpr int P = G::P, RB = G::RB, RS = G::RS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wb[];
+
+    const int nblk = C / 64, nb2 = nblk * nblk, nsplit = gridDim.x / nb2;
+    int blk, split;
+    if (nsplit % 8 == 0) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = xcd + 8 * (j / nb2); blk = j % nb2; }
+    else { blk = blockIdx.x % nb2; split = blockIdx.x / nb2; }
+    const int co0 = (blk / nblk) * 64, ci0 = (blk % nblk) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool loader = wave >= 4;
+    const int ltid = tid & 255;
+
+    for (int e = tid; e < (int)(G::LDS_BYTES / 16); e += 512) reinterpret_cast<f32x4 *>(wb)[e] = f32x4{0.f, 0.f, 0.f, 0.f};   // halo cells: once
+
+    const int b_lo = split * boards_per_split, b_hi = (b_lo + boards_per_split < B) ? b_lo + boards_per_split : B;
+    const int nitems = b_hi > b_lo ? (b_hi - b_lo) * G::BANDS : 0;
+    __syncthreads();
+
+    if (loader) {
+        auto put = [&](unsigned char *img, int row, int qq, f32x4 v) {      // 4 channels (qq-th quad of the block's 64) of one cell
+            bf16x4_t hi, mid;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { hi[r] = (__bf16)v[r]; mid[r] = (__bf16)(v[r] - (float)hi[r]); }
+            *reinterpret_cast<bf16x4_t *>(img + row * RS + qq * 8) = hi;
+            *reinterpret_cast<bf16x4_t *>(img + row * RS + 128 + qq * 8) = mid;
+        };
+        constexpr int DYI = (RB * N * 16 + 255) / 256, XI = ((RB + 2) * N * 16 + 255) / 256;
+        struct Band { f32x4 vd[DYI], vx[XI]; };
+        // the loads of band `it` (all in flight at once) ...
+        auto issue = [&](int it, Band &r) {
+            const int b = b_lo + it / G::BANDS, band = it % G::BANDS;
+            const int y0 = band * RB, rows = (y0 + RB <= N) ? RB : N - y0;
+            const int cnt_d = rows * N * 16, cnt_x = (rows + 2) * N * 16;
+#pragma unroll
+            for (int u = 0; u < DYI; u++) {
+                int e = u * 256 + ltid;
+                e = e < cnt_d ? e : cnt_d - 1;
+                r.vd[u] = *reinterpret_cast<const f32x4 *>(dy + ((size_t)b * N * N + (size_t)y0 * N + e / 16) * C + co0 + (e % 16) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < XI; u++) {
+                int e = u * 256 + ltid;
+                e = e < cnt_x ? e : cnt_x - 1;
+                const int pix = e / 16, yy = pix / N, xx = pix % N, gy = y0 - 1 + yy;
+                const int cy = gy < 0 ? 0 : (gy >= N ? N - 1 : gy);
+                r.vx[u] = *reinterpret_cast<const f32x4 *>(x + ((size_t)b * N * N + (size_t)cy * N + xx) * C + ci0 + (e % 16) * 4);
+            }
+        };
+        // ... and their split + store into the half of the image that band uses: dy cell (yy, xx) -> image row yy*P + xx + 1,
+        // x rows y0-1 .. y0+rows: cell (yy, xx) -> image row yy*P + xx + 2 (grid cell + 1)
+        auto commit = [&](int it, const Band &r) {
+            unsigned char *dyL = wb + (size_t)(it & 1) * G::IMG_BYTES, *xL = dyL + (size_t)G::DY_ROWS * RS;
+            const int band = it % G::BANDS;
+            const int y0 = band * RB, rows = (y0 + RB <= N) ? RB : N - y0;
+            const int cnt_d = rows * N * 16, cnt_x = (rows + 2) * N * 16;
+            if (G::BANDS > 1 && rows < RB) {      // rows a shorter last band leaves over from a full band (disjoint from what is written below)
+                for (int e = ltid; e < (RB - rows) * P * (RS / 16); e += 256) {
+                    reinterpret_cast<f32x4 *>(dyL + (size_t)rows * P * RS)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    reinterpret_cast<f32x4 *>(xL + (size_t)((rows + 2) * P + 1) * RS)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < DYI; u++) {
+                const int e = u * 256 + ltid;
+                if (e < cnt_d) { const int pix = e / 16; put(dyL, (pix / N) * P + pix % N + 1, e % 16, r.vd[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < XI; u++) {
+                const int e = u * 256 + ltid;
+                if (e < cnt_x) {
+                    const int pix = e / 16, gy = y0 - 1 + pix / N;
+                    put(xL, (pix / N) * P + pix % N + 2, e % 16, (gy < 0 || gy >= N) ? f32x4{0.f, 0.f, 0.f, 0.f} : r.vx[u]);   // rows off the board: zero
+                }
+            }
+        };
+        Band ra, rb;
+        if (nitems > 0) { issue(0, ra); if (nitems > 1) issue(1, rb); commit(0, ra); }
+        __syncthreads();
+#pragma unroll 1
+        for (int it = 0; it < nitems; it += 2) {
+            if (it + 2 < nitems) issue(it + 2, ra);
+            if (it + 1 < nitems) commit(it + 1, rb);
+            __syncthreads();
+            if (it + 1 < nitems) {
+                if (it + 3 < nitems) issue(it + 3, rb);
+                if (it + 2 < nitems) commit(it + 2, ra);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const int g = lane >> 4, i = lane & 15, q = (lane >> 2) & 3, p = lane & 3;
+    f32x4 acc[2][2][9];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int tp = 0; tp < 9; tp++) acc[t][u][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane 4q + p of group g supplies 8 bytes (4 channels) of row 4g + q (second half of the fragment: + 16 rows)
+    const int laneA = (4 * g + q) * RS + 2 * wco + 8 * p, laneB = (4 * g + q) * RS + 2 * wci + 8 * p;
+    s16x4_t fa[2][2][2][2];   // [set = K step parity][t][plane hi/mid][half]
+    s16x4_t fb[3][2][2][2];   // [slot = tap % 3][u][plane][half]
+    auto cat = [](s16x4_t lo, s16x4_t hi) -> bf16x8_t {
+        union { s16x4_t s[2]; bf16x8_t v; } uu;
+        uu.s[0] = lo; uu.s[1] = hi;
+        return uu.v;
+    };
+    auto rd = [&](const unsigned char *img, int base, int off) -> s16x4_t {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(img + base + off));
+    };
+    __syncthreads();   // item 0 staged
+#pragma unroll 1
+    for (int it = 0; it < nitems; it++) {
+        const unsigned char *dyL = wb + (size_t)(it & 1) * G::IMG_BYTES, *xL = dyL + (size_t)G::DY_ROWS * RS;
+        const int band = it % G::BANDS, y0 = band * RB, rows = (y0 + RB <= N) ? RB : N - y0;
+        const int ksteps = (rows * P + 31) / 32;
+        // read number r = 0..7 of a fragment set: (t or u) = r >> 2, plane = (r >> 1) & 1, half = r & 1
+        auto rdA = [&](auto SET, int r, int base) {
+            constexpr int set = decltype(SET)::value;
+            fa[set][r >> 2][(r >> 1) & 1][r & 1] = rd(dyL, base, (r & 1) * 16 * RS + 32 * (r >> 2) + 128 * ((r >> 1) & 1));
+        };
+        auto rdB = [&](auto SLOT, int tp, int r, int base) {
+            constexpr int slot = decltype(SLOT)::value;
+            fb[slot][r >> 2][(r >> 1) & 1][r & 1] = rd(xL, base, ((tp / 3) * P + tp % 3 + (r & 1) * 16) * RS + 32 * (r >> 2) + 128 * ((r >> 1) & 1));
+        };
+        auto kstep = [&](auto PAR, int ks) {
+            constexpr int par = decltype(PAR)::value;
+            const int bA = laneA + ks * 32 * RS, bB = laneB + ks * 32 * RS;
+            const bool nxt = ks + 1 < ksteps;
+#pragma unroll
+            for (int tp = 0; tp < 9; tp++) {
+                const int sl = tp % 3;                                      // 9 taps: the slot of a tap does not depend on the K step
+                const int ntp = (tp + 2) % 9, nb = bB + (tp >= 7 ? 32 * RS : 0);   // the tap two ahead (of the next K step from tap 7 on)
+                const bool pre = tp < 7 || nxt;
+#pragma unroll
+                for (int m = 0; m < 12; m++) {
+                    // product-major over the four accumulators of the tap; each accumulator still sees k = 0, 1, 2 in order
+                    const int k = m / 4, u = (m >> 1) & 1, t = m & 1;
+                    const bf16x8_t a = cat(fa[par][t][k == 0][0], fa[par][t][k == 0][1]);       // k 0: mid plane of dy, k 1, 2: hi
+                    const bf16x8_t bq = cat(fb[sl][u][k == 1][0], fb[sl][u][k == 1][1]);        // k 1: mid plane of x
+                    acc[t][u][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc[t][u][tp], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m < 8) {
+                        if (pre) {
+                            if (ntp % 3 == 0) rdB(std::integral_constant<int, 0>{}, ntp, m, nb);
+                            else if (ntp % 3 == 1) rdB(std::integral_constant<int, 1>{}, ntp, m, nb);
+                            else rdB(std::integral_constant<int, 2>{}, ntp, m, nb);
+                        }
+                    } else if (nxt && (tp == 5 || tp == 6)) rdA(std::integral_constant<int, par ^ 1>{}, (tp - 5) * 4 + (m - 8), bA + 32 * RS);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < 8; r++) { rdA(std::integral_constant<int, 0>{}, r, laneA); rdB(std::integral_constant<int, 0>{}, 0, r, laneB); rdB(std::integral_constant<int, 1>{}, 1, r, laneB); }
+#pragma unroll 1
+        for (int ks = 0; ks < ksteps; ks += 2) {
+            kstep(std::integral_constant<int, 0>{}, ks);
+            if (ks + 1 < ksteps) kstep(std::integral_constant<int, 1>{}, ks + 1);
+        }
+        __syncthreads();   // band it multiplied, band it + 1 staged
+    }
+    // D tile (t, u): lane (column i = ci, g) holds rows co = 4g + r
+    float *pp = partial + (size_t)split * 9 * C * C;
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int co = co0 + wco + 16 * t + 4 * g + r, ci = ci0 + wci + 16 * u + i;
+                    pp[((size_t)tp * C + co) * C + ci] = acc[t][u][tp][r];
+                }
+}
+
 int c6t_wgrad_splits(int C, int B) {
     const int blocks = (C / 64) * (C / 64);
     int splits = (512 + blocks - 1) / blocks;      // about two workgroups per CU
@@ -974,7 +1192,12 @@ size_t c6t_wgrad_partial_floats(int C, int B) { return (size_t)c6t_wgrad_splits(
 template <int N>
 static void launch_wgrad(int C, int B, const float *dy, const float *x, float *partial, float *dw, int split_bf16, hipStream_t s) {
     const int splits = c6t_wgrad_splits(C, B), per = (B + splits - 1) / splits;
-    if (split_bf16) {
+    static const int ws = [] { const char *e = getenv("C6_WGRAD_WS"); return e ? atoi(e) : 1; }();   // 0: the two-workgroup kernel (A/B)
+    if (split_bf16 && ws) {
+        using G = WGradWSGeom<N>;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wgrad_b3w_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        hipLaunchKernelGGL(c6_wgrad_b3w_kernel<N>, dim3((C / 64) * (C / 64) * splits), dim3(512), G::LDS_BYTES, s, C, B, per, dy, x, partial);
+    } else if (split_bf16) {
         using G = WGradB3Geom<N>;
         hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wgrad_b3_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         hipLaunchKernelGGL(c6_wgrad_b3_kernel<N>, dim3((C / 64) * (C / 64), splits), dim3(256), G::LDS_BYTES, s, C, B, per, dy, x, partial);
