@@ -278,22 +278,23 @@ __global__ __launch_bounds__(256) void c6t_colstats4_kernel(int mode, size_t R, 
         *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 1) * C + c) = s1;
     }
 }
-// mode 0: out0 = mean, out1 = biased variance; otherwise out0 = s0, out1 = s1.  32 columns x 8 chunk lanes per
-// workgroup: lane ky sums chunks ky, ky + 8, ... in order, the eight lane sums are then added in lane order (fixed order,
-// double accumulators).
-__global__ __launch_bounds__(256) void c6t_colstats_finalize_kernel(int mode, size_t R, int C, int nchunk, const float *__restrict__ partial,
-                                                                    float *__restrict__ out0, float *__restrict__ out1) {
-    __shared__ double l0[8][32], l1[8][32];
+// mode 0: out0 = mean, out1 = biased variance; otherwise out0 = s0, out1 = s1.  32 columns x 32 chunk lanes per
+// workgroup: lane ky sums chunks ky, ky + 32, ... in order, the 32 lane sums are then added in lane order (fixed order,
+// double accumulators).  (8 chunk lanes took 70 us per call, 65 calls per step: the chain of ~225 dependent adds per lane.)
+#define CSF_LANES 32
+__global__ __launch_bounds__(32 * CSF_LANES) void c6t_colstats_finalize_kernel(int mode, size_t R, int C, int nchunk, const float *__restrict__ partial,
+                                                                              float *__restrict__ out0, float *__restrict__ out1) {
+    __shared__ double l0[CSF_LANES][32], l1[CSF_LANES][32];
     const int cx = threadIdx.x & 31, ky = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     double s0 = 0.0, s1 = 0.0;
     if (c < C)
-        for (int k = ky; k < nchunk; k += 8) { s0 += (double)partial[((size_t)k * 2 + 0) * C + c]; s1 += (double)partial[((size_t)k * 2 + 1) * C + c]; }
+        for (int k = ky; k < nchunk; k += CSF_LANES) { s0 += (double)partial[((size_t)k * 2 + 0) * C + c]; s1 += (double)partial[((size_t)k * 2 + 1) * C + c]; }
     l0[ky][cx] = s0; l1[ky][cx] = s1;
     __syncthreads();
     if (ky != 0 || c >= C) return;
     s0 = 0.0; s1 = 0.0;
-    for (int q = 0; q < 8; q++) { s0 += l0[q][cx]; s1 += l1[q][cx]; }
+    for (int q = 0; q < CSF_LANES; q++) { s0 += l0[q][cx]; s1 += l1[q][cx]; }
     if (mode == 0) {
         const double m = s0 / (double)R;
         double v = s1 / (double)R - m * m;
@@ -311,7 +312,7 @@ void c6t_colstats(int mode, size_t R, int C, const float *x, const float *aout, 
     const int nchunk = (int)((R + CS_ROWS - 1) / CS_ROWS);
     if (C == 64 || C == 128 || C == 256) hipLaunchKernelGGL(c6t_colstats4_kernel, dim3(nchunk), dim3(256), 0, s, mode, R, C, x, aout, y, mean, var, partial);
     else hipLaunchKernelGGL(c6t_colstats_kernel, dim3(nchunk), dim3(256), 0, s, mode, R, C, x, aout, y, mean, var, partial);
-    hipLaunchKernelGGL(c6t_colstats_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, mode, R, C, nchunk, partial, out0, out1);
+    hipLaunchKernelGGL(c6t_colstats_finalize_kernel, dim3((C + 31) / 32), dim3(32 * CSF_LANES), 0, s, mode, R, C, nchunk, partial, out0, out1);
 }
 
 // a = relu?( (y - mean) * invstd * gamma + beta (+ res) )      (train-mode BatchNorm with the batch statistics)
