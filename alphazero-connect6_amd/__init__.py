@@ -35,7 +35,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
                   "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
-                  "c6_bench_conv", "c6_bench_board", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
+                  "c6_bench_conv", "c6_bench_board", "c6_bench_board_scan", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
@@ -161,6 +161,7 @@ def lib():
     L.c6_net_forward_prec.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_size_t, C.c_int, i8p, i8p, f32p, f32p]
     L.c6_bench_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)]
     L.c6_bench_board.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.c6_bench_board_scan.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.c6_replay_create.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
     L.c6_replay_destroy.argtypes = [C.c_void_p]
     L.c6_replay_push_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -769,10 +770,11 @@ def bench_conv(n, channels, nboards, iters=3, variant=1, ablate=0, with_residual
     return ms.value
 
 
-def bench_board(n, num_games, iters=20):
-    """average ms of one K1 board-step launch over `num_games` resident games"""
+def bench_board(n, num_games, iters=20, scan_only=False):
+    """average ms of one K1 launch over `num_games` resident games: a board-step (one stone per game) or, scan_only,
+    the search-only launch (is_game_end of every game)"""
     ms = C.c_double()
-    _chk(lib().c6_bench_board(n, num_games, iters, C.byref(ms)))
+    _chk((lib().c6_bench_board_scan if scan_only else lib().c6_bench_board)(n, num_games, iters, C.byref(ms)))
     return ms.value
 
 

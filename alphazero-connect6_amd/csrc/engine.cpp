@@ -1026,7 +1026,7 @@ __global__ void c6_bench_pos_kernel(int cells, int G, int step, int32_t *pos) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < G) pos[g] = (int)(((unsigned)g * 2654435761u + (unsigned)step * 40503u) % (unsigned)cells);
 }
-extern "C" int c6_bench_board(int n, int G, int iters, double *avg_ms) {
+static int bench_board(int n, int G, int iters, bool scan_only, double *avg_ms) {
     int rc = check_n(n); if (rc) return rc;
     rc = require_gpu(0); if (rc) return rc;
     const int cells = n * n, Gpad = (G + 3) & ~3;
@@ -1043,7 +1043,8 @@ extern "C" int c6_bench_board(int n, int G, int iters, double *avg_ms) {
     for (int i = -1; i < iters; i++) {   // occupied cells are rejected by the kernel ("already set position"): still a full board read
         hipLaunchKernelGGL(c6_bench_pos_kernel, dim3((Gpad + 255) / 256), dim3(256), 0, nullptr, cells, Gpad, i + 1, dp);
         hipEventRecord(e0, nullptr);
-        c6_launch_board_step(n, Gpad, db, dt, dr, dp, dw, de, nullptr);
+        if (scan_only) c6_launch_search_winner(n, Gpad, db, dw, nullptr);      // is_game_end alone: N*N bytes read + 1 written
+        else c6_launch_board_step(n, Gpad, db, dt, dr, dp, dw, de, nullptr);
         hipEventRecord(e1, nullptr);
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0;
@@ -1054,3 +1055,5 @@ extern "C" int c6_bench_board(int n, int G, int iters, double *avg_ms) {
     hipEventDestroy(e0); hipEventDestroy(e1);
     return C6_OK;
 }
+extern "C" int c6_bench_board(int n, int G, int iters, double *avg_ms) { return bench_board(n, G, iters, false, avg_ms); }
+extern "C" int c6_bench_board_scan(int n, int G, int iters, double *avg_ms) { return bench_board(n, G, iters, true, avg_ms); }

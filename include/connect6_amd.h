@@ -279,6 +279,8 @@ int c6_net_forward_prec(int board_size, int channels, int blocks, int precision,
 int c6_bench_conv(int board_size, int channels, int nboards, int iters, int variant, int ablate, int with_residual, double *avg_ms);
 /* K1 alone: `num_games` resident games, one stone per game per launch (average ms over `iters` launches) */
 int c6_bench_board(int board_size, int num_games, int iters, double *avg_ms);
+/* K1's search-only launch (is_game_end of every resident game, no stone: N*N bytes read + 1 written per board) */
+int c6_bench_board_scan(int board_size, int num_games, int iters, double *avg_ms);
 /* C6RNG Dirichlet noise of select step (search, depth) for `num` boards (keys k0/k1 per board) */
 int c6_dirichlet_noise(int board_size, int num, double alpha, const uint32_t *k0, const uint32_t *k1,
                        const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise);
