@@ -330,8 +330,7 @@ __global__ __launch_bounds__(256) void c6_legal_mask_kernel(int Gpad, const int8
             const int c = by * 8 + bit;
             if (c < N * N) {
                 const uint32_t v = *reinterpret_cast<const uint32_t *>(boards + (size_t)c * Gpad + g0);
-#pragma unroll
-                for (int k = 0; k < 4; k++) out |= (uint32_t)(((v >> (8 * k)) & 0xffu) == 0u) << (8 * k + bit);
+                out |= (~v & 0x01010101u) << bit;      // SWAR over the four games: bit 0 of a byte is set iff the cell is occupied
             }
         }
         *reinterpret_cast<uint32_t *>(mask + (size_t)by * Gpad + g0) = out;
@@ -343,7 +342,10 @@ static void launch_board(int N, int Gpad, int8_t *boards, int8_t *turn, int8_t *
                          int8_t *err, hipStream_t s) {
     const int quads = Gpad / 4, block = 256, grid = (quads + block - 1) / block;
     if (grid == 0) return;
-    static const bool v1 = [] { const char *e = getenv("C6_BOARD_VARIANT"); return e && e[0] == '1'; }();   // A/B only
+    static const bool v1env = [] { const char *e = getenv("C6_BOARD_VARIANT"); return e && e[0] == '1'; }();   // A/B only
+    // the row descriptors of c6_board_kernel hold N * Gpad bytes in 32 bits (Gpad < 226 M games at N = 19: an 81 GB board
+    // array); anything larger runs on the global-load kernel
+    const bool v1 = v1env || (size_t)N * (size_t)Gpad > 0xffffffffull;
 #define C6_BOARD_CASE(NN)                                                                                                        \
     case NN:                                                                                                                      \
         if (v1) hipLaunchKernelGGL((c6_board_kernel_v1<NN, STEP>), dim3(grid), dim3(block), 0, s, Gpad, boards, turn, remain, pos, winner, err); \
