@@ -313,17 +313,32 @@ __device__ __forceinline__ int wave_winner(const int8_t *board, int N, int lane)
     return first < cells ? (int)board[first] : 0;
 }
 
+// The kernel is a chain of memory round trips (53 VGPRs, 8 waves per SIMD, 88 % of the wave-cycles waiting), so its shape is
+// dictated by how many of them are serial: everything that depends only on g is loaded up front (one trip), the record scan
+// fetches four 64-record chunks per trip, the free-list pop / record initialisation / table insert overlap the scan's loads,
+// and the backup updates the path's records lane-parallel (they are distinct: levels strictly increase along a path).
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= E.G) return;
-    const int kind = E.leaf_kind[g];
-    if (kind == C6_LEAF_NONE) return;
     const int cells = E.cells;
     const size_t rbase = (size_t)g * E.R;
+    // ---- trip 1: everything addressed by g alone
+    const int kind = E.leaf_kind[g];
     const int len = E.path_len[g];
     const int level = E.leaf_level[g];
     const int turn = E.leaf_turn[g];
+    const int top = E.free_top[g];
+    const int hi0 = E.rec_hi[g];
+    const float evalue = E.eval_value[g];
+    const unsigned long long key = E.leaf_key[g];
+    const uint4 qv = *reinterpret_cast<const uint4 *>(E.leaf_sig + (size_t)g * 4);
+    const uint32_t nsearch = E.nsearch[g];
+    const int sim_in_move = E.sim_in_move[g];
+    const unsigned long long gsims = E.g_sims[g];
+    const uint32_t maxrec = E.g_maxrec[g];
+    const int my_path = E.path_rec[(size_t)g * C6_MAXD + (lane < C6_MAXD ? lane : 0)];
+    if (kind == C6_LEAF_NONE) return;
     float value;
 
     if (kind == C6_LEAF_TERMINAL) {   // mod.rs:338-348: value by winner, no visit increment, no children
@@ -331,83 +346,93 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
         const float cost = (float)turn;
         value = w == turn ? cost : (w != 0 ? -cost : 0.f);
     } else {
-        // allocate the record of the newly expanded node
-        int idx = -1;
-        if (lane == 0) {
-            const int top = E.free_top[g];
-            if (top > 0) { idx = E.free_stack[rbase + top - 1]; E.free_top[g] = top - 1; }
-        }
-        idx = __shfl(idx, 0, 64);
-        int hi = E.rec_hi[g];
-        if (idx + 1 > hi) { hi = idx + 1; if (lane == 0) E.rec_hi[g] = hi; }
-        if (idx < 0) {
+        // allocate the record of the newly expanded node (every lane reads the same stack slot)
+        if (top <= 0) {
             if (lane == 0) E.status[g] = C6_ST_ERROR;
             return;
         }
-        value = E.eval_value[g];
+        const int idx = E.free_stack[rbase + top - 1];
+        const int hi = idx + 1 > hi0 ? idx + 1 : hi0;
+        value = evalue;
         const float *prob = E.eval_prior + (size_t)g * cells;
         float *prior = E.rec_prior + (rbase + idx) * (size_t)cells;
         for (int c = lane; c < cells; c += 64) prior[c] = prob[c];      // child.n_prob = prob[r][c], mod.rs:370
-        const unsigned long long key = E.leaf_key[g];
-        const uint32_t q0 = E.leaf_sig[g * 4 + 0], q1 = E.leaf_sig[g * 4 + 1], q2 = E.leaf_sig[g * 4 + 2], q3 = E.leaf_sig[g * 4 + 3];
-        if (lane == 0) {
-            E.rec_key[rbase + idx] = key;
-            E.rec_visit[rbase + idx] = 1;          // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
-            E.rec_value[rbase + idx] = value;
-            E.rec_qsum[rbase + idx] = 0.f;
-            E.rec_q[rbase + idx] = 0.f;
-            E.rec_sig[(rbase + idx) * 4 + 0] = q0; E.rec_sig[(rbase + idx) * 4 + 1] = q1;
-            E.rec_sig[(rbase + idx) * 4 + 2] = q2; E.rec_sig[(rbase + idx) * 4 + 3] = q3;
-            if (!ht_insert(E.ht + (size_t)g * E.H, E.H, key, idx)) E.status[g] = C6_ST_ERROR;
-            if (len == 0) E.root_rec[g] = idx;
-            const uint32_t used = (uint32_t)(E.R - E.free_top[g]);
-            if (used > E.g_maxrec[g]) E.g_maxrec[g] = used;
-        }
+        const uint32_t q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
         // last-writer rule for transposed children (entry().or_insert + n_prob overwrite, mod.rs:366-370):
         // every expanded P on this level with P + i == Q + s sees its child i's prior become prob_Q[s]
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const uint32_t ms = turn == C6_BLACK ? q0 : q2, mq = turn == C6_BLACK ? q1 : q3;   // mover colour sums of Q
         const uint32_t os = turn == C6_BLACK ? q2 : q0, oq = turn == C6_BLACK ? q3 : q1;
-        for (int r = lane; r < hi; r += 64) {      // records at or above hi were never used: level -1
-            // level, signature and key are fetched together (three independent loads in flight: one memory round trip per
-            // 64 records instead of up to three dependent ones -- this scan is most of the kernel's latency chain)
-            const int lv = E.rec_level[rbase + r];
-            const uint4 sgv = *reinterpret_cast<const uint4 *>(E.rec_sig + (rbase + r) * 4);
-            const unsigned long long rk = E.rec_key[rbase + r];
-            if (r == idx || lv != level) continue;
-            const uint32_t sg[4] = {sgv.x, sgv.y, sgv.z, sgv.w};
-            const uint32_t pms = turn == C6_BLACK ? sg[0] : sg[2], pmq = turn == C6_BLACK ? sg[1] : sg[3];
-            const uint32_t pos_ = turn == C6_BLACK ? sg[2] : sg[0], poq = turn == C6_BLACK ? sg[3] : sg[1];
-            if (pos_ != os || poq != oq) continue;
-            const long long D1 = (long long)pms - (long long)ms, D2 = (long long)pmq - (long long)mq;   // s1 - i1, s1^2 - i1^2
-            if (D1 == 0 || D2 % D1 != 0) continue;
-            const long long T = D2 / D1;          // s1 + i1
-            if (((T + D1) & 1) != 0) continue;
-            const long long s1 = (T + D1) / 2, i1 = (T - D1) / 2;
-            if (s1 < 1 || i1 < 1 || s1 > cells || i1 > cells) continue;
-            const int s = (int)s1 - 1, i = (int)i1 - 1;
-            if (rk != (key ^ zk[i] ^ zk[s])) continue;
-            E.rec_prior[(rbase + r) * (size_t)cells + i] = prob[s];
+        constexpr int CH = 4;
+        bool first_batch = true;
+        for (int r0 = 0; r0 < hi; r0 += 64 * CH) {      // records at or above hi were never used: level -1
+            // level, signature and key of 4 x 64 records in flight together (indices clamped: loads stay unconditional)
+            int lv[CH];
+            uint4 sgv[CH];
+            unsigned long long rk[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int r = r0 + 64 * u + lane, rc = r < hi ? r : idx;
+                lv[u] = E.rec_level[rbase + rc];
+                sgv[u] = *reinterpret_cast<const uint4 *>(E.rec_sig + (rbase + rc) * 4);
+                rk[u] = E.rec_key[rbase + rc];
+            }
+            if (first_batch) {      // behind the first batch's loads: the new record and its table entry
+                first_batch = false;
+                if (lane == 0) {
+                    E.free_top[g] = top - 1;
+                    if (hi != hi0) E.rec_hi[g] = hi;
+                    E.rec_key[rbase + idx] = key;
+                    E.rec_visit[rbase + idx] = 1;          // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
+                    E.rec_value[rbase + idx] = value;
+                    E.rec_qsum[rbase + idx] = 0.f;
+                    E.rec_q[rbase + idx] = 0.f;
+                    *reinterpret_cast<uint4 *>(E.rec_sig + (rbase + idx) * 4) = qv;
+                    if (!ht_insert(E.ht + (size_t)g * E.H, E.H, key, idx)) E.status[g] = C6_ST_ERROR;
+                    if (len == 0) E.root_rec[g] = idx;
+                    const uint32_t used = (uint32_t)(E.R - (top - 1));
+                    if (used > maxrec) E.g_maxrec[g] = used;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int r = r0 + 64 * u + lane;
+                if (r >= hi || r == idx || lv[u] != level) continue;
+                const uint32_t sg[4] = {sgv[u].x, sgv[u].y, sgv[u].z, sgv[u].w};
+                const uint32_t pms = turn == C6_BLACK ? sg[0] : sg[2], pmq = turn == C6_BLACK ? sg[1] : sg[3];
+                const uint32_t pos_ = turn == C6_BLACK ? sg[2] : sg[0], poq = turn == C6_BLACK ? sg[3] : sg[1];
+                if (pos_ != os || poq != oq) continue;
+                const long long D1 = (long long)pms - (long long)ms, D2 = (long long)pmq - (long long)mq;   // s1 - i1, s1^2 - i1^2
+                if (D1 == 0 || D2 % D1 != 0) continue;
+                const long long T = D2 / D1;          // s1 + i1
+                if (((T + D1) & 1) != 0) continue;
+                const long long s1 = (T + D1) / 2, i1 = (T - D1) / 2;
+                if (s1 < 1 || i1 < 1 || s1 > cells || i1 > cells) continue;
+                const int s_ = (int)s1 - 1, i = (int)i1 - 1;
+                if (rk[u] != (key ^ zk[i] ^ zk[s_])) continue;
+                E.rec_prior[(rbase + r) * (size_t)cells + i] = prob[s_];
+            }
         }
+        if (lane == 0) E.rec_level[rbase + idx] = (int16_t)level;   // after the scan: Q never matches itself
         if (lane == 0) E.rec_level[rbase + idx] = (int16_t)level;   // after the scan: Q never matches itself
     }
 
-    // update, mod.rs:386-408 (one-level backup)
-    if (lane == 0) {
-        if (len > 0) {
-            const uint16_t *path = E.path_rec + (size_t)g * C6_MAXD;
-            const int par = path[len - 1];
-            E.rec_qsum[rbase + par] += value;
-            for (int i = len - 1; i >= 0; i--) {
-                const int r = path[i];
-                const int v = E.rec_visit[rbase + r] + 1;
-                E.rec_visit[rbase + r] = v;
-                E.rec_q[rbase + r] = E.rec_qsum[rbase + r] / (float)v;   // recalc_q :77-79
-            }
+    // update, mod.rs:386-408 (one-level backup): lane i owns the path's i-th record
+    if (lane < len) {
+        const int r = my_path;
+        const int v = E.rec_visit[rbase + r] + 1;
+        float qs = E.rec_qsum[rbase + r];
+        if (lane == len - 1) {      // the leaf's parent receives the value
+            qs = qs + value;
+            E.rec_qsum[rbase + r] = qs;
         }
-        E.nsearch[g] += 1;
-        E.sim_in_move[g] += 1;
-        E.g_sims[g] += 1ull;
+        E.rec_visit[rbase + r] = v;
+        E.rec_q[rbase + r] = qs / (float)v;   // recalc_q :77-79
+    }
+    if (lane == 0) {
+        E.nsearch[g] = nsearch + 1;
+        E.sim_in_move[g] = sim_in_move + 1;
+        E.g_sims[g] = gsims + 1ull;
     }
 }
 

@@ -268,7 +268,7 @@ static inline double open01(uint32_t hi, uint32_t lo) {
 static inline float bits2f(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline uint32_t f2bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 
-/* single-precision log / exp of the Gamma sampler (C6RNG v2): explicit polynomials on IEEE + - * / -- this file is
+/* single-precision log / exp of the Gamma sampler (C6RNG v2/v3): explicit polynomials on IEEE + - * / -- this file is
  * compiled with -ffp-contract=off and x86-64 evaluates float expressions in float, so the bits equal the GPU's */
 float c6o_det_logf(float x) {
     uint32_t b = f2bits(x);
@@ -310,24 +310,52 @@ float c6o_det_expf_parts(float x, int *kout) {
 /* 24-bit uniform strictly inside (0,1) */
 static inline float open01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
+/* m * 2^k, exact for a normal m and a normal result */
+static inline float scale2f(float m, int k) { return m * bits2f((uint32_t)(k + 127) << 23); }
+
 /*
- * Gamma(alpha, 1), alpha < 1 -- the algorithm of rand 0.6 `Gamma` (GammaSmallShape:
- * Marsaglia-Tsang for shape alpha+1 times U^(1/alpha)), which is what
- * `Dirichlet::new_with_param(alpha, n).sample` draws per component
- * (called from alphazero_policy/mod.rs:262,283).  Normal deviates come from the
- * polar method so that only log/sqrt are needed.  C6RNG v2: the variate is computed in
- * single precision (the reference casts the noise to f32 before use, mod.rs:283) and one
- * Philox block serves an attempt: words = polar v1, polar v2, squeeze u, power u.
+ * Gamma(alpha, 1): what `Dirichlet::new_with_param(alpha, n).sample` draws per component
+ * (rand 0.6, called from alphazero_policy/mod.rs:262,283).  The reference's generator is unseeded and rand's own
+ * stream cannot be reproduced, so only the DISTRIBUTION is the reference's; the algorithm is C6RNG's (v3), in single
+ * precision (the reference casts the noise to f32 before use, mod.rs:283), one Philox block per attempt:
+ *   alpha < 1:  Ahrens-Dieter GS (1974).  b = 1 + alpha/e, p = b u1.  p <= 1: x = p^(1/alpha), accept iff
+ *               u2 <= exp(-x); else x = -log((b - p)/alpha), accept iff u2 <= x^(alpha-1).  Attempts 2i and 2i + 1
+ *               share the Philox block with counter word c1 = i (words 0, 1 and 2, 3).
+ *   alpha >= 1: Marsaglia-Tsang for shape alpha+1 times U^(1/alpha) (rand's GammaSmallShape form) with polar-method
+ *               normals.  Words: polar v1, polar v2, squeeze u, power u.
+ * x = p^(1/alpha) reaches 1e-250 at alpha = 0.03: exp returns mantissa and exponent, the power of two is applied in
+ * double.
  */
 double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth) {
     const double shape = alpha + 1.0;
     const double dd = shape - 1.0 / 3.0;
     const double cd = 1.0 / sqrt(9.0 * dd);
     const float d = (float)dd, c = (float)cd, inv_alpha = 1.0f / (float)alpha;
+    const float a = (float)alpha, b = 1.0f + a * 0.36787944f;
     uint32_t key[2] = {k0, k1};
     for (uint32_t att = 0;; att++) {
-        uint32_t ctr[4] = {cell, att, search, (uint32_t)C6O_TAG_NOISE | (depth << 8)}, w[4];
+        /* alpha < 1: one Philox block serves the attempts 2i (words 0, 1) and 2i + 1 (words 2, 3) */
+        uint32_t ctr[4] = {cell, alpha < 1.0 ? att >> 1 : att, search, (uint32_t)C6O_TAG_NOISE | (depth << 8)}, w[4];
         c6o_philox4x32_10(ctr, key, w);
+        if (alpha < 1.0) {
+            const float u1 = open01f(w[2 * (att & 1)]), u2 = open01f(w[2 * (att & 1) + 1]);
+            const float p = b * u1;
+            int k, k2;
+            if (p <= 1.0f) {
+                const float m = c6o_det_expf_parts(c6o_det_logf(p) * inv_alpha, &k);
+                if (k >= -30) { /* below 2^-30 exp(-x) exceeds every u2 */
+                    const float e2 = c6o_det_expf_parts(-scale2f(m, k), &k2);
+                    if (!(u2 <= scale2f(e2, k2))) continue;
+                }
+                return k < -1000 ? 0.0 : (double)m * bits2d((uint64_t)(k + 1023) << 52); /* 2^k exactly, in double */
+            }
+            const float y = (b - p) * inv_alpha;
+            if (!(y > 0.0f)) continue;
+            const float x = 0.0f - c6o_det_logf(y);
+            const float e2 = c6o_det_expf_parts((a - 1.0f) * c6o_det_logf(x), &k2);
+            if (!(u2 <= scale2f(e2, k2))) continue;
+            return (double)x;
+        }
         const float v1 = 2.0f * open01f(w[0]) - 1.0f, v2 = 2.0f * open01f(w[1]) - 1.0f;
         const float s = v1 * v1 + v2 * v2;
         if (s >= 1.0f || s == 0.0f) continue;
@@ -340,7 +368,7 @@ double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uin
         if (u < 1.0f - 0.0331f * x2 * x2 || c6o_det_logf(u) < 0.5f * x2 + d * (1.0f - v + c6o_det_logf(v))) {
             int k;
             const float g = (d * v) * c6o_det_expf_parts(c6o_det_logf(u2) * inv_alpha, &k);
-            return k < -1000 ? 0.0 : (double)g * bits2d((uint64_t)(k + 1023) << 52);   /* 2^k exactly, in double */
+            return k < -1000 ? 0.0 : (double)g * bits2d((uint64_t)(k + 1023) << 52);
         }
     }
 }
@@ -348,7 +376,7 @@ double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uin
 double c6o_butterfly_sum64(const double part[64]) {
     double v[64], t[64];
     memcpy(v, part, sizeof v);
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 1; off <= 32; off <<= 1) { /* C6RNG v3: ascending offsets */
         for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
         memcpy(v, t, sizeof v);
     }

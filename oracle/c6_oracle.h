@@ -109,7 +109,7 @@ enum {
     C6O_TAG_ROLL_POLICY = 7 /* DefaultPolicy::policy fallback,  ctr = (0, 0, searches so far, tag) word 0 */
 };
 void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-float c6o_det_logf(float x);   /* single-precision pair used by the Gamma sampler (C6RNG v2) */
+float c6o_det_logf(float x);   /* single-precision pair used by the Gamma sampler (C6RNG v2/v3) */
 float c6o_det_expf_parts(float x, int *k);   /* exp(x) = return value * 2^k */
 /* Gamma(alpha<1,1) draw number `cell` of select step (search, depth) of a game */
 double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth);
