@@ -136,6 +136,7 @@ struct C6NetDev {
     const float *pl_wT;   // [2*cells][cells]
     const float *pl_b;    // [cells]
     const float *vc_w;    // [C]
+    const float *head_w;  // [3][C]: pc_w rows 0-1, vc_w -- the filters the last b3s convolution applies in its epilogue
     float vc_b;
     const float *vn_scale, *vn_shift; // [cells]
     const float *v1_wT;   // [cells][256]
@@ -167,7 +168,8 @@ bool c6_conv_f32n_dispatch(int C, int N, int nboards, const float *in, const flo
 bool c6_conv_fp32_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            hipStream_t s, int relu);
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                          float *out, int num_cus, hipStream_t s, int relu = 1, int split = 1);
+                          float *out, int num_cus, hipStream_t s, int relu = 1, int split = 1, const float *head_w = nullptr);
+int c6_conv_b3s_head_rows(int N);
 bool c6_conv_b3n_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                           float *out, int num_cus, hipStream_t s);
 void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,

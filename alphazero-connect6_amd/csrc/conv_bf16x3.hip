@@ -428,10 +428,16 @@ struct B3SGeom {
 
 // SPLIT = false: plain bf16 products (x_hi * w_hi only, one MFMA instead of three) -- C6_PREC_BF16, a RELAXED-tolerance
 // evaluator (net outputs ~1e-3, not the 1e-5 parity grade), SURVEY 8f rank 4
-template <int C, int N, bool SPLIT = true>
+// HEAD = true (the tower's last convolution in the evaluator): the activations are not stored; the epilogue applies the
+// three 1x1 head filters (policy conv 2 channels + value conv 1 channel, model.hpp:80,86) to the wave's 32 channels and
+// writes per-wave partial sums head_part[board][filter][wave][GEMM row] into `out` (3 * C/32 * PT*16 floats per board, 10 %
+// of an activation) -- c6_head_reduce_kernel adds the C/32 partials in wave order.  Saves the 1 KB per pixel the head
+// convolution would read back and the store of an activation nobody else reads.
+template <int C, int N, bool SPLIT = true, bool HEAD = false>
 __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const float *__restrict__ in, const unsigned short *__restrict__ wp,
                                                                        const float *__restrict__ bias, const float *__restrict__ res,
-                                                                       float *__restrict__ out, int nboards, int relu) {
+                                                                       float *__restrict__ out, int nboards, int relu,
+                                                                       const float *__restrict__ head_w) {
     using G = B3SGeom<C, N>;
     constexpr int W = G::W, PT = G::PT, KS = C / 32, THREADS = G::THREADS, WAVES = G::WAVES, CELLS = N * N;
     constexpr int PH0 = (PT + 1) / 2;                      // a tap's pixel tiles run in two halves (trickle sub-stages)
@@ -596,6 +602,36 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_b3s_kernel(const flo
         const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 bi0 = bias ? *reinterpret_cast<const f32x4 *>(bias + n4) : zero4, bi1 = bias ? *reinterpret_cast<const f32x4 *>(bias + n4 + 16) : zero4;
         const float floor_ = relu ? 0.f : -INFINITY;
+        if (HEAD) {
+#pragma unroll
+            for (int pt = 0; pt < PT; pt++) {      // activations in place of the accumulators
+                f32x4 y0 = acc[0][pt] + bi0, y1 = acc[1][pt] + bi1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    y0[r] = y0[r] > floor_ ? y0[r] : floor_;
+                    y1[r] = y1[r] > floor_ ? y1[r] : floor_;
+                }
+                acc[0][pt] = y0;
+                acc[1][pt] = y1;
+            }
+            float *hp = out + b * (size_t)(3 * WAVES * PT * 16) + (size_t)wave * (PT * 16) + pj;
+#pragma unroll 1
+            for (int o = 0; o < 3; o++) {
+                const f32x4 h0 = *reinterpret_cast<const f32x4 *>(head_w + o * C + n4), h1 = *reinterpret_cast<const f32x4 *>(head_w + o * C + n4 + 16);
+#pragma unroll
+                for (int pt = 0; pt < PT; pt++) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sum = __builtin_fmaf(acc[0][pt][r], h0[r], sum);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sum = __builtin_fmaf(acc[1][pt][r], h1[r], sum);
+                    sum += __shfl_xor(sum, 16, 64);      // the four channel quarters of the pixel row
+                    sum += __shfl_xor(sum, 32, 64);
+                    if (lane_o < 16) hp[(size_t)o * (WAVES * PT * 16) + pt * 16] = sum;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
             bool ok;
@@ -727,26 +763,37 @@ void c6_pack_conv_weights_b3s(int C, const float *w, unsigned short *packed) {
                         }
 }
 
-template <int C, int N>
-static void launch_b3s(int nboards, int grid, const float *in, const unsigned short *wp, const float *bias, const float *res, float *out,
-                       int relu, int split, hipStream_t s) {
+template <int C, int N, bool SPLIT, bool HEAD>
+static void launch_b3s_k(int nboards, int grid, const float *in, const unsigned short *wp, const float *bias, const float *res, float *out,
+                         int relu, const float *head_w, hipStream_t s) {
     using G = B3SGeom<C, N>;
     const size_t smem = G::LDS_BYTES;
-    if (split) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3s_kernel<C, N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N, true>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3s_kernel<C, N, SPLIT, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N, SPLIT, HEAD>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu, head_w);
+}
+
+template <int C, int N>
+static void launch_b3s(int nboards, int grid, const float *in, const unsigned short *wp, const float *bias, const float *res, float *out,
+                       int relu, int split, const float *head_w, hipStream_t s) {
+    if (head_w) {
+        if (split) launch_b3s_k<C, N, true, true>(nboards, grid, in, wp, bias, res, out, relu, head_w, s);
+        else launch_b3s_k<C, N, false, true>(nboards, grid, in, wp, bias, res, out, relu, head_w, s);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_b3s_kernel<C, N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((c6_conv3x3_b3s_kernel<C, N, false>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu);
+        if (split) launch_b3s_k<C, N, true, false>(nboards, grid, in, wp, bias, res, out, relu, nullptr, s);
+        else launch_b3s_k<C, N, false, false>(nboards, grid, in, wp, bias, res, out, relu, nullptr, s);
     }
 }
 
+// GEMM rows per board of the head partials written by the HEAD instantiation (PT * 16)
+int c6_conv_b3s_head_rows(int N) { return ((N * (N + 1) + 15) / 16) * 16; }
+
+// head_w != nullptr: [3][C] head filters; `out` receives the head partials instead of the activations (see the kernel)
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                          float *out, int num_cus, hipStream_t s, int relu, int split) {
+                          float *out, int num_cus, hipStream_t s, int relu, int split, const float *head_w) {
     if (nboards <= 0) return true;
     const int per_cu = C == 256 ? 1 : (C == 128 ? 2 : 4);
     const int grid = nboards < num_cus * per_cu ? nboards : num_cus * per_cu;
-#define B3SCASE(CC, NN) if (C == CC && N == NN) { launch_b3s<CC, NN>(nboards, grid, in, wp, bias, res, out, relu, split, s); return true; }
+#define B3SCASE(CC, NN) if (C == CC && N == NN) { launch_b3s<CC, NN>(nboards, grid, in, wp, bias, res, out, relu, split, head_w, s); return true; }
     B3SCASE(256, 19) B3SCASE(256, 15) B3SCASE(256, 9)
     B3SCASE(128, 19) B3SCASE(128, 15) B3SCASE(128, 9)
     B3SCASE(64, 19) B3SCASE(64, 15) B3SCASE(64, 9)

@@ -263,6 +263,10 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
             for (int k = 0; k < cells; k++) w1T[(size_t)k * 256 + h] = w1[(size_t)h * cells + k];
         d.v2_b = b2[0];
         int rc;
+        std::vector<float> hw((size_t)3 * C);      // [pc_w row 0 | pc_w row 1 | vc_w]
+        if (hipMemcpy(hw.data(), d.pc_w, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return fail(C6_ERR_HIP, "head weights");
+        std::copy(vw.begin(), vw.end(), hw.begin() + (size_t)2 * C);
+        if ((rc = upload(nh.pool, hw, &d.head_w))) return rc;
         if ((rc = upload(nh.pool, vw, &d.vc_w)) || (rc = upload(nh.pool, sc, &d.vn_scale)) || (rc = upload(nh.pool, sh, &d.vn_shift)) ||
             (rc = upload(nh.pool, w1T, &d.v1_wT)) || (rc = upload(nh.pool, b1v, &d.v1_b)) || (rc = upload(nh.pool, w2v, &d.v2_w)))
             return rc;

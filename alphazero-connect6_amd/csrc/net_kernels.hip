@@ -17,6 +17,8 @@
 // (no im2col in HBM).  Weights are pre-packed on the host so that a (tap, 32-channel slice)
 // stage is one contiguous 32*C-float block and a lane's 4 consecutive k values are one
 // ds_read_b128; stages are double-buffered in LDS and prefetched into registers behind the MFMAs.
+#include <cstdlib>
+
 #include "c6_device.h"
 #include "c6_engine.h"
 
@@ -287,6 +289,30 @@ __global__ __launch_bounds__(256) void c6_head_conv_kernel(const float *__restri
     }
 }
 
+// the same outputs from the per-wave partial sums the tower's last convolution leaves behind (c6_conv3x3_b3s_kernel<.., HEAD>):
+// part[board][filter][wave][GEMM row], row m = y * (N + 1) + x; the partials are added in wave order
+__global__ __launch_bounds__(256) void c6_head_reduce_kernel(const float *__restrict__ part, const float *__restrict__ pc_b, float vc_b,
+                                                            const float *__restrict__ vn_scale, const float *__restrict__ vn_shift,
+                                                            float *__restrict__ ph, float *__restrict__ vh, int N, int waves, int mp, int nb) {
+    const int cells = N * N;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)nb * cells) return;
+    const size_t b = i / cells;
+    const int p = (int)(i - b * cells);
+    const float *q = part + b * (size_t)(3 * waves * mp) + (p / N) * (N + 1) + p % N;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < waves; w++) {
+        s0 += q[(size_t)w * mp];
+        s1 += q[(size_t)(waves + w) * mp];
+        s2 += q[(size_t)(2 * waves + w) * mp];
+    }
+    const float y0 = s0 + pc_b[0], y1 = s1 + pc_b[1];
+    ph[b * (size_t)(2 * cells) + p] = y0 > 0.f ? y0 : 0.f;             // flatten is channel-major (NCHW view)
+    ph[b * (size_t)(2 * cells) + cells + p] = y1 > 0.f ? y1 : 0.f;
+    const float v = (s2 + vc_b) * vn_scale[p] + vn_shift[p];
+    vh[b * (size_t)cells + p] = v > 0.f ? v : 0.f;
+}
+
 #define HB 8   // boards per workgroup in the dense heads
 
 // policy_linear (2N^2 -> N^2) + softmax, model.hpp:83-84
@@ -458,6 +484,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
     float *x = act0, *y = act1, *z = act2;
     const size_t wsz = c6_conv_packed_floats(C);
     const bool timed = timers && timers->enabled;
+    static const bool fuse_heads = [] { const char *e = getenv("C6_HEAD_FUSE"); return !(e && e[0] == '0'); }();   // A/B switch
+    bool head_fused = false;
     for (int i = 0; i < net.blocks - 1; i++) {     // res_block, model.hpp:61-78
         for (int half = 0; half < 2; half++) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -466,7 +494,11 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
             const float *cin = half == 0 ? x : y, *cres = half == 0 ? nullptr : x;
             float *cout = half == 0 ? y : z;
             if (net.variant == 5) c6_conv_f32n_dispatch(C, net.N, nb, cin, net.conv_w5 + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
-            else if (net.variant == 7 || net.variant == 8) c6_conv_b3s_dispatch(C, net.N, nb, cin, net.conv_w7 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s, 1, net.variant == 7);
+            else if (net.variant == 7 || net.variant == 8) {
+                // the last convolution keeps its activations to itself and hands the heads their 1x1 partial sums
+                head_fused = fuse_heads && l == 2 * (net.blocks - 1) - 1;
+                c6_conv_b3s_dispatch(C, net.N, nb, cin, net.conv_w7 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s, 1, net.variant == 7, head_fused ? net.head_w : nullptr);
+            }
             else if (net.variant == 6) c6_conv_b3n_dispatch(C, net.N, nb, cin, net.conv_w6 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
             else if (net.variant == 3) c6_conv_b3_dispatch(C, net.N, nb, cin, net.conv_w3 + (size_t)l * c6_conv_packed_b3_units(C), net.conv_b + (size_t)l * C, cres, cout, s);
             else if (v2) c6_conv_v2_dispatch(C, net.N, nb, cin, net.conv_w2 + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
@@ -479,8 +511,12 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
         }
         float *t = x; x = z; z = t;
     }
-    hipLaunchKernelGGL(c6_head_conv_kernel, dim3(nb), dim3(256), 0, s, x, net.pc_w, net.pc_b, net.vc_w, net.vc_b, net.vn_scale,
-                       net.vn_shift, ph, vh, cells, C, v2);
+    if (head_fused)
+        hipLaunchKernelGGL(c6_head_reduce_kernel, dim3((unsigned)(((size_t)nb * cells + 255) / 256)), dim3(256), 0, s, x, net.pc_b, net.vc_b,
+                           net.vn_scale, net.vn_shift, ph, vh, net.N, C / 32, c6_conv_b3s_head_rows(net.N), nb);
+    else
+        hipLaunchKernelGGL(c6_head_conv_kernel, dim3(nb), dim3(256), 0, s, x, net.pc_w, net.pc_b, net.vc_w, net.vc_b, net.vn_scale,
+                           net.vn_shift, ph, vh, cells, C, v2);
     const int hgrid = (nb + HB - 1) / HB;
     const size_t sm_p = (size_t)(HB * 2 * cells + HB * cells) * sizeof(float);
     hipLaunchKernelGGL(c6_head_policy_kernel, dim3(hgrid), dim3(256), sm_p, s, ph, net.pl_wT, net.pl_b, pol, cells, nb);
