@@ -40,6 +40,9 @@ WORKLOADS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
+# c6_conv3x3_b3s_kernel<256, 19, SPLIT = true, HEAD = false>: the split (parity-grade) instantiation that stores activations --
+# five of the six conv launches of a round; the sixth (HEAD = true) hands the heads their 1x1 partial sums instead
+B3S_SPLIT = "19, true, false>"
 
 
 def net_flops_per_board(n, C, blocks):
@@ -257,11 +260,11 @@ def main():
             name, peak = ("c6_conv3x3_%s_kernel<256,19> (split-bf16 implicit GEMM, v_mfma_f32_%s_bf16)" % (b3, "32x32x16" if b3 == "b3n" else "16x16x32")), PEAK_BF16_MFMA_TFLOPS
             note = {"mfma_flops_per_algorithmic_flop": 3, "executed_mfma_tflops": 3 * ach, "frac_executed": 3 * ach / peak}
         r = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-             "traffic": pmc_traffic("true>" if precision != pkg.PREC_FP32 else "f32n") if args.workload == "config2" and not args.games else None,
+             "traffic": pmc_traffic(B3S_SPLIT if precision != pkg.PREC_FP32 else "f32n") if args.workload == "config2" and not args.games else None,
              "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
              "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
         if args.workload == "config2" and not args.games:
-            rec = pmc_record("true>" if precision != pkg.PREC_FP32 else "f32n")      # c6_conv3x3_b3s_kernel<256, 19, true>: the split (parity-grade) instantiation
+            rec = pmc_record(B3S_SPLIT if precision != pkg.PREC_FP32 else "f32n")
             if "mfma_util" in rec:      # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (profiles/)
                 r["pmc_mfma_busy_frac"] = rec["mfma_util"]
                 r["pmc_effective_clock_ghz"] = rec.get("effective_clock_ghz")
