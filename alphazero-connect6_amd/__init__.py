@@ -24,6 +24,7 @@ BLACK, NONE, WHITE = -1, 0, 1
 EVAL_RANDOM, EVAL_UNIFORM, EVAL_NET, EVAL_CALLBACK = 1, 2, 3, 4
 OK, ERR_NO_GPU, ERR_BAD_ARG, ERR_OVERFLOW, ERR_HIP, ERR_INVALID_POSITION, ERR_ALREADY_SET = range(7)
 PREC_DEFAULT, PREC_FP32, PREC_BF16X3, PREC_BF16 = 0, 1, 3, 4      # PREC_BF16: relaxed tolerance (~1e-3), not parity grade
+PREC_F16F8 = 5      # fp16 main term + MX-fp8 cross terms: parity grade (1e-5), 70 % of the bf16 split's matrix-pipe cycles
 REF_N = 15
 
 DROPIN_SYMBOLS = ["cpp_play", "cpp_self_play", "cpp_play_with", "test_new_raw_path", "test_with_raw_path",

@@ -130,6 +130,7 @@ struct C6NetDev {
     const unsigned short *conv_w6; // split planes packed per wave (c6_conv3x3_b3n_kernel)
     const unsigned short *conv_w7; // the same for the 16x16x32 tiling (c6_conv3x3_b3s_kernel)
     const float *conv_w5;          // FP32 weights packed per wave (c6_conv3x3_f32n_kernel)
+    const unsigned char *conv_w9;  // fp16 + fp8 planes packed per wave (c6_conv3x3_m8_kernel)
     const float *conv_b;  // [(blocks-1)*2][C]
     const float *pc_w;    // [2][C] folded
     const float *pc_b;    // [2]
@@ -170,6 +171,11 @@ bool c6_conv_fp32_dispatch(int C, int N, int nboards, const float *in, const flo
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                           float *out, int num_cus, hipStream_t s, int relu = 1, int split = 1, const float *head_w = nullptr);
 int c6_conv_b3s_head_rows(int N);
+// mixed fp16 + MX-fp8 products (conv_m8.hip, C6_PREC_F16F8)
+size_t c6_conv_packed_m8_bytes(int C);
+void c6_pack_conv_weights_m8(int C, const float *w_oihw_folded, unsigned char *packed);
+bool c6_conv_m8_dispatch(int C, int N, int nboards, const float *in, const unsigned char *wp, const float *bias, const float *res,
+                         float *out, int num_cus, hipStream_t s, int relu = 1, const float *head_w = nullptr);
 bool c6_conv_b3n_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                           float *out, int num_cus, hipStream_t s);
 void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,

@@ -183,6 +183,7 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         const char *v = std::getenv("C6_CONV_VARIANT");
         const int ev = v ? std::atoi(v) : 0;
         if (precision == C6_PREC_BF16) d.variant = 8;      // plain bf16 products: relaxed tolerance, not parity grade
+        else if (precision == C6_PREC_F16F8) d.variant = 9;   // fp16 main term + MX-fp8 cross terms (c6_conv3x3_m8_kernel)
         else if (precision == C6_PREC_FP32) d.variant = (ev == 1 || ev == 2) ? ev : 5;   // 5 = c6_conv3x3_f32n_kernel (N-split persistent FP32), the default
         else if (precision == C6_PREC_BF16X3) d.variant = (ev == 3 || ev == 6) ? ev : 7;
         else d.variant = (ev == 1 || ev == 2 || ev == 3 || ev == 5 || ev == 6) ? ev : 7;
@@ -213,6 +214,8 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         const size_t w6 = c6_conv_packed_b3n_units(C);
         std::vector<unsigned short> cw6((size_t)std::max(L, 1) * w6), cw7((size_t)std::max(L, 1) * w6);
         std::vector<float> cw5((size_t)std::max(L, 1) * wsz);
+        const size_t w9 = c6_conv_packed_m8_bytes(C);
+        std::vector<unsigned char> cw9((size_t)std::max(L, 1) * w9);
         for (int l = 0; l < L; l++) {
             const float *w = take((size_t)C * C * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
             for (int co = 0; co < C; co++) {
@@ -226,9 +229,10 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
             c6_pack_conv_weights_b3n(C, folded.data(), cw6.data() + (size_t)l * w6);
             c6_pack_conv_weights_b3s(C, folded.data(), cw7.data() + (size_t)l * w6);
             c6_pack_conv_weights_f32n(C, folded.data(), cw5.data() + (size_t)l * wsz);
+            if (d.variant == 9) c6_pack_conv_weights_m8(C, folded.data(), cw9.data() + (size_t)l * w9);
         }
         int rc;
-        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) || (rc = upload(nh.pool, cw6, &d.conv_w6)) || (rc = upload(nh.pool, cw7, &d.conv_w7)) || (rc = upload(nh.pool, cw5, &d.conv_w5)) ||
+        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) || (rc = upload(nh.pool, cw6, &d.conv_w6)) || (rc = upload(nh.pool, cw7, &d.conv_w7)) || (rc = upload(nh.pool, cw5, &d.conv_w5)) || (rc = upload(nh.pool, cw9, &d.conv_w9)) ||
             (rc = upload(nh.pool, cb, &d.conv_b)))
             return rc;
     }
@@ -999,7 +1003,8 @@ __global__ void c6_fill_random_kernel(float *p, size_t n, uint32_t seed, float l
 extern "C" int c6_bench_conv(int n, int C, int nboards, int iters, int variant, int ablate, int with_res, double *avg_ms) {
     int rc = check_n(n); if (rc) return rc;
     rc = require_gpu(0); if (rc) return rc;
-    const size_t cells = (size_t)n * n, act = (size_t)nboards * cells * C + C6_ACT_SLACK, wsz = c6_conv_packed_floats(C);
+    const size_t cells = (size_t)n * n, act = (size_t)nboards * cells * C + C6_ACT_SLACK,
+                 wsz = std::max(c6_conv_packed_floats(C), (c6_conv_packed_m8_bytes(C) + 3) / 4);      // the largest packed layout
     float *in, *res, *out, *w, *bias;
     HIPCHK(hipMalloc(&in, act * 4)); HIPCHK(hipMalloc(&res, act * 4)); HIPCHK(hipMalloc(&out, act * 4));
     HIPCHK(hipMalloc(&w, wsz * 4)); HIPCHK(hipMalloc(&bias, C * 4));

@@ -499,6 +499,10 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                 head_fused = fuse_heads && l == 2 * (net.blocks - 1) - 1;
                 c6_conv_b3s_dispatch(C, net.N, nb, cin, net.conv_w7 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s, 1, net.variant == 7, head_fused ? net.head_w : nullptr);
             }
+            else if (net.variant == 9) {
+                head_fused = fuse_heads && l == 2 * (net.blocks - 1) - 1;
+                c6_conv_m8_dispatch(C, net.N, nb, cin, net.conv_w9 + (size_t)l * c6_conv_packed_m8_bytes(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s, 1, head_fused ? net.head_w : nullptr);
+            }
             else if (net.variant == 6) c6_conv_b3n_dispatch(C, net.N, nb, cin, net.conv_w6 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
             else if (net.variant == 3) c6_conv_b3_dispatch(C, net.N, nb, cin, net.conv_w3 + (size_t)l * c6_conv_packed_b3_units(C), net.conv_b + (size_t)l * C, cres, cout, s);
             else if (v2) c6_conv_v2_dispatch(C, net.N, nb, cin, net.conv_w2 + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
@@ -559,6 +563,7 @@ void c6_conv_bench_launch(int variant, int ablate, int C, int N, int nboards, co
     if (variant == 5) { c6_conv_f32n_dispatch(C, N, nboards, in, w2, bias, res, out, num_cus, s); return; }
     if (variant == 6) { c6_conv_b3n_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, num_cus, s); return; }
     if (variant == 7 || variant == 8) { c6_conv_b3s_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, num_cus, s, 1, variant == 7); return; }
+    if (variant == 9) { c6_conv_m8_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned char *>(w2), bias, res, out, num_cus, s, 1, nullptr); return; }
     if (variant == 3 && ablate != 0 && C == 256 && N == 19) { c6_conv_b3_ablate(ablate, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, s); return; }
     if (variant == 3) { c6_conv_b3_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, s); return; }
     if (C != 256 || N != 19 || ablate == 0) { conv_dispatch(C, N, nboards, in, w1, bias, res, out, s); return; }

@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--games", type=int, default=0, help="override games per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "f16f8"],
                     help="arithmetic of the 3x3 convolutions for the headline value; the other one is measured too and reported "
                          "beside it (fp32_path / bf16x3_path) unless --single-precision")
     ap.add_argument("--single-precision", action="store_true")
@@ -271,7 +271,7 @@ def main():
         r.update(note)
         return r
 
-    prec = {"bf16x3": pkg.PREC_BF16X3, "fp32": pkg.PREC_FP32}[args.precision]
+    prec = {"bf16x3": pkg.PREC_BF16X3, "fp32": pkg.PREC_FP32, "f16f8": pkg.PREC_F16F8}[args.precision]
     dt, prof, st, pooled_tuples = measure(prec, args.steps, args.warmup)
     second = None
     relaxed = None

@@ -130,15 +130,19 @@ enum {
     C6_EVAL_CALLBACK = 4  /* host callback with the reference's signature */
 };
 
-/* arithmetic of the net's 3x3 convolutions.  Both hold the net outputs to the 1e-5 parity bar of the tests. */
+/* arithmetic of the net's 3x3 convolutions.  FP32, BF16X3 and F16F8 hold the net outputs to the 1e-5 parity bar of the tests. */
 enum {
     C6_PREC_DEFAULT = 0,  /* = C6_PREC_BF16X3 unless the environment sets C6_CONV_VARIANT */
     C6_PREC_FP32 = 1,     /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate */
     C6_PREC_BF16X3 = 3,   /* operands split hi+mid in bf16, x_hi*w_hi + x_hi*w_mid + x_mid*w_hi on bf16 MFMAs,
                              f32 accumulate: error <= 3*2^-16 per product, 16x the FP32 matrix rate at 3 MFMAs per product */
-    C6_PREC_BF16 = 4      /* plain bf16 products (x_hi*w_hi only), f32 accumulate: RELAXED tolerance -- net outputs agree with
+    C6_PREC_BF16 = 4,     /* plain bf16 products (x_hi*w_hi only), f32 accumulate: RELAXED tolerance -- net outputs agree with
                              FP32 to ~1e-3, NOT the 1e-5 parity grade; for evaluation matches / throughput headroom (SURVEY 8f
                              rank 4).  Never the benchmark's `value`. */
+    C6_PREC_F16F8 = 5     /* x_h*w_h on fp16 MFMAs (11-bit significands) + the two cross terms x_h*w_l + x_l*w_h on MX-scaled fp8
+                             MFMAs (v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 rate), f32 accumulate: ~2^-15 per product,
+                             the accuracy class of C6_PREC_BF16X3 (parity grade: net outputs within 1e-5) at 70 % of its
+                             matrix-pipe cycles */
 };
 
 /* policy/alphazero_policy/mod.rs:91-96 HyperParameter + engine geometry */

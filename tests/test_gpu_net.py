@@ -18,7 +18,7 @@ def rand_blob(n, C, blocks, seed):
     return ge.make_random_blob(n, C, blocks, np.random.default_rng(seed))
 
 
-PRECISIONS = [pytest.param(1, id="fp32-mfma"), pytest.param(3, id="bf16x3-split")]
+PRECISIONS = [pytest.param(1, id="fp32-mfma"), pytest.param(3, id="bf16x3-split"), pytest.param(5, id="f16f8-mixed")]
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)

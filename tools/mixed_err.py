@@ -1,0 +1,74 @@
+"""Numerics of the candidate mixed-precision product (CPU emulation, PyTorch float64 accumulate):
+    x*w ~= fp16(x)*fp16(w)  +  fp8(xh)*fp8(wl * 2^16)*2^-16  +  fp8(xl * 2^11)*fp8(wh * 2^5) * 2^-16
+with xh = fp16(x), xl = x - xh, wh = fp16(w), wl = w - wh, fp8 = OCP e4m3 (what v_mfma_scale_f32_16x16x128_f8f6f4 takes;
+the powers of two are its block scales).  Prints the output error of the benchmark-shaped net against float64 and beside the
+bf16x3 split's error.    python tools/mixed_err.py [N] [C] [blocks] [boards]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np, torch, torch.nn.functional as F
+import torch_ref as tr
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 19
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+torch.manual_seed(0)
+m = tr.WeightedPolicy(n, C, blocks).double().eval()
+tr.randomize_bn(m)
+
+
+def q8(t):
+    return t.float().to(torch.float8_e4m3fn).double()
+
+
+def fold(conv, bn):
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return (conv.weight * s.view(-1, 1, 1, 1)).float(), ((conv.bias - bn.running_mean) * s + bn.bias).float()
+
+
+def conv_mode(x, w, mode):
+    """x float32 NCHW, w float32 folded OIHW -> float64 result of the emulated product"""
+    if mode == "f32":
+        return F.conv2d(x.double(), w.double(), padding=1)
+    if mode == "bf16x3":
+        xh = x.bfloat16().float(); xm = (x - xh).bfloat16().float()
+        wh = w.bfloat16().float(); wm = (w - wh).bfloat16().float()
+        c = lambda a, b: F.conv2d(a.double(), b.double(), padding=1)
+        return c(xh, wh) + c(xh, wm) + c(xm, wh)
+    if mode == "mixed":
+        xh = x.half().float(); xl = x - xh
+        wh = w.half().float(); wl = w - wh
+        c = lambda a, b: F.conv2d(a.double(), b.double(), padding=1)
+        return c(xh, wh) + c(q8(xh), q8(wl * 2.0 ** 16)) * 2.0 ** -16 + c(q8(xl * 2.0 ** 11), q8(wh * 2.0 ** 5)) * 2.0 ** -16
+    raise ValueError(mode)
+
+
+def forward(player, board, mode):
+    n2 = n * n
+    with torch.no_grad():
+        p = player.view(-1, 1).repeat(1, n2).view(-1, 1, n, n)
+        x = torch.cat([p, board.view(-1, 1, n, n)], 1).double()
+        x = F.relu(m.norm(m.conv(x))).float()                       # stem in f32
+        for c0, n0, c1, n1 in m.tower:
+            w0, b0 = fold(c0, n0); w1, b1 = fold(c1, n1)
+            t = F.relu(conv_mode(x, w0, mode) + b0.double().view(1, -1, 1, 1)).float()
+            t = conv_mode(t, w1, mode) + b1.double().view(1, -1, 1, 1)
+            x = F.relu(t + x.double()).float()
+        x = x.double()
+        pol = F.relu(m.policy_norm(m.policy_conv(x)))
+        pol = torch.softmax(m.policy_linear(pol.view(-1, 2 * n2)), 1)
+        v = m.value_conv(x)
+        v = F.relu(m.value_norm(v.view(-1, n2)))
+        v = torch.tanh(m.value_linear2(F.relu(m.value_linear1(v))))
+    return pol, v.view(-1), x
+
+
+rng = np.random.default_rng(1)
+board = torch.tensor(rng.integers(-1, 2, (B, n * n)).astype(np.float64))
+player = torch.tensor(rng.choice([-1.0, 1.0], B))
+ref = forward(player, board, "f32")
+print(f"net {n}x{n}, C={C}, stem + {blocks-1} blocks, {B} boards; |activation| max {ref[2].abs().max():.2f}")
+for mode in ("bf16x3", "mixed"):
+    got = forward(player, board, mode)
+    print(f"{mode:7s}: policy max err {float((got[0]-ref[0]).abs().max()):.3e}   value max err {float((got[1]-ref[1]).abs().max()):.3e}   "
+          f"last activation max err {float((got[2]-ref[2]).abs().max()):.3e}")
