@@ -177,7 +177,8 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         // A/B switch (C6_CONV_VARIANT).  FP32 precision: 5 = c6_conv3x3_f32n_kernel (N-split persistent schedule, the default:
         // 137-139 TFLOP/s), 1 = c6_conv3x3_kernel (M x N wave grid, weight stages in LDS by LDS-DMA, barrier per tap; 127-132),
         // 2 = c6_conv3x3_v2_kernel (16x16x4 tiles, slice-major activations; experimental, 119 TFLOP/s).
-        // Split-bf16 precision (the default): 7 = c6_conv3x3_b3s_kernel (persistent N-split schedule on 16x16x32 MFMAs,
+        // Mixed precision (C6_PREC_F16F8, the default): 9 = c6_conv3x3_m8_kernel (fp16 main term + MX-fp8 cross terms).
+        // Split-bf16 precision: 7 = c6_conv3x3_b3s_kernel (persistent N-split schedule on 16x16x32 MFMAs,
         // the default: the chip holds a higher clock on that shape), 6 = c6_conv3x3_b3n_kernel (same schedule on
         // 32x32x16), 3 = c6_conv3x3_bf16x3_kernel (M x N wave grid with weight stages in LDS)
         const char *v = std::getenv("C6_CONV_VARIANT");
@@ -186,7 +187,7 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         else if (precision == C6_PREC_F16F8) d.variant = 9;   // fp16 main term + MX-fp8 cross terms (c6_conv3x3_m8_kernel)
         else if (precision == C6_PREC_FP32) d.variant = (ev == 1 || ev == 2) ? ev : 5;   // 5 = c6_conv3x3_f32n_kernel (N-split persistent FP32), the default
         else if (precision == C6_PREC_BF16X3) d.variant = (ev == 3 || ev == 6) ? ev : 7;
-        else d.variant = (ev == 1 || ev == 2 || ev == 3 || ev == 5 || ev == 6) ? ev : 7;
+        else d.variant = (ev == 1 || ev == 2 || ev == 3 || ev == 5 || ev == 6 || ev == 7) ? ev : 9;      // default: C6_PREC_F16F8
         hipDeviceProp_t prop;
         int dev = 0;
         hipGetDevice(&dev);

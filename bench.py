@@ -6,10 +6,10 @@
 
 Workload at every N (weak scaling: per-GPU work fixed): BASELINE.json configs[1] --
 4096 concurrent 19x19 games per GPU, 400 simulations/move, random-init policy/value net with
-"4 blocks" = stem + 3 residual blocks, C = 256.  The 3x3 convolutions run either as exact-FP32 MFMAs or as the
-bf16x3 split (f32 operands split into bf16 hi+mid, three bf16 MFMAs per product, f32 accumulation); both paths
-hold the net outputs to the 1e-5 parity bar (tests/test_gpu_net.py).  The headline `value` is the split path
-(--precision bf16x3, default); the exact-FP32 path is measured in the same run and reported as `fp32_path`.
+"4 blocks" = stem + 3 residual blocks, C = 256.  The 3x3 convolutions run in one of three parity-grade
+arithmetics (net outputs within 1e-5 of the FP32 oracle, tests/test_gpu_net.py): `f16f8` (default: fp16 main term + MX-scaled
+fp8 cross terms), `bf16x3` (operands split into bf16 hi+mid, three bf16 MFMAs per product) and `fp32` (exact-FP32 MFMAs).  The
+headline `value` is the --precision path; the other two are measured in the same run: `bf16x3_path`, `fp32_path`.
 
 A "step" is one simulation ROUND: every live game performs one search() (select -> 8 dihedral
 net evaluations -> expand -> one-level backup); game phases are staggered, so each round
@@ -43,6 +43,7 @@ PEAK_HBM_GBS = 8000.0
 # c6_conv3x3_b3s_kernel<256, 19, SPLIT = true, HEAD = false>: the split (parity-grade) instantiation that stores activations --
 # five of the six conv launches of a round; the sixth (HEAD = true) hands the heads their 1x1 partial sums instead
 B3S_SPLIT = "19, true, false>"
+M8_PLAIN = "m8_kernel<256, 19, false>"      # c6_conv3x3_m8_kernel<256, 19, HEAD = false>: five of the six conv launches of a round
 
 
 def net_flops_per_board(n, C, blocks):
@@ -147,7 +148,7 @@ def main():
     ap.add_argument("--games", type=int, default=0, help="override games per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "f16f8"],
+    ap.add_argument("--precision", default="f16f8", choices=["f16f8", "bf16x3", "fp32"],
                     help="arithmetic of the 3x3 convolutions for the headline value; the other one is measured too and reported "
                          "beside it (fp32_path / bf16x3_path) unless --single-precision")
     ap.add_argument("--single-precision", action="store_true")
@@ -254,30 +255,41 @@ def main():
         ach = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
         if precision == pkg.PREC_FP32:
             f32k = "c6_conv3x3_kernel<256,3>" if os.environ.get("C6_CONV_VARIANT") == "1" else "c6_conv3x3_f32n_kernel<256,19>"
-            name, peak, note = f32k + " (FP32 MFMA implicit GEMM, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, {}
+            name, peak, note, key = f32k + " (FP32 MFMA implicit GEMM, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, {}, "f32n"
+        elif precision == pkg.PREC_F16F8:
+            # per algorithmic flop: one fp16 MFMA flop (dense peak 2 500 TF) + the two cross terms on fp8 MFMAs (dense peak 5 000 TF)
+            # whose K = 128 covers two taps, the ninth tap alone: 10/9 * 2 fp8 flops.  Matrix-pipe time per algorithmic flop is
+            # (1 + 10/9) / 2 500 TF, i.e. the scheme's ceiling is 1 184 TF algorithmic
+            name, peak, key = ("c6_conv3x3_m8_kernel<256,19> (mixed fp16 + MX-fp8 implicit GEMM, v_mfma_f32_16x16x32_f16 + "
+                               "v_mfma_scale_f32_16x16x128_f8f6f4)"), PEAK_BF16_MFMA_TFLOPS, M8_PLAIN
+            note = {"matrix_pipe_time_per_algorithmic_flop_vs_fp16": 1.0 + 10.0 / 9.0, "scheme_ceiling_tflops": peak / (1.0 + 10.0 / 9.0),
+                    "frac_of_scheme_ceiling": ach * (1.0 + 10.0 / 9.0) / peak}
         else:
             b3 = "b3n" if os.environ.get("C6_CONV_VARIANT") == "6" else "b3s"
-            name, peak = ("c6_conv3x3_%s_kernel<256,19> (split-bf16 implicit GEMM, v_mfma_f32_%s_bf16)" % (b3, "32x32x16" if b3 == "b3n" else "16x16x32")), PEAK_BF16_MFMA_TFLOPS
+            name, peak, key = ("c6_conv3x3_%s_kernel<256,19> (split-bf16 implicit GEMM, v_mfma_f32_%s_bf16)" % (b3, "32x32x16" if b3 == "b3n" else "16x16x32")), PEAK_BF16_MFMA_TFLOPS, B3S_SPLIT
             note = {"mfma_flops_per_algorithmic_flop": 3, "executed_mfma_tflops": 3 * ach, "frac_executed": 3 * ach / peak}
+        std = args.workload == "config2" and not args.games
         r = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-             "traffic": pmc_traffic(B3S_SPLIT if precision != pkg.PREC_FP32 else "f32n") if args.workload == "config2" and not args.games else None,
+             "traffic": pmc_traffic(key) if std else None,
              "avg_launch_ms": prof["conv_ms"] / prof["conv_launches"], "launches": prof["conv_launches"],
              "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt)}
-        if args.workload == "config2" and not args.games:
-            rec = pmc_record(B3S_SPLIT if precision != pkg.PREC_FP32 else "f32n")
+        if std:
+            rec = pmc_record(key)
             if "mfma_util" in rec:      # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (profiles/)
                 r["pmc_mfma_busy_frac"] = rec["mfma_util"]
                 r["pmc_effective_clock_ghz"] = rec.get("effective_clock_ghz")
         r.update(note)
         return r
 
-    prec = {"bf16x3": pkg.PREC_BF16X3, "fp32": pkg.PREC_FP32, "f16f8": pkg.PREC_F16F8}[args.precision]
+    PRECS = {"f16f8": pkg.PREC_F16F8, "bf16x3": pkg.PREC_BF16X3, "fp32": pkg.PREC_FP32}
+    prec = PRECS[args.precision]
     dt, prof, st, pooled_tuples = measure(prec, args.steps, args.warmup)
-    second = None
+    others = []
     relaxed = None
     if ev == pkg.EVAL_NET and not args.single_precision:
-        other = pkg.PREC_FP32 if prec == pkg.PREC_BF16X3 else pkg.PREC_BF16X3
-        second = (other,) + measure(other, args.steps, args.warmup)
+        for name, o_prec in PRECS.items():      # the other parity-grade paths, measured in the same run and reported beside `value`
+            if o_prec != prec:
+                others.append((name, o_prec) + measure(o_prec, args.steps, args.warmup))
         relaxed = measure(pkg.PREC_BF16, args.steps, args.warmup)      # side report only, never `value`
 
     if rank == 0:
@@ -286,8 +298,10 @@ def main():
             sims = rounds_s * G * world
             return sims, sims / (S * wl["stones"])
         sims_s, games_s = line(dt)
-        dtype = ("bf16x3 (f32 operands split hi+mid in bf16, 3 bf16 MFMAs per product, f32 accumulate; net outputs within 1e-5)"
-                 if prec == pkg.PREC_BF16X3 else "f32") if ev == pkg.EVAL_NET else "f32/f64 (tree arithmetic), int8 boards"
+        DTYPES = {pkg.PREC_F16F8: "f16+f8 (f32 operands split hi+lo in fp16: x_hi*w_hi on fp16 MFMAs, the cross terms x_hi*w_lo + x_lo*w_hi on MX-scaled fp8 MFMAs, f32 accumulate; net outputs within 1e-5)",
+                  pkg.PREC_BF16X3: "bf16x3 (f32 operands split hi+mid in bf16, 3 bf16 MFMAs per product, f32 accumulate; net outputs within 1e-5)",
+                  pkg.PREC_FP32: "f32 (v_mfma_f32_32x32x2_f32, exact f32 products)"}
+        dtype = DTYPES[prec] if ev == pkg.EVAL_NET else "f32/f64 (tree arithmetic), int8 boards"
         out = {
             "metric": "self-play games/sec at 400 sims/move, 19x19, 1/2/4/8 MI355X" if args.workload in ("config2", "config4")
                       else f"self-play games/sec ({args.workload})",
@@ -307,13 +321,10 @@ def main():
         if ev == pkg.EVAL_NET and prof["conv_launches"]:
             out["roofline"] = conv_roofline(prof, dt, prec)
             out["net_tflops_end_to_end"] = net_flops_per_board(n, wl["channels"], wl["blocks"]) * 8 * sims_s / 1e12
-            if second:
-                o_prec, o_dt, o_prof, o_st, _ = second
+            for name, o_prec, o_dt, o_prof, o_st, _ in others:
                 o_sims, o_games = line(o_dt)
-                key = "fp32_path" if o_prec == pkg.PREC_FP32 else "bf16x3_path"
-                out[key] = {"value": o_games, "unit": "games/s", "ms_per_step": 1000.0 * o_dt / args.steps, "sims_per_s": o_sims,
-                            "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact f32 products)" if o_prec == pkg.PREC_FP32 else "bf16x3",
-                            "roofline": conv_roofline(o_prof, o_dt, o_prec)}
+                out[name + "_path"] = {"value": o_games, "unit": "games/s", "ms_per_step": 1000.0 * o_dt / args.steps, "sims_per_s": o_sims,
+                                       "dtype": DTYPES[o_prec], "roofline": conv_roofline(o_prof, o_dt, o_prec)}
             if relaxed:      # C6_PREC_BF16: NOT parity grade (value error ~1e-4..1e-3 > the 1e-5 bar) -- a side report, never `value`
                 r_dt, r_prof, _, _ = relaxed
                 r_sims, r_games = line(r_dt)

@@ -132,7 +132,7 @@ enum {
 
 /* arithmetic of the net's 3x3 convolutions.  FP32, BF16X3 and F16F8 hold the net outputs to the 1e-5 parity bar of the tests. */
 enum {
-    C6_PREC_DEFAULT = 0,  /* = C6_PREC_BF16X3 unless the environment sets C6_CONV_VARIANT */
+    C6_PREC_DEFAULT = 0,  /* = C6_PREC_F16F8 unless the environment sets C6_CONV_VARIANT */
     C6_PREC_FP32 = 1,     /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate */
     C6_PREC_BF16X3 = 3,   /* operands split hi+mid in bf16, x_hi*w_hi + x_hi*w_mid + x_mid*w_hi on bf16 MFMAs,
                              f32 accumulate: error <= 3*2^-16 per product, 16x the FP32 matrix rate at 3 MFMAs per product */
