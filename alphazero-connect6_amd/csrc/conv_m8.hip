@@ -204,19 +204,20 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const floa
         // ... and on the fp8 MFMA (weights w8) with the lane's own tap offset toff8 (groups 0-1: tap 2p, 2-3: tap 2p+1)
         auto run8 = [&](int toff8, auto half_c) __attribute__((always_inline)) {
             constexpr int half = decltype(half_c)::value;
-            i32x8 px[1];
+            i32x8 px[2];
             constexpr int p_lo = half == 0 ? 0 : PH0, p_hi = half == 0 ? PH0 : PT;
             const unsigned short *ap = lds_in + base8 + toff8 * M8_SLOT;
             auto ld = [&](int pt) -> i32x8 {
                 const i32x4 h = *reinterpret_cast<const i32x4 *>(ap + (pt * 16) * M8_SLOT), l = *reinterpret_cast<const i32x4 *>(ap + (pt * 16) * M8_SLOT + 16);
                 return i32x8{h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3]};
             };
+            px[0] = ld(p_lo);
 #pragma unroll
-            for (int pt = p_lo; pt < p_hi; pt++) {      // single-buffered: a second 8-register fragment does not fit beside the accumulators
-                px[0] = ld(pt);
+            for (int pt = p_lo, sl = 0; pt < p_hi; pt++, sl ^= 1) {
+                if (pt + 1 < p_hi) px[sl ^ 1] = ld(pt + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ct = 0; ct < 2; ct++) M8_MFMA8(acc[ct][pt], w8[ct], px[0], vscale_w, vscale_x);
+                for (int ct = 0; ct < 2; ct++) M8_MFMA8(acc[ct][pt], w8[ct], px[sl], vscale_w, vscale_x);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
