@@ -36,7 +36,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
                   "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
-                  "c6_bench_conv", "c6_bench_board", "c6_bench_board_scan", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
+                  "c6_bench_conv", "c6_bench_board", "c6_bench_board_scan", "c6_conv_pack_m8_bytes", "c6_conv_pack_m8", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
@@ -163,6 +163,9 @@ def lib():
     L.c6_bench_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)]
     L.c6_bench_board.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.c6_bench_board_scan.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.c6_conv_pack_m8_bytes.argtypes = [C.c_int]
+    L.c6_conv_pack_m8_bytes.restype = C.c_size_t
+    L.c6_conv_pack_m8.argtypes = [C.c_int, f32p, C.POINTER(C.c_uint8), C.c_size_t]
     L.c6_replay_create.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
     L.c6_replay_destroy.argtypes = [C.c_void_p]
     L.c6_replay_push_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -769,6 +772,15 @@ def bench_conv(n, channels, nboards, iters=3, variant=1, ablate=0, with_residual
     ms = C.c_double()
     _chk(lib().c6_bench_conv(n, channels, nboards, iters, variant, ablate, with_residual, C.byref(ms)))
     return ms.value
+
+
+def conv_pack_m8(channels, w_oihw):
+    """host-side weight image of the mixed-precision convolution (no GPU needed): uint8 array"""
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    nbytes = lib().c6_conv_pack_m8_bytes(channels)
+    out = np.zeros(nbytes, np.uint8)
+    _chk(lib().c6_conv_pack_m8(channels, _p(w, C.c_float), _p(out, C.c_uint8), nbytes))
+    return out
 
 
 def bench_board(n, num_games, iters=20, scan_only=False):

@@ -27,6 +27,8 @@
 #include "c6_device.h"
 #include "c6_engine.h"
 
+#include "../../include/connect6_amd.h"
+
 #include <cmath>
 #include <cstring>
 #include <type_traits>
@@ -434,4 +436,12 @@ bool c6_conv_m8_dispatch(int C, int N, int nboards, const float *in, const unsig
     M8CASE(64, 19) M8CASE(64, 15) M8CASE(64, 9)
 #undef M8CASE
     return false;
+}
+
+// host-only hook for the tests: the packed image of one layer's folded weights (nbytes = c6_conv_pack_m8_bytes(channels))
+extern "C" size_t c6_conv_pack_m8_bytes(int channels) { return (channels == 64 || channels == 128 || channels == 256) ? c6_conv_packed_m8_bytes(channels) : 0; }
+extern "C" int c6_conv_pack_m8(int channels, const float *w_oihw, unsigned char *packed, size_t nbytes) {
+    if (!w_oihw || !packed || c6_conv_pack_m8_bytes(channels) == 0 || nbytes != c6_conv_packed_m8_bytes(channels)) return C6_ERR_BAD_ARG;
+    c6_pack_conv_weights_m8(channels, w_oihw, packed);
+    return C6_OK;
 }

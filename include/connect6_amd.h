@@ -281,6 +281,11 @@ int c6_net_forward_prec(int board_size, int channels, int blocks, int precision,
 /* development / profiling hook: average duration (ms) of `iters` launches of one 3x3 conv variant on random data
  * (variant 1 = FP32 MFMA, 2 = experimental 16x16x4 kernel, 3 = bf16x3; ablate != 0 only for variant 1) */
 int c6_bench_conv(int board_size, int channels, int nboards, int iters, int variant, int ablate, int with_residual, double *avg_ms);
+/* host-only (no GPU needed): the weight image c6_conv3x3_m8_kernel (C6_PREC_F16F8) reads for one layer's folded OIHW weights --
+ * fp16 planes [slice][tap 0..9 (9 = zeros)][wave][16-channel tile][lane][8], then per tap pair the fp8 planes
+ * [slice][pair][wave][tile][lane][16 x q8(w_l 2^16) | 16 x q8(w_h 2^5)] (OCP e4m3, round to nearest even, saturating) */
+size_t c6_conv_pack_m8_bytes(int channels);
+int c6_conv_pack_m8(int channels, const float *w_oihw, unsigned char *packed, size_t nbytes);
 /* K1 alone: `num_games` resident games, one stone per game per launch (average ms over `iters` launches) */
 int c6_bench_board(int board_size, int num_games, int iters, double *avg_ms);
 /* K1's search-only launch (is_game_end of every resident game, no stone: N*N bytes read + 1 written per board) */
