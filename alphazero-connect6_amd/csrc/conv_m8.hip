@@ -19,11 +19,12 @@
 // (N+1)-wide row grid, the next slice trickled in by LDS-DMA behind the MFMAs, one barrier per slice, residual = initial
 // accumulator, optional head epilogue.  A slice runs as the sub-steps  A0 B0 C0  A1 B1 C1 ... A3 B3 C3  A4 C4:
 //   A_p = fp16 MFMAs of tap 2p, B_p = fp16 MFMAs of tap 2p+1, C_p = fp8 MFMAs of the pair (2p, 2p+1).
-// LDS slot of a pixel (160 bytes): [x_h fp16 x 32 | q8(x_h) x 32 | q8(x_l * 2^11) x 32 | 32 pad].
+// LDS slot of a pixel (160 bytes): [x_h fp16 x 32 | q8(x_h 2^-3) x 32 | q8(x_l 2^8) x 32 | 32 pad].
 // Operand layout of the fp8 MFMA (found with tools/probe/mfma_fp8_*.hip): lane (row r, group g) holds K = 16 g + i in
 // bytes i = 0..15 and K = 64 + 16 g + i in bytes 16..31; the E8M0 scale of (row, K block b = K / 32) is read from lane
 // r + 16 b.  Hence groups 0-1 carry tap 2p, groups 2-3 tap 2p+1; bytes 0-15 = q8(x_h) (weights: q8(w_l)), bytes 16-31 =
-// q8(x_l) (weights: q8(w_h)), channel 16 (g & 1) + i; lanes 0-31 supply the scale of the first plane, lanes 32-63 of the second.
+// q8(x_l) (weights: q8(w_h)), channel 16 (g & 1) + i; lanes 0-31 supply the scale of the first plane, lanes 32-63 of the second
+// (the planes are shifted so that one scale pair fits both: see M8_XH_SHIFT below).
 #include "c6_device.h"
 #include "c6_engine.h"
 
@@ -41,9 +42,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define M8_SLOT 80          // ushort (2-byte) units per LDS pixel slot (160 bytes: conflict-free stride of the b3s lane mapping)
 // block scales (E8M0, bias 127) and the powers of two folded into the fp8 planes
-#define M8_XL_SHIFT 11      // q8(x_l * 2^11), scale 2^-11
-#define M8_WL_SHIFT 16      // q8(w_l * 2^16), scale 2^-16
-#define M8_WH_SHIFT 5       // q8(w_h * 2^5),  scale 2^-5
+// The fp8 planes hold  q8(x_h 2^-3)  [x up to 3584; beyond that x_h is clamped -- v_cvt_pk_fp8_f32 turns out-of-range values into
+// NaN, not 448],  q8(x_l 2^8),  q8(w_l 2^(d+11)),  q8(w_h 2^d)  with a per-layer weight shift d chosen by the packer (max |w_h| 2^d
+// just below 448; d sits in the 16-byte header of the packed image).  Both cross terms then carry 2^(d+8), so one pair of E8M0
+// scales (2^-4 for the pixels, 2^-(d+4) for the weights) serves every block and lane.
+#define M8_XH_SHIFT (-3)
+#define M8_XL_SHIFT 8
+#define M8_XH_MAX 3584.0f   // 448 * 2^3
+#define M8_HEADER 16        // bytes in front of the weight planes: int32 d
 
 // The MFMAs are issued as inline asm with the accumulator TIED (dst = src C).  Through the builtins hipcc picks the three-address
 // form, renames accumulator tiles from one MFMA to the next and, at 256 VGPRs, ends up moving and spilling whole tiles inside
@@ -69,11 +75,12 @@ struct M8Geom {
 };
 
 template <int C, int N, bool HEAD = false>
-__global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wp,
+__global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wp_,
                                                                       const float *__restrict__ bias, const float *__restrict__ res,
                                                                       float *__restrict__ out, int nboards, int relu,
                                                                       const float *__restrict__ head_w) {
     using G = M8Geom<C, N>;
+    const unsigned char *wp = wp_;
     constexpr int W = G::W, PT = G::PT, KS = C / 32, THREADS = G::THREADS, WAVES = G::WAVES, CELLS = N * N;
     constexpr int PH0 = (PT + 1) / 2;                      // a sub-step's pixel tiles run in two halves
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
@@ -97,18 +104,23 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const floa
         if (item < CELLS * 8) {
             const int p = item >> 3, q = item & 7;
             f16x4 h;
-            float hf[4], lo[4];
+            float hf[4], lo[4], hc[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 h[r] = (_Float16)v[r];
                 hf[r] = (float)h[r];
-                lo[r] = (v[r] - hf[r]) * (float)(1 << M8_XL_SHIFT);
+                lo[r] = v[r] - hf[r];
+                hc[r] = __builtin_amdgcn_fmed3f(hf[r], -M8_XH_MAX, M8_XH_MAX);      // out of range would convert to NaN
             }
-            int h8 = 0, l8 = 0;
-            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[0], hf[1], h8, false);
-            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[2], hf[3], h8, true);
-            l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], l8, false);
-            l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], l8, true);
+            // v_cvt_scalef32_pk_fp8_f32 converts src / scale (tools/probe/cvt_scale_fp8.hip): the shifts cost no multiply
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            s16x2 ha = {0, 0}, hb = {0, 0}, la = {0, 0}, lb = {0, 0};
+            ha = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(ha, hc[0], hc[1], 8.0f, false);
+            hb = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(hb, hc[2], hc[3], 8.0f, false);
+            la = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(la, lo[0], lo[1], 0.00390625f, false);
+            lb = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(lb, lo[2], lo[3], 0.00390625f, false);
+            const int h8 = (int)((unsigned)(unsigned short)ha[0] | ((unsigned)(unsigned short)hb[0] << 16));
+            const int l8 = (int)((unsigned)(unsigned short)la[0] | ((unsigned)(unsigned short)lb[0] << 16));
             unsigned short *dst = buf + ((p / N + 1) * W + (p % N + 1)) * M8_SLOT;
             *reinterpret_cast<f16x4 *>(dst + q * 4) = h;
             *reinterpret_cast<int *>(dst + 32 + q * 2) = h8;
@@ -132,11 +144,12 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const floa
         const i32x4 a = w8ptr(stage, ct)[0], b = w8ptr(stage, ct)[1];
         return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     };
-    // E8M0 block scales.  Lanes 0-31 serve the first fp8 plane of a tap (q8(x_h) with q8(w_l 2^16)), lanes 32-63 the second
-    // (q8(x_l 2^11) with q8(w_h 2^5)): both products carry 2^16, so ONE pair of scales with product 2^-16 serves every block
-    // and lane -- two scalars instead of two per-lane registers
-    static_assert(M8_WL_SHIFT == M8_XL_SHIFT + M8_WH_SHIFT, "the two cross terms must carry the same power of two");
-    const int scale_w = 127 - M8_WL_SHIFT / 2, scale_x = 127 - (M8_WL_SHIFT - M8_WL_SHIFT / 2);
+    // E8M0 block scales.  Lanes 0-31 serve the first fp8 plane of a tap (q8(x_h 2^-3) with q8(w_l 2^(d+11))), lanes 32-63 the
+    // second (q8(x_l 2^8) with q8(w_h 2^d)): both products carry 2^(d+8), so ONE pair of scales serves every block and lane
+    static_assert(M8_XL_SHIFT - M8_XH_SHIFT == 11, "x_l is 2^-11 of x_h: the two cross terms must carry the same power of two");
+    const int wshift = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(wp));      // the layer's weight shift d
+    wp += M8_HEADER;
+    const int scale_x = 127 - 4, scale_w = 127 - (wshift + M8_XL_SHIFT - 4);
     int vscale_w = scale_w, vscale_x = scale_x;      // the asm form takes the scales from VGPRs
     asm volatile("" : "+v"(vscale_w), "+v"(vscale_x));
 
@@ -367,17 +380,27 @@ static inline unsigned short f32_to_f16_bits(float f) {
 
 size_t c6_conv_packed_m8_bytes(int C) {
     const size_t KS = C / 32, WAVES = C / 32;
-    return KS * 10 * WAVES * 2 * 64 * 16 + KS * 5 * WAVES * 2 * 64 * 32;
+    return M8_HEADER + KS * 10 * WAVES * 2 * 64 * 16 + KS * 5 * WAVES * 2 * 64 * 32;
 }
 
 // w: folded OIHW [C][C][3][3] ->
 //   fp16 planes [stage = ks*10 + tap][wave][ct][lane][8] (tap 9 = zeros):   fp16(W[n = wave*32 + ct*16 + (lane & 15)][k = ks*32 + (lane >> 4)*8 + j][tap])
 //   fp8 planes  [ks*5 + pair][wave][ct][lane][32 bytes]:   lane (r, g): tap = 2 pair + (g >> 1) (zeros beyond tap 8),
-//               k = ks*32 + 16 (g & 1) + i;  bytes i = q8(w_l * 2^16), bytes 16 + i = q8(w_h * 2^5)
+//               k = ks*32 + 16 (g & 1) + i;  bytes i = q8(w_l * 2^(d+11)), bytes 16 + i = q8(w_h * 2^d); 16-byte header = int32 d
 void c6_pack_conv_weights_m8(int C, const float *w, unsigned char *packed) {
     const int KS = C / 32, WAVES = C / 32;
-    unsigned short *p16 = reinterpret_cast<unsigned short *>(packed);
-    unsigned char *p8 = packed + (size_t)KS * 10 * WAVES * 2 * 64 * 16;
+    // header: the weight shift d -- the largest power of two that keeps max |w_h| 2^d within fp8 (416 leaves rounding headroom below 448)
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)C * C * 9; i++) wmax = std::fmax(wmax, std::fabs((float)(_Float16)w[i]));
+    int d = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) {
+        d = (int)std::floor(std::log2(416.0f / wmax));
+        d = d < -16 ? -16 : (d > 24 ? 24 : d);
+    }
+    memset(packed, 0, M8_HEADER);
+    memcpy(packed, &d, sizeof(int));
+    unsigned short *p16 = reinterpret_cast<unsigned short *>(packed + M8_HEADER);
+    unsigned char *p8 = packed + M8_HEADER + (size_t)KS * 10 * WAVES * 2 * 64 * 16;
     for (int ks = 0; ks < KS; ks++)
         for (int tap = 0; tap < 10; tap++)      // tap 9: zeros (the B sub-step beside the lone tap 8)
             for (int wave = 0; wave < WAVES; wave++)
@@ -401,8 +424,8 @@ void c6_pack_conv_weights_m8(int C, const float *w, unsigned char *packed) {
                                 const int k = ks * 32 + 16 * (g & 1) + i;
                                 const float x = w[((size_t)n * C + k) * 9 + tap];
                                 const float xh = (float)(_Float16)x, xl = x - xh;
-                                lo = f32_to_e4m3(std::ldexp(xl, M8_WL_SHIFT));
-                                hi = f32_to_e4m3(std::ldexp(xh, M8_WH_SHIFT));
+                                lo = f32_to_e4m3(std::ldexp(xl, d + 11));
+                                hi = f32_to_e4m3(std::ldexp(xh, d));
                             }
                             dst[i] = lo;
                             dst[16 + i] = hi;

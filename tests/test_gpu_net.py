@@ -40,6 +40,32 @@ def test_net_forward_vs_oracle(n, C, blocks, num, prec):
     net.close()
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_net_forward_large_activations(prec):
+    """Activations in the hundreds (stem gain x300; the 1x1 head filters scaled back so that the outputs stay in their sensitive
+    range).  The fp8 planes of the mixed path hold x_h / 8 (range 3584; a plain fp8 conversion turns values above 448 into NaN)
+    and every layer's weights carry their own shift: same 1e-5 as at ordinary magnitudes."""
+    need_gpu()
+    n, C, blocks, num, gain = 19, 128, 3, 3, 300.0
+    cells = n * n
+    blob = rand_blob(n, C, blocks, seed=77).copy()
+    stem_gamma = C * 18 + C
+    blob[stem_gamma:stem_gamma + C] *= gain
+    tower = C * 18 + C + 4 * C + 2 * (blocks - 1) * (C * C * 9 + C + 4 * C)
+    blob[tower:tower + 2 * C] /= gain                                              # policy conv1x1 weights
+    vconv = tower + 2 * C + 2 + 8 + cells * 2 * cells + cells
+    blob[vconv:vconv + C] /= gain                                                  # value conv1x1 weights
+    rng = np.random.default_rng(3)
+    boards = rng.integers(-1, 2, size=(num, n * n)).astype(np.int8)
+    pol, val = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=prec)
+    net = o.Net(n, C, blocks, blob)
+    rp, rv = net.forward(1.0, boards.astype(np.float32))
+    net.close()
+    assert np.isfinite(pol).all() and np.isfinite(val).all()
+    assert 0.05 < np.abs(rv).max() < 0.999 and rp.max() < 0.9                      # not saturated: the comparison means something
+    assert np.abs(pol - rp).max() <= TOL and np.abs(val - rv).max() <= TOL, (np.abs(pol - rp).max(), np.abs(val - rv).max())
+
+
 @pytest.mark.parametrize("variant", ["7", "6", "3"])
 @pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 128, 3, 5), (19, 256, 2, 300), (15, 256, 2, 7)])
 def test_split_conv_variants_vs_oracle(n, C, blocks, num, variant, monkeypatch):

@@ -12,21 +12,25 @@ def e4m3(x):
     return torch.tensor(np.asarray(x, np.float32)).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
 
 
-@pytest.mark.parametrize("C", [64, 128])
-def test_pack_m8_layout_and_rounding(C):
-    rng = np.random.default_rng(C)
+@pytest.mark.parametrize("C,big", [(64, 13.9), (128, 0.11), (64, 700.0)])
+def test_pack_m8_layout_and_rounding(C, big):
+    rng = np.random.default_rng(C + int(big))
     w = (rng.standard_normal((C, C, 3, 3)) * 10.0 ** rng.uniform(-6, -0.5, (C, C, 3, 3))).astype(np.float32)
     w[0, 0, 0, 0] = 0.0
-    w[1, 2, 1, 1] = 13.9        # w_h * 2^5 = 444.8 -> saturates to 448
+    w[1, 2, 1, 1] = big        # sets the layer's weight shift d
     img = pkg.conv_pack_m8(C, w)
     KS = WAVES = C // 32
     n16 = KS * 10 * WAVES * 2 * 64 * 8
-    p16 = img[:n16 * 2].view(np.float16).reshape(KS, 10, WAVES, 2, 64, 8)
-    p8 = img[n16 * 2:].reshape(KS, 5, WAVES, 2, 64, 32)
-    assert img.size == n16 * 2 + p8.size
+    d = int(img[:4].view(np.int32)[0])      # 16-byte header: the largest shift that keeps max |w_h| 2^d below 448 (416 with headroom)
     wt = w.reshape(C, C, 9)
     wh = wt.astype(np.float16)
     wl = wt - wh.astype(np.float32)
+    wmax = float(np.abs(wh.astype(np.float32)).max())
+    assert d == int(np.clip(np.floor(np.log2(416.0 / wmax)), -16, 24)) and (img[4:16] == 0).all()
+    assert wmax * 2.0 ** d <= 416.0 < wmax * 2.0 ** (d + 1) or d in (-16, 24)
+    p16 = img[16:16 + n16 * 2].view(np.float16).reshape(KS, 10, WAVES, 2, 64, 8)
+    p8 = img[16 + n16 * 2:].reshape(KS, 5, WAVES, 2, 64, 32)
+    assert img.size == 16 + n16 * 2 + p8.size
     lane = np.arange(64)
     for ks in range(KS):
         for wave in range(WAVES):
@@ -42,8 +46,8 @@ def test_pack_m8_layout_and_rounding(C):
                     tap = 2 * pair + (g >> 1)                                 # groups 0-1: tap 2 pair, groups 2-3: tap 2 pair + 1
                     ok = tap < 9
                     t = np.minimum(tap, 8)
-                    lo = np.where(ok[:, None], e4m3(np.ldexp(wl[n[:, None], k8, t[:, None]], 16)), 0)
-                    hi = np.where(ok[:, None], e4m3(np.ldexp(wh[n[:, None], k8, t[:, None]].astype(np.float32), 5)), 0)
+                    lo = np.where(ok[:, None], e4m3(np.ldexp(wl[n[:, None], k8, t[:, None]], d + 11)), 0)
+                    hi = np.where(ok[:, None], e4m3(np.ldexp(wh[n[:, None], k8, t[:, None]].astype(np.float32), d)), 0)
                     got = p8[ks, pair, wave, ct]
                     assert (got[:, :16] == lo).all() and (got[:, 16:] == hi).all()
 
