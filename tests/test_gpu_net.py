@@ -22,7 +22,8 @@ PRECISIONS = [pytest.param(1, id="fp32-mfma"), pytest.param(3, id="bf16x3-split"
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
-@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 64, 3, 5), (19, 128, 2, 4), (19, 256, 2, 3), (9, 256, 4, 8), (19, 256, 4, 2)])
+@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 64, 3, 5), (19, 128, 2, 4), (19, 256, 2, 3), (9, 256, 4, 8), (19, 256, 4, 2),
+                                            (19, 256, 8, 2)])      # the last one: BASELINE config 3's tower (stem + 7 blocks)
 def test_net_forward_vs_oracle(n, C, blocks, num, prec):
     need_gpu()
     rng = np.random.default_rng(n * 1000 + C)
