@@ -333,7 +333,7 @@ typedef struct c6_trainer c6_trainer;
 int c6_trainer_create(int board_size, int channels, int blocks, int batch, float lr, float momentum, int device, c6_trainer **out);
 void c6_trainer_destroy(c6_trainer *t);
 int c6_trainer_set_lr(c6_trainer *t, float lr, float momentum);
-/* precision of the 3x3 convolutions of the forward pass and of the input gradient: C6_PREC_BF16X3 (default, the evaluator's
+/* precision of the 3x3 convolutions of the forward pass and of the input gradient: C6_PREC_BF16X3 (the trainer's default, the evaluator's
  * split-bf16 kernels, weight gradient included) or C6_PREC_FP32 (exact-FP32 MFMA everywhere, 2.4x slower; gradient parity with
  * an FP32 framework to ~1e-6). */
 int c6_trainer_set_precision(c6_trainer *t, int precision);
