@@ -152,11 +152,13 @@ __global__ __launch_bounds__(512) void kmix(float *out, int iters, unsigned long
         }
 #pragma unroll
         for (int i = 0; i < NACC; i++) {
-            if (MODE != 2) {
+            if (MODE < 2) {
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc[i], 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a1.v, acc[i], 0, 0, 0);
             }
-            if (MODE != 1) acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pb.v, pa.v, acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            if (MODE == 3) acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pb.v, pa.v, acc[i], 3, 3, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);      // bf6 (e3m2) x bf6
+            else if (MODE == 4) acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pb.v, pa.v, acc[i], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);   // fp4 (e2m1) x fp4
+            else if (MODE != 1) acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pb.v, pa.v, acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -202,6 +204,8 @@ int main(int argc, char **argv) {
     run("MIX 2 f16 + 1 fp8(K128) per 2 units", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((kmix<48, 0>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 48 * 2 * 3 * 16384.0, iters / 4, 2500.0);
     run("f16 16x16x32 only (2 per pair)", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((kmix<48, 1>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 48 * 2 * 16384.0, iters / 4, 2500.0);
     run("fp8 16x16x128 scaled only", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((kmix<48, 2>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 48 * 65536.0, iters / 4, 5000.0);
+    run("bf6 (e3m2) 16x16x128 scaled only", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((kmix<48, 3>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 48 * 65536.0, iters / 4, 10000.0);
+    run("fp4 (e2m1) 16x16x128 scaled only", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((kmix<48, 4>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 48 * 65536.0, iters / 4, 10000.0);
     run("bf16 16x16x32 48acc x3 8w RANDOM", [](float *o, int it, unsigned long long *c) { hipLaunchKernelGGL((kb16s<48, true>), dim3(256), dim3(512), 0, 0, o, it, c); }, 512, 144 * 16384.0, iters / 4, 2500.0);
     return 0;
 }
