@@ -21,6 +21,22 @@ def q8(t):
     return t.float().to(torch.float8_e4m3fn).double()
 
 
+def q6(t, shift):
+    """OCP e3m2 ("bf6": 3 significant bits, normal range 0.25 ... 28, subnormal step 0.0625) of t * 2^shift, returned unscaled;
+    round to nearest even, saturating -- candidate format of the cross terms (the scaled MFMA runs it at 1.54x the fp8 rate)"""
+    x = t.double() * 2.0 ** shift
+    a = x.abs().clamp(max=28.0)
+    e = torch.floor(torch.log2(a.clamp(min=0.25))).clamp(max=4.0)
+    step = 2.0 ** (e - 2.0)
+    q = torch.round(a / step) * step
+    return torch.sign(x) * q.clamp(max=28.0) * 2.0 ** -shift
+
+
+def wshift(w, top):
+    m = float(w.abs().max())
+    return int(np.floor(np.log2(top / m))) if m > 0 else 0
+
+
 def fold(conv, bn):
     s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
     return (conv.weight * s.view(-1, 1, 1, 1)).float(), ((conv.bias - bn.running_mean) * s + bn.bias).float()
@@ -40,6 +56,13 @@ def conv_mode(x, w, mode):
         wh = w.half().float(); wl = w - wh
         c = lambda a, b: F.conv2d(a.double(), b.double(), padding=1)
         return c(xh, wh) + c(q8(xh), q8(wl * 2.0 ** 16)) * 2.0 ** -16 + c(q8(xl * 2.0 ** 11), q8(wh * 2.0 ** 5)) * 2.0 ** -16
+    if mode.startswith("mixed6"):      # fp16 main term + e3m2 cross terms; mode = "mixed6:<x_h shift>"
+        sx = int(mode.split(":")[1])
+        xh = x.half().float(); xl = x - xh
+        wh = w.half().float(); wl = w - wh
+        d = wshift(wh, 24.0)
+        c = lambda a, b: F.conv2d(a.double(), b.double(), padding=1)
+        return c(xh, wh) + c(q6(xh, sx), q6(wl, d + 11)) + c(q6(xl, sx + 11), q6(wh, d))
     raise ValueError(mode)
 
 
@@ -68,7 +91,7 @@ board = torch.tensor(rng.integers(-1, 2, (B, n * n)).astype(np.float64))
 player = torch.tensor(rng.choice([-1.0, 1.0], B))
 ref = forward(player, board, "f32")
 print(f"net {n}x{n}, C={C}, stem + {blocks-1} blocks, {B} boards; |activation| max {ref[2].abs().max():.2f}")
-for mode in ("bf16x3", "mixed"):
+for mode in ("bf16x3", "mixed", "mixed6:0", "mixed6:-2", "mixed6:2"):
     got = forward(player, board, mode)
-    print(f"{mode:7s}: policy max err {float((got[0]-ref[0]).abs().max()):.3e}   value max err {float((got[1]-ref[1]).abs().max()):.3e}   "
+    print(f"{mode:9s}: policy max err {float((got[0]-ref[0]).abs().max()):.3e}   value max err {float((got[1]-ref[1]).abs().max()):.3e}   "
           f"last activation max err {float((got[2]-ref[2]).abs().max()):.3e}")
