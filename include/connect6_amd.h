@@ -142,7 +142,9 @@ enum {
     C6_PREC_F16F8 = 5     /* x_h*w_h on fp16 MFMAs (11-bit significands) + the two cross terms x_h*w_l + x_l*w_h on MX-scaled fp8
                              MFMAs (v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 rate), f32 accumulate: ~2^-15 per product,
                              the accuracy class of C6_PREC_BF16X3 (parity grade: net outputs within 1e-5) at 70 % of its
-                             matrix-pipe cycles */
+                             matrix-pipe cycles.  Range: activations and BatchNorm-folded weights must stay inside fp16
+                             (|v| < 65504; the cross terms are complete up to |activation| 3584, clamped beyond) -- a net that
+                             leaves it wants C6_PREC_BF16X3, which covers the whole FP32 range */
 };
 
 /* policy/alphazero_policy/mod.rs:91-96 HyperParameter + engine geometry */
