@@ -1,21 +1,12 @@
 """Numerics of the candidate mixed-precision product (CPU emulation, PyTorch float64 accumulate):
-    x*w ~= fp16(x)*fp16(w)  +  fp8(xh)*fp8(wl * 2^16)*2^-16  +  fp8(xl * 2^11)*fp8(wh * 2^5) * 2^-16
+    x*w ~= fp16(x)*fp16(w)  +  [fp8(xh / 8)*fp8(wl * 2^(d+11))  +  fp8(xl * 2^8)*fp8(wh * 2^d)] * 2^-(d+8)
 with xh = fp16(x), xl = x - xh, wh = fp16(w), wl = w - wh, fp8 = OCP e4m3 (what v_mfma_scale_f32_16x16x128_f8f6f4 takes;
-the powers of two are its block scales).  Prints the output error of the benchmark-shaped net against float64 and beside the
+the powers of two are its block scales; d = the layer's weight shift, conv_m8.hip).  Prints the output error of the benchmark-shaped net against float64 and beside the
 bf16x3 split's error.    python tools/mixed_err.py [N] [C] [blocks] [boards]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np, torch, torch.nn.functional as F
 import torch_ref as tr
-
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 19
-C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-torch.manual_seed(0)
-m = tr.WeightedPolicy(n, C, blocks).double().eval()
-tr.randomize_bn(m)
-
 
 def q8(t):
     return t.float().to(torch.float8_e4m3fn).double()
@@ -51,11 +42,13 @@ def conv_mode(x, w, mode):
         wh = w.bfloat16().float(); wm = (w - wh).bfloat16().float()
         c = lambda a, b: F.conv2d(a.double(), b.double(), padding=1)
         return c(xh, wh) + c(xh, wm) + c(xm, wh)
-    if mode == "mixed":
+    if mode == "mixed":      # the shipped scheme (conv_m8.hip): q8(x_h / 8) clamped at 3584, q8(x_l 2^8), per-layer weight shift d
         xh = x.half().float(); xl = x - xh
         wh = w.half().float(); wl = w - wh
+        d = wshift(wh, 416.0)
         c = lambda a, b: F.conv2d(a.double(), b.double(), padding=1)
-        return c(xh, wh) + c(q8(xh), q8(wl * 2.0 ** 16)) * 2.0 ** -16 + c(q8(xl * 2.0 ** 11), q8(wh * 2.0 ** 5)) * 2.0 ** -16
+        return (c(xh, wh) + c(q8(xh.clamp(-3584.0, 3584.0) * 2.0 ** -3), q8(wl * 2.0 ** (d + 11))) * 2.0 ** -(d + 8)
+                + c(q8(xl * 2.0 ** 8), q8(wh * 2.0 ** d)) * 2.0 ** -(d + 8))
     if mode.startswith("mixed6"):      # fp16 main term + e3m2 cross terms; mode = "mixed6:<x_h shift>"
         sx = int(mode.split(":")[1])
         xh = x.half().float(); xl = x - xh
@@ -66,7 +59,8 @@ def conv_mode(x, w, mode):
     raise ValueError(mode)
 
 
-def forward(player, board, mode):
+def forward(m, player, board, mode):
+    n = m.n
     n2 = n * n
     with torch.no_grad():
         p = player.view(-1, 1).repeat(1, n2).view(-1, 1, n, n)
@@ -86,12 +80,29 @@ def forward(player, board, mode):
     return pol, v.view(-1), x
 
 
-rng = np.random.default_rng(1)
-board = torch.tensor(rng.integers(-1, 2, (B, n * n)).astype(np.float64))
-player = torch.tensor(rng.choice([-1.0, 1.0], B))
-ref = forward(player, board, "f32")
-print(f"net {n}x{n}, C={C}, stem + {blocks-1} blocks, {B} boards; |activation| max {ref[2].abs().max():.2f}")
-for mode in ("bf16x3", "mixed", "mixed6:0", "mixed6:-2", "mixed6:2"):
-    got = forward(player, board, mode)
-    print(f"{mode:9s}: policy max err {float((got[0]-ref[0]).abs().max()):.3e}   value max err {float((got[1]-ref[1]).abs().max()):.3e}   "
-          f"last activation max err {float((got[2]-ref[2]).abs().max()):.3e}")
+def run(n, C, blocks, B, modes=("bf16x3", "mixed"), seed=0):
+    """{mode: (policy max error, value max error)} against the float64 evaluation of the same float32 net"""
+    torch.manual_seed(seed)
+    m = tr.WeightedPolicy(n, C, blocks).double().eval()
+    tr.randomize_bn(m)
+    rng = np.random.default_rng(1)
+    board = torch.tensor(rng.integers(-1, 2, (B, n * n)).astype(np.float64))
+    player = torch.tensor(rng.choice([-1.0, 1.0], B))
+    ref = forward(m, player, board, "f32")
+    out = {"_max_activation": float(ref[2].abs().max())}
+    for mode in modes:
+        got = forward(m, player, board, mode)
+        out[mode] = (float((got[0] - ref[0]).abs().max()), float((got[1] - ref[1]).abs().max()), float((got[2] - ref[2]).abs().max()))
+    return out
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 19
+    C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+    res = run(n, C, blocks, B, modes=("bf16x3", "mixed", "mixed6:0", "mixed6:-2", "mixed6:2"))
+    print(f"net {n}x{n}, C={C}, stem + {blocks-1} blocks, {B} boards; |activation| max {res['_max_activation']:.2f}")
+    for mode, v in res.items():
+        if not mode.startswith("_"):
+            print(f"{mode:9s}: policy max err {v[0]:.3e}   value max err {v[1]:.3e}   last activation max err {v[2]:.3e}")
