@@ -32,8 +32,8 @@ DROPIN_SYMBOLS = ["cpp_play", "cpp_self_play", "cpp_play_with", "test_new_raw_pa
                   "test_echo_raw_vec", "test_echo_cppeval", "test_cpp_policy"]
 ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_config", "c6_engine_create",
                   "c6_engine_destroy", "c6_net_blob_floats", "c6_engine_load_weights", "c6_engine_set_callback",
-                  "c6_engine_step", "c6_engine_run", "c6_engine_sync", "c6_engine_stats", "c6_engine_fetch_games",
-                  "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
+                  "c6_engine_step", "c6_engine_run", "c6_engine_maintain", "c6_engine_sync", "c6_engine_stats", "c6_engine_fetch_games",
+                  "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_swap_tuple_buffer", "c6_engine_stream", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
                   "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
                   "c6_bench_conv", "c6_bench_board", "c6_bench_board_scan", "c6_conv_pack_m8_bytes", "c6_conv_pack_m8", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
@@ -54,13 +54,15 @@ class Config(C.Structure):
                 ("dirichlet_alpha", C.c_double), ("c_puct", C.c_float), ("seed", C.c_uint64),
                 ("game_uid_base", C.c_uint32), ("game_uid_stride", C.c_uint32), ("evaluator", C.c_int),
                 ("net_channels", C.c_int), ("net_blocks", C.c_int), ("records_per_game", C.c_int), ("recycle", C.c_int),
-                ("stagger", C.c_int), ("device", C.c_int), ("net_chunk_boards", C.c_int), ("net_precision", C.c_int)]
+                ("stagger", C.c_int), ("device", C.c_int), ("net_chunk_boards", C.c_int), ("net_precision", C.c_int),
+                ("max_records_per_game", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rounds", C.c_uint64), ("simulations", C.c_uint64), ("select_steps", C.c_uint64), ("stones", C.c_uint64),
                 ("games_finished", C.c_uint64), ("tuples", C.c_uint64), ("live_games", C.c_uint32),
-                ("overflow_games", C.c_uint32), ("max_records_used", C.c_uint32), ("max_depth", C.c_uint32)]
+                ("overflow_games", C.c_uint32), ("max_records_used", C.c_uint32), ("max_depth", C.c_uint32),
+                ("abandoned_games", C.c_uint64), ("records_per_game", C.c_uint32), ("pool_grows", C.c_uint32)]
 
 
 class RootInfo(C.Structure):
@@ -132,6 +134,7 @@ def lib():
     L.c6_engine_step.argtypes = [C.c_void_p, C.c_int]
     L.c6_engine_run.argtypes = [C.c_void_p, C.c_long]
     L.c6_engine_sync.argtypes = [C.c_void_p]
+    L.c6_engine_maintain.argtypes = [C.c_void_p]
     L.c6_engine_apply_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_last_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -148,6 +151,9 @@ def lib():
     L.c6_tuple_stride.argtypes = [C.c_int]
     L.c6_engine_set_tuple_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.c6_engine_enable_tuples.argtypes = [C.c_void_p, C.c_size_t]
+    L.c6_engine_swap_tuple_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.c6_engine_stream.argtypes = [C.c_void_p]
+    L.c6_engine_stream.restype = C.c_void_p
     L.c6_engine_fetch_tuples.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     L.c6_engine_root.argtypes = [C.c_void_p, C.c_int, C.POINTER(RootInfo), i8p, i32p, f32p, f32p]
     L.c6_engine_profile.argtypes = [C.c_void_p, C.c_int]
@@ -361,7 +367,8 @@ class Engine:
 
     def __init__(self, board_size=15, num_games=1, num_simulation=800, epsilon=0.25, dirichlet_alpha=0.03, c_puct=1.0,
                  seed=0, evaluator=EVAL_RANDOM, net_channels=256, net_blocks=10, records_per_game=0, recycle=False,
-                 stagger=False, device=0, game_uid_base=0, game_uid_stride=0, net_chunk_boards=0, net_precision=PREC_DEFAULT):
+                 stagger=False, device=0, game_uid_base=0, game_uid_stride=0, net_chunk_boards=0, net_precision=PREC_DEFAULT,
+                 max_records_per_game=0):
         L = lib()
         cfg = Config()
         L.c6_default_config(C.byref(cfg))
@@ -371,6 +378,7 @@ class Engine:
         cfg.records_per_game, cfg.recycle, cfg.stagger, cfg.device = records_per_game, int(recycle), int(stagger), device
         cfg.game_uid_base, cfg.game_uid_stride, cfg.net_chunk_boards = game_uid_base, game_uid_stride, net_chunk_boards
         cfg.net_precision = net_precision
+        cfg.max_records_per_game = max_records_per_game
         self.cfg = cfg
         self.n, self.cells, self.G = board_size, board_size * board_size, num_games
         self.h = C.c_void_p()
@@ -412,6 +420,11 @@ class Engine:
     def sync(self):
         _chk(lib().c6_engine_sync(self.h))
 
+    def maintain(self):
+        """synchronise and double the per-game record pools if a game is waiting for space or they pass 3/4 (c6_engine_run does
+        this by itself; callers of step() call it now and then)"""
+        _chk(lib().c6_engine_maintain(self.h))
+
     def last_moves(self):
         """cells chosen in the last move phase: cell, -1 = no move (draw), -2 = the game did not move"""
         p = np.zeros(self.G, np.int32)
@@ -447,6 +460,14 @@ class Engine:
 
     def set_tuple_buffer(self, dev_ptr, capacity, count_dev_ptr):
         _chk(lib().c6_engine_set_tuple_buffer(self.h, C.c_void_p(dev_ptr), capacity, C.c_void_p(count_dev_ptr)))
+
+    def swap_tuple_buffer(self, dev_ptr, capacity, count_dev_ptr):
+        """set_tuple_buffer without draining the engine's stream (double-buffered exchange, shard.TuplePool)"""
+        _chk(lib().c6_engine_swap_tuple_buffer(self.h, C.c_void_p(dev_ptr), capacity, C.c_void_p(count_dev_ptr)))
+
+    def stream_ptr(self):
+        """the engine's HIP stream as an integer (torch.cuda.ExternalStream(ptr))"""
+        return int(lib().c6_engine_stream(self.h) or 0)
 
     def push_tuples(self, replay):
         """device-to-device hand-off of the emitted tuples to a ReplayBuffer"""

@@ -48,6 +48,16 @@ static c6_play_result make_result(int winner, int len, const int16_t *moves, c6_
     return r;
 }
 
+static void print_board(const int8_t *board);
+
+// "{player:?} ({row}, {col}), remain {n}, {s}.{ms} elapsed", agent_impl/mod.rs:147-160 (num_remain: after the decrement,
+// before the reset -- SetResult, game_impl/mod.rs:158-160)
+static void print_stone(int turn, int pos, int remain_before, long long ms) {
+    std::printf("%s (%c, %c), remain %d, %lld.%lld elapsed\n", turn == -1 ? "Black" : "White", 'a' + pos / N, 'A' + pos % N, remain_before - 1,
+                ms / 1000, ms % 1000);
+    std::fflush(stdout);
+}
+
 extern "C" c6_vec cpp_self_play(c6_callback callback, c6_alloc_path alloc_path, c6_alloc_result alloc_result, int num_simulation,
                                 float epsilon, double dirichlet_alpha, float c_puct, bool debug, int num_game_thread) {
     c6_config cfg;
@@ -60,25 +70,63 @@ extern "C" c6_vec cpp_self_play(c6_callback callback, c6_alloc_path alloc_path, 
     cfg.c_puct = c_puct;
     cfg.seed = pick_seed();
     cfg.evaluator = C6_EVAL_CALLBACK;
+    // the reference ABI has no field for the engine's pool sizes: environment knobs (defaults: 4 * num_simulation + 64 records
+    // per game, doubled on demand up to 65000)
+    if (const char *r = std::getenv("C6_RECORDS")) cfg.records_per_game = std::atoi(r);
+    if (const char *r = std::getenv("C6_MAX_RECORDS")) cfg.max_records_per_game = std::atoi(r);
     c6_engine *e = nullptr;
     if (c6_engine_create(&cfg, &e) != C6_OK) die("cpp_self_play: engine");
     c6_engine_set_callback(e, callback);
-    if (c6_engine_run(e, 0) != C6_OK) die("cpp_self_play: run");
     const int G = cfg.num_games;
+    const auto t_start = std::chrono::steady_clock::now();
+    int rc = C6_OK;
+    if (debug && G == 1) {
+        // lib.rs:98-108: one game on the caller's thread through Agent::debug -- the board before every stone, one line per
+        // stone, the final board (agent_impl/mod.rs:126-176).  The engine is stepped one move (= num_simulation rounds) at a time.
+        std::vector<int8_t> board(CELLS, 0), after(CELLS, 0);
+        for (;;) {
+            c6_root_info info;
+            if (c6_engine_root(e, 0, &info, board.data(), nullptr, nullptr, nullptr) != C6_OK) die("cpp_self_play: root");
+            if (info.status != 0) break;
+            print_board(board.data());
+            const auto t0 = std::chrono::steady_clock::now();
+            c6_root_info ai = info;
+            while (rc == C6_OK && ai.status == 0 && ai.stones == info.stones) {      // one move = num_simulation rounds (more calls only
+                rc = c6_engine_run(e, ai.stones == info.stones && ai.nsearch == info.nsearch ? num_simulation : 1);   // after a pool growth)
+                if (rc == C6_OK && c6_engine_root(e, 0, &ai, after.data(), nullptr, nullptr, nullptr) != C6_OK) die("cpp_self_play: root");
+            }
+            if (rc != C6_OK) break;
+            int pos = -1;
+            for (int c = 0; c < CELLS; c++) if (after[c] != board[c]) pos = c;
+            if (pos < 0) break;                         // the policy had no move (agent_impl/mod.rs:135-137) or the game stopped
+            const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            print_stone(info.turn, pos, info.remain, ms);
+        }
+        if (rc == C6_OK) rc = c6_engine_run(e, 0);      // closes the books (flushes a game that stopped in an error state)
+        c6_engine_root(e, 0, nullptr, board.data(), nullptr, nullptr, nullptr);
+        print_board(board.data());
+    } else {
+        rc = c6_engine_run(e, 0);
+    }
+    if (rc == C6_ERR_OVERFLOW) {
+        // The reference has no error channel here (SURVEY 8b "Errors": its unwrap() would abort the process).  The games that
+        // stopped are handed back as they stand -- winner 0, the stones played so far -- and the reason goes to stderr.
+        std::fprintf(stderr, "libconnect6_amd: cpp_self_play: %s\n", c6_last_error());
+    } else if (rc != C6_OK) {
+        die("cpp_self_play: run");
+    }
     std::vector<int> winners(G), lens(G);
     std::vector<int16_t> moves((size_t)G * CELLS);
     int count = 0;
     if (c6_engine_fetch_games(e, G, &count, winners.data(), lens.data(), nullptr, moves.data()) != C6_OK) die("cpp_self_play: fetch");
-    c6_stats st;
-    c6_engine_stats(e, &st);
-    if (st.overflow_games) { c6_engine_destroy(e); die("cpp_self_play: a game overflowed its node pool"); }
+    const long long ms_all = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
     c6_vec v;
     v.len = count;
     v.vec = alloc_result(count);                              // RawVec::with_vec, rawobj/mod.rs:112-123
     for (int i = 0; i < count; i++) {
         v.vec[i] = make_result(winners[i], lens[i], &moves[(size_t)i * CELLS], alloc_path);
-        if (debug)
-            std::printf("run: %d, winner %d, %d stones\n", i, winners[i], lens[i]);   // async_agent/mod.rs:117-124
+        // AsyncAgent::debug, async_agent/mod.rs:117-124 (the games of a call run concurrently in one batch: one clock)
+        if (debug && G > 1) std::printf("run: %d, elapsed %lld.%llds\n", i, ms_all / 1000, ms_all % 1000);
     }
     c6_engine_destroy(e);
     return v;
@@ -94,7 +142,13 @@ extern "C" c6_vec cpp_play(c6_policy_callback callback, c6_alloc_path alloc_path
     std::vector<char> done(G, 0);
     std::vector<int> result(G, 0);
     int live = G;
+    const bool trace = debug && G == 1;      // lib.rs:32-41: one game through Agent::debug
+    const auto t_start = std::chrono::steady_clock::now();
+    auto col0 = [&](int g) { std::vector<int8_t> b(CELLS); for (int c = 0; c < CELLS; c++) b[c] = boards[(size_t)c * G + g]; return b; };
     while (live > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int turn0 = turn[0], remain0 = remain[0];
+        if (trace) print_board(col0(0).data());
         for (int g = 0; g < G; g++) {
             pos[g] = -1;
             if (done[g]) continue;
@@ -122,13 +176,17 @@ extern "C" c6_vec cpp_play(c6_policy_callback callback, c6_alloc_path alloc_path
             }
             if (winner[g] != 0) { result[g] = winner[g]; done[g] = 1; live--; }
         }
+        if (trace && pos[0] >= 0)
+            print_stone(turn0, pos[0], remain0, std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count());
     }
+    if (trace) print_board(col0(0).data());
+    const long long ms_all = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
     c6_vec v;
     v.len = G;
     v.vec = alloc_result(G);
     for (int g = 0; g < G; g++) {
         v.vec[g] = make_result(result[g], (int)hist[g].size(), hist[g].data(), alloc_path);
-        if (debug) std::printf("run: %d, winner %d, %d stones\n", g, result[g], (int)hist[g].size());
+        if (debug && G > 1) std::printf("run: %d, elapsed %lld.%llds\n", g, ms_all / 1000, ms_all % 1000);      // async_agent/mod.rs:117-124
     }
     return v;
 }
@@ -221,9 +279,8 @@ extern "C" c6_play_result cpp_play_with(c6_callback callback, c6_alloc_path allo
         hist.push_back((int16_t)pos);
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
         const int remain_after = info.remain - 1;                // SetResult::num_remain: after the decrement, before the reset
-        std::printf("%s (%c, %c), remain %d, %lld.%lld elapsed\n", info.turn == -1 ? "Black" : "White", 'a' + pos / N, 'A' + pos % N, remain_after,
-                    (long long)(ms / 1000), (long long)(ms % 1000));
-        std::fflush(stdout);
+        (void)remain_after;
+        print_stone(info.turn, pos, info.remain, (long long)ms);
     }
     c6_engine_root(e, 0, nullptr, board.data(), nullptr, nullptr, nullptr);
     print_board(board.data());

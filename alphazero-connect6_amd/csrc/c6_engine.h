@@ -19,16 +19,19 @@ struct C6HtEntry {       // 16 bytes
     uint32_t pad;
 };
 
-#define C6_MAXD 64        // longest select path kept per search
+#define C6_MAXD0 64       // initial capacity of the select path kept per search (C6Dev::maxd; grown with the record pool)
 
-enum { C6_ST_PLAYING = 0, C6_ST_FINISHED = 1, C6_ST_ERROR = 2 };
+// C6_ST_OVERFLOW: the game ran out of records (or of select-path slots) BEFORE anything of the current search was written:
+// once the host has grown the pool (engine.cpp: grow_pool) the game continues exactly where it stopped.
+// C6_ST_ERROR: NaN scores (the reference panics, mod.rs:287) or an illegal stone from outside (Game::set Err).
+enum { C6_ST_PLAYING = 0, C6_ST_FINISHED = 1, C6_ST_ERROR = 2, C6_ST_OVERFLOW = 3 };
 enum { C6_LEAF_NONE = 0, C6_LEAF_EVAL = 1, C6_LEAF_TERMINAL = 2 };
 enum { C6_CNT_SIMS = 0, C6_CNT_SELECT, C6_CNT_STONES, C6_CNT_FINISHED, C6_CNT_TUPLES, C6_CNT_OVERFLOW, C6_CNT_MAXDEPTH,
        C6_CNT_MAXREC, C6_CNT_LIVE, C6_CNT_FETCHQ, C6_CNT_N };
 
 struct C6Dev {
     // geometry / hyper-parameters (policy/alphazero_policy/mod.rs:91-96)
-    int N, cells, cellsP, G, Gpad, S, R, H;
+    int N, cells, cellsP, G, Gpad, S, R, H, maxd;
     float eps, cpuct;
     double alpha, gam_d, gam_c;
     uint32_t seed_lo, seed_hi, uid_base, uid_stride;
@@ -65,7 +68,7 @@ struct C6Dev {
     uint32_t *leaf_sig;    // [G][4]
     int16_t *leaf_level;
     int *path_len;
-    uint16_t *path_rec;    // [G][C6_MAXD]
+    uint16_t *path_rec;    // [G][maxd]
     float *eval_value;     // [G]
     float *eval_prior;     // [G][cells]
     float *img_val;        // [G][8]
@@ -103,6 +106,11 @@ void c6_launch_augment(const C6Dev &d, float *img_boards, hipStream_t s);
 void c6_launch_move_select(const C6Dev &d, hipStream_t s);
 void c6_launch_post_move(const C6Dev &d, hipStream_t s);
 void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s);
+// record-pool growth (engine.cpp grow_pool): `nw` has the new R / H and freshly allocated, zeroed arrays whose [G][R] prefix was
+// copied from `old`; this fills the tails, rebuilds free stacks and tables and re-opens the games that stopped for space
+void c6_launch_grow_fix(const C6Dev &old, const C6Dev &nw, hipStream_t s);
+// games in an error state -> the finished queue as they stand (winner 0, the stones played so far), agent_impl/mod.rs:163
+void c6_launch_flush_errors(const C6Dev &d, hipStream_t s);
 void c6_launch_noise_op(int N, int num, double alpha, double gd, double gc, const uint32_t *k0, const uint32_t *k1,
                         const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise, hipStream_t s);
 void c6_launch_augment_op(int N, int num, const int8_t *boards, const int16_t *aug_map, int8_t *out, hipStream_t s);

@@ -127,6 +127,10 @@ struct DevPool {
         for (void *p : ptrs) hipFree(p);
         ptrs.clear();
     }
+    void free_one(void *p) {
+        auto it = std::find(ptrs.begin(), ptrs.end(), p);
+        if (it != ptrs.end()) { ptrs.erase(it); hipFree(p); }
+    }
 };
 #define ALLOC(p, n)                                     \
     do {                                                \
@@ -334,6 +338,10 @@ struct c6_engine {
     uint64_t rounds = 0;
     int round_in_move = 0;
     unsigned long long fetched = 0;   // finished games already handed to the caller
+    bool desync = false;              // a game resumed after a pool growth: it is out of step with the aligned move rounds,
+                                      // so the move phase runs every round from then on (it only acts on games at S simulations)
+    uint32_t pool_grows = 0;
+    bool grow_failed = false;
 };
 
 extern "C" void c6_default_config(c6_config *cfg) {
@@ -363,6 +371,7 @@ static int engine_alloc(c6_engine *e) {
     d.S = c.num_simulation;
     d.R = c.records_per_game > 0 ? c.records_per_game : 4 * c.num_simulation + 64;
     if (d.R > 65000) return fail(C6_ERR_BAD_ARG, "records_per_game too large (max 65000)");
+    d.maxd = C6_MAXD0;
     int H = 64;
     while (H < 2 * d.R) H <<= 1;
     d.H = H;
@@ -384,7 +393,7 @@ static int engine_alloc(c6_engine *e) {
     ALLOC(d.rec_level, GR); ALLOC(d.rec_sig, GR * 4); ALLOC(d.rec_prior, GR * cells);
     ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.free_stack, GR); ALLOC(d.free_top, G);
     ALLOC(d.leaf_board, (size_t)G * d.cellsP); ALLOC(d.leaf_turn, G); ALLOC(d.leaf_kind, G); ALLOC(d.leaf_key, G);
-    ALLOC(d.leaf_sig, (size_t)G * 4); ALLOC(d.leaf_level, G); ALLOC(d.path_len, G); ALLOC(d.path_rec, (size_t)G * C6_MAXD);
+    ALLOC(d.leaf_sig, (size_t)G * 4); ALLOC(d.leaf_level, G); ALLOC(d.path_len, G); ALLOC(d.path_rec, (size_t)G * d.maxd);
     ALLOC(d.eval_value, G); ALLOC(d.eval_prior, (size_t)G * cells);
     ALLOC(d.move_pos, d.Gpad); ALLOC(d.move_turn, G);
     d.finq_cap = std::max(4 * G, 1024);
@@ -471,6 +480,16 @@ extern "C" int c6_engine_set_tuple_buffer(c6_engine *e, void *dev_buf, size_t ca
     e->d.tuple_count = count_dev;
     return C6_OK;
 }
+
+extern "C" int c6_engine_swap_tuple_buffer(c6_engine *e, void *dev_buf, size_t capacity_records, uint32_t *count_dev) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    e->d.tuple_buf = reinterpret_cast<uint8_t *>(dev_buf);      // C6Dev travels by value with every launch: no drain needed
+    e->d.tuple_cap = capacity_records;
+    e->d.tuple_count = count_dev;
+    return C6_OK;
+}
+
+extern "C" void *c6_engine_stream(c6_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 static int ensure_own_tuples(c6_engine *e, size_t cap) {
     if (e->d.tuple_buf) return C6_OK;
@@ -565,7 +584,7 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
         e->rounds++;
         e->round_in_move++;
         // aligned games all move on the same round; staggered games move a few at a time every round
-        if (e->cfg.stagger || e->round_in_move >= d.S) {
+        if (e->cfg.stagger || e->desync || e->round_in_move >= d.S) {
             Scoped t(&e->t_move, e->stream, e->profiling);
             c6_launch_move_select(d, e->stream);
             c6_launch_board_step(d.N, d.Gpad, d.board_soa, d.turn, d.remain, d.move_pos, d.winner, d.err, e->stream);
@@ -615,33 +634,151 @@ extern "C" int c6_engine_sync(c6_engine *e) {
     return C6_OK;
 }
 
-static int live_games(c6_engine *e, int *live, int *errors) {
+static int live_games(c6_engine *e, int *live, int *errors, int *overflow = nullptr) {
     std::vector<int8_t> st(e->d.G);
     HIPCHK(hipMemcpyAsync(st.data(), e->d.status, e->d.G, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    int l = 0, er = 0;
-    for (int8_t s : st) { l += s == C6_ST_PLAYING; er += s == C6_ST_ERROR; }
+    int l = 0, er = 0, ov = 0;
+    for (int8_t s : st) { l += s == C6_ST_PLAYING; er += s == C6_ST_ERROR; ov += s == C6_ST_OVERFLOW; }
     *live = l;
-    *errors = er;
+    *errors = er + ov;
+    if (overflow) *overflow = ov;
     return C6_OK;
+}
+
+// ---- record-pool growth -------------------------------------------------------------------------------------------
+// The reference's HashMap<u64, Node> grows without limit (alphazero_policy/mod.rs:186-190, 360-377); the engine's per-game
+// pool of R expanded-node records is a device allocation.  When a game runs out (status C6_ST_OVERFLOW: it stopped BEFORE
+// writing anything of the search it could not finish) or the high-water mark passes 3/4 of R, the host doubles R (and the
+// select-path capacity): new arrays, every game's prefix copied with one strided copy per array, free stacks / tables
+// rebuilt on the device, stopped games re-opened.  Results are unchanged -- a record's index is never observable.
+template <typename T> static int grow_array(DevPool &pool, T **arr, int G, size_t old_row, size_t new_row, std::vector<void *> &fresh,
+                                            std::vector<void *> &stale) {
+    T *n = nullptr;
+    int rc = pool.alloc(&n, (size_t)G * new_row);
+    if (rc != C6_OK) return rc;
+    fresh.push_back(n);
+    hipError_t he = hipMemcpy2D(n, new_row * sizeof(T), *arr, old_row * sizeof(T), old_row * sizeof(T), (size_t)G, hipMemcpyDeviceToDevice);
+    if (he != hipSuccess) return fail(C6_ERR_HIP, std::string("grow copy: ") + hipGetErrorString(he));
+    stale.push_back(*arr);
+    *arr = n;
+    return C6_OK;
+}
+
+static int grow_pool(c6_engine *e) {
+    C6Dev &d = e->d;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int maxR = e->cfg.max_records_per_game > 0 ? std::min(65000, e->cfg.max_records_per_game) : 65000;
+    if (d.R >= maxR) { e->grow_failed = true; return fail(C6_ERR_OVERFLOW, "record pool is at its maximum (max_records_per_game / 65000 records per game)"); }
+    const C6Dev old = d;
+    C6Dev nw = d;
+    nw.R = std::min(maxR, 2 * d.R);
+    nw.maxd = std::min(8192, 2 * d.maxd);
+    int H = 64;
+    while (H < 2 * nw.R) H <<= 1;
+    nw.H = H;
+    const int G = d.G, cells = d.cells;
+    DevPool &pool = e->pool;
+    {   // old and new pools live side by side during the copy
+        size_t fr = 0, tot = 0;
+        hipMemGetInfo(&fr, &tot);
+        const size_t need = (size_t)G * nw.R * ((size_t)cells * 4 + 64) + (size_t)G * nw.H * sizeof(C6HtEntry);
+        if (need + ((size_t)256 << 20) > fr) { e->grow_failed = true; return fail(C6_ERR_OVERFLOW, "not enough device memory to grow the record pool"); }
+    }
+    std::vector<void *> fresh, stale;
+    uint16_t *nfs = nullptr;
+    C6HtEntry *nht = nullptr;
+    int rc;
+    if ((rc = grow_array(pool, &nw.rec_prior, G, (size_t)old.R * cells, (size_t)nw.R * cells, fresh, stale)) ||
+        (rc = grow_array(pool, &nw.rec_key, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_visit, G, old.R, nw.R, fresh, stale)) ||
+        (rc = grow_array(pool, &nw.rec_value, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_qsum, G, old.R, nw.R, fresh, stale)) ||
+        (rc = grow_array(pool, &nw.rec_q, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_level, G, old.R, nw.R, fresh, stale)) ||
+        (rc = grow_array(pool, &nw.rec_sig, G, (size_t)old.R * 4, (size_t)nw.R * 4, fresh, stale)) ||
+        (rc = grow_array(pool, &nw.path_rec, G, old.maxd, nw.maxd, fresh, stale)) ||
+        (rc = pool.alloc(&nfs, (size_t)G * nw.R)) || (rc = pool.alloc(&nht, (size_t)G * nw.H))) {
+        for (void *p : fresh) pool.free_one(p);      // the engine keeps running on the old, untouched pool
+        if (nfs) pool.free_one(nfs);
+        if (nht) pool.free_one(nht);
+        e->grow_failed = true;
+        return rc;
+    }
+    // free stack and table are rebuilt from the old ones by the device (c6_grow_fix_kernel)
+    nw.free_stack = nfs;
+    nw.ht = nht;
+    c6_launch_grow_fix(old, nw, e->stream);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (void *p : stale) pool.free_one(p);
+    pool.free_one(old.free_stack);
+    pool.free_one(old.ht);
+    d = nw;
+    e->pool_grows++;
+    if (!e->cfg.stagger) e->desync = true;
+    return C6_OK;
+}
+
+// grow when a game has stopped for space or the pools are filling up; C6_OK also when there was nothing to do
+static int maintain(c6_engine *e, int overflowed) {
+    C6Dev &d = e->d;
+    if (e->grow_failed) return C6_OK;
+    bool want = overflowed > 0;
+    if (!want) {
+        std::vector<uint32_t> mr(d.G);
+        HIPCHK(hipMemcpy(mr.data(), d.g_maxrec, (size_t)d.G * 4, hipMemcpyDeviceToHost));
+        uint32_t hi = 0;
+        for (uint32_t v : mr) hi = std::max(hi, v);
+        want = (size_t)hi * 4 > (size_t)d.R * 3;
+        if (want) {      // g_maxrec is a high-water mark since the game's reset: grow only if the pool is that full NOW
+            std::vector<int> ft(d.G);
+            HIPCHK(hipMemcpy(ft.data(), d.free_top, (size_t)d.G * 4, hipMemcpyDeviceToHost));
+            int lo = d.R;
+            for (int v : ft) lo = std::min(lo, v);
+            want = (size_t)(d.R - lo) * 4 > (size_t)d.R * 3;
+        }
+    }
+    if (!want) return C6_OK;
+    int rc = grow_pool(e);
+    if (rc != C6_OK && !e->grow_failed) return rc;
+    return C6_OK;
+}
+
+extern "C" int c6_engine_maintain(c6_engine *e) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    int live = 0, errs = 0, ov = 0;
+    int rc = live_games(e, &live, &errs, &ov);
+    if (rc != C6_OK) return rc;
+    return maintain(e, ov);
 }
 
 extern "C" int c6_engine_run(c6_engine *e, long max_rounds) {
     if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
     long done = 0;
+    int errs = 0;
     for (;;) {
-        int live = 0, errs = 0;
-        int rc = live_games(e, &live, &errs);
+        int live = 0, ov = 0;
+        int rc = live_games(e, &live, &errs, &ov);
         if (rc != C6_OK) return rc;
+        rc = maintain(e, ov);
+        if (rc != C6_OK) return rc;
+        if (ov > 0 && !e->grow_failed) continue;      // re-opened games: count them as live
         if (live == 0) break;
         if (max_rounds > 0 && done >= max_rounds) break;
-        int chunk = e->cfg.stagger ? std::min(e->d.S, 64) : e->d.S - e->round_in_move;
+        int chunk = (e->cfg.stagger || e->desync) ? std::min(e->d.S, 64) : e->d.S - e->round_in_move;
         if (max_rounds > 0) chunk = (int)std::min<long>(chunk, max_rounds - done);
         rc = c6_engine_step(e, chunk);
         if (rc != C6_OK) return rc;
         done += chunk;
     }
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (errs > 0 && !(max_rounds > 0 && done >= max_rounds)) {
+        // never silently: the stopped games leave as partial results (winner 0, stones so far) and the call says so
+        c6_launch_flush_errors(e->d, e->stream);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        char msg[160];
+        snprintf(msg, sizeof msg, "%d game(s) stopped in an error state (record pool exhausted or NaN scores); they are returned as "
+                 "partial games with winner 0", errs);
+        return fail(C6_ERR_OVERFLOW, msg);
+    }
     return C6_OK;
 }
 
@@ -673,7 +810,10 @@ extern "C" int c6_engine_stats(c6_engine *e, c6_stats *out) {
     out->games_finished = c[C6_CNT_FINISHED];
     out->tuples = c[C6_CNT_TUPLES];
     out->live_games = (uint32_t)live;
-    out->overflow_games = (uint32_t)errs;
+    out->overflow_games = (uint32_t)errs + (uint32_t)c[C6_CNT_OVERFLOW];   // stopped now + abandoned / flushed so far: 0 means none was lost
+    out->abandoned_games = c[C6_CNT_OVERFLOW];
+    out->records_per_game = (uint32_t)e->d.R;
+    out->pool_grows = e->pool_grows;
     out->max_records_used = (uint32_t)c[C6_CNT_MAXREC];
     out->max_depth = (uint32_t)c[C6_CNT_MAXDEPTH];
     return C6_OK;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     while (p >= 0) {
         const int nchild = cells - level;
         if (nchild == 0) break;                 // cannot happen: full boards are never records
-        if (d >= C6_MAXD) { kind = -1; break; } // path overflow
+        if (d >= E.maxd) { kind = -2; break; }  // path overflow: nothing written yet, the host grows the path buffer
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const float *prior = E.rec_prior + (rbase + p) * (size_t)cells;
 
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
 #pragma unroll
         for (int j = 0; j < J; j++) if (j == cj) child = cidx[j];
         child = __shfl(child, cl, 64);
-        if (lane == 0) E.path_rec[(size_t)g * C6_MAXD + d] = (uint16_t)p;
+        if (lane == 0) E.path_rec[(size_t)g * E.maxd + d] = (uint16_t)p;
         d++;
         key ^= zk[chosen];
         const uint32_t c1 = (uint32_t)chosen + 1u;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     }
     if (lane == 0) {
         if (kind < 0) {   // overflow / NaN: stop this game, reported through status
-            E.status[g] = C6_ST_ERROR;
+            E.status[g] = kind == -2 ? C6_ST_OVERFLOW : C6_ST_ERROR;
             E.leaf_kind[g] = C6_LEAF_NONE;
         } else {
             E.leaf_kind[g] = (int8_t)kind;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
     const int sim_in_move = E.sim_in_move[g];
     const unsigned long long gsims = E.g_sims[g];
     const uint32_t maxrec = E.g_maxrec[g];
-    const int my_path = E.path_rec[(size_t)g * C6_MAXD + (lane < C6_MAXD ? lane : 0)];
+    const int my_path = E.path_rec[(size_t)g * E.maxd + (lane < E.maxd ? lane : 0)];
     if (kind == C6_LEAF_NONE) return;
     float value;
 
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
         value = w == turn ? cost : (w != 0 ? -cost : 0.f);
     } else {
         // allocate the record of the newly expanded node (every lane reads the same stack slot)
-        if (top <= 0) {
-            if (lane == 0) E.status[g] = C6_ST_ERROR;
+        if (top <= 0) {      // pool exhausted; nothing of this search has been written: resumable after grow_pool
+            if (lane == 0) E.status[g] = C6_ST_OVERFLOW;
             return;
         }
         const int idx = E.free_stack[rbase + top - 1];
@@ -414,20 +414,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
             }
         }
         if (lane == 0) E.rec_level[rbase + idx] = (int16_t)level;   // after the scan: Q never matches itself
-        if (lane == 0) E.rec_level[rbase + idx] = (int16_t)level;   // after the scan: Q never matches itself
     }
 
-    // update, mod.rs:386-408 (one-level backup): lane i owns the path's i-th record
-    if (lane < len) {
-        const int r = my_path;
-        const int v = E.rec_visit[rbase + r] + 1;
-        float qs = E.rec_qsum[rbase + r];
-        if (lane == len - 1) {      // the leaf's parent receives the value
-            qs = qs + value;
-            E.rec_qsum[rbase + r] = qs;
+    // update, mod.rs:386-408 (one-level backup): lane i owns the path's i-th record (paths beyond 64 steps: further passes)
+    for (int base = 0; base < len; base += 64) {
+        const int i = base + lane;
+        if (i < len) {
+            const int r = base == 0 ? my_path : (int)E.path_rec[(size_t)g * E.maxd + i];
+            const int v = E.rec_visit[rbase + r] + 1;
+            float qs = E.rec_qsum[rbase + r];
+            if (i == len - 1) {      // the leaf's parent receives the value
+                qs = qs + value;
+                E.rec_qsum[rbase + r] = qs;
+            }
+            E.rec_visit[rbase + r] = v;
+            E.rec_q[rbase + r] = qs / (float)v;   // recalc_q :77-79
         }
-        E.rec_visit[rbase + r] = v;
-        E.rec_q[rbase + r] = qs / (float)v;   // recalc_q :77-79
     }
     if (lane == 0) {
         E.nsearch[g] = nsearch + 1;
@@ -549,7 +551,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= E.G) return;
     const int pos = E.move_pos[g];
-    if (pos == -2) return;
+    if (pos == -2) {
+        // steady-state mode: a slot whose game stopped in an error state (pool exhausted with no host to grow it, NaN scores)
+        // is abandoned -- counted, never silently -- and starts the next game
+        const int stt = E.status[g];
+        if (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW)) {
+            const uint32_t uid_ = E.game_uid[g];
+            if (lane == 0) atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull);
+            reset_game_wave(E, g, lane, uid_ + E.uid_stride, 0);
+        }
+        return;
+    }
     const int cells = E.cells;
     const size_t rbase = (size_t)g * E.R;
     const int old_level = E.nstones[g];
@@ -683,6 +695,60 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
 __global__ void c6_stagger_kernel(C6Dev E) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < E.G) E.sim_in_move[g] = g % E.S;
+}
+
+// ---- record-pool growth ---------------------------------------------------------------------
+// Host side (engine.cpp grow_pool) allocated arrays for N.R > O.R records per game and copied every game's [0, O.R) prefix.
+// Here: the new records are free (level -1) and go UNDER the old free stack (old free indices are handed out first), the
+// table is rebuilt at its new size from the live records, and a game that had stopped for space plays on -- its interrupted
+// search had written nothing (select: before the path store; expand: before the pop), so it is repeated identically.
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_grow_fix_kernel(C6Dev O, C6Dev Nw) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= Nw.G) return;
+    const size_t ob = (size_t)g * O.R, nb = (size_t)g * Nw.R;
+    const int add = Nw.R - O.R, top = O.free_top[g];
+    for (int r = O.R + lane; r < Nw.R; r += 64) Nw.rec_level[nb + r] = -1;
+    for (int i = lane; i < add; i += 64) Nw.free_stack[nb + i] = (uint16_t)(Nw.R - 1 - i);       // bottom of the stack: pops O.R, O.R+1, ... last
+    for (int i = lane; i < top; i += 64) Nw.free_stack[nb + add + i] = O.free_stack[ob + i];
+    C6HtEntry *ht = Nw.ht + (size_t)g * Nw.H;
+    for (int i = lane; i < Nw.H; i += 64) { ht[i].key = 0ull; ht[i].idx1 = 0; }
+    __threadfence_block();
+    const int hi = O.rec_hi[g];
+    for (int r = lane; r < hi; r += 64)
+        if (Nw.rec_level[nb + r] >= 0) ht_insert(ht, Nw.H, Nw.rec_key[nb + r], r);
+    if (lane == 0) {
+        Nw.free_top[g] = top + add;
+        if (Nw.status[g] == C6_ST_OVERFLOW) Nw.status[g] = C6_ST_PLAYING;
+    }
+}
+void c6_launch_grow_fix(const C6Dev &old, const C6Dev &nw, hipStream_t s) {
+    hipLaunchKernelGGL(c6_grow_fix_kernel, dim3((nw.G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(64 * WAVES_PER_BLOCK), 0, s, old, nw);
+}
+
+// Games that stopped in an error state leave as they stand: PlayResult{winner None, the path so far} -- what a caller of the
+// reference would hold had Agent::play returned its Err (agent_impl/mod.rs:163) instead of the bindings' unwrap().
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_flush_errors_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G) return;
+    const int stt = E.status[g];
+    if (stt != C6_ST_ERROR && stt != C6_ST_OVERFLOW) return;
+    const int nst = E.nstones[g];
+    int slot = -1;
+    if (lane == 0) {
+        slot = (int)atomicAdd(&E.counters[C6_CNT_FETCHQ], 1ull);
+        atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull);
+    }
+    slot = __shfl(slot, 0, 64);
+    if (slot < E.finq_cap) {
+        if (lane == 0) { E.fin_winner[slot] = 0; E.fin_len[slot] = nst; E.fin_uid[slot] = E.game_uid[g]; }
+        for (int k = lane; k < nst; k += 64) E.fin_moves[(size_t)slot * E.cells + k] = (int16_t)E.moves[(size_t)g * E.cells + k];
+    }
+    if (lane == 0) { E.status[g] = C6_ST_FINISHED; E.winner[g] = 0; }
+}
+void c6_launch_flush_errors(const C6Dev &d, hipStream_t s) {
+    hipLaunchKernelGGL(c6_flush_errors_kernel, dim3((d.G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
 }
 
 static inline int wave_grid(int G) { return (G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }

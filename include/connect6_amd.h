@@ -168,6 +168,7 @@ typedef struct c6_config {
     int device;              /* HIP device ordinal */
     int net_chunk_boards;    /* 0: automatic; boards (dihedral images) per net pass */
     int net_precision;       /* C6_PREC_*: arithmetic of the 3x3 convolutions (everything else is FP32) */
+    int max_records_per_game;/* 0: 65000.  Ceiling for the automatic growth of records_per_game (c6_engine_run / c6_engine_maintain) */
 } c6_config;
 
 typedef struct c6_engine c6_engine;
@@ -189,8 +190,16 @@ int c6_engine_set_callback(c6_engine *e, c6_callback cb);
  * a game whose simulation count reaches num_simulation makes its move (mod.rs:464-489 +
  * agent/agent_impl/mod.rs:131-171).  Asynchronous on the engine's stream unless noted. */
 int c6_engine_step(c6_engine *e, int rounds);
-/* step until every game has finished (recycle == 0) or max_rounds; synchronous */
+/* step until every game has finished (recycle == 0) or max_rounds; synchronous.  The reference's node map grows without limit
+ * (alphazero_policy/mod.rs:186-190); here the per-game record pool is doubled whenever a game runs out or the pools pass 3/4
+ * (a stopped game resumes exactly where it was).  If that is impossible (65 000 records per game, or device memory), or a game
+ * produced NaN scores, the call returns C6_ERR_OVERFLOW -- after all other games have finished -- and those games are in the
+ * finished queue as PARTIAL results: winner 0, the stones played so far. */
 int c6_engine_run(c6_engine *e, long max_rounds);
+/* c6_engine_step never synchronises, so it cannot grow the pools: a game that runs out there waits in status overflow (in
+ * recycle mode its slot is abandoned at the next move round: c6_stats.abandoned_games).  Callers that drive the engine with
+ * c6_engine_step call this every now and then (it synchronises): grows the pools when a game is waiting or they pass 3/4. */
+int c6_engine_maintain(c6_engine *e);
 int c6_engine_sync(c6_engine *e);
 
 typedef struct c6_stats {
@@ -204,6 +213,9 @@ typedef struct c6_stats {
     uint32_t overflow_games;
     uint32_t max_records_used;
     uint32_t max_depth;
+    uint64_t abandoned_games;  /* games given up in an error state (recycled slots, or flushed as partial results by c6_engine_run) */
+    uint32_t records_per_game; /* current capacity R of a game's record pool (grows, see c6_engine_maintain) */
+    uint32_t pool_grows;       /* times the pool was doubled */
 } c6_stats;
 int c6_engine_stats(c6_engine *e, c6_stats *out); /* synchronises */
 
@@ -221,6 +233,14 @@ int c6_engine_fetch_games(c6_engine *e, int cap, int *count, int *winners, int *
 size_t c6_tuple_stride(int board_size);
 int c6_engine_set_tuple_buffer(c6_engine *e, void *dev_buf, size_t capacity_records, uint32_t *count_dev);
 int c6_engine_enable_tuples(c6_engine *e, size_t capacity_records); /* engine-owned tuple buffer */
+/* The same as c6_engine_set_tuple_buffer WITHOUT draining the engine's stream: rounds enqueued before the call keep writing the
+ * old buffer, rounds enqueued after it write the new one (the buffer travels with each launch).  With c6_engine_stream this is
+ * what a double-buffered exchange needs (alphazero-connect6_amd/shard.py TuplePool: the retired buffer is all-gathered on a
+ * side stream while the engine plays on) -- the caller orders the streams with events. */
+int c6_engine_swap_tuple_buffer(c6_engine *e, void *dev_buf, size_t capacity_records, uint32_t *count_dev);
+/* the HIP stream (hipStream_t as void*) every engine launch goes to: record / wait events on it to order other streams against
+ * the engine's rounds without a host synchronisation */
+void *c6_engine_stream(c6_engine *e);
 int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, void *host_buf); /* copies + resets */
 
 /* inspection for parity tests: the root of game `g`, synchronises.

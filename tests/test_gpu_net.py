@@ -134,6 +134,30 @@ def test_net_forward_vs_torch_golden(prec):
     assert np.abs(pol - z["policy"]).max() <= TOL and np.abs(val - z["value"]).max() <= TOL
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_net_forward_vs_torch_fp64_at_baseline_shape(prec):
+    """HIP <-> PyTorch DIRECTLY at BASELINE config 2's net (19x19, C = 256, stem + 3 residual blocks): tests/torch_ref.py's
+    restatement of model.hpp:9-95 on PyTorch's own CPU kernels in float64, built live (no 15 MB fixture), seeded weights with
+    non-trivial BatchNorm statistics, against every parity-grade arithmetic at 1e-5."""
+    need_gpu()
+    import torch
+    import torch_ref as tr
+    n, C, blocks, num = 19, 256, 4, 2
+    torch.manual_seed(1234)
+    m = tr.WeightedPolicy(n, C, blocks)
+    tr.randomize_bn(m)
+    blob = tr.blob_of(m)
+    rng = np.random.default_rng(11)
+    boards = rng.integers(-1, 2, size=(num, n * n)).astype(np.int8)
+    player = np.array([1, -1], np.int8)
+    m = m.double().eval()
+    with torch.no_grad():
+        rp, rv = m(torch.from_numpy(player.astype(np.float64)), torch.from_numpy(boards.astype(np.float64)))
+    rp, rv = rp.numpy(), rv.numpy().reshape(-1)
+    pol, val = pkg.net_forward(n, C, blocks, blob, boards, player, precision=prec)
+    assert np.abs(pol - rp).max() <= TOL and np.abs(val - rv).max() <= TOL, (np.abs(pol - rp).max(), np.abs(val - rv).max())
+
+
 def test_split_path_agrees_with_fp32_path_at_benchmark_shape():
     """19x19, C = 256: the bf16x3 split path and the exact-FP32 MFMA path agree to the 1e-5 bar (the split error is
     relative, <= 3 * 2^-16 per product, and shrinks by 1/sqrt(K) in the 2304-term sums)"""
