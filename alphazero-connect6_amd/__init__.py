@@ -23,15 +23,20 @@ LIB_PATH = os.environ.get("C6_LIB_PATH") or os.path.join(_HERE, "libconnect6_amd
 BLACK, NONE, WHITE = -1, 0, 1
 EVAL_RANDOM, EVAL_UNIFORM, EVAL_NET, EVAL_CALLBACK = 1, 2, 3, 4
 OK, ERR_NO_GPU, ERR_BAD_ARG, ERR_OVERFLOW, ERR_HIP, ERR_INVALID_POSITION, ERR_ALREADY_SET = range(7)
+# arithmetic of the 3x3 convolutions (include/connect6_amd.h C6_PREC_*).  DEFAULT = FP32: f32 like the reference net, evaluated as
+# Winograd F(2x2,3x3) on the FP32 matrix cores; FP32_DIRECT: the same arithmetic as a direct implicit GEMM
 PREC_DEFAULT, PREC_FP32, PREC_BF16X3, PREC_BF16 = 0, 1, 3, 4      # PREC_BF16: relaxed tolerance (~1e-3), not parity grade
-PREC_F16F8 = 5      # fp16 main term + MX-fp8 cross terms: parity grade (1e-5), 70 % of the bf16 split's matrix-pipe cycles
+PREC_F16F8 = 5      # opt-in: fp16 main term + MX-fp8 cross terms, bounded range (guarded: C6_ERR_RANGE)
+PREC_FP32_DIRECT = 6
+ERR_OVERFLOW, ERR_RANGE = 3, 7
 REF_N = 15
 
 DROPIN_SYMBOLS = ["cpp_play", "cpp_self_play", "cpp_play_with", "test_new_raw_path", "test_with_raw_path",
                   "test_echo_raw_path", "test_with_raw_play_result", "test_echo_raw_play_result", "test_with_raw_vec",
                   "test_echo_raw_vec", "test_echo_cppeval", "test_cpp_policy"]
 ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_config", "c6_engine_create",
-                  "c6_engine_destroy", "c6_net_blob_floats", "c6_engine_load_weights", "c6_engine_set_callback",
+                  "c6_engine_destroy", "c6_net_blob_floats", "c6_net_blob_header_floats", "c6_net_blob_write_header",
+                  "c6_net_blob_check_header", "c6_engine_load_weights", "c6_engine_set_callback",
                   "c6_engine_step", "c6_engine_run", "c6_engine_maintain", "c6_engine_sync", "c6_engine_stats", "c6_engine_fetch_games",
                   "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_swap_tuple_buffer", "c6_engine_stream", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
@@ -129,6 +134,9 @@ def lib():
     L.c6_engine_destroy.argtypes = [C.c_void_p]
     L.c6_net_blob_floats.restype = C.c_size_t
     L.c6_net_blob_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.c6_net_blob_header_floats.restype = C.c_size_t
+    L.c6_net_blob_write_header.argtypes = [f32p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    L.c6_net_blob_check_header.argtypes = [f32p, C.c_size_t, C.c_int, C.c_int, C.c_int]
     L.c6_engine_load_weights.argtypes = [C.c_void_p, f32p, C.c_size_t]
     L.c6_engine_set_callback.argtypes = [C.c_void_p, CALLBACK]
     L.c6_engine_step.argtypes = [C.c_void_p, C.c_int]
@@ -788,11 +796,116 @@ def net_forward(n, channels, blocks, blob, boards, player, precision=PREC_DEFAUL
     return pol, val
 
 
-def bench_conv(n, channels, nboards, iters=3, variant=1, ablate=0, with_residual=0):
-    """average ms of one 3x3 conv launch on random data (development / profiling hook)"""
+def bench_conv(n, channels, nboards, iters=3, precision=PREC_FP32, with_residual=0):
+    """average ms of one 3x3 conv launch of a PREC_* arithmetic on random data (development / profiling hook)"""
     ms = C.c_double()
-    _chk(lib().c6_bench_conv(n, channels, nboards, iters, variant, ablate, with_residual, C.byref(ms)))
+    _chk(lib().c6_bench_conv(n, channels, nboards, iters, precision, 0, with_residual, C.byref(ms)))
     return ms.value
+
+
+def blob_floats(n, channels, blocks):
+    return int(lib().c6_net_blob_floats(n, channels, blocks))
+
+
+def _blob_names(blocks):
+    """tensor names of WeightedPolicy (AlphaZero/cpp_weighted/model.hpp:10-50) in BLOB order = forward order, each BatchNorm's
+    running statistics right behind its affine parameters.  (libtorch's registration order differs: heads before the tower,
+    buffers listed separately -- which is why the blob is assembled by name.)"""
+    def bn(p):
+        return [p + ".weight", p + ".bias", p + ".running_mean", p + ".running_var"]
+    names = ["conv.weight", "conv.bias"] + bn("norm")
+    for i in range(blocks - 1):
+        for j in range(2):
+            names += [f"conv{i}_{j}.weight", f"conv{i}_{j}.bias"] + bn(f"norm{i}_{j}")
+    names += ["policy_conv.weight", "policy_conv.bias"] + bn("policy_norm") + ["policy_linear.weight", "policy_linear.bias"]
+    names += ["value_conv.weight", "value_conv.bias"] + bn("value_norm")
+    names += ["value_linear1.weight", "value_linear1.bias", "value_linear2.weight", "value_linear2.bias"]
+    return names
+
+
+def blob_from_state_dict(sd, n, channels, blocks, header=True):
+    """Weight blob for Engine.load_weights / Trainer.load_weights from a state_dict of the reference's WeightedPolicy
+    (model.hpp:10-50; names as its register_module calls: conv, norm, conv{i}_{j}, norm{i}_{j}, policy_*, value_*).
+    `sd`: mapping name -> array-like (torch tensors, numpy arrays; a torch.load()-ed / torch.jit-exported state_dict works as it
+    is).  Tensors are looked up BY NAME and shape-checked, so a re-ordered state_dict cannot produce a permuted blob.
+    Aliases: ModuleList-style names tower.{i}.{0,1,2,3}.* (tests/torch_ref.py) are accepted too.
+    header=True prepends the 8-float self-describing header (geometry + checksum) that load_weights verifies."""
+    cells = n * n
+    C_ = channels
+    shapes = {"conv.weight": (C_, 2, 3, 3), "policy_conv.weight": (2, C_, 1, 1), "policy_linear.weight": (cells, 2 * cells),
+              "value_conv.weight": (1, C_, 1, 1), "value_linear1.weight": (256, cells), "value_linear2.weight": (1, 256),
+              "conv.bias": (C_,), "policy_conv.bias": (2,), "policy_linear.bias": (cells,), "value_conv.bias": (1,),
+              "value_linear1.bias": (256,), "value_linear2.bias": (1,)}
+    for p_, k in (("norm", C_), ("policy_norm", 2), ("value_norm", cells)):
+        for f in ("weight", "bias", "running_mean", "running_var"):
+            shapes[f"{p_}.{f}"] = (k,)
+    for i in range(blocks - 1):
+        for j in range(2):
+            shapes[f"conv{i}_{j}.weight"] = (C_, C_, 3, 3)
+            shapes[f"conv{i}_{j}.bias"] = (C_,)
+            for f in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"norm{i}_{j}.{f}"] = (C_,)
+
+    def alias(name):
+        import re
+        m = re.match(r"(conv|norm)(\d+)_(\d+)\.(.*)", name)
+        if m:
+            kind, i, j, f = m.group(1), int(m.group(2)), int(m.group(3)), m.group(4)
+            return f"tower.{i}.{2 * j + (0 if kind == 'conv' else 1)}.{f}"
+        return None
+
+    parts = []
+    for name in _blob_names(blocks):
+        t = sd.get(name) if hasattr(sd, "get") else None
+        if t is None and alias(name) is not None:
+            t = sd.get(alias(name))
+        if t is None:
+            raise C6Error(f"state_dict lacks {name}")
+        a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+        if tuple(a.shape) != shapes[name]:
+            raise C6Error(f"{name}: shape {tuple(a.shape)}, expected {shapes[name]}")
+        parts.append(np.ascontiguousarray(a, dtype=np.float32).reshape(-1))
+    payload = np.concatenate(parts)
+    assert payload.size == blob_floats(n, channels, blocks)
+    return add_blob_header(payload, n, channels, blocks) if header else payload
+
+
+def add_blob_header(payload, n, channels, blocks):
+    """payload (blob_floats floats) -> self-describing blob: 8-float header (magic, version, N, C, blocks, size, checksum) + payload"""
+    H = int(lib().c6_net_blob_header_floats())
+    out = np.empty(H + payload.size, np.float32)
+    out[H:] = np.asarray(payload, np.float32).reshape(-1)
+    _chk(lib().c6_net_blob_write_header(_p(out, C.c_float), out.size, n, channels, blocks))
+    return out
+
+
+def check_blob(blob, n, channels, blocks):
+    """verify a headed blob (raises C6Error with the reason); returns the payload view"""
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    _chk(lib().c6_net_blob_check_header(_p(blob, C.c_float), blob.size, n, channels, blocks))
+    return blob[int(lib().c6_net_blob_header_floats()):]
+
+
+def save_blob(path, blob_or_sd, n, channels, blocks):
+    """write a self-describing weight blob (.c6w: raw little-endian f32, header first).  blob_or_sd: a state_dict, a payload
+    or an already headed blob"""
+    if hasattr(blob_or_sd, "keys"):
+        b = blob_from_state_dict(blob_or_sd, n, channels, blocks, header=True)
+    else:
+        b = np.ascontiguousarray(blob_or_sd, dtype=np.float32).reshape(-1)
+        if b.size == blob_floats(n, channels, blocks):
+            b = add_blob_header(b, n, channels, blocks)
+        else:
+            check_blob(b, n, channels, blocks)
+    b.astype("<f4").tofile(path)
+    return b
+
+
+def load_blob(path, n, channels, blocks):
+    """read a .c6w file written by save_blob, verify header and checksum, return the headed blob"""
+    b = np.fromfile(path, dtype="<f4")
+    check_blob(b, n, channels, blocks)
+    return b
 
 
 def conv_pack_m8(channels, w_oihw):

@@ -21,8 +21,9 @@
 // reference's run counter of that direction reaches >= 6 (search_winner/mod.rs:206-222).  The first row with a non-empty
 // E (black | white) and its lowest column give the first such cell in row-major order, which is the reference's answer --
 // overlines and boards with several sixes included.  21 VALU per colour and row instead of the 46 of a re-evaluated
-// six-row window; the previous kernel (window form, per-byte decode) is kept as c6_board_kernel_v1 for the A/B in
-// c6_bench_board (C6_BOARD_VARIANT=1).
+// six-row window.  c6_board_kernel_wide (window form, per-byte decode, plain 64-bit global loads) is the fallback the launcher
+// takes for board arrays beyond the 32-bit row descriptors of c6_board_kernel (N * Gpad > 4 GiB: more than 226 M resident
+// 19x19 games); C6_BOARD_WIDE=1 forces it so that the tests can reach it with small arrays (tests/test_gpu_variants.py).
 #include <cstdlib>
 
 #include "c6_device.h"
@@ -31,7 +32,7 @@
 #include "../../include/connect6_amd.h"
 
 template <int N, bool STEP>
-__global__ __launch_bounds__(256) void c6_board_kernel_v1(int Gpad, int8_t *__restrict__ boards, int8_t *__restrict__ turn,
+__global__ __launch_bounds__(256) void c6_board_kernel_wide(int Gpad, int8_t *__restrict__ boards, int8_t *__restrict__ turn,
                                                       int8_t *__restrict__ remain, const int32_t *__restrict__ pos,
                                                       int8_t *__restrict__ winner, int8_t *__restrict__ err) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -342,13 +343,13 @@ static void launch_board(int N, int Gpad, int8_t *boards, int8_t *turn, int8_t *
                          int8_t *err, hipStream_t s) {
     const int quads = Gpad / 4, block = 256, grid = (quads + block - 1) / block;
     if (grid == 0) return;
-    static const bool v1env = [] { const char *e = getenv("C6_BOARD_VARIANT"); return e && e[0] == '1'; }();   // A/B only
+    static const bool v1env = [] { const char *e = getenv("C6_BOARD_WIDE"); return e && e[0] == '1'; }();   // test hook
     // the row descriptors of c6_board_kernel hold N * Gpad bytes in 32 bits (Gpad < 226 M games at N = 19: an 81 GB board
     // array); anything larger runs on the global-load kernel
     const bool v1 = v1env || (size_t)N * (size_t)Gpad > 0xffffffffull;
 #define C6_BOARD_CASE(NN)                                                                                                        \
     case NN:                                                                                                                      \
-        if (v1) hipLaunchKernelGGL((c6_board_kernel_v1<NN, STEP>), dim3(grid), dim3(block), 0, s, Gpad, boards, turn, remain, pos, winner, err); \
+        if (v1) hipLaunchKernelGGL((c6_board_kernel_wide<NN, STEP>), dim3(grid), dim3(block), 0, s, Gpad, boards, turn, remain, pos, winner, err); \
         else hipLaunchKernelGGL((c6_board_kernel<NN, STEP>), dim3(grid), dim3(block), 0, s, Gpad, boards, turn, remain, pos, winner, err);      \
         break;
     switch (N) {

@@ -124,20 +124,25 @@ void c6_launch_search_winner(int N, int Gpad, const int8_t *boards_soa, int8_t *
 void c6_launch_legal_mask(int N, int Gpad, const int8_t *boards_soa, uint8_t *mask, hipStream_t s);
 
 // net_kernels.hip  (K3 + K4)
+// 3x3 convolution kernels (C6NetDev::variant), one per C6_PREC_* arithmetic:
+enum {
+    C6_CONV_F32N = 5,   // c6_conv3x3_f32n_kernel: FP32 direct (implicit GEMM on v_mfma_f32_32x32x2_f32), C6_PREC_FP32_DIRECT
+    C6_CONV_B3S = 7,    // c6_conv3x3_b3s_kernel: split bf16 (3 bf16 MFMAs per product), C6_PREC_BF16X3
+    C6_CONV_BF16 = 8,   // the same kernel with plain bf16 products: relaxed tolerance, C6_PREC_BF16
+    C6_CONV_M8 = 9,     // c6_conv3x3_m8_kernel: fp16 main term + MX-fp8 cross terms, C6_PREC_F16F8
+    C6_CONV_WINO = 10   // c6_wino_in_kernel + c6_wino_gemm_kernel: FP32 Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, C6_PREC_FP32 (default)
+};
 struct C6NetDev {
     int N, cells, C, blocks;
     // packed weights (BatchNorm folded), see net_kernels.hip
     const float *stem_w;  // [9][2][C]
     const float *stem_b;  // [C]
-    int variant;          // 1: c6_conv3x3_kernel (NHWC), 2: c6_conv3x3_v2_kernel (slice-major S32 activations), 3/6/7: split bf16,
-                          // 8: c6_conv3x3_b3s_kernel without the split (plain bf16 products, relaxed tolerance)
+    int variant;          // C6_CONV_*
     int num_cus;
-    const float *conv_w;  // [(blocks-1)*2][packed 9*C*C]
-    const float *conv_w2; // same weights packed for conv v2
-    const unsigned short *conv_w3; // same weights split into bf16 hi/mid planes (conv_bf16x3.hip)
-    const unsigned short *conv_w6; // split planes packed per wave (c6_conv3x3_b3n_kernel)
-    const unsigned short *conv_w7; // the same for the 16x16x32 tiling (c6_conv3x3_b3s_kernel)
-    const float *conv_w5;          // FP32 weights packed per wave (c6_conv3x3_f32n_kernel)
+    // per layer [(blocks-1)*2], only the image of the selected kernel is resident:
+    const float *conv_ww;          // Winograd-transformed weights G g G^T packed per wave (conv_wino.hip), 16 C^2 floats
+    const float *conv_w5;          // FP32 weights packed per wave (c6_conv3x3_f32n_kernel), 9 C^2 floats
+    const unsigned short *conv_w7; // split bf16 hi/mid planes packed per wave (c6_conv3x3_b3s_kernel)
     const unsigned char *conv_w9;  // fp16 + fp8 planes packed per wave (c6_conv3x3_m8_kernel)
     const float *conv_b;  // [(blocks-1)*2][C]
     const float *pc_w;    // [2][C] folded
@@ -145,48 +150,58 @@ struct C6NetDev {
     const float *pl_wT;   // [2*cells][cells]
     const float *pl_b;    // [cells]
     const float *vc_w;    // [C]
-    const float *head_w;  // [3][C]: pc_w rows 0-1, vc_w -- the filters the last b3s convolution applies in its epilogue
+    const float *head_w;  // [3][C]: pc_w rows 0-1, vc_w -- the filters the last b3s / m8 convolution applies in its epilogue
     float vc_b;
     const float *vn_scale, *vn_shift; // [cells]
     const float *v1_wT;   // [cells][256]
     const float *v1_b;    // [256]
     const float *v2_w;    // [256]
     float v2_b;
+    // range guard of the reduced-range arithmetic (C6_PREC_F16F8): device flag set by c6_range_check_kernel when an activation
+    // leaves the range the fp16 / fp8 planes represent (nullptr: no check)
+    unsigned int *range_flag;
+    float range_limit;
 };
 // boards: int8 [nleaf][cellsP]; player int8 [nleaf]; images = 8 (dihedral, aug_map) or 1 (identity).
-// act0/act1/act2: [nleaf*images][cells][C] f32 scratch.  Outputs pol [nleaf*images][cells], val [nleaf*images].
+// act0/act1/act2: [nleaf*images][cells][C] f32 scratch; vbuf: c6_conv_wino_vbuf_floats(...) floats (C6_CONV_WINO only).
+// Outputs pol [nleaf*images][cells], val [nleaf*images].
 struct C6NetTimers;
 void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t *boards, int board_stride,
-                        const int8_t *player, const int16_t *aug_map, float *act0, float *act1, float *act2, float *ph,
+                        const int8_t *player, const int16_t *aug_map, float *act0, float *act1, float *act2, float *vbuf, float *ph,
                         float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers);
-size_t c6_conv_packed_floats(int C);
-void c6_pack_conv_weights_v2(int C, const float *w_oihw_folded, float *packed);
-bool c6_conv_v2_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                         int num_cus, hipStream_t s);
-size_t c6_conv_packed_b3_units(int C);
-void c6_pack_conv_weights_b3(int C, const float *w_oihw_folded, unsigned short *packed);
-bool c6_conv_b3_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                         float *out, hipStream_t s);
-size_t c6_conv_packed_b3n_units(int C);
-void c6_pack_conv_weights_b3n(int C, const float *w_oihw_folded, unsigned short *packed);
-void c6_pack_conv_weights_b3s(int C, const float *w_oihw_folded, unsigned short *packed);
+void c6_conv_bench_launch(int variant, int C, int N, int nboards, const float *in, const float *w, const float *bias, const float *res,
+                          float *out, float *vbuf, int num_cus, hipStream_t s);
+// FP32 Winograd F(2x2,3x3) (conv_wino.hip)
+size_t c6_conv_packed_wino_floats(int C);
+void c6_pack_conv_weights_wino(int C, const float *w_oihw_folded, float *packed);
+size_t c6_conv_wino_vbuf_floats(int C, int N, int nboards);
+bool c6_conv_wino_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
+                           float *vbuf, int num_cus, hipStream_t s, int relu = 1);
+// FP32 direct (conv_f32n.hip)
 size_t c6_conv_packed_f32n_floats(int C);
 void c6_pack_conv_weights_f32n(int C, const float *w_oihw_folded, float *packed);
 bool c6_conv_f32n_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            int num_cus, hipStream_t s, int relu = 1);
-bool c6_conv_fp32_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                           hipStream_t s, int relu);
+// split bf16 (conv_bf16x3.hip)
+size_t c6_conv_packed_b3s_units(int C);
+void c6_pack_conv_weights_b3s(int C, const float *w_oihw_folded, unsigned short *packed);
 bool c6_conv_b3s_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
                           float *out, int num_cus, hipStream_t s, int relu = 1, int split = 1, const float *head_w = nullptr);
 int c6_conv_b3s_head_rows(int N);
 // mixed fp16 + MX-fp8 products (conv_m8.hip, C6_PREC_F16F8)
 size_t c6_conv_packed_m8_bytes(int C);
 void c6_pack_conv_weights_m8(int C, const float *w_oihw_folded, unsigned char *packed);
+// range_flag / range_hi: the arithmetic's range guard -- bit 0 of *range_flag is set when an output is not finite or beyond range_hi
 bool c6_conv_m8_dispatch(int C, int N, int nboards, const float *in, const unsigned char *wp, const float *bias, const float *res,
-                         float *out, int num_cus, hipStream_t s, int relu = 1, const float *head_w = nullptr);
-bool c6_conv_b3n_dispatch(int C, int N, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                          float *out, int num_cus, hipStream_t s);
-void c6_conv_b3_ablate(int ablate, int nboards, const float *in, const unsigned short *wp, const float *bias, const float *res,
-                       float *out, hipStream_t s);
-#define C6_ACT_SLACK 1024   // floats of slack behind every activation buffer (conv v2's last DMA piece over-reads < 1 KiB)
-void c6_pack_conv_weights(int C, const float *w_oihw_folded, float *packed);
+                         float *out, int num_cus, hipStream_t s, int relu = 1, const float *head_w = nullptr,
+                         unsigned int *range_flag = nullptr, float range_hi = 3.0e38f);
+// the other half of the guard: the largest |activation| of a SAMPLE of `nboards` boards must reach range_lo (bit 1 of *range_flag
+// otherwise; an all-zero layer is exact and passes): below it the fp8 cross-term planes run out of bits
+void c6_launch_range_sample(const float *act, int nboards, size_t board_floats, float range_lo, float range_hi, unsigned int *range_flag, hipStream_t s);
+// the validated range of C6_PREC_F16F8: per-board max |activation| of every tower layer in [2^-3, 3584] (3584: beyond it the fp8 plane of
+// x_h / 8 saturates and the cross terms are clamped; 2^-3: the low parts x_l 2^8 drop below e4m3's normal range and the 16x margin of the
+// parity tests, taken at activations of order 1, is used up), folded weights inside fp16 with every output channel within 2^-10 of the
+// layer's largest (the fp8 weight planes share one shift per layer)
+#define C6_M8_RANGE_HI 3584.0f
+#define C6_M8_RANGE_LO 0.125f
+#define C6_ACT_SLACK 1024   // floats of slack behind every activation buffer

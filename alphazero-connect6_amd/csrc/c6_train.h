@@ -4,7 +4,6 @@
 #include <stddef.h>
 
 void c6t_pack_b3s(int C, const float *w_oihw, unsigned short *packed, int transpose_flip, hipStream_t s);
-void c6t_pack_fp32(int C, const float *w_oihw, float *packed, int transpose_flip, hipStream_t s);
 void c6t_pack_f32n(int C, const float *w_oihw, float *packed, int transpose_flip, hipStream_t s);
 
 void c6t_stem_fwd(int N, int C, int B, const float *boards, const float *players, const float *w, const float *bias, float *y, hipStream_t s);

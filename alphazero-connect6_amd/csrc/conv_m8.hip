@@ -78,7 +78,8 @@ template <int C, int N, bool HEAD = false>
 __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wp_,
                                                                       const float *__restrict__ bias, const float *__restrict__ res,
                                                                       float *__restrict__ out, int nboards, int relu,
-                                                                      const float *__restrict__ head_w) {
+                                                                      const float *__restrict__ head_w, unsigned int *__restrict__ range_flag,
+                                                                      float range_hi) {
     using G = M8Geom<C, N>;
     const unsigned char *wp = wp_;
     constexpr int W = G::W, PT = G::PT, KS = C / 32, THREADS = G::THREADS, WAVES = G::WAVES, CELLS = N * N;
@@ -296,6 +297,9 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const floa
         const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 bi0 = bias ? *reinterpret_cast<const f32x4 *>(bias + n4) : zero4, bi1 = bias ? *reinterpret_cast<const f32x4 *>(bias + n4 + 16) : zero4;
         const float floor_ = relu ? 0.f : -INFINITY;
+        // range guard of this arithmetic: an output beyond range_hi (or not finite) would reach the next layer's fp16 / fp8 planes
+        // clamped or as inf -- never silently: the flag is sticky and the host turns it into C6_ERR_RANGE (engine.cpp)
+        bool bad = false;
         if (HEAD) {      // see c6_conv3x3_b3s_kernel: per-wave partial sums of the three 1x1 head filters instead of the activations
 #pragma unroll
             for (int pt = 0; pt < PT; pt++) {
@@ -304,10 +308,12 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const floa
                 for (int r = 0; r < 4; r++) {
                     y0[r] = y0[r] > floor_ ? y0[r] : floor_;
                     y1[r] = y1[r] > floor_ ? y1[r] : floor_;
+                    bad = bad || !(__builtin_fabsf(y0[r]) <= range_hi) || !(__builtin_fabsf(y1[r]) <= range_hi);
                 }
                 acc[0][pt] = y0;
                 acc[1][pt] = y1;
             }
+            if (bad && range_flag) atomicOr(range_flag, 1u);
             float *hp = out + b * (size_t)(3 * WAVES * PT * 16) + (size_t)wave * (PT * 16) + pj;
 #pragma unroll 1
             for (int o = 0; o < 3; o++) {
@@ -343,10 +349,12 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const floa
             for (int r = 0; r < 4; r++) {
                 y0[r] = y0[r] > floor_ ? y0[r] : floor_;
                 y1[r] = y1[r] > floor_ ? y1[r] : floor_;
+                bad = bad || (ok && (!(__builtin_fabsf(y0[r]) <= range_hi) || !(__builtin_fabsf(y1[r]) <= range_hi)));
             }
             *reinterpret_cast<f32x4 *>(op) = y0;
             *reinterpret_cast<f32x4 *>(op + (ok ? 16 : 4)) = y1;
         }
+        if (bad && range_flag) atomicOr(range_flag, 1u);
     }
 }
 
@@ -435,23 +443,23 @@ void c6_pack_conv_weights_m8(int C, const float *w, unsigned char *packed) {
 
 template <int C, int N, bool HEAD>
 static void launch_m8_k(int nboards, int grid, const float *in, const unsigned char *wp, const float *bias, const float *res, float *out,
-                        int relu, const float *head_w, hipStream_t s) {
+                        int relu, const float *head_w, unsigned int *range_flag, float range_hi, hipStream_t s) {
     using G = M8Geom<C, N>;
     const size_t smem = G::LDS_BYTES;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_m8_kernel<C, N, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((c6_conv3x3_m8_kernel<C, N, HEAD>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu, head_w);
+    hipLaunchKernelGGL((c6_conv3x3_m8_kernel<C, N, HEAD>), dim3(grid), dim3(G::THREADS), smem, s, in, wp, bias, res, out, nboards, relu, head_w, range_flag, range_hi);
 }
 
 // head_w != nullptr: [3][C] head filters; `out` receives the head partials instead of the activations (see c6_conv3x3_b3s_kernel)
 bool c6_conv_m8_dispatch(int C, int N, int nboards, const float *in, const unsigned char *wp, const float *bias, const float *res,
-                         float *out, int num_cus, hipStream_t s, int relu, const float *head_w) {
+                         float *out, int num_cus, hipStream_t s, int relu, const float *head_w, unsigned int *range_flag, float range_hi) {
     if (nboards <= 0) return true;
     const int per_cu = C == 256 ? 1 : (C == 128 ? 2 : 4);
     const int grid = nboards < num_cus * per_cu ? nboards : num_cus * per_cu;
 #define M8CASE(CC, NN)                                                                                              \
     if (C == CC && N == NN) {                                                                                       \
-        if (head_w) launch_m8_k<CC, NN, true>(nboards, grid, in, wp, bias, res, out, relu, head_w, s);              \
-        else launch_m8_k<CC, NN, false>(nboards, grid, in, wp, bias, res, out, relu, nullptr, s);                   \
+        if (head_w) launch_m8_k<CC, NN, true>(nboards, grid, in, wp, bias, res, out, relu, head_w, range_flag, range_hi, s);   \
+        else launch_m8_k<CC, NN, false>(nboards, grid, in, wp, bias, res, out, relu, nullptr, range_flag, range_hi, s);        \
         return true;                                                                                                \
     }
     M8CASE(256, 19) M8CASE(256, 15) M8CASE(256, 9)

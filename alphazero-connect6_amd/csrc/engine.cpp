@@ -138,6 +138,38 @@ struct DevPool {
         if (rc_ != C6_OK) return rc_;                   \
     } while (0)
 
+// ---- self-describing weight blobs -------------------------------------------------------------------
+// header = 8 floats in front of the payload: magic "C6WB" (bit pattern), layout version, N, C, num_block, payload floats (as two
+// 24-bit halves) and a checksum of the payload (FNV-1a of the u32 bit patterns folded to 24 bits, exactly representable)
+#define C6_BLOB_MAGIC 0x42573643u       /* "C6WB" little endian */
+#define C6_BLOB_VERSION 1
+static float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static uint32_t blob_checksum(const float *p, size_t n) {      // FNV-1a over the bit patterns: order-sensitive, folded to 24 bits
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) h = (h ^ f_bits(p[i])) * 0x100000001b3ull;
+    return (uint32_t)((h ^ (h >> 24) ^ (h >> 48)) & 0xffffffu);
+}
+extern "C" size_t c6_net_blob_header_floats(void) { return C6_BLOB_HEADER_FLOATS; }
+extern "C" int c6_net_blob_write_header(float *dst, size_t nfloats, int n, int C, int nb) {
+    if (!dst || nfloats != c6_net_blob_floats(n, C, nb) + C6_BLOB_HEADER_FLOATS) return fail(C6_ERR_BAD_ARG, "blob buffer has the wrong size for this geometry");
+    const size_t payload = nfloats - C6_BLOB_HEADER_FLOATS;
+    dst[0] = bits_f(C6_BLOB_MAGIC); dst[1] = (float)C6_BLOB_VERSION; dst[2] = (float)n; dst[3] = (float)C; dst[4] = (float)nb;
+    dst[5] = (float)(payload >> 24); dst[6] = (float)(payload & 0xffffffu);
+    dst[7] = (float)blob_checksum(dst + C6_BLOB_HEADER_FLOATS, payload);
+    return C6_OK;
+}
+extern "C" int c6_net_blob_check_header(const float *blob, size_t nfloats, int n, int C, int nb) {
+    if (!blob || nfloats < C6_BLOB_HEADER_FLOATS) return fail(C6_ERR_BAD_ARG, "blob too short for a header");
+    if (f_bits(blob[0]) != C6_BLOB_MAGIC) return fail(C6_ERR_BAD_ARG, "weight blob: bad magic (not written by save_blob / c6_net_blob_write_header)");
+    if (blob[1] != (float)C6_BLOB_VERSION) return fail(C6_ERR_BAD_ARG, "weight blob: unknown layout version");
+    if (blob[2] != (float)n || blob[3] != (float)C || blob[4] != (float)nb) return fail(C6_ERR_BAD_ARG, "weight blob was written for another board size / channel count / block count");
+    const size_t payload = ((size_t)blob[5] << 24) | (size_t)blob[6];
+    if (payload != nfloats - C6_BLOB_HEADER_FLOATS || payload != c6_net_blob_floats(n, C, nb)) return fail(C6_ERR_BAD_ARG, "weight blob: payload size does not match its header");
+    if (blob[7] != (float)blob_checksum(blob + C6_BLOB_HEADER_FLOATS, payload)) return fail(C6_ERR_BAD_ARG, "weight blob: checksum mismatch (corrupted or re-ordered payload)");
+    return C6_OK;
+}
+
 // ---- resident net ---------------------------------------------------------------------------
 
 struct NetHost {
@@ -165,81 +197,143 @@ template <typename T> static int upload(DevPool &pool, const std::vector<T> &h, 
     return C6_OK;
 }
 
-// blob layout: AlphaZero/cpp_weighted/model.hpp:10-50 registration order, PyTorch layouts
+// which kernel serves a C6_PREC_* (see include/connect6_amd.h)
+static int conv_variant(int precision) {
+    switch (precision) {
+    case C6_PREC_FP32_DIRECT: return C6_CONV_F32N;
+    case C6_PREC_BF16X3: return C6_CONV_B3S;
+    case C6_PREC_BF16: return C6_CONV_BF16;
+    case C6_PREC_F16F8: return C6_CONV_M8;
+    default: return C6_CONV_WINO;      // C6_PREC_DEFAULT = C6_PREC_FP32: the reference's arithmetic (model.hpp:52-95 is f32)
+    }
+}
+
+// Weight blob: flat f32, the tensors of WeightedPolicy (AlphaZero/cpp_weighted/model.hpp:10-50) in FORWARD order with each
+// BatchNorm's running statistics beside its affine parameters -- NOT libtorch's registration order (model.hpp registers conv, norm,
+// the two heads and only then the tower, and named_buffers() lists running statistics separately).  Per tensor PyTorch's own layout:
+//   stem    conv.weight [C,2,3,3], conv.bias [C], norm.{weight, bias, running_mean, running_var} [C] each
+//   tower   for i in 0 .. num_block-2, for j in 0, 1:  conv{i}_{j}.weight [C,C,3,3], .bias [C], norm{i}_{j}.{weight, bias, running_mean, running_var}
+//   policy  policy_conv.weight [2,C,1,1], .bias [2], policy_norm.{weight, bias, running_mean, running_var} [2] each,
+//           policy_linear.weight [N^2, 2N^2], .bias [N^2]
+//   value   value_conv.weight [1,C,1,1], .bias [1], value_norm.{weight, bias, running_mean, running_var} [N^2] each,
+//           value_linear1.weight [256, N^2], .bias [256], value_linear2.weight [1,256], .bias [1]
+// alphazero_connect6_amd.blob_from_state_dict builds it from a state_dict (by NAME, so a permuted blob cannot happen there);
+// c6_net_blob_check_header validates the optional 8-float header that save_blob writes (magic, version, N, C, blocks, count,
+// checksum) so that a blob of the right size but the wrong layout or geometry is rejected before it is played with.
 static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t nfloats, int precision = C6_PREC_DEFAULT) {
     if (C != 64 && C != 128 && C != 256) return fail(C6_ERR_BAD_ARG, "net_channels must be 64, 128 or 256");
     if (nb < 1) return fail(C6_ERR_BAD_ARG, "net_blocks must be >= 1");
+    if (precision != C6_PREC_DEFAULT && precision != C6_PREC_FP32 && precision != C6_PREC_FP32_DIRECT && precision != C6_PREC_BF16X3 &&
+        precision != C6_PREC_BF16 && precision != C6_PREC_F16F8)
+        return fail(C6_ERR_BAD_ARG, "net_precision must be a C6_PREC_* value");
+    if (nfloats == c6_net_blob_floats(n, C, nb) + C6_BLOB_HEADER_FLOATS) {      // self-describing blob (save_blob): check and skip the header
+        int rc = c6_net_blob_check_header(blob, nfloats, n, C, nb);
+        if (rc != C6_OK) return rc;
+        blob += C6_BLOB_HEADER_FLOATS;
+        nfloats -= C6_BLOB_HEADER_FLOATS;
+    }
     if (nfloats != c6_net_blob_floats(n, C, nb)) return fail(C6_ERR_BAD_ARG, "weight blob has the wrong size");
+    for (size_t i = 0; i < nfloats; i++)
+        if (!std::isfinite(blob[i])) return fail(C6_ERR_BAD_ARG, "weight blob holds a non-finite value");
     nh.pool.release();
+    nh.loaded = false;
     const int cells = n * n;
     const float eps = 1e-5f;
     const float *p = blob;
     auto take = [&](size_t k) { const float *r = p; p += k; return r; };
     C6NetDev &d = nh.dev;
+    d = C6NetDev{};
     d.N = n; d.cells = cells; d.C = C; d.blocks = nb;
+    d.variant = conv_variant(precision);
     {
-        // A/B switch (C6_CONV_VARIANT).  FP32 precision: 5 = c6_conv3x3_f32n_kernel (N-split persistent schedule, the default:
-        // 137-139 TFLOP/s), 1 = c6_conv3x3_kernel (M x N wave grid, weight stages in LDS by LDS-DMA, barrier per tap; 127-132),
-        // 2 = c6_conv3x3_v2_kernel (16x16x4 tiles, slice-major activations; experimental, 119 TFLOP/s).
-        // Mixed precision (C6_PREC_F16F8, the default): 9 = c6_conv3x3_m8_kernel (fp16 main term + MX-fp8 cross terms).
-        // Split-bf16 precision: 7 = c6_conv3x3_b3s_kernel (persistent N-split schedule on 16x16x32 MFMAs,
-        // the default: the chip holds a higher clock on that shape), 6 = c6_conv3x3_b3n_kernel (same schedule on
-        // 32x32x16), 3 = c6_conv3x3_bf16x3_kernel (M x N wave grid with weight stages in LDS)
-        const char *v = std::getenv("C6_CONV_VARIANT");
-        const int ev = v ? std::atoi(v) : 0;
-        if (precision == C6_PREC_BF16) d.variant = 8;      // plain bf16 products: relaxed tolerance, not parity grade
-        else if (precision == C6_PREC_F16F8) d.variant = 9;   // fp16 main term + MX-fp8 cross terms (c6_conv3x3_m8_kernel)
-        else if (precision == C6_PREC_FP32) d.variant = (ev == 1 || ev == 2) ? ev : 5;   // 5 = c6_conv3x3_f32n_kernel (N-split persistent FP32), the default
-        else if (precision == C6_PREC_BF16X3) d.variant = (ev == 3 || ev == 6) ? ev : 7;
-        else d.variant = (ev == 1 || ev == 2 || ev == 3 || ev == 5 || ev == 6 || ev == 7) ? ev : 9;      // default: C6_PREC_F16F8
         hipDeviceProp_t prop;
         int dev = 0;
         hipGetDevice(&dev);
         d.num_cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
     }
+    const bool guard = d.variant == C6_CONV_M8;      // the reduced-range arithmetic: validate what it is given (c6_engine.h, C6_M8_RANGE_*)
 
     {   // stem
         const float *w = take((size_t)C * 2 * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
         std::vector<float> sw((size_t)9 * 2 * C), sb(C);
+        double bound = 0.0;
         for (int co = 0; co < C; co++) {
             const float s = g[co] / std::sqrt(v[co] + eps);
             sb[co] = (b[co] - m[co]) * s + be[co];
+            double l1 = std::fabs((double)sb[co]);
             for (int ch = 0; ch < 2; ch++)
-                for (int t = 0; t < 9; t++) sw[(size_t)(t * 2 + ch) * C + co] = w[((size_t)co * 2 + ch) * 9 + t] * s;
+                for (int t = 0; t < 9; t++) {
+                    sw[(size_t)(t * 2 + ch) * C + co] = w[((size_t)co * 2 + ch) * 9 + t] * s;
+                    l1 += std::fabs((double)sw[(size_t)(t * 2 + ch) * C + co]);
+                }
+            bound = std::max(bound, l1);      // |stem output| <= sum |w| + |b|: its inputs are player / cells in {-1, 0, +1}
         }
+        if (guard && !(bound <= C6_M8_RANGE_HI))
+            return fail(C6_ERR_RANGE, "C6_PREC_F16F8: the stem's activations can exceed 3584 with these weights; use C6_PREC_FP32 or C6_PREC_BF16X3");
+        if (guard && bound < C6_M8_RANGE_LO)
+            return fail(C6_ERR_RANGE, "C6_PREC_F16F8: the stem's activations cannot reach 2^-3, the low end of this arithmetic's validated range; use C6_PREC_FP32 or C6_PREC_BF16X3");
         int rc;
         if ((rc = upload(nh.pool, sw, &d.stem_w)) || (rc = upload(nh.pool, sb, &d.stem_b))) return rc;
     }
-    {   // tower
-        const int L = 2 * (nb - 1);
-        const size_t wsz = c6_conv_packed_floats(C);
-        std::vector<float> cw((size_t)std::max(L, 1) * wsz), cw2((size_t)std::max(L, 1) * wsz), cb((size_t)std::max(L, 1) * C), folded((size_t)C * C * 9);
-        const size_t w3 = c6_conv_packed_b3_units(C);
-        std::vector<unsigned short> cw3((size_t)std::max(L, 1) * w3);
-        const size_t w6 = c6_conv_packed_b3n_units(C);
-        std::vector<unsigned short> cw6((size_t)std::max(L, 1) * w6), cw7((size_t)std::max(L, 1) * w6);
-        std::vector<float> cw5((size_t)std::max(L, 1) * wsz);
-        const size_t w9 = c6_conv_packed_m8_bytes(C);
-        std::vector<unsigned char> cw9((size_t)std::max(L, 1) * w9);
+    {   // tower: only the weight image of the selected kernel is built and kept
+        const int L = 2 * (nb - 1), Lm = std::max(L, 1);
+        std::vector<float> cb((size_t)Lm * C), folded((size_t)C * C * 9);
+        std::vector<float> cw5, cww;
+        std::vector<unsigned short> cw7;
+        std::vector<unsigned char> cw9;
+        const size_t w5 = c6_conv_packed_f32n_floats(C), ww = c6_conv_packed_wino_floats(C), w7 = c6_conv_packed_b3s_units(C), w9 = c6_conv_packed_m8_bytes(C);
+        if (d.variant == C6_CONV_F32N) cw5.resize((size_t)Lm * w5);
+        else if (d.variant == C6_CONV_WINO) cww.resize((size_t)Lm * ww);
+        else if (d.variant == C6_CONV_M8) cw9.resize((size_t)Lm * w9);
+        else cw7.resize((size_t)Lm * w7);
         for (int l = 0; l < L; l++) {
             const float *w = take((size_t)C * C * 9), *b = take(C), *g = take(C), *be = take(C), *m = take(C), *v = take(C);
+            float wmax = 0.f, cmin = INFINITY;
             for (int co = 0; co < C; co++) {
                 const float s = g[co] / std::sqrt(v[co] + eps);
                 cb[(size_t)l * C + co] = (b[co] - m[co]) * s + be[co];
-                for (size_t k = 0; k < (size_t)C * 9; k++) folded[(size_t)co * C * 9 + k] = w[(size_t)co * C * 9 + k] * s;
+                float cmax = 0.f;
+                for (size_t k = 0; k < (size_t)C * 9; k++) {
+                    const float f = w[(size_t)co * C * 9 + k] * s;
+                    folded[(size_t)co * C * 9 + k] = f;
+                    cmax = std::max(cmax, std::fabs(f));
+                }
+                if (!std::isfinite(cmax) || !std::isfinite(cb[(size_t)l * C + co])) return fail(C6_ERR_BAD_ARG, "BatchNorm folding of a tower layer overflowed FP32");
+                wmax = std::max(wmax, cmax);
+                if (cmax > 0.f) cmin = std::min(cmin, cmax);
             }
-            c6_pack_conv_weights(C, folded.data(), cw.data() + (size_t)l * wsz);
-            c6_pack_conv_weights_v2(C, folded.data(), cw2.data() + (size_t)l * wsz);
-            c6_pack_conv_weights_b3(C, folded.data(), cw3.data() + (size_t)l * w3);
-            c6_pack_conv_weights_b3n(C, folded.data(), cw6.data() + (size_t)l * w6);
-            c6_pack_conv_weights_b3s(C, folded.data(), cw7.data() + (size_t)l * w6);
-            c6_pack_conv_weights_f32n(C, folded.data(), cw5.data() + (size_t)l * wsz);
-            if (d.variant == 9) c6_pack_conv_weights_m8(C, folded.data(), cw9.data() + (size_t)l * w9);
+            if (guard) {
+                char msg[200];
+                if (!(wmax < 65504.f)) {
+                    snprintf(msg, sizeof msg, "C6_PREC_F16F8: folded weights of tower layer %d reach %.3g, outside fp16; use C6_PREC_FP32 or C6_PREC_BF16X3", l, wmax);
+                    return fail(C6_ERR_RANGE, msg);
+                }
+                if (wmax < 1.0f / 512.0f) {
+                    snprintf(msg, sizeof msg, "C6_PREC_F16F8: folded weights of tower layer %d stay below 2^-9 (largest %.3g): their fp16 parts are subnormal; "
+                             "use C6_PREC_FP32 or C6_PREC_BF16X3", l, wmax);
+                    return fail(C6_ERR_RANGE, msg);
+                }
+                if (cmin < wmax * (1.0f / 1024.0f)) {
+                    snprintf(msg, sizeof msg, "C6_PREC_F16F8: output channels of tower layer %d span %.3g .. %.3g (more than 2^10): the layer's fp8 weight "
+                             "planes share one shift; use C6_PREC_FP32 or C6_PREC_BF16X3", l, cmin, wmax);
+                    return fail(C6_ERR_RANGE, msg);
+                }
+            }
+            if (d.variant == C6_CONV_F32N) c6_pack_conv_weights_f32n(C, folded.data(), cw5.data() + (size_t)l * w5);
+            else if (d.variant == C6_CONV_WINO) c6_pack_conv_weights_wino(C, folded.data(), cww.data() + (size_t)l * ww);
+            else if (d.variant == C6_CONV_M8) c6_pack_conv_weights_m8(C, folded.data(), cw9.data() + (size_t)l * w9);
+            else c6_pack_conv_weights_b3s(C, folded.data(), cw7.data() + (size_t)l * w7);
         }
         int rc;
-        if ((rc = upload(nh.pool, cw, &d.conv_w)) || (rc = upload(nh.pool, cw2, &d.conv_w2)) || (rc = upload(nh.pool, cw3, &d.conv_w3)) || (rc = upload(nh.pool, cw6, &d.conv_w6)) || (rc = upload(nh.pool, cw7, &d.conv_w7)) || (rc = upload(nh.pool, cw5, &d.conv_w5)) || (rc = upload(nh.pool, cw9, &d.conv_w9)) ||
+        if ((!cw5.empty() && (rc = upload(nh.pool, cw5, &d.conv_w5))) || (!cww.empty() && (rc = upload(nh.pool, cww, &d.conv_ww))) ||
+            (!cw7.empty() && (rc = upload(nh.pool, cw7, &d.conv_w7))) || (!cw9.empty() && (rc = upload(nh.pool, cw9, &d.conv_w9))) ||
             (rc = upload(nh.pool, cb, &d.conv_b)))
             return rc;
+        if (guard) {
+            unsigned int *fl = nullptr;
+            if ((rc = nh.pool.alloc(&fl, 1))) return rc;
+            d.range_flag = fl;
+        }
     }
     {   // policy head
         const float *w = take((size_t)2 * C), *b = take(2), *bn = take(8);
@@ -327,6 +421,7 @@ struct c6_engine {
     c6_callback cb = nullptr;
     // net scratch
     float *act0 = nullptr, *act1 = nullptr, *act2 = nullptr, *ph = nullptr, *vh = nullptr;
+    float *vbuf = nullptr;         // Winograd-transformed activations of one chunk (C6_PREC_FP32)
     int chunk_leaves = 0;
     // callback scratch
     float *img_boards = nullptr;   // device [G][8][cells]
@@ -423,6 +518,11 @@ static int engine_alloc(c6_engine *e) {
         const size_t nb = (size_t)chunk_leaves * 8, act = nb * cells * c.net_channels + C6_ACT_SLACK;
         ALLOC(e->act0, act); ALLOC(e->act1, act); ALLOC(e->act2, act);
         ALLOC(e->ph, nb * 2 * cells); ALLOC(e->vh, nb * cells);
+        if (conv_variant(c.net_precision) == C6_CONV_WINO) {
+            // the largest buffer of the net (16/4 of an activation): not zero-filled, every float the GEMM reads is written first
+            int rc_ = pool.alloc(&e->vbuf, c6_conv_wino_vbuf_floats(c.net_channels, N, (int)nb), false);
+            if (rc_ != C6_OK) return rc_;
+        }
     }
     return C6_OK;
 }
@@ -558,7 +658,7 @@ static int evaluate(c6_engine *e) {
         for (int l0 = 0; l0 < d.G; l0 += e->chunk_leaves) {
             const int nl = std::min(e->chunk_leaves, d.G - l0);
             c6_net_forward_dev(e->net.dev, nl, 8, d.leaf_board + (size_t)l0 * d.cellsP, d.cellsP, d.leaf_turn + l0, d.aug_map,
-                               e->act0, e->act1, e->act2, e->ph, e->vh, d.img_pol + (size_t)l0 * 8 * d.cells,
+                               e->act0, e->act1, e->act2, e->vbuf, e->ph, e->vh, d.img_pol + (size_t)l0 * 8 * d.cells,
                                d.img_val + (size_t)l0 * 8, e->stream, e->timers);
         }
         c6_launch_recover(d, e->stream);
@@ -634,6 +734,17 @@ extern "C" int c6_engine_sync(c6_engine *e) {
     return C6_OK;
 }
 
+// C6_PREC_F16F8's runtime guard: the sticky device flag of the convolution epilogues / the per-layer sample (c6_engine.h).
+// Call with the stream drained.
+static int range_status(const NetHost &net) {
+    if (!net.loaded || !net.dev.range_flag) return C6_OK;
+    unsigned int f = 0;
+    HIPCHK(hipMemcpy(&f, net.dev.range_flag, sizeof f, hipMemcpyDeviceToHost));
+    if (f & 1u) return fail(C6_ERR_RANGE, "C6_PREC_F16F8: an activation exceeded 3584 (or was not finite): priors since the last check are not the FP32 net's; use C6_PREC_FP32 or C6_PREC_BF16X3");
+    if (f & 2u) return fail(C6_ERR_RANGE, "C6_PREC_F16F8: a layer's activations fell below 2^-3, the low end of this arithmetic's validated range; use C6_PREC_FP32 or C6_PREC_BF16X3");
+    return C6_OK;
+}
+
 static int live_games(c6_engine *e, int *live, int *errors, int *overflow = nullptr) {
     std::vector<int8_t> st(e->d.G);
     HIPCHK(hipMemcpyAsync(st.data(), e->d.status, e->d.G, hipMemcpyDeviceToHost, e->stream));
@@ -643,7 +754,7 @@ static int live_games(c6_engine *e, int *live, int *errors, int *overflow = null
     *live = l;
     *errors = er + ov;
     if (overflow) *overflow = ov;
-    return C6_OK;
+    return range_status(e->net);      // every host-synchronising entry point passes through here
 }
 
 // ---- record-pool growth -------------------------------------------------------------------------------------------
@@ -823,6 +934,7 @@ extern "C" int c6_engine_fetch_games(c6_engine *e, int cap, int *count, int *win
     if (!e || !count) return fail(C6_ERR_BAD_ARG, "null argument");
     C6Dev &d = e->d;
     HIPCHK(hipStreamSynchronize(e->stream));
+    { int rc_ = range_status(e->net); if (rc_ != C6_OK) return rc_; }
     unsigned long long q = 0;
     HIPCHK(hipMemcpy(&q, d.counters + C6_CNT_FETCHQ, sizeof q, hipMemcpyDeviceToHost));
     if (q > (unsigned long long)d.finq_cap) q = d.finq_cap;
@@ -843,6 +955,7 @@ extern "C" int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, v
     if (!e || !count) return fail(C6_ERR_BAD_ARG, "null argument");
     C6Dev &d = e->d;
     HIPCHK(hipStreamSynchronize(e->stream));
+    { int rc_ = range_status(e->net); if (rc_ != C6_OK) return rc_; }
     if (!d.tuple_buf) { *count = 0; return C6_OK; }
     uint32_t n = 0;
     HIPCHK(hipMemcpy(&n, d.tuple_count, sizeof n, hipMemcpyDeviceToHost));
@@ -1119,9 +1232,11 @@ extern "C" int c6_net_forward_prec(int n, int C, int blocks, int precision, cons
     int16_t *dm = t.get<int16_t>(aug.size(), aug.data());
     float *a0 = t.get<float>(act), *a1 = t.get<float>(act), *a2 = t.get<float>(act), *ph = t.get<float>((size_t)num * 2 * cells),
           *vh = t.get<float>((size_t)num * cells), *dp = t.get<float>((size_t)num * cells), *dv = t.get<float>(num);
-    if (!db || !dpl || !dm || !a0 || !a1 || !a2 || !ph || !vh || !dp || !dv) { nh.pool.release(); return fail(C6_ERR_HIP, "hipMalloc failed"); }
-    c6_net_forward_dev(nh.dev, num, 1, db, cells, dpl, dm, a0, a1, a2, ph, vh, dp, dv, nullptr, nullptr);
+    float *vb = nh.dev.variant == C6_CONV_WINO ? t.get<float>(c6_conv_wino_vbuf_floats(C, n, num)) : a0;
+    if (!db || !dpl || !dm || !a0 || !a1 || !a2 || !ph || !vh || !dp || !dv || !vb) { nh.pool.release(); return fail(C6_ERR_HIP, "hipMalloc failed"); }
+    c6_net_forward_dev(nh.dev, num, 1, db, cells, dpl, dm, a0, a1, a2, vb, ph, vh, dp, dv, nullptr, nullptr);
     hipError_t he = hipDeviceSynchronize();
+    if (he == hipSuccess && (rc = range_status(nh)) != C6_OK) { nh.pool.release(); return rc; }
     if (he == hipSuccess) he = hipMemcpy(policy, dp, (size_t)num * cells * 4, hipMemcpyDeviceToHost);
     if (he == hipSuccess) he = hipMemcpy(value, dv, (size_t)num * 4, hipMemcpyDeviceToHost);
     nh.pool.release();
@@ -1130,8 +1245,6 @@ extern "C" int c6_net_forward_prec(int n, int C, int blocks, int precision, cons
 }
 
 // ---- conv micro-benchmark (development tool; also used to collect per-kernel profiles) ----------
-void c6_conv_bench_launch(int variant, int ablate, int C, int N, int nboards, const float *in, const float *w1, const float *w2,
-                          const float *bias, const float *res, float *out, int num_cus, hipStream_t s);
 __global__ void c6_fill_random_kernel(float *p, size_t n, uint32_t seed, float lo, float hi) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1141,14 +1254,18 @@ __global__ void c6_fill_random_kernel(float *p, size_t n, uint32_t seed, float l
         p[i] = lo + (hi - lo) * ((float)(x >> 8) * (1.0f / 16777216.0f));
     }
 }
-extern "C" int c6_bench_conv(int n, int C, int nboards, int iters, int variant, int ablate, int with_res, double *avg_ms) {
+extern "C" int c6_bench_conv(int n, int C, int nboards, int iters, int precision, int ablate, int with_res, double *avg_ms) {
     int rc = check_n(n); if (rc) return rc;
     rc = require_gpu(0); if (rc) return rc;
+    if (ablate != 0) return fail(C6_ERR_BAD_ARG, "c6_bench_conv: ablations were removed with the kernels they belonged to");
+    if (C != 64 && C != 128 && C != 256) return fail(C6_ERR_BAD_ARG, "channels must be 64, 128 or 256");
+    const int variant = conv_variant(precision);
     const size_t cells = (size_t)n * n, act = (size_t)nboards * cells * C + C6_ACT_SLACK,
-                 wsz = std::max(c6_conv_packed_floats(C), (c6_conv_packed_m8_bytes(C) + 3) / 4);      // the largest packed layout
-    float *in, *res, *out, *w, *bias;
+                 wsz = std::max(c6_conv_packed_wino_floats(C), (c6_conv_packed_m8_bytes(C) + 3) / 4);      // the largest packed layout
+    float *in, *res, *out, *w, *bias, *vb = nullptr;
     HIPCHK(hipMalloc(&in, act * 4)); HIPCHK(hipMalloc(&res, act * 4)); HIPCHK(hipMalloc(&out, act * 4));
     HIPCHK(hipMalloc(&w, wsz * 4)); HIPCHK(hipMalloc(&bias, C * 4));
+    if (variant == C6_CONV_WINO) HIPCHK(hipMalloc(&vb, c6_conv_wino_vbuf_floats(C, n, nboards) * 4));
     hipLaunchKernelGGL(c6_fill_random_kernel, dim3(4096), dim3(256), 0, nullptr, in, act, 1u, 0.f, 1.f);
     hipLaunchKernelGGL(c6_fill_random_kernel, dim3(4096), dim3(256), 0, nullptr, res, act, 2u, 0.f, 1.f);
     hipLaunchKernelGGL(c6_fill_random_kernel, dim3(256), dim3(256), 0, nullptr, w, wsz, 3u, -0.02f, 0.02f);
@@ -1157,10 +1274,10 @@ extern "C" int c6_bench_conv(int n, int C, int nboards, int iters, int variant, 
     const int cus = hipGetDeviceProperties(&prop, 0) == hipSuccess ? prop.multiProcessorCount : 256;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    c6_conv_bench_launch(variant, ablate, C, n, nboards, in, w, w, bias, with_res ? res : nullptr, out, cus, nullptr);
+    c6_conv_bench_launch(variant, C, n, nboards, in, w, bias, with_res ? res : nullptr, out, vb, cus, nullptr);
     HIPCHK(hipDeviceSynchronize());
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; i++) c6_conv_bench_launch(variant, ablate, C, n, nboards, in, w, w, bias, with_res ? res : nullptr, out, cus, nullptr);
+    for (int i = 0; i < iters; i++) c6_conv_bench_launch(variant, C, n, nboards, in, w, bias, with_res ? res : nullptr, out, vb, cus, nullptr);
     hipEventRecord(e1, nullptr);
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;
@@ -1168,6 +1285,7 @@ extern "C" int c6_bench_conv(int n, int C, int nboards, int iters, int variant, 
     *avg_ms = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(in); hipFree(res); hipFree(out); hipFree(w); hipFree(bias);
+    if (vb) hipFree(vb);
     return C6_OK;
 }
 

@@ -6,17 +6,9 @@
 //   conv1x1 C->1, BatchNorm over the N^2 features, ReLU, Linear(N^2->256), ReLU, Linear(256->1), tanh
 //   (:86-92).  BatchNorm is eval-mode and folded into the preceding convolution on the host.
 //
-// The 3x3 convolutions are >99.9 % of the FLOPs.  c6_conv3x3_kernel is an implicit GEMM on the
-// FP32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 products, f32 accumulate):
-//   M = the N*N pixels of ONE board (padded to a multiple of 32), N = C output channels,
-//   K = 9 taps x C input channels.
-// One 512-thread workgroup (8 waves = 4 along M x 2 along N) owns one board and all C output
-// channels, so activations are read from HBM exactly once per layer.  Activations are NHWC
-// ([board][pixel][C]); a 32-channel slice of the board is staged in LDS on a zero-haloed
-// (N+2)x(N+2) grid, so the nine taps are nine constant LDS offsets from the same staged slice
-// (no im2col in HBM).  Weights are pre-packed on the host so that a (tap, 32-channel slice)
-// stage is one contiguous 32*C-float block and a lane's 4 consecutive k values are one
-// ds_read_b128; stages are double-buffered in LDS and prefetched into registers behind the MFMAs.
+// The 3x3 convolutions are >99.9 % of the FLOPs; their kernels live in conv_wino.hip (FP32 Winograd F(2x2,3x3), the default),
+// conv_f32n.hip (FP32 direct), conv_bf16x3.hip (split bf16) and conv_m8.hip (fp16 + MX-fp8).  This file holds the stem, the
+// heads and the forward driver.  Activations are NHWC ([board][pixel][C]).
 #include <cstdlib>
 
 #include "c6_device.h"
@@ -26,9 +18,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define CONV_THREADS 512
-#define SLOT_F 36   // floats per LDS pixel slot: 32 channels + 4 pad (bank spread for ds_read_b128)
 
 struct C6NetTimers {
     bool enabled = false;
@@ -40,164 +29,12 @@ struct C6NetTimers {
 };
 
 // ----------------------------------------------------------------------------------------
-// conv3x3 C->C, pad 1, + bias (+ residual) + ReLU
-// ----------------------------------------------------------------------------------------
-// ABL: ablation switch used only by c6_bench_conv (0 = the product kernel):
-//   1 no weight staging, 2 no input staging, 3 neither and no barriers, 4 operands from registers (no LDS reads)
-template <int C, int MTW, int ABL = 0>
-__global__ __launch_bounds__(CONV_THREADS) void c6_conv3x3_kernel(const float *__restrict__ in, const float *__restrict__ wp,
-                                                                 const float *__restrict__ bias, const float *__restrict__ res,
-                                                                 float *__restrict__ out, int N, int relu) {
-    constexpr int NTW = C / 64;          // 32-wide n-tiles per wave (2 waves along N)
-    constexpr int KS = C / 32;           // 32-channel k-slices
-    constexpr int WSTAGE = 32 * C;       // floats per weight stage
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int cells = N * N, P = N + 2;
-    const int in_floats = P * P * SLOT_F;
-    float *lds_in = smem;
-    float *lds_w = smem + ((in_floats + 3) & ~3);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int i = lane & 31, h = lane >> 5;
-    const size_t b = blockIdx.x;
-    const float *inb = in + b * (size_t)cells * C;
-
-    int aoff[MTW];
-#pragma unroll
-    for (int mt = 0; mt < MTW; mt++) {
-        int p = (wm * MTW + mt) * 32 + i;
-        if (p >= cells) p = 0;          // padding rows: read pixel 0 (in bounds), never stored
-        aoff[mt] = ((p / N + 1) * P + (p % N + 1)) * SLOT_F + 4 * h;
-    }
-
-    f32x16 acc[MTW][NTW];
-#pragma unroll
-    for (int mt = 0; mt < MTW; mt++)
-#pragma unroll
-        for (int nt = 0; nt < NTW; nt++)
-#pragma unroll
-            for (int v = 0; v < 16; v++) acc[mt][nt][v] = 0.f;
-
-    for (int k = tid; k < in_floats; k += CONV_THREADS) lds_in[k] = 0.f;   // halo stays zero for the whole kernel
-
-    // weight stages (one contiguous 32*C-float block per (slice, tap)) stream into LDS by LDS-DMA
-    // (global_load_lds_dwordx4: no registers, no ds_write), one stage ahead of the MFMAs, double-buffered
-    constexpr int WPIECES = WSTAGE / 256;           // 1-KiB pieces per stage
-    auto dma_w = [&](int stage, int buf) {
-        const float *src = wp + (size_t)stage * WSTAGE;
-        float *dst = lds_w + buf * WSTAGE;
-        for (int pc = wave; pc < WPIECES; pc += CONV_THREADS / 64)
-            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)(src + pc * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void *)(dst + pc * 256), 16, 0, 0);
-    };
-
-    if (ABL != 1 && ABL != 3) dma_w(0, 0);   // stage index = ks * 9 + tap
-    for (int ks = 0; ks < KS; ks++) {
-        if (ABL != 3) __syncthreads();   // previous slice fully consumed (and the zero fill done)
-        // stage the 32-channel input slice: pixel p -> slot (y+1, x+1)
-        if (ABL != 2 && ABL != 3)
-        for (int item = tid; item < cells * 8; item += CONV_THREADS) {
-            const int p = item >> 3, q = item & 7;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(inb + (size_t)p * C + ks * 32 + q * 4);
-            *reinterpret_cast<f32x4 *>(lds_in + ((p / N + 1) * P + (p % N + 1)) * SLOT_F + q * 4) = v;
-        }
-#pragma unroll 1
-        for (int tap = 0; tap < 9; tap++) {
-            const int stage = ks * 9 + tap, buf = stage & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of `stage` have landed
-            if (ABL != 3) __syncthreads();                     // ... and everybody's; the other buffer is free again
-            if (ABL != 1 && ABL != 3) if (stage + 1 < KS * 9) dma_w(stage + 1, buf ^ 1);   // behind the MFMAs below
-            const int toff = ((tap / 3 - 1) * P + (tap % 3 - 1)) * SLOT_F;
-            const float *wb = lds_w + buf * WSTAGE;
-#pragma unroll
-            for (int kq = 0; kq < 4; kq++) {
-                f32x4 a[MTW], bf[NTW];
-#pragma unroll
-                for (int mt = 0; mt < MTW; mt++) {
-                    if (ABL == 4) { a[mt] = f32x4{(float)tap, (float)kq, (float)mt, 1.f}; asm volatile("" : "+v"(a[mt])); }
-                    else a[mt] = *reinterpret_cast<const f32x4 *>(lds_in + aoff[mt] + toff + kq * 8);
-                }
-#pragma unroll
-                for (int nt = 0; nt < NTW; nt++) {
-                    if (ABL == 4) { bf[nt] = f32x4{(float)ks, 0.5f, (float)nt, 2.f}; asm volatile("" : "+v"(bf[nt])); }
-                    else bf[nt] = *reinterpret_cast<const f32x4 *>(wb + ((kq * 2 + h) * C + (wn * NTW + nt) * 32 + i) * 4);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int mt = 0; mt < MTW; mt++)
-#pragma unroll
-                        for (int nt = 0; nt < NTW; nt++)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][r], bf[nt][r], acc[mt][nt], 0, 0, 0);
-            }
-        }
-    }
-
-    // epilogue.  In the C/D layout a lane owns ONE channel (col = lane & 31) and 16 rows
-    // (row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)), which would make every residual load / output store a 4-byte
-    // access.  Each 32x32 tile is therefore transposed through a wave-private LDS patch so that a lane handles four
-    // consecutive channels of a pixel: residual and output move as 16-byte vectors, 1 KiB per wave-instruction.
-    __syncthreads();                                   // every wave is done with the staging buffers
-    constexpr int PSTR = 36;                           // patch row stride in floats (16-byte aligned rows)
-    float *patch = smem + wave * (32 * PSTR);          // 8 x 4.5 KiB; the launcher sizes LDS for it
-    float *outb = out + b * (size_t)cells * C;
-    const float *resb = res ? res + b * (size_t)cells * C : nullptr;
-    const int r8 = lane >> 3, c4 = (lane & 7) * 4;
-#pragma unroll
-    for (int nt = 0; nt < NTW; nt++) {
-        const int n4 = (wn * NTW + nt) * 32 + c4;
-        // bias == nullptr / relu == 0: the training path (plain convolution)
-        const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + n4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const float floor_ = relu ? 0.f : -INFINITY;
-#pragma unroll
-        for (int mt = 0; mt < MTW; mt++) {
-#pragma unroll
-            for (int v = 0; v < 16; v++) patch[((v & 3) + 8 * (v >> 2) + 4 * h) * PSTR + i] = acc[mt][nt][v];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = j * 8 + r8;
-                const int p = (wm * MTW + mt) * 32 + row;
-                f32x4 y = *reinterpret_cast<const f32x4 *>(patch + row * PSTR + c4);
-                if (p < cells) {
-                    y = y + bi;
-                    if (resb) y = y + *reinterpret_cast<const f32x4 *>(resb + (size_t)p * C + n4);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) y[q] = y[q] > floor_ ? y[q] : floor_;
-                    *reinterpret_cast<f32x4 *>(outb + (size_t)p * C + n4) = y;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next tile overwrites it
-        }
-    }
-}
-
-size_t c6_conv_packed_floats(int C) { return (size_t)9 * C * C; }
-
-// w: folded OIHW [C][C][3][3]  ->  [tap][ks][kq][h][n][r], k = ks*32 + kq*8 + h*4 + r
-void c6_pack_conv_weights(int C, const float *w, float *packed) {
-    const int KS = C / 32;
-    for (int t = 0; t < 9; t++)
-        for (int ks = 0; ks < KS; ks++)
-            for (int kq = 0; kq < 4; kq++)
-                for (int h = 0; h < 2; h++)
-                    for (int n = 0; n < C; n++)
-                        for (int r = 0; r < 4; r++) {
-                            const int k = ks * 32 + kq * 8 + h * 4 + r;
-                            // stage index inside the kernel is ks*9 + tap
-                            packed[((((size_t)(ks * 9 + t) * 4 + kq) * 2 + h) * C + n) * 4 + r] = w[((size_t)n * C + k) * 9 + t];
-                        }
-}
-
-// ----------------------------------------------------------------------------------------
 // stem: dihedral gather (augment_way8, augment.rs:60-73) fused with conv3x3 2->C + folded BN + ReLU
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void c6_stem_kernel(const int8_t *__restrict__ boards, int board_stride,
                                                      const int8_t *__restrict__ player, const int16_t *__restrict__ aug_map,
                                                      int images, const float *__restrict__ w /*[9][2][C]*/,
-                                                     const float *__restrict__ bias, float *__restrict__ out, int N, int C,
-                                                     int s32) {
+                                                     const float *__restrict__ bias, float *__restrict__ out, int N, int C) {
     __shared__ float pl[21 * 21], bd[21 * 21];
     const int cells = N * N, P = N + 2;
     const size_t b = blockIdx.x;
@@ -240,9 +77,7 @@ __global__ __launch_bounds__(256) void c6_stem_kernel(const int8_t *__restrict__
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
-        // NHWC, or slice-major S32 = [C/32][pixel][32] (conv_v2.hip)
-        const size_t o = s32 ? ((size_t)(co >> 5) * cells + p) * 32 + (co & 31) : (size_t)p * C + co;
-        *reinterpret_cast<f32x4 *>(ob + o) = acc;
+        *reinterpret_cast<f32x4 *>(ob + (size_t)p * C + co) = acc;
     }
 }
 
@@ -254,15 +89,14 @@ __global__ __launch_bounds__(256) void c6_head_conv_kernel(const float *__restri
                                                           const float *__restrict__ pc_b, const float *__restrict__ vc_w,
                                                           float vc_b, const float *__restrict__ vn_scale,
                                                           const float *__restrict__ vn_shift, float *__restrict__ ph,
-                                                          float *__restrict__ vh, int cells, int C, int s32) {
+                                                          float *__restrict__ vh, int cells, int C) {
     const size_t b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *ab = act + b * (size_t)cells * C;
     for (int p = wave; p < cells; p += 4) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         for (int c = lane * 4; c < C; c += 256) {
-            const size_t o = s32 ? ((size_t)(c >> 5) * cells + p) * 32 + (c & 31) : (size_t)p * C + c;
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(ab + o);
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(ab + (size_t)p * C + c);
             const f32x4 a = *reinterpret_cast<const f32x4 *>(pc_w + c);
             const f32x4 d = *reinterpret_cast<const f32x4 *>(pc_w + C + c);
             const f32x4 e = *reinterpret_cast<const f32x4 *>(vc_w + c);
@@ -426,46 +260,6 @@ __global__ __launch_bounds__(256) void c6_head_value_kernel(const float *__restr
 // ----------------------------------------------------------------------------------------
 // host-side driver
 // ----------------------------------------------------------------------------------------
-template <int C>
-static void launch_conv(int MTW, int nboards, size_t smem, const float *in, const float *wp, const float *bias, const float *res,
-                        float *out, int N, hipStream_t s, int relu) {
-    switch (MTW) {
-    case 1:
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 1>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N, relu);
-        break;
-    case 2:
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<C, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 2>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N, relu);
-        break;
-    default:
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<C, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((c6_conv3x3_kernel<C, 3>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, wp, bias, res, out, N, relu);
-        break;
-    }
-}
-
-static void conv_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res,
-                          float *out, hipStream_t s, int relu = 1) {
-    const int cells = N * N, MT = (cells + 31) / 32, MTW = (MT + 3) / 4, P = N + 2;
-    size_t smem = ((size_t)((P * P * SLOT_F + 3) & ~3) + 2 * 32 * (size_t)C) * sizeof(float);
-    if (smem < (size_t)8 * 32 * 36 * sizeof(float)) smem = (size_t)8 * 32 * 36 * sizeof(float);   // epilogue patches
-    switch (C) {
-    case 64: launch_conv<64>(MTW, nboards, smem, in, wp, bias, res, out, N, s, relu); break;
-    case 128: launch_conv<128>(MTW, nboards, smem, in, wp, bias, res, out, N, s, relu); break;
-    case 256: launch_conv<256>(MTW, nboards, smem, in, wp, bias, res, out, N, s, relu); break;
-    default: break;
-    }
-}
-
-// exact-FP32 convolution for the trainer (csrc/trainer.cpp): plain conv (bias nullable, relu selectable) + residual
-bool c6_conv_fp32_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                           hipStream_t s, int relu) {
-    if (C != 64 && C != 128 && C != 256) return false;
-    conv_dispatch(C, N, nboards, in, wp, bias, res, out, s, relu);
-    return true;
-}
-
 static hipEvent_t timer_event(C6NetTimers *t) {
     hipEvent_t e;
     if (!t->pool.empty()) { e = t->pool.back(); t->pool.pop_back(); }
@@ -474,15 +268,13 @@ static hipEvent_t timer_event(C6NetTimers *t) {
 }
 
 void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t *boards, int board_stride,
-                        const int8_t *player, const int16_t *aug_map, float *act0, float *act1, float *act2, float *ph,
+                        const int8_t *player, const int16_t *aug_map, float *act0, float *act1, float *act2, float *vbuf, float *ph,
                         float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers) {
     const int nb = nleaf * images, cells = net.cells, C = net.C;
     if (nb == 0) return;
-    const int v2 = net.variant == 2 ? 1 : 0;
     hipLaunchKernelGGL(c6_stem_kernel, dim3(nb), dim3(256), 0, s, boards, board_stride, player, aug_map, images, net.stem_w,
-                       net.stem_b, act0, net.N, C, v2);
+                       net.stem_b, act0, net.N, C);
     float *x = act0, *y = act1, *z = act2;
-    const size_t wsz = c6_conv_packed_floats(C);
     const bool timed = timers && timers->enabled;
     static const bool fuse_heads = [] { const char *e = getenv("C6_HEAD_FUSE"); return !(e && e[0] == '0'); }();   // A/B switch
     bool head_fused = false;
@@ -493,20 +285,23 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
             const int l = 2 * i + half;
             const float *cin = half == 0 ? x : y, *cres = half == 0 ? nullptr : x;
             float *cout = half == 0 ? y : z;
-            if (net.variant == 5) c6_conv_f32n_dispatch(C, net.N, nb, cin, net.conv_w5 + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
-            else if (net.variant == 7 || net.variant == 8) {
+            const float *cb = net.conv_b + (size_t)l * C;
+            if (net.variant == C6_CONV_WINO)
+                c6_conv_wino_dispatch(C, net.N, nb, cin, net.conv_ww + (size_t)l * c6_conv_packed_wino_floats(C), cb, cres, cout, vbuf, net.num_cus, s, 1);
+            else if (net.variant == C6_CONV_F32N)
+                c6_conv_f32n_dispatch(C, net.N, nb, cin, net.conv_w5 + (size_t)l * c6_conv_packed_f32n_floats(C), cb, cres, cout, net.num_cus, s);
+            else if (net.variant == C6_CONV_B3S || net.variant == C6_CONV_BF16) {
                 // the last convolution keeps its activations to itself and hands the heads their 1x1 partial sums
                 head_fused = fuse_heads && l == 2 * (net.blocks - 1) - 1;
-                c6_conv_b3s_dispatch(C, net.N, nb, cin, net.conv_w7 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s, 1, net.variant == 7, head_fused ? net.head_w : nullptr);
-            }
-            else if (net.variant == 9) {
+                c6_conv_b3s_dispatch(C, net.N, nb, cin, net.conv_w7 + (size_t)l * c6_conv_packed_b3s_units(C), cb, cres, cout, net.num_cus, s, 1,
+                                     net.variant == C6_CONV_B3S, head_fused ? net.head_w : nullptr);
+            } else {      // C6_CONV_M8
                 head_fused = fuse_heads && l == 2 * (net.blocks - 1) - 1;
-                c6_conv_m8_dispatch(C, net.N, nb, cin, net.conv_w9 + (size_t)l * c6_conv_packed_m8_bytes(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s, 1, head_fused ? net.head_w : nullptr);
+                c6_conv_m8_dispatch(C, net.N, nb, cin, net.conv_w9 + (size_t)l * c6_conv_packed_m8_bytes(C), cb, cres, cout, net.num_cus, s, 1,
+                                    head_fused ? net.head_w : nullptr, net.range_flag, C6_M8_RANGE_HI);
+                if (net.range_flag && !head_fused)        // a sample of boards: each one's output must reach the lower end of the range
+                    c6_launch_range_sample(cout, nb < 32 ? nb : 32, (size_t)cells * C, C6_M8_RANGE_LO, C6_M8_RANGE_HI, net.range_flag, s);
             }
-            else if (net.variant == 6) c6_conv_b3n_dispatch(C, net.N, nb, cin, net.conv_w6 + (size_t)l * c6_conv_packed_b3n_units(C), net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
-            else if (net.variant == 3) c6_conv_b3_dispatch(C, net.N, nb, cin, net.conv_w3 + (size_t)l * c6_conv_packed_b3_units(C), net.conv_b + (size_t)l * C, cres, cout, s);
-            else if (v2) c6_conv_v2_dispatch(C, net.N, nb, cin, net.conv_w2 + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, net.num_cus, s);
-            else conv_dispatch(C, net.N, nb, cin, net.conv_w + (size_t)l * wsz, net.conv_b + (size_t)l * C, cres, cout, s);
             if (timed) {
                 hipEventRecord(e1, s);
                 timers->conv.emplace_back(e0, e1);
@@ -520,7 +315,7 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                            net.vn_scale, net.vn_shift, ph, vh, net.N, C / 32, c6_conv_b3s_head_rows(net.N), nb);
     else
         hipLaunchKernelGGL(c6_head_conv_kernel, dim3(nb), dim3(256), 0, s, x, net.pc_w, net.pc_b, net.vc_w, net.vc_b, net.vn_scale,
-                           net.vn_shift, ph, vh, cells, C, v2);
+                           net.vn_shift, ph, vh, cells, C);
     const int hgrid = (nb + HB - 1) / HB;
     const size_t sm_p = (size_t)(HB * 2 * cells + HB * cells) * sizeof(float);
     hipLaunchKernelGGL(c6_head_policy_kernel, dim3(hgrid), dim3(256), sm_p, s, ph, net.pl_wT, net.pl_b, pol, cells, nb);
@@ -556,21 +351,43 @@ void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches,
     if (reset) { t->acc_ms = 0; t->acc_n = 0; t->conv_flops = 0; }
 }
 
-// ---- micro-benchmark hook (c6_bench_conv in engine.cpp): one conv launch of a variant / ablation ----
-void c6_conv_bench_launch(int variant, int ablate, int C, int N, int nboards, const float *in, const float *w1, const float *w2,
-                          const float *bias, const float *res, float *out, int num_cus, hipStream_t s) {
-    if (variant == 2) { c6_conv_v2_dispatch(C, N, nboards, in, w2, bias, res, out, num_cus, s); return; }
-    if (variant == 5) { c6_conv_f32n_dispatch(C, N, nboards, in, w2, bias, res, out, num_cus, s); return; }
-    if (variant == 6) { c6_conv_b3n_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, num_cus, s); return; }
-    if (variant == 7 || variant == 8) { c6_conv_b3s_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, num_cus, s, 1, variant == 7); return; }
-    if (variant == 9) { c6_conv_m8_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned char *>(w2), bias, res, out, num_cus, s, 1, nullptr); return; }
-    if (variant == 3 && ablate != 0 && C == 256 && N == 19) { c6_conv_b3_ablate(ablate, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, s); return; }
-    if (variant == 3) { c6_conv_b3_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w2), bias, res, out, s); return; }
-    if (C != 256 || N != 19 || ablate == 0) { conv_dispatch(C, N, nboards, in, w1, bias, res, out, s); return; }
-    const int P = N + 2;
-    const size_t smem = ((size_t)((P * P * SLOT_F + 3) & ~3) + 2 * 32 * (size_t)C) * sizeof(float);
-#define ABLCASE(A) case A: hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_conv3x3_kernel<256, 3, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((c6_conv3x3_kernel<256, 3, A>), dim3(nboards), dim3(CONV_THREADS), smem, s, in, w1, bias, res, out, N, 1); break;
-    switch (ablate) { ABLCASE(1) ABLCASE(2) ABLCASE(3) ABLCASE(4) default: break; }
-#undef ABLCASE
+// range guard, second half: max |activation| of each board of a sample (one workgroup per board; see c6_engine.h)
+__global__ __launch_bounds__(1024) void c6_range_sample_kernel(const float *__restrict__ act, size_t board_floats, float lo, float hi, unsigned int *flag) {
+    __shared__ float red[16];
+    const f32x4 *a4 = reinterpret_cast<const f32x4 *>(act + (size_t)blockIdx.x * board_floats);
+    float mx = 0.f;
+    bool bad = false;
+    for (size_t i = threadIdx.x; i < board_floats / 4; i += 1024) {
+        const f32x4 v = a4[i];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float a = __builtin_fabsf(v[r]);
+            bad = bad || !(a <= hi);
+            mx = a > mx ? a : mx;
+        }
+    }
+    mx = c6_wave_max_f32(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    const bool anybad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int w = 0; w < 16; w++) m = red[w] > m ? red[w] : m;
+        unsigned int f = 0;
+        if (anybad) f |= 1u;
+        if (m > 0.f && m < lo) f |= 2u;
+        if (f) atomicOr(flag, f);
+    }
+}
+void c6_launch_range_sample(const float *act, int nboards, size_t board_floats, float range_lo, float range_hi, unsigned int *range_flag, hipStream_t s) {
+    if (nboards > 0) hipLaunchKernelGGL(c6_range_sample_kernel, dim3(nboards), dim3(1024), 0, s, act, board_floats, range_lo, range_hi, range_flag);
+}
+
+// ---- micro-benchmark hook (c6_bench_conv in engine.cpp): one conv launch of a kernel on random data ----
+void c6_conv_bench_launch(int variant, int C, int N, int nboards, const float *in, const float *w, const float *bias, const float *res,
+                          float *out, float *vbuf, int num_cus, hipStream_t s) {
+    if (variant == C6_CONV_WINO) c6_conv_wino_dispatch(C, N, nboards, in, w, bias, res, out, vbuf, num_cus, s, 1);
+    else if (variant == C6_CONV_F32N) c6_conv_f32n_dispatch(C, N, nboards, in, w, bias, res, out, num_cus, s);
+    else if (variant == C6_CONV_B3S || variant == C6_CONV_BF16)
+        c6_conv_b3s_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned short *>(w), bias, res, out, num_cus, s, 1, variant == C6_CONV_B3S);
+    else if (variant == C6_CONV_M8) c6_conv_m8_dispatch(C, N, nboards, in, reinterpret_cast<const unsigned char *>(w), bias, res, out, num_cus, s, 1, nullptr);
 }

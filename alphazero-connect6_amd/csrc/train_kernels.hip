@@ -56,26 +56,6 @@ void c6t_pack_b3s(int C, const float *w, unsigned short *packed, int transpose_f
 
 // the same for the exact-FP32 kernel (c6_conv3x3_kernel, net_kernels.hip): [stage = ks*9 + tap][kq][h][n][r],
 // k = ks*32 + kq*8 + h*4 + r
-__global__ void c6_pack_fp32_kernel(int C, const float *__restrict__ w, float *__restrict__ packed, int transpose_flip) {
-    const size_t total = (size_t)9 * C * C;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        size_t q = e;
-        const int r = (int)(q % 4); q /= 4;
-        const int n = (int)(q % C); q /= C;
-        const int h = (int)(q % 2); q /= 2;
-        const int kq = (int)(q % 4); q /= 4;
-        const int t = (int)(q % 9); q /= 9;
-        const int ks = (int)q;
-        const int k = ks * 32 + kq * 8 + h * 4 + r;
-        packed[e] = transpose_flip ? w[((size_t)k * C + n) * 9 + (8 - t)] : w[((size_t)n * C + k) * 9 + t];
-    }
-}
-void c6t_pack_fp32(int C, const float *w, float *packed, int transpose_flip, hipStream_t s) {
-    hipLaunchKernelGGL(c6_pack_fp32_kernel, dim3(512), dim3(256), 0, s, C, w, packed, transpose_flip);
-}
-
-// ... and for c6_conv3x3_f32n_kernel (conv_f32n.hip): [stage = ks*9 + tap][wave][u][lane][r],
-// n = wave*32 + (lane & 31), k = ks*32 + 8u + 4(lane >> 5) + r
 __global__ void c6_pack_f32n_kernel(int C, const float *__restrict__ w, float *__restrict__ packed, int transpose_flip) {
     const int WAVES = C / 32;
     const size_t total = (size_t)9 * C * C;

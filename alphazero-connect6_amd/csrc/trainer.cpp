@@ -133,8 +133,8 @@ extern "C" int c6_trainer_create(int board_size, int channels, int blocks, int b
     TA(t->partial, part);
     TA(t->sum0, std::max<size_t>(C, std::max<size_t>(n2, 256))); TA(t->sum1, std::max<size_t>(C, std::max<size_t>(n2, 256)));
     for (int q = 0; q < 4; q++) TA(t->X[q], t->act);
-    TA(t->wpack, c6_conv_packed_b3n_units((int)C));
-    TA(t->wpack32, c6_conv_packed_floats((int)C));
+    TA(t->wpack, c6_conv_packed_b3s_units((int)C));
+    TA(t->wpack32, c6_conv_packed_f32n_floats((int)C));
 #undef TA
     if (rc == C6_OK && hipMemcpy(t->mask, mask.data(), t->nfloats, hipMemcpyHostToDevice) != hipSuccess) rc = tfail(C6_ERR_HIP, "mask upload");
     if (rc != C6_OK) {
@@ -158,6 +158,11 @@ extern "C" void c6_trainer_destroy(c6_trainer *t) {
 
 extern "C" int c6_trainer_load_weights(c6_trainer *t, const float *blob, size_t nfloats) {
     if (!t || !blob) return tfail(C6_ERR_BAD_ARG, "c6_trainer_load_weights: NULL argument");
+    if (nfloats == t->nfloats + C6_BLOB_HEADER_FLOATS) {      // self-describing blob: verify geometry + checksum, skip the header
+        if (c6_net_blob_check_header(blob, nfloats, t->n, t->C, t->nb) != C6_OK) return tfail(C6_ERR_BAD_ARG, c6_last_error());
+        blob += C6_BLOB_HEADER_FLOATS;
+        nfloats -= C6_BLOB_HEADER_FLOATS;
+    }
     if (nfloats != t->nfloats) return tfail(C6_ERR_BAD_ARG, "c6_trainer_load_weights: blob size does not match c6_net_blob_floats()");
     TCHK(hipSetDevice(t->device));
     TCHK(hipMemcpy(t->P, blob, nfloats * sizeof(float), hipMemcpyHostToDevice));

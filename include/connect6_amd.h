@@ -119,7 +119,9 @@ enum {
     C6_ERR_OVERFLOW = 3,      /* a per-game record pool or path buffer overflowed */
     C6_ERR_HIP = 4,
     C6_ERR_INVALID_POSITION = 5, /* game/game_impl/mod.rs:151-153 "invalid position" */
-    C6_ERR_ALREADY_SET = 6       /* game/game_impl/mod.rs:155-157 "already set position" */
+    C6_ERR_ALREADY_SET = 6,      /* game/game_impl/mod.rs:155-157 "already set position" */
+    C6_ERR_RANGE = 7          /* C6_PREC_F16F8 only: weights (at load) or activations (while playing) left the range that arithmetic
+                                 is validated for -- the net's outputs would no longer be the FP32 net's.  Use C6_PREC_FP32 / _BF16X3 */
 };
 
 /* evaluator kinds (policy/alphazero_policy/mod.rs:128-134 `Evaluator`) */
@@ -130,21 +132,24 @@ enum {
     C6_EVAL_CALLBACK = 4  /* host callback with the reference's signature */
 };
 
-/* arithmetic of the net's 3x3 convolutions.  FP32, BF16X3 and F16F8 hold the net outputs to the 1e-5 parity bar of the tests. */
+/* Arithmetic of the net's 3x3 convolutions (everything else is FP32).  The reference net is f32 (AlphaZero/cpp_weighted/model.hpp:52-95),
+ * and so is the default. */
 enum {
-    C6_PREC_DEFAULT = 0,  /* = C6_PREC_F16F8 unless the environment sets C6_CONV_VARIANT */
-    C6_PREC_FP32 = 1,     /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate */
-    C6_PREC_BF16X3 = 3,   /* operands split hi+mid in bf16, x_hi*w_hi + x_hi*w_mid + x_mid*w_hi on bf16 MFMAs,
-                             f32 accumulate: error <= 3*2^-16 per product, 16x the FP32 matrix rate at 3 MFMAs per product */
-    C6_PREC_BF16 = 4,     /* plain bf16 products (x_hi*w_hi only), f32 accumulate: RELAXED tolerance -- net outputs agree with
-                             FP32 to ~1e-3, NOT the 1e-5 parity grade; for evaluation matches / throughput headroom (SURVEY 8f
-                             rank 4).  Never the benchmark's `value`. */
-    C6_PREC_F16F8 = 5     /* x_h*w_h on fp16 MFMAs (11-bit significands) + the two cross terms x_h*w_l + x_l*w_h on MX-scaled fp8
-                             MFMAs (v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 rate), f32 accumulate: ~2^-15 per product,
-                             the accuracy class of C6_PREC_BF16X3 (parity grade: net outputs within 1e-5) at 70 % of its
-                             matrix-pipe cycles.  Range: activations and BatchNorm-folded weights must stay inside fp16
-                             (|v| < 65504; the cross terms are complete up to |activation| 3584, clamped beyond) -- a net that
-                             leaves it wants C6_PREC_BF16X3, which covers the whole FP32 range */
+    C6_PREC_DEFAULT = 0,     /* = C6_PREC_FP32 */
+    C6_PREC_FP32 = 1,        /* f32 operands, exact f32 products, f32 accumulate on v_mfma_f32_32x32x2_f32, evaluated as Winograd F(2x2,3x3):
+                                2.03x fewer matrix FLOPs than the direct form at N = 19, same arithmetic type, the whole FP32 range */
+    C6_PREC_BF16X3 = 3,      /* operands split hi+mid in bf16, x_hi*w_hi + x_hi*w_mid + x_mid*w_hi on bf16 MFMAs, f32 accumulate: error
+                                <= 3*2^-16 per product; covers the whole FP32 range.  Net outputs within 1e-5 of FP32 in the tests */
+    C6_PREC_BF16 = 4,        /* plain bf16 products (x_hi*w_hi only): RELAXED tolerance -- net outputs agree with FP32 to ~1e-3, NOT the 1e-5
+                                parity grade; for evaluation matches / throughput headroom.  Never the benchmark's `value` */
+    C6_PREC_F16F8 = 5,       /* opt-in.  x_h*w_h on fp16 MFMAs + the cross terms x_h*w_l + x_l*w_h on MX-scaled fp8 MFMAs, f32 accumulate:
+                                ~2^-15 per product like C6_PREC_BF16X3 at 70 % of its matrix-pipe cycles, but a BOUNDED range: per-board
+                                max |activation| of every tower layer in [2^-3, 3584], BatchNorm-folded weights inside fp16 with the output
+                                channels of a layer within 2^10 of each other.  Guarded: c6_engine_load_weights returns C6_ERR_RANGE for weights
+                                outside it, and activations that leave it while playing set a sticky device flag that c6_engine_run /
+                                _stats / _maintain / _fetch_* report as C6_ERR_RANGE -- wrong priors are never returned with C6_OK */
+    C6_PREC_FP32_DIRECT = 6  /* the same f32 arithmetic as C6_PREC_FP32 as a direct implicit GEMM (no Winograd transforms): round 1's FP32
+                                kernel, kept as the yardstick of the Winograd path */
 };
 
 /* policy/alphazero_policy/mod.rs:91-96 HyperParameter + engine geometry */
@@ -181,8 +186,24 @@ void c6_default_config(c6_config *cfg); /* HyperParameter::default (mod.rs:98-10
 int c6_engine_create(const c6_config *cfg, c6_engine **out);
 void c6_engine_destroy(c6_engine *e);
 
-/* weight blob: flat f32 in PyTorch state order, see DESIGN.md "weight blob"; host pointer */
+/* Weight blob (host pointer): flat f32, the tensors of WeightedPolicy (AlphaZero/cpp_weighted/model.hpp:10-50) in FORWARD order, each
+ * BatchNorm's running statistics right behind its affine parameters, every tensor in PyTorch's layout:
+ *   conv.weight [C,2,3,3], conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var;
+ *   for each residual block i, for j = 0, 1: conv{i}_{j}.weight [C,C,3,3], .bias, norm{i}_{j}.weight, .bias, .running_mean, .running_var;
+ *   policy_conv.weight [2,C,1,1], .bias, policy_norm.{weight, bias, running_mean, running_var}, policy_linear.weight [N^2,2N^2], .bias;
+ *   value_conv.weight [1,C,1,1], .bias, value_norm.{weight, bias, running_mean, running_var} [N^2], value_linear1.weight [256,N^2], .bias,
+ *   value_linear2.weight [1,256], .bias.
+ * This is NOT libtorch's registration order (model.hpp registers the heads before the tower and lists buffers separately): build the
+ * blob by tensor NAME -- alphazero_connect6_amd.blob_from_state_dict does, INTEGRATION.md has the C++ loop.  A blob may carry the
+ * 8-float header of c6_net_blob_write_header in front (magic, version, geometry, payload size, checksum): c6_engine_load_weights
+ * accepts both sizes and rejects a headed blob whose geometry or checksum does not match. */
 size_t c6_net_blob_floats(int board_size, int channels, int blocks);
+#define C6_BLOB_HEADER_FLOATS 8
+size_t c6_net_blob_header_floats(void);
+/* dst = header + payload (payload already in place behind the header); nfloats = c6_net_blob_floats(...) + C6_BLOB_HEADER_FLOATS */
+int c6_net_blob_write_header(float *dst, size_t nfloats, int board_size, int channels, int blocks);
+int c6_net_blob_check_header(const float *blob, size_t nfloats, int board_size, int channels, int blocks);
+/* C6_ERR_RANGE: the engine's net_precision is C6_PREC_F16F8 and the weights are outside its validated range (message says which layer) */
 int c6_engine_load_weights(c6_engine *e, const float *blob, size_t nfloats);
 int c6_engine_set_callback(c6_engine *e, c6_callback cb);
 
@@ -300,9 +321,9 @@ int c6_net_forward(int board_size, int channels, int blocks, const float *blob, 
 /* same with an explicit C6_PREC_* */
 int c6_net_forward_prec(int board_size, int channels, int blocks, int precision, const float *blob, size_t nfloats, int num,
                         const int8_t *boards, const int8_t *player, float *policy, float *value);
-/* development / profiling hook: average duration (ms) of `iters` launches of one 3x3 conv variant on random data
- * (variant 1 = FP32 MFMA, 2 = experimental 16x16x4 kernel, 3 = bf16x3; ablate != 0 only for variant 1) */
-int c6_bench_conv(int board_size, int channels, int nboards, int iters, int variant, int ablate, int with_residual, double *avg_ms);
+/* development / profiling hook: average duration (ms) of `iters` launches of the 3x3 convolution of one C6_PREC_* on random data
+ * (`ablate` is unused and must be 0) */
+int c6_bench_conv(int board_size, int channels, int nboards, int iters, int precision, int ablate, int with_residual, double *avg_ms);
 /* host-only (no GPU needed): the weight image c6_conv3x3_m8_kernel (C6_PREC_F16F8) reads for one layer's folded OIHW weights --
  * fp16 planes [slice][tap 0..9 (9 = zeros)][wave][16-channel tile][lane][8], then per tap pair the fp8 planes
  * [slice][pair][wave][tile][lane][16 x q8(w_l 2^16) | 16 x q8(w_h 2^5)] (OCP e4m3, round to nearest even, saturating) */

@@ -18,12 +18,18 @@ def rand_blob(n, C, blocks, seed):
     return ge.make_random_blob(n, C, blocks, np.random.default_rng(seed))
 
 
-PRECISIONS = [pytest.param(1, id="fp32-mfma"), pytest.param(3, id="bf16x3-split"), pytest.param(5, id="f16f8-mixed")]
+# every parity-grade arithmetic of the 3x3 convolutions (C6_PREC_*): FP32 Winograd F(2x2,3x3) (the default), FP32 direct,
+# split bf16, fp16 + MX-fp8
+PRECISIONS = [pytest.param(1, id="fp32-winograd"), pytest.param(6, id="fp32-direct"), pytest.param(3, id="bf16x3-split"),
+              pytest.param(5, id="f16f8-mixed")]
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 64, 3, 5), (19, 128, 2, 4), (19, 256, 2, 3), (9, 256, 4, 8), (19, 256, 4, 2),
-                                            (19, 256, 8, 2)])      # the last one: BASELINE config 3's tower (stem + 7 blocks)
+                                            (19, 256, 8, 2),      # BASELINE config 3's tower (stem + 7 blocks)
+                                            # more boards than CUs, all distinct: persistent workgroups hand over from board to board
+                                            # (double-buffered LDS slices, trickle across boards; Winograd blocks straddle boards)
+                                            (19, 256, 2, 300), (15, 128, 3, 300), (9, 64, 2, 700)])
 def test_net_forward_vs_oracle(n, C, blocks, num, prec):
     need_gpu()
     rng = np.random.default_rng(n * 1000 + C)
@@ -33,7 +39,8 @@ def test_net_forward_vs_oracle(n, C, blocks, num, prec):
     player = rng.choice(np.array([-1, 1], np.int8), size=num)
     pol, val = pkg.net_forward(n, C, blocks, blob, boards, player, precision=prec)
     net = o.Net(n, C, blocks, blob)
-    for i in range(num):
+    check = range(num) if num <= 16 else sorted(set(list(range(6)) + [63, 64, 99, 100, 255, 256, 257, num // 2, num - 2, num - 1]))
+    for i in check:
         rp, rv = net.forward(float(player[i]), boards[i].astype(np.float32))
         assert np.abs(pol[i] - rp[0]).max() <= TOL, (i, np.abs(pol[i] - rp[0]).max())
         assert abs(val[i] - rv[0]) <= TOL
@@ -65,45 +72,6 @@ def test_net_forward_large_activations(prec):
     assert np.isfinite(pol).all() and np.isfinite(val).all()
     assert 0.05 < np.abs(rv).max() < 0.999 and rp.max() < 0.9                      # not saturated: the comparison means something
     assert np.abs(pol - rp).max() <= TOL and np.abs(val - rv).max() <= TOL, (np.abs(pol - rp).max(), np.abs(val - rv).max())
-
-
-@pytest.mark.parametrize("variant", ["7", "6", "3"])
-@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (15, 128, 3, 5), (19, 256, 2, 300), (15, 256, 2, 7)])
-def test_split_conv_variants_vs_oracle(n, C, blocks, num, variant, monkeypatch):
-    """every split-bf16 conv kernel (C6_CONV_VARIANT: 7 = 16x16x32 N-split, the default; 6 = 32x32x16 N-split; 3 = M x N
-    grid) against the oracle; num = 300 > 256 CUs makes the persistent workgroups walk over more than one board"""
-    need_gpu()
-    monkeypatch.setenv("C6_CONV_VARIANT", variant)
-    rng = np.random.default_rng(n * 77 + C)
-    blob = rand_blob(n, C, blocks, seed=n + C + blocks + 1)
-    boards = rng.integers(-1, 2, size=(num, n * n)).astype(np.int8)
-    player = rng.choice(np.array([-1, 1], np.int8), size=num)
-    pol, val = pkg.net_forward(n, C, blocks, blob, boards, player, precision=3)
-    net = o.Net(n, C, blocks, blob)
-    for i in list(range(min(num, 4))) + ([num - 1, num // 2, 257] if num > 257 else []):
-        rp, rv = net.forward(float(player[i]), boards[i].astype(np.float32))
-        assert np.abs(pol[i] - rp[0]).max() <= TOL, (i, np.abs(pol[i] - rp[0]).max())
-        assert abs(val[i] - rv[0]) <= TOL
-    net.close()
-
-
-@pytest.mark.parametrize("n,C,blocks,num", [(9, 64, 2, 9), (19, 256, 2, 300), (15, 128, 3, 6), (15, 256, 2, 7)])
-@pytest.mark.parametrize("variant", ["2", "5"])
-def test_fp32_conv_variants_vs_oracle(n, C, blocks, num, variant, monkeypatch):
-    """the other FP32 kernels: C6_CONV_VARIANT=2 (experimental: 16x16x4 tiles, slice-major activations, conv_v2.hip) and
-    5 (N-split persistent schedule, conv_f32n.hip)"""
-    need_gpu()
-    monkeypatch.setenv("C6_CONV_VARIANT", variant)
-    rng = np.random.default_rng(n + C)
-    blob = rand_blob(n, C, blocks, seed=n + C + blocks + 2)
-    boards = rng.integers(-1, 2, size=(num, n * n)).astype(np.int8)
-    player = rng.choice(np.array([-1, 1], np.int8), size=num)
-    pol, val = pkg.net_forward(n, C, blocks, blob, boards, player, precision=1)
-    net = o.Net(n, C, blocks, blob)
-    for i in list(range(min(num, 6))) + ([num - 1, 257] if num > 257 else []):
-        rp, rv = net.forward(float(player[i]), boards[i].astype(np.float32))
-        assert np.abs(pol[i] - rp[0]).max() <= TOL and abs(val[i] - rv[0]) <= TOL
-    net.close()
 
 
 @pytest.mark.parametrize("n,C,blocks,num", [(19, 256, 4, 20), (15, 128, 3, 300), (9, 64, 3, 9)])
@@ -158,17 +126,20 @@ def test_net_forward_vs_torch_fp64_at_baseline_shape(prec):
     assert np.abs(pol - rp).max() <= TOL and np.abs(val - rv).max() <= TOL, (np.abs(pol - rp).max(), np.abs(val - rv).max())
 
 
-def test_split_path_agrees_with_fp32_path_at_benchmark_shape():
-    """19x19, C = 256: the bf16x3 split path and the exact-FP32 MFMA path agree to the 1e-5 bar (the split error is
-    relative, <= 3 * 2^-16 per product, and shrinks by 1/sqrt(K) in the 2304-term sums)"""
+def test_all_paths_agree_at_benchmark_shape():
+    """19x19, C = 256: Winograd FP32, the bf16x3 split and the mixed path agree with the direct FP32 MFMA path to the 1e-5 bar
+    (the split error is relative, <= 3 * 2^-16 per product, and shrinks by 1/sqrt(K) in the 2304-term sums; Winograd's is a
+    few f32 roundings in the transforms)"""
     need_gpu()
     n, C, blocks = 19, 256, 3
     blob = rand_blob(n, C, blocks, seed=77)
     rng = np.random.default_rng(5)
     boards = rng.integers(-1, 2, size=(3, n * n)).astype(np.int8)
-    ref = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=1)
-    got = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=3)
-    assert np.abs(ref[0] - got[0]).max() <= TOL and np.abs(ref[1] - got[1]).max() <= TOL
+    ref = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=pkg.PREC_FP32_DIRECT)
+    for prec in (pkg.PREC_FP32, pkg.PREC_BF16X3, pkg.PREC_F16F8):
+        got = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=prec)
+        assert np.abs(ref[0] - got[0]).max() <= TOL and np.abs(ref[1] - got[1]).max() <= TOL, prec
+    assert (pkg.net_forward(n, C, blocks, blob, boards, 1, precision=pkg.PREC_DEFAULT)[0] == pkg.net_forward(n, C, blocks, blob, boards, 1, precision=pkg.PREC_FP32)[0]).all()
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
@@ -198,3 +169,196 @@ def test_engine_net_evaluator_matches_oracle_priors(prec):
     assert st["simulations"] == 31 * 5 and st["overflow_games"] == 0
     eng.close()
     net.close()
+
+
+# ---- trained-like weights and the range guard of C6_PREC_F16F8 ---------------------------------------------------------
+
+def _blob_offsets(n, C, blocks):
+    """start of every BatchNorm gamma in the blob: [(name, offset, count)]"""
+    cells = n * n
+    out, off = [], C * 18 + C
+    out.append(("stem", off, C)); off += 4 * C
+    for l in range(2 * (blocks - 1)):
+        off += C * C * 9 + C
+        out.append((f"tower{l}", off, C)); off += 4 * C
+    return out
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_net_after_training_steps(prec):
+    """weights after 60 SGD steps of the HIP trainer (train mode moves every BatchNorm statistic away from its initial value,
+    momentum spreads the channel scales): every parity-grade arithmetic still meets 1e-5 against the oracle's FP32 net"""
+    need_gpu()
+    import torch_ref as tr
+    import torch
+    n, C, blocks, B = 9, 64, 3, 64
+    blob = rand_blob(n, C, blocks, seed=21)
+    t = pkg.Trainer(n, C, blocks, B, lr=2e-2, momentum=0.9, precision=pkg.PREC_FP32)
+    t.load_weights(blob)
+    for k in range(60):
+        w, p, b, q = [x.numpy() for x in tr.make_batch(n, B, 100 + k)]
+        t.step(w, p, b, q)
+    trained = t.export_weights()
+    t.close()
+    assert np.isfinite(trained).all() and np.abs(trained - blob).max() > 1e-3
+    rng = np.random.default_rng(2)
+    boards = rng.integers(-1, 2, size=(6, n * n)).astype(np.int8)
+    player = rng.choice(np.array([-1, 1], np.int8), size=6)
+    try:
+        pol, val = pkg.net_forward(n, C, blocks, trained, boards, player, precision=prec)
+    except pkg.C6Error as e:      # the bounded-range arithmetic may refuse a net -- loudly -- but never answers wrongly
+        assert prec == pkg.PREC_F16F8 and f"error {pkg.ERR_RANGE}" in str(e)
+        return
+    net = o.Net(n, C, blocks, trained)
+    for i in range(6):
+        rp, rv = net.forward(float(player[i]), boards[i].astype(np.float32))
+        assert np.abs(pol[i] - rp[0]).max() <= TOL and abs(val[i] - rv[0]) <= TOL
+    net.close()
+
+
+def _scaled_blob(n, C, blocks, spread, seed):
+    """per-channel BatchNorm scales spanning `spread` decades around 1 in every tower layer, compensated in the NEXT layer's
+    input weights so that the function stays well conditioned (what an optimiser does to a scale-invariant net): folded
+    weights and activations then span the same decades"""
+    blob = rand_blob(n, C, blocks, seed=seed).copy()
+    rng = np.random.default_rng(seed)
+    offs = _blob_offsets(n, C, blocks)
+    L = 2 * (blocks - 1)
+    # residual sums tie the scales of a block's output to its input: scale only the FIRST conv of each block (its output feeds
+    # nothing but the block's second conv)
+    for l in range(0, L, 2):
+        name, goff, k = offs[1 + l]
+        sc = 10.0 ** rng.uniform(-spread / 2, spread / 2, C).astype(np.float32)
+        blob[goff:goff + C] *= sc                       # gamma
+        blob[goff + C:goff + 2 * C] *= sc               # beta
+        w2 = offs[1 + l][1] + 4 * C                     # next layer's conv weight [C_out, C_in, 3, 3]
+        wv = blob[w2:w2 + C * C * 9].reshape(C, C, 9)
+        wv /= sc[None, :, None]
+    return blob
+
+
+@pytest.mark.parametrize("prec", [pytest.param(1, id="fp32-winograd"), pytest.param(6, id="fp32-direct"), pytest.param(3, id="bf16x3-split")])
+def test_net_channel_scales_spanning_six_decades(prec):
+    """BatchNorm scales from 1e-3 to 1e3 inside every block: the full-range arithmetics (FP32 both ways, split bf16) hold 1e-5"""
+    need_gpu()
+    n, C, blocks = 15, 64, 3
+    blob = _scaled_blob(n, C, blocks, spread=6.0, seed=5)
+    rng = np.random.default_rng(8)
+    boards = rng.integers(-1, 2, size=(4, n * n)).astype(np.int8)
+    pol, val = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=prec)
+    net = o.Net(n, C, blocks, blob)
+    rp, rv = net.forward(1.0, boards.astype(np.float32))
+    net.close()
+    assert np.abs(pol - rp).max() <= TOL and np.abs(val - rv).max() <= TOL, (np.abs(pol - rp).max(), np.abs(val - rv).max())
+
+
+def test_f16f8_guard_rejects_weights_outside_its_range():
+    """the same six-decade net on C6_PREC_F16F8: refused at load time with C6_ERR_RANGE (never wrong priors with C6_OK); a
+    two-decade spread is inside the validated range and meets 1e-5"""
+    need_gpu()
+    n, C, blocks = 15, 64, 3
+    boards = np.random.default_rng(8).integers(-1, 2, size=(4, n * n)).astype(np.int8)
+    with pytest.raises(pkg.C6Error) as ei:
+        pkg.net_forward(n, C, blocks, _scaled_blob(n, C, blocks, 6.0, 5), boards, 1, precision=pkg.PREC_F16F8)
+    assert f"error {pkg.ERR_RANGE}" in str(ei.value) and "F16F8" in str(ei.value)
+    eng = pkg.Engine(board_size=n, num_games=2, num_simulation=4, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks, net_precision=pkg.PREC_F16F8)
+    with pytest.raises(pkg.C6Error):
+        eng.load_weights(_scaled_blob(n, C, blocks, 6.0, 5))
+    with pytest.raises(pkg.C6Error):      # ... and the engine is left without weights, not with half-loaded ones
+        eng.step(1)
+    eng.close()
+    blob = _scaled_blob(n, C, blocks, 2.0, 6)
+    pol, val = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=pkg.PREC_F16F8)
+    net = o.Net(n, C, blocks, blob)
+    rp, rv = net.forward(1.0, boards.astype(np.float32))
+    net.close()
+    assert np.abs(pol - rp).max() <= TOL and np.abs(val - rv).max() <= TOL
+
+
+@pytest.mark.parametrize("gain,what", [(1e4, "3584"), (1e-4, "2^-3")])
+def test_f16f8_guard_flags_activations_outside_its_range(gain, what):
+    """stem activations far above 3584 (gain 1e4) or in fp16's subnormal neighbourhood (gain 1e-4): C6_PREC_F16F8 answers
+    C6_ERR_RANGE (here already from the load-time bound of the stem; test_f16f8_engine_reports_range_error_while_playing covers
+    the device-side flag); the full-range paths evaluate the same net to 1e-5"""
+    need_gpu()
+    n, C, blocks, num = 9, 64, 3, 3
+    cells = n * n
+    blob = rand_blob(n, C, blocks, seed=31).copy()
+    # scale the stem's OUTPUT (gamma, beta) and compensate in the 1x1 head filters, as test_net_forward_large_activations does
+    g0 = C * 18 + C
+    blob[g0:g0 + 2 * C] *= gain
+    tower = C * 18 + C + 4 * C + 2 * (blocks - 1) * (C * C * 9 + C + 4 * C)
+    blob[tower:tower + 2 * C] /= gain
+    vconv = tower + 2 * C + 2 + 8 + cells * 2 * cells + cells
+    blob[vconv:vconv + C] /= gain
+    boards = np.random.default_rng(3).integers(-1, 2, size=(num, cells)).astype(np.int8)
+    with pytest.raises(pkg.C6Error) as ei:
+        pkg.net_forward(n, C, blocks, blob, boards, 1, precision=pkg.PREC_F16F8)
+    assert f"error {pkg.ERR_RANGE}" in str(ei.value) and what in str(ei.value)
+    net = o.Net(n, C, blocks, blob)
+    rp, rv = net.forward(1.0, boards.astype(np.float32))
+    net.close()
+    for prec in (pkg.PREC_FP32, pkg.PREC_FP32_DIRECT, pkg.PREC_BF16X3):
+        pol, val = pkg.net_forward(n, C, blocks, blob, boards, 1, precision=prec)
+        assert np.abs(pol - rp).max() <= TOL and np.abs(val - rv).max() <= TOL, (prec, np.abs(pol - rp).max(), np.abs(val - rv).max())
+
+
+def test_f16f8_engine_reports_range_error_while_playing():
+    """inside the engine the flag is sticky: step() itself never synchronises, the next synchronising call (stats) returns
+    C6_ERR_RANGE instead of statistics built on wrong priors"""
+    need_gpu()
+    n, C, blocks = 9, 64, 3
+    cells = n * n
+    blob = rand_blob(n, C, blocks, seed=31).copy()
+    # the residual stream grows by x30 per block: the stem passes the load-time bound, the second block's output does not
+    offs = _blob_offsets(n, C, blocks)
+    for l in (1, 3):
+        goff = offs[1 + l][1]
+        blob[goff:goff + 2 * C] *= 300.0
+    eng = pkg.Engine(board_size=n, num_games=4, num_simulation=8, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks,
+                     net_precision=pkg.PREC_F16F8)
+    eng.load_weights(blob)
+    eng.step(3)
+    with pytest.raises(pkg.C6Error) as ei:
+        eng.stats()
+    assert f"error {pkg.ERR_RANGE}" in str(ei.value)
+    eng.close()
+
+
+def test_blob_header_rejects_a_permuted_blob():
+    """a blob with the right float count but libtorch's registration order (heads before the tower) used to load and
+    play garbage.  blob_from_state_dict assembles by NAME; the header's checksum / geometry reject everything else."""
+    need_gpu()
+    import torch
+    import torch_ref as tr
+    n, C, blocks = 9, 64, 3
+    torch.manual_seed(3)
+    m = tr.WeightedPolicy(n, C, blocks)
+    tr.randomize_bn(m)
+    want = tr.blob_of(m)
+    sd = {k: v for k, v in m.state_dict().items()}
+    headed = pkg.blob_from_state_dict(sd, n, C, blocks)                  # ModuleList names (tower.i.j.*) via the alias table
+    assert (headed[8:] == want).all()
+    # the reference's own names (model.hpp:44-49: conv{i}_{j}, norm{i}_{j}), in libtorch's registration order: heads first
+    ref_sd = {}
+    for k, v in reversed(list(sd.items())):
+        parts = k.split(".")
+        if parts[0] == "tower":
+            i, j = int(parts[1]), int(parts[2])
+            k = ("conv" if j % 2 == 0 else "norm") + f"{i}_{j // 2}." + parts[3]
+        ref_sd[k] = v
+    assert (pkg.blob_from_state_dict(ref_sd, n, C, blocks)[8:] == want).all()
+    boards = np.random.default_rng(1).integers(-1, 2, size=(2, n * n)).astype(np.int8)
+    p1, v1 = pkg.net_forward(n, C, blocks, headed, boards, 1)
+    p0, v0 = pkg.net_forward(n, C, blocks, want, boards, 1)
+    assert (p1 == p0).all() and (v1 == v0).all()
+    # a permuted payload under a valid header
+    bad = headed.copy()
+    k = C * 18
+    bad[8:8 + k], bad[8 + k:8 + 2 * k] = headed[8 + k:8 + 2 * k].copy(), headed[8:8 + k].copy()
+    with pytest.raises(pkg.C6Error) as ei:
+        pkg.net_forward(n, C, blocks, bad, boards, 1)
+    assert "checksum" in str(ei.value)
+    with pytest.raises(pkg.C6Error) as ei:
+        pkg.net_forward(n, C, blocks + 1, np.concatenate([headed, np.zeros(pkg.blob_floats(n, C, blocks + 1) - want.size, np.float32)]), boards, 1)
+    assert "another board size" in str(ei.value) or "payload" in str(ei.value)

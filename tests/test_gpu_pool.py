@@ -13,16 +13,18 @@ pytestmark = pytest.mark.gpu
 N = 9
 
 
-def peaked(player, boards):
-    """value 0 and a prior concentrated on the empty cell nearest the centre (invariant under the 8 dihedral images, so the
-    averaged prior keeps the peak): nearly every search follows the peaked child, level after level -- deep trees"""
-    b = np.asarray(boards).reshape(-1, N * N)
-    rr, cc = np.divmod(np.arange(N * N), N)
-    d2 = ((rr - N // 2) ** 2 + (cc - N // 2) ** 2).astype(np.float32)
-    logits = np.where(b == 0, -3.0 * d2[None, :], -1e9).astype(np.float32)
+def peaked(player, boards, n=N):
+    """A prior of e^(-14 d^2) around the centre-most empty cell (invariant under the 8 dihedral images, so the averaged prior
+    keeps the peak; every other child is ~1e-6) and a value every mover likes two plies up (-0.9 * side to move: with
+    two-stone turns the mover two plies above a leaf is always the other colour): with epsilon = 0.001 nearly every search
+    follows the peaked child level after level -- the select depth reaches the teens (mean 6.5 on the oracle)"""
+    b = np.asarray(boards).reshape(-1, n * n)
+    rr, cc = np.divmod(np.arange(n * n), n)
+    d2 = ((rr - n // 2) ** 2 + (cc - n // 2) ** 2).astype(np.float32)
+    logits = np.where(b == 0, -14.0 * d2[None, :], -1e9).astype(np.float32)
     e = np.exp(logits - logits.max(axis=1, keepdims=True))
     pol = e / e.sum(axis=1, keepdims=True)
-    return np.zeros(b.shape[0], np.float32), pol.astype(np.float32)
+    return np.full(b.shape[0], -0.9 * player, np.float32), pol.astype(np.float32)
 
 
 def oracle_eval(ctx, turn, nn, ln, boards, values, policies):
@@ -42,7 +44,7 @@ def test_pool_grows_under_a_peaked_prior_and_games_stay_exact():
     """8 records per game to start with, a prior that drives the select depth far beyond 8: c6_engine_run doubles the pools (and
     the select-path buffer) as often as needed and every game still equals the oracle's unbounded map stone for stone."""
     need_gpu()
-    G, S, seed, eps = 4, 60, 5, 0.05
+    G, S, seed, eps = 4, 60, 5, 0.001
     eng = pkg.Engine(board_size=N, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_CALLBACK, records_per_game=8)
     eng.set_callback(peaked)
     eng.run()
@@ -59,7 +61,7 @@ def test_step_without_maintain_parks_the_game_and_maintain_resumes_it_exactly():
     """c6_engine_step never synchronises, so it cannot grow: the game waits in status overflow (visible in the stats), loses
     nothing, and continues after c6_engine_maintain -- same final game as the oracle."""
     need_gpu()
-    G, S, seed, eps = 2, 30, 9, 0.05
+    G, S, seed, eps = 2, 30, 9, 0.001
     eng = pkg.Engine(board_size=N, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_CALLBACK, records_per_game=8)
     eng.set_callback(peaked)
     eng.step(20)
@@ -80,7 +82,7 @@ def test_exhausted_pool_returns_partial_games_and_says_so():
     hands the stopped games back as partial results (winner 0, a prefix of the oracle's game) -- never C6_OK with games
     missing, never an abort."""
     need_gpu()
-    G, S, seed, eps = 3, 40, 5, 0.05
+    G, S, seed, eps = 3, 40, 5, 0.001
     eng = pkg.Engine(board_size=N, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_CALLBACK, records_per_game=8,
                      max_records_per_game=32)
     eng.set_callback(peaked)
@@ -113,15 +115,10 @@ def test_dropin_self_play_survives_an_exhausted_pool(monkeypatch, capfd):
     n = pkg.REF_N
 
     def pol(turn, boards):
-        b = np.asarray(boards).reshape(-1, n * n)
-        rr, cc = np.divmod(np.arange(n * n), n)
-        d2 = ((rr - n // 2) ** 2 + (cc - n // 2) ** 2).astype(np.float32)
-        logits = np.where(b == 0, -3.0 * d2[None, :], -1e9).astype(np.float32)
-        e = np.exp(logits - logits.max(axis=1, keepdims=True))
-        return np.zeros(b.shape[0], np.float32), (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+        return peaked(turn, boards, n)
 
     param = pkg.default_param()
-    param.update(num_simulation=40, epsilon=0.05, num_game_thread=2)
+    param.update(num_simulation=40, epsilon=0.001, num_game_thread=2)
     res = pkg.self_play(pol, param)
     err = capfd.readouterr().err
     assert len(res) == 2 and "partial" in err

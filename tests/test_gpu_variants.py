@@ -1,6 +1,6 @@
 """The env-switched fallback paths of the library, each in a child process (the switches are read once per process):
 
-* C6_BOARD_VARIANT=1 -- K1's global-load kernel, which the launcher also takes when a board array is too large for the
+* C6_BOARD_WIDE=1 -- K1's global-load kernel, which the launcher also takes when a board array is too large for the
   32-bit row descriptors of the default kernel (board_kernel.hip): same bits as the default kernel and as the oracle
   (game_impl/mod.rs:148-169, search_winner/mod.rs:201-246);
 * C6_HEAD_FUSE=0 -- the evaluator with a separate 1x1 head convolution instead of the partial sums the tower's last
@@ -60,7 +60,7 @@ def test_board_global_load_kernel_matches(n):
     pos = rng.integers(-1, n * n + 2, G).astype(np.int32)      # includes "no move" (-1) and invalid positions
     here = dict(winner=pkg.search_winner(n, soa), mask=pkg.legal_mask(n, soa))
     here["b"], here["t"], here["r"], here["w"], here["e"] = pkg.board_step(n, soa, turn, remain, pos)
-    other = run_child({"C6_BOARD_VARIANT": "1"}, n=n, boards=soa, turn=turn, remain=remain, pos=pos)
+    other = run_child({"C6_BOARD_WIDE": "1"}, n=n, boards=soa, turn=turn, remain=remain, pos=pos)
     for k, v in here.items():
         assert (other[k] == v).all(), k
     assert (here["winner"] == np.array([o.search(b) for b in boards], np.int8)).all()
