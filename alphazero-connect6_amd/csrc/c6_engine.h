@@ -177,6 +177,10 @@ void c6_pack_conv_weights_wino(int C, const float *w_oihw_folded, float *packed)
 size_t c6_conv_wino_vbuf_floats(int C, int N, int nboards);
 bool c6_conv_wino_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            float *vbuf, int num_cus, hipStream_t s, int relu = 1);
+bool c6_conv_wino_transform(int C, int N, int nboards, const float *in, float *vbuf, int num_cus, hipStream_t s);      // the two steps of a dispatch
+bool c6_conv_wino_gemm(int C, int N, int nboards, const float *vbuf, const float *wp, const float *bias, const float *res, float *out, int num_cus,
+                       hipStream_t s, int relu = 1);
+double c6_conv_wino_exec_flops(int C, int N, int nboards);
 // FP32 direct (conv_f32n.hip)
 size_t c6_conv_packed_f32n_floats(int C);
 void c6_pack_conv_weights_f32n(int C, const float *w_oihw_folded, float *packed);

@@ -8,7 +8,8 @@
 //
 //  K-in   c6_wino_in_kernel:  activations NHWC -> V[block][pos 16][tile 64][C + 4]  (B^T d B per tile and channel; a block = 64
 //         consecutive tiles of the batch, tiles of a board in row-major order, 4 pad floats per row so that the GEMM kernel's
-//         LDS image IS this memory image).  HBM bound: reads the activations once, writes 16/4 x their size.
+//         LDS image IS this memory image).  HBM bound: reads the activations once (rolling row window in LDS), writes 16/4 x
+//         their size.
 //  K-gemm c6_wino_gemm_kernel: per block and position p the GEMM  M_p[cout][tile] = sum_cin U_p[cout][cin] V_p[cin][tile]
 //         on 32x32x2 MFMAs, the output transform  Y += A^T-coefficient(p) * M_p  accumulated in registers position by
 //         position (position-outer order: 2 + 8 accumulator tiles per wave instead of 32), epilogue = bias + residual + ReLU +
@@ -43,50 +44,115 @@ struct WinoGeom {
 };
 
 // ---- input transform ------------------------------------------------------------------------------------------------
+// One workgroup walks over boards; a board's rows pass through a rolling 4-row window in LDS (row y in slot (y + 1) & 3, columns
+// x = -1 .. 2 TW with a zero halo), so every activation is read from HBM ONCE although each pixel belongs to up to four 4x4
+// patches (the first form of this kernel gathered the patches straight from memory: 35 GB fetched for 12 GB of activations at
+// 32 768 boards, profiles/r02_wino_prof_v1.json).  Per tile row: the two new rows are prefetched into registers while the tiles
+// of the current row are transformed (C / 4 lanes per tile, each 4 channels: B^T d B is 32 + 32 adds on f32x4) and stored --
+// 16 positions x one 1-KiB run per tile at C = 256.
+#define WINO_IN_THREADS 320
+template <int C>
+struct WinoInGeom {
+    static constexpr int CS = C < 128 ? C : 128;      // channels per workgroup: a 256-channel board is two work items (45 KB of LDS
+    static constexpr int NS = C / CS;                 // each: three workgroups per CU keep enough loads and stores in flight)
+};
 template <int C, int N>
-__global__ __launch_bounds__(256) void c6_wino_in_kernel(const float *__restrict__ in, float *__restrict__ V, long total_tiles) {
+__global__ __launch_bounds__(WINO_IN_THREADS) void c6_wino_in_kernel(const float *__restrict__ in, float *__restrict__ V, int nboards) {
     using G = WinoGeom<C, N>;
-    constexpr int LPT = C / 4, TPI = 256 / LPT, CP = G::CP, T = G::T, TW = G::TW;
+    constexpr int CS = WinoInGeom<C>::CS, NS = WinoInGeom<C>::NS;
+    constexpr int LPT = CS / 4, TPI = WINO_IN_THREADS / LPT, CP = G::CP, T = G::T, TW = G::TW, COLS = 2 * TW + 2;
+    constexpr int ROWF = COLS * CS;                                 // floats of one window row
+    constexpr int NPF = (2 * N * LPT + WINO_IN_THREADS - 1) / WINO_IN_THREADS;      // prefetch items (f32x4) per thread and step
+    extern __shared__ __attribute__((aligned(16))) float win[];    // [4][COLS][CS]
     const int tid = threadIdx.x, cq = tid % LPT, tsub = tid / LPT;
-    const long b = blockIdx.x;
-    float *vb = V + (size_t)b * 16 * G::SLAB;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = tid; k < 4 * ROWF / 4; k += WINO_IN_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
+    // item k of a 2-row load: row y0 + k / (N LPT), pixel (k / LPT) % N, channel quad k % LPT; rows outside the board are zeros
+    auto item_src = [&](const float *ib, int y0, int k, bool &ok) -> const float * {
+        const int r = k / (N * LPT), px = (k / LPT) % N, q = k % LPT, y = y0 + r;
+        ok = k < 2 * N * LPT && y >= 0 && y < N;
+        return ib + (size_t)((ok ? y : 0) * N + px) * C + q * 4;
+    };
+    auto item_dst = [&](int y0, int k) -> float * {
+        const int r = k / (N * LPT), px = (k / LPT) % N, q = k % LPT, y = y0 + r;
+        return win + ((y + 1) & 3) * ROWF + (px + 1) * CS + q * 4;
+    };
 #pragma unroll 1
-    for (int it = 0; it < WINO_BT / TPI; it++) {
-        const int tl = it * TPI + tsub;
-        const long t = b * WINO_BT + tl;
-        const bool valid = t < total_tiles;
-        const long bd = valid ? t / T : 0;
-        const int tt = valid ? (int)(t - bd * T) : 0, ty = tt / TW, tx = tt - ty * TW;
-        const float *ib = in + (size_t)bd * (N * N) * C + cq * 4;
-        f32x4 d[4][4];
+    for (int item = blockIdx.x; item < nboards * NS; item += gridDim.x) {
+        const int bd = item / NS, c0 = (item % NS) * CS;           // board and first channel of this work item
+        const float *ib = in + (size_t)bd * (N * N) * C + c0;
+        __syncthreads();                                            // the previous item's last reads (and the zero fill)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int half = 0; half < 2; half++)                        // rows -1, 0 and 1, 2
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + c;
-                const bool ok = valid && y >= 0 && y < N && x >= 0 && x < N;
-                d[r][c] = ok ? *reinterpret_cast<const f32x4 *>(ib + (size_t)(y * N + x) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NPF; i++) {
+                const int k = tid + i * WINO_IN_THREADS;
+                bool ok;
+                const float *sp = item_src(ib, 2 * half - 1, k, ok);
+                const f32x4 v = ok ? *reinterpret_cast<const f32x4 *>(sp) : zero4;
+                if (k < 2 * N * LPT) *reinterpret_cast<f32x4 *>(item_dst(2 * half - 1, k)) = v;
             }
-        // B^T d: rows
-        f32x4 w[4][4];
+#pragma unroll 1
+        for (int ty = 0; ty < TW; ty++) {
+            __syncthreads();                                        // rows 2 ty - 1 .. 2 ty + 2 are in the window
+            f32x4 pf[NPF];
+            const bool more = ty + 1 < TW;
+            if (more) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            w[0][c] = d[0][c] - d[2][c];
-            w[1][c] = d[1][c] + d[2][c];
-            w[2][c] = d[2][c] - d[1][c];
-            w[3][c] = d[1][c] - d[3][c];
-        }
-        // (B^T d) B: columns
+                for (int i = 0; i < NPF; i++) {
+                    bool ok;
+                    const float *sp = item_src(ib, 2 * ty + 3, tid + i * WINO_IN_THREADS, ok);
+                    pf[i] = ok ? *reinterpret_cast<const f32x4 *>(sp) : zero4;
+                }
+            }
+#pragma unroll 1
+            for (int tx = tsub; tx < TW; tx += TPI) {
+                const long t = (long)bd * T + ty * TW + tx;
+                float *vb = V + (size_t)(t / WINO_BT) * 16 * G::SLAB + (size_t)(t % WINO_BT) * CP + c0 + cq * 4;
+                f32x4 d[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const f32x4 v0 = w[i][0] - w[i][2], v1 = w[i][1] + w[i][2], v2 = w[i][2] - w[i][1], v3 = w[i][1] - w[i][3];
-            float *o = vb + (size_t)(i * 4) * G::SLAB + (size_t)tl * CP + cq * 4;
-            *reinterpret_cast<f32x4 *>(o) = v0;
-            *reinterpret_cast<f32x4 *>(o + G::SLAB) = v1;
-            *reinterpret_cast<f32x4 *>(o + 2 * G::SLAB) = v2;
-            *reinterpret_cast<f32x4 *>(o + 3 * G::SLAB) = v3;
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        d[r][c] = *reinterpret_cast<const f32x4 *>(win + ((2 * ty + r) & 3) * ROWF + (2 * tx + c) * CS + cq * 4);      // row 2 ty - 1 + r, column 2 tx - 1 + c
+                f32x4 w[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {                       // B^T d: rows
+                    w[0][c] = d[0][c] - d[2][c];
+                    w[1][c] = d[1][c] + d[2][c];
+                    w[2][c] = d[2][c] - d[1][c];
+                    w[3][c] = d[1][c] - d[3][c];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {                       // (B^T d) B: columns
+                    const f32x4 v0 = w[i][0] - w[i][2], v1 = w[i][1] + w[i][2], v2 = w[i][2] - w[i][1], v3 = w[i][1] - w[i][3];
+                    float *o = vb + (size_t)(i * 4) * G::SLAB;
+                    *reinterpret_cast<f32x4 *>(o) = v0;
+                    *reinterpret_cast<f32x4 *>(o + G::SLAB) = v1;
+                    *reinterpret_cast<f32x4 *>(o + 2 * G::SLAB) = v2;
+                    *reinterpret_cast<f32x4 *>(o + 3 * G::SLAB) = v3;
+                }
+            }
+            if (more) {
+                __syncthreads();                                    // rows 2 ty - 1, 2 ty are read no more: their slots take rows 2 ty + 3, 2 ty + 4
+#pragma unroll
+                for (int i = 0; i < NPF; i++) {
+                    const int k = tid + i * WINO_IN_THREADS;
+                    if (k < 2 * N * LPT) *reinterpret_cast<f32x4 *>(item_dst(2 * ty + 3, k)) = pf[i];
+                }
+            }
         }
     }
+}
+
+// the tail of the last block (tiles beyond the batch) is never written by the kernel above: zero it once per launch so that the GEMM
+// multiplies zeros, not stale bits (their products only reach accumulators that are never stored, but NaNs would still be ugly)
+__global__ void c6_wino_tail_kernel(float *__restrict__ V, long total_tiles, int slab, int cp) {
+    const long nblocks = (total_tiles + WINO_BT - 1) / WINO_BT;
+    const int first = (int)(total_tiles - (nblocks - 1) * WINO_BT);      // valid tiles of the last block
+    const int n = (WINO_BT - first) * cp;
+    float *base = V + (size_t)(nblocks - 1) * 16 * slab + (size_t)first * cp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 16 * n; i += gridDim.x * blockDim.x) base[(size_t)(i / n) * slab + i % n] = 0.f;
 }
 
 // ---- GEMM + output transform ---------------------------------------------------------------------------------------
@@ -94,6 +160,11 @@ __global__ __launch_bounds__(256) void c6_wino_in_kernel(const float *__restrict
 // issued behind the slab DMAs cannot be waited for without waiting for them.  With the compiler's own loads its s_waitcnt
 // counts do not see the DMAs and wait for far too much; here each wait names exactly the operations that are younger than
 // the group it needs: the WINO_PF weight groups behind it, plus the ND slab DMAs while those are younger too.
+// operations younger than the weights of group i when they are waited for, SPREAD schedule (see the kernel)
+constexpr int wino_wait(int i, int nd) {
+    const int lo = i - WINO_PF > 0 ? i - WINO_PF : 0, hi = (nd - 1 < i - 1) ? nd - 1 : i - 1;
+    return WINO_PF + (hi >= lo ? hi - lo + 1 : 0);
+}
 #define WINO_ULOAD(dst, voff, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define WINO_UWAIT(dst, n) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dst) : "n"(n) : "memory")
 
@@ -106,6 +177,7 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
     constexpr int NGT = 16 * NG;                     // weight groups of a whole block (all 16 positions)
     constexpr int ND = (NCH + WAVES - 1) / WAVES;    // slab DMAs per wave and position (the same count in every wave)
     static_assert(PF == 7 && NG % 8 == 0, "ring of 8 weight groups, 7 in flight");
+    constexpr bool SPREAD = NG >= 16 && ND <= 16;    // one slab DMA per group instead of all of them behind the barrier (C >= 128)
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -119,15 +191,17 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
 
     // LDS-DMA of one (block, position) slab: NCH linear 1-KiB chunks, chunk c by wave c mod WAVES; a wave whose last turn
     // falls behind the slab copies the last chunk again (same bytes, same place) so that every wave issues ND operations
+    // (scalar chunk address + the lane's constant 16-byte offset: no address VGPRs)
+    auto dma_chunk = [&](const float *src, int buf, int c0) {
+        int c = c0 * WAVES + wave;
+        c = c < NCH ? c : NCH - 1;
+        const float *gp = src + (size_t)c * 256;
+        const int lds_off = (buf * SLAB + c * 256) * 4;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lds_off) : "memory");
+    };
     auto dma_slab = [&](const float *src, int buf) {
 #pragma unroll
-        for (int c0 = 0; c0 < ND; c0++) {
-            int c = c0 * WAVES + wave;
-            c = c < NCH ? c : NCH - 1;
-            const float *gp = src + (size_t)c * 256 + lane * 4;
-            const int lds_off = __builtin_amdgcn_readfirstlane((int)((buf * SLAB + c * 256) * 4));
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_off) : "memory", "m0");
-        }
+        for (int c0 = 0; c0 < ND; c0++) dma_chunk(src, buf, c0);
     };
 
     dma_slab(V + (size_t)b * 16 * SLAB, 0);
@@ -190,19 +264,22 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
             // requests, all younger than those DMAs -- may still be in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");
             __syncthreads();
+            const float *nsrc;
             {
                 int nb = p < 15 ? b : b + (int)gridDim.x;
                 nb = nb < nblocks ? nb : b;          // no next block: copy this block's slab 0 again (never read)
-                dma_slab(V + ((size_t)nb * 16 + (p < 15 ? p + 1 : 0)) * SLAB, (p + 1) & 1);
+                nsrc = V + ((size_t)nb * 16 + (p < 15 ? p + 1 : 0)) * SLAB;
             }
+            if (!SPREAD) dma_slab(nsrc, (p + 1) & 1);
             const float *vb = wsm + (p & 1) * SLAB + j * CP + 4 * h;
             f32x16 m0, m1;
 #pragma unroll
             for (int v = 0; v < 16; v++) { m0[v] = 0.f; m1[v] = 0.f; }
             // one 8-channel group: request group + PF, fetch the next group's tile fragments, wait for this group's weights,
-            // 2 x 4 MFMAs.  (u) + 1 == NG reads one group into the row padding / the next row: loaded, never used.
+            // (SPREAD: issue one slab DMA in the shadow of the MFMAs), 2 x 4 MFMAs.
+            // (u) + 1 == NG reads one group into the row padding / the next row: loaded, never used.
             f32x4 va0 = *reinterpret_cast<const f32x4 *>(vb), va1 = *reinterpret_cast<const f32x4 *>(vb + 32 * CP), vn0, vn1;
-#define WINO_GROUP(q, u, NWAIT)                                                                                  \
+#define WINO_GROUP(q, u, NWAIT, DMA)                                                                             \
             {                                                                                                    \
                 WINO_ULOAD(ring[((q) + PF) & 7], lane16 + (unsigned)gi * 1024u, ubase);                          \
                 gi = gi + 1 == NGT ? 0 : gi + 1;                                                                 \
@@ -211,33 +288,51 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
                 WINO_UWAIT(ring[(q)], NWAIT);                                                                    \
                 const f32x4 w = ring[(q)];                                                                       \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
-                _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                  \
+                m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va0[0], m0, 0, 0, 0);                            \
+                m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va1[0], m1, 0, 0, 0);                            \
+                if ((DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (p + 1) & 1, (DMA));                               \
+                _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                  \
                     m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va0[r], m0, 0, 0, 0);                        \
                     m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va1[r], m1, 0, 0, 0);                        \
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
                 va0 = vn0; va1 = vn1;                                                                            \
             }
-            // groups 0..6 were requested before this position's DMAs: those are younger too
-            WINO_GROUP(0, 0, PF + ND) WINO_GROUP(1, 1, PF + ND) WINO_GROUP(2, 2, PF + ND) WINO_GROUP(3, 3, PF + ND)
-            WINO_GROUP(4, 4, PF + ND) WINO_GROUP(5, 5, PF + ND) WINO_GROUP(6, 6, PF + ND) WINO_GROUP(7, 7, PF)
+            if (SPREAD) {
+                // DMA k is issued in group k, behind that group's weight wait: younger than the weights of group i are its 7
+                // followers plus the DMAs k with max(0, i - 7) <= k <= min(ND - 1, i - 1)   (wino_wait)
+#define WG_(i) WINO_GROUP((i) & 7, (i), wino_wait((i), ND), (i))
+                WG_(0) WG_(1) WG_(2) WG_(3) WG_(4) WG_(5) WG_(6) WG_(7) WG_(8) WG_(9) WG_(10) WG_(11) WG_(12) WG_(13) WG_(14) WG_(15)
+#undef WG_
 #pragma unroll 1
-            for (int u0 = 8; u0 < NG; u0 += 8) {
-                WINO_GROUP(0, u0, PF) WINO_GROUP(1, u0 + 1, PF) WINO_GROUP(2, u0 + 2, PF) WINO_GROUP(3, u0 + 3, PF)
-                WINO_GROUP(4, u0 + 4, PF) WINO_GROUP(5, u0 + 5, PF) WINO_GROUP(6, u0 + 6, PF) WINO_GROUP(7, u0 + 7, PF)
+                for (int u0 = 16; u0 < NG; u0 += 8) {
+                    WINO_GROUP(0, u0, PF, -1) WINO_GROUP(1, u0 + 1, PF, -1) WINO_GROUP(2, u0 + 2, PF, -1) WINO_GROUP(3, u0 + 3, PF, -1)
+                    WINO_GROUP(4, u0 + 4, PF, -1) WINO_GROUP(5, u0 + 5, PF, -1) WINO_GROUP(6, u0 + 6, PF, -1) WINO_GROUP(7, u0 + 7, PF, -1)
+                }
+            } else {
+                // all ND DMAs went out before group 0; groups 0..6 were requested before them: those DMAs are younger too
+                WINO_GROUP(0, 0, PF + ND, -1) WINO_GROUP(1, 1, PF + ND, -1) WINO_GROUP(2, 2, PF + ND, -1) WINO_GROUP(3, 3, PF + ND, -1)
+                WINO_GROUP(4, 4, PF + ND, -1) WINO_GROUP(5, 5, PF + ND, -1) WINO_GROUP(6, 6, PF + ND, -1) WINO_GROUP(7, 7, PF, -1)
+#pragma unroll 1
+                for (int u0 = 8; u0 < NG; u0 += 8) {
+                    WINO_GROUP(0, u0, PF, -1) WINO_GROUP(1, u0 + 1, PF, -1) WINO_GROUP(2, u0 + 2, PF, -1) WINO_GROUP(3, u0 + 3, PF, -1)
+                    WINO_GROUP(4, u0 + 4, PF, -1) WINO_GROUP(5, u0 + 5, PF, -1) WINO_GROUP(6, u0 + 6, PF, -1) WINO_GROUP(7, u0 + 7, PF, -1)
+                }
             }
 #undef WINO_GROUP
-            // output transform, one position's share: Y[a][b] += A^T[a][i] A^T[b][j] M_(i,j)   (A^T = [1 1 1 0; 0 1 -1 -1])
+            // output transform, one position's share: Y[a][b] += A^T[a][i] A^T[b][j] M_(i,j)   (A^T = [1 1 1 0; 0 1 -1 -1]).  One fma
+            // per accumulator register: the coefficients are 0 / +-1, so c * m is exact and the result is the plain sum.  (Branch-free
+            // on purpose: a switch over the 16 positions that skips the zero coefficients costs 24 more VGPRs -- spills.)
             const int pi = p >> 2, pj = p & 3;
             const float ai0 = pi < 3 ? 1.f : 0.f, ai1 = pi == 0 ? 0.f : (pi == 1 ? 1.f : -1.f);
             const float bj0 = pj < 3 ? 1.f : 0.f, bj1 = pj == 0 ? 0.f : (pj == 1 ? 1.f : -1.f);
             const float c00 = ai0 * bj0, c01 = ai0 * bj1, c10 = ai1 * bj0, c11 = ai1 * bj1;
 #pragma unroll
             for (int v = 0; v < 16; v++) {
-                y[0][0][0][v] += c00 * m0[v]; y[0][0][1][v] += c00 * m1[v];
-                y[0][1][0][v] += c01 * m0[v]; y[0][1][1][v] += c01 * m1[v];
-                y[1][0][0][v] += c10 * m0[v]; y[1][0][1][v] += c10 * m1[v];
-                y[1][1][0][v] += c11 * m0[v]; y[1][1][1][v] += c11 * m1[v];
+                y[0][0][0][v] = __builtin_fmaf(c00, m0[v], y[0][0][0][v]); y[0][0][1][v] = __builtin_fmaf(c00, m1[v], y[0][0][1][v]);
+                y[0][1][0][v] = __builtin_fmaf(c01, m0[v], y[0][1][0][v]); y[0][1][1][v] = __builtin_fmaf(c01, m1[v], y[0][1][1][v]);
+                y[1][0][0][v] = __builtin_fmaf(c10, m0[v], y[1][0][0][v]); y[1][0][1][v] = __builtin_fmaf(c10, m1[v], y[1][0][1][v]);
+                y[1][1][0][v] = __builtin_fmaf(c11, m0[v], y[1][1][0][v]); y[1][1][1][v] = __builtin_fmaf(c11, m1[v], y[1][1][1][v]);
             }
         }
 
@@ -300,12 +395,25 @@ size_t c6_conv_wino_vbuf_floats(int C, int N, int nboards) {
 }
 
 template <int C, int N>
-static void launch_wino(int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out, float *vbuf, int num_cus,
-                        int relu, hipStream_t s) {
+static void launch_wino_in(int nboards, const float *in, float *vbuf, int num_cus, hipStream_t s) {
+    using G = WinoGeom<C, N>;
+    const long tiles = (long)nboards * G::T;
+    constexpr size_t in_smem = (size_t)4 * (2 * G::TW + 2) * WinoInGeom<C>::CS * 4;
+    int per_cu_in = (int)(((size_t)160 * 1024) / in_smem);
+    per_cu_in = per_cu_in < 1 ? 1 : (per_cu_in > 4 ? 4 : per_cu_in);
+    const int items = nboards * WinoInGeom<C>::NS;
+    const int grid_in = items < num_cus * per_cu_in ? items : num_cus * per_cu_in;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino_in_kernel<C, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)in_smem);
+    hipLaunchKernelGGL((c6_wino_in_kernel<C, N>), dim3(grid_in), dim3(WINO_IN_THREADS), in_smem, s, in, vbuf, nboards);
+    if (tiles % WINO_BT) hipLaunchKernelGGL(c6_wino_tail_kernel, dim3(16), dim3(256), 0, s, vbuf, tiles, G::SLAB, G::CP);
+}
+
+template <int C, int N>
+static void launch_wino_gemm(int nboards, const float *vbuf, const float *wp, const float *bias, const float *res, float *out, int num_cus, int relu,
+                             hipStream_t s) {
     using G = WinoGeom<C, N>;
     const long tiles = (long)nboards * G::T;
     const int nblocks = (int)((tiles + WINO_BT - 1) / WINO_BT);
-    hipLaunchKernelGGL((c6_wino_in_kernel<C, N>), dim3(nblocks), dim3(256), 0, s, in, vbuf, tiles);
     const size_t smem = G::LDS_BYTES;
     const int per_cu = (int)(((size_t)160 * 1024) / smem) < 1 ? 1 : (int)(((size_t)160 * 1024) / smem);
     const int wg_per_cu = per_cu > (16 / G::WAVES) ? (16 / G::WAVES) : per_cu;      // two waves per SIMD
@@ -314,13 +422,30 @@ static void launch_wino(int nboards, const float *in, const float *wp, const flo
     hipLaunchKernelGGL((c6_wino_gemm_kernel<C, N>), dim3(grid), dim3(G::THREADS), smem, s, vbuf, wp, bias, res, out, tiles, nblocks, relu);
 }
 
-bool c6_conv_wino_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                           float *vbuf, int num_cus, hipStream_t s, int relu) {
+#define WINO_ALL(M) M(256, 19) M(256, 15) M(256, 9) M(128, 19) M(128, 15) M(128, 9) M(64, 19) M(64, 15) M(64, 9)
+// step 1 of a layer: activations -> transformed tiles in vbuf
+bool c6_conv_wino_transform(int C, int N, int nboards, const float *in, float *vbuf, int num_cus, hipStream_t s) {
     if (nboards <= 0) return true;
-#define WINOCASE(CC, NN) if (C == CC && N == NN) { launch_wino<CC, NN>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, s); return true; }
-    WINOCASE(256, 19) WINOCASE(256, 15) WINOCASE(256, 9)
-    WINOCASE(128, 19) WINOCASE(128, 15) WINOCASE(128, 9)
-    WINOCASE(64, 19) WINOCASE(64, 15) WINOCASE(64, 9)
+#define WINOCASE(CC, NN) if (C == CC && N == NN) { launch_wino_in<CC, NN>(nboards, in, vbuf, num_cus, s); return true; }
+    WINO_ALL(WINOCASE)
 #undef WINOCASE
     return false;
+}
+// step 2: the 16 GEMMs + output transform + bias / residual / ReLU
+bool c6_conv_wino_gemm(int C, int N, int nboards, const float *vbuf, const float *wp, const float *bias, const float *res, float *out, int num_cus,
+                       hipStream_t s, int relu) {
+    if (nboards <= 0) return true;
+#define WINOCASE(CC, NN) if (C == CC && N == NN) { launch_wino_gemm<CC, NN>(nboards, vbuf, wp, bias, res, out, num_cus, relu, s); return true; }
+    WINO_ALL(WINOCASE)
+#undef WINOCASE
+    return false;
+}
+bool c6_conv_wino_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
+                           float *vbuf, int num_cus, hipStream_t s, int relu) {
+    return c6_conv_wino_transform(C, N, nboards, in, vbuf, num_cus, s) && c6_conv_wino_gemm(C, N, nboards, vbuf, wp, bias, res, out, num_cus, s, relu);
+}
+// matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 16 positions x C x C MACs)
+double c6_conv_wino_exec_flops(int C, int N, int nboards) {
+    const long TW = (N + 1) / 2, tiles = (long)nboards * TW * TW, nblocks = (tiles + WINO_BT - 1) / WINO_BT;
+    return 2.0 * 16.0 * (double)nblocks * WINO_BT * (double)C * C;
 }

@@ -21,7 +21,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct C6NetTimers {
     bool enabled = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> conv;   // one pair per conv launch
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> conv;   // one pair per conv layer (all its kernels)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pre;    // Winograd: the input-transform kernel of that layer
+    double pre_ms = 0.0, exec_flops = 0.0;
     std::vector<hipEvent_t> pool;
     double conv_flops = 0.0;
     double acc_ms = 0.0;
@@ -286,8 +288,16 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
             const float *cin = half == 0 ? x : y, *cres = half == 0 ? nullptr : x;
             float *cout = half == 0 ? y : z;
             const float *cb = net.conv_b + (size_t)l * C;
-            if (net.variant == C6_CONV_WINO)
-                c6_conv_wino_dispatch(C, net.N, nb, cin, net.conv_ww + (size_t)l * c6_conv_packed_wino_floats(C), cb, cres, cout, vbuf, net.num_cus, s, 1);
+            if (net.variant == C6_CONV_WINO) {
+                c6_conv_wino_transform(C, net.N, nb, cin, vbuf, net.num_cus, s);
+                if (timed) {
+                    hipEvent_t em = timer_event(timers);
+                    hipEventRecord(em, s);
+                    timers->pre.emplace_back(e0, em);
+                    timers->exec_flops += c6_conv_wino_exec_flops(C, net.N, nb);
+                }
+                c6_conv_wino_gemm(C, net.N, nb, vbuf, net.conv_ww + (size_t)l * c6_conv_packed_wino_floats(C), cb, cres, cout, net.num_cus, s, 1);
+            }
             else if (net.variant == C6_CONV_F32N)
                 c6_conv_f32n_dispatch(C, net.N, nb, cin, net.conv_w5 + (size_t)l * c6_conv_packed_f32n_floats(C), cb, cres, cout, net.num_cus, s);
             else if (net.variant == C6_CONV_B3S || net.variant == C6_CONV_BF16) {
@@ -306,6 +316,7 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                 hipEventRecord(e1, s);
                 timers->conv.emplace_back(e0, e1);
                 timers->conv_flops += 2.0 * 9.0 * C * C * cells * (double)nb;
+                if (net.variant != C6_CONV_WINO) timers->exec_flops += 2.0 * 9.0 * C * C * (double)nb * (net.variant == C6_CONV_F32N ? 32 * ((net.N * (net.N + 1) + 31) / 32) : cells);
             }
         }
         float *t = x; x = z; z = t;
@@ -329,12 +340,21 @@ C6NetTimers *c6_timers_new() { return new C6NetTimers(); }
 void c6_timers_free(C6NetTimers *t) {
     if (!t) return;
     for (auto &p : t->conv) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto &p : t->pre) hipEventDestroy(p.second);      // .first is shared with the layer's pair
     for (auto e : t->pool) hipEventDestroy(e);
     delete t;
 }
 void c6_timers_enable(C6NetTimers *t, bool on) { t->enabled = on; }
-// drains finished event pairs; returns (ms, launches, flops)
-void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches, double *flops, bool reset) {
+// drains finished event pairs; returns (ms, launches, algorithmic flops) and the Winograd extras (input-transform ms, executed flops)
+void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches, double *flops, double *pre_ms, double *exec_flops, bool reset) {
+    for (auto &p : t->pre) {      // before the layer pairs: they recycle the shared start events
+        float m = 0.f;
+        hipEventSynchronize(p.second);
+        hipEventElapsedTime(&m, p.first, p.second);
+        t->pre_ms += m;
+        t->pool.push_back(p.second);
+    }
+    t->pre.clear();
     for (auto &p : t->conv) {
         float m = 0.f;
         hipEventSynchronize(p.second);
@@ -348,7 +368,9 @@ void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches,
     *ms = t->acc_ms;
     *launches = t->acc_n;
     *flops = t->conv_flops;
-    if (reset) { t->acc_ms = 0; t->acc_n = 0; t->conv_flops = 0; }
+    *pre_ms = t->pre_ms;
+    *exec_flops = t->exec_flops;
+    if (reset) { t->acc_ms = 0; t->acc_n = 0; t->conv_flops = 0; t->pre_ms = 0; t->exec_flops = 0; }
 }
 
 // range guard, second half: max |activation| of each board of a sample (one workgroup per board; see c6_engine.h)

@@ -290,11 +290,13 @@ int c6_engine_last_moves(c6_engine *e, int32_t *pos);
  * engine's stream; totals since the last reset. */
 int c6_engine_profile(c6_engine *e, int enable);
 typedef struct c6_profile {
-    double conv_ms;        /* summed duration of conv3x3 launches */
-    uint64_t conv_launches;
+    double conv_ms;        /* summed duration of the conv3x3 layers (all kernels of a layer) */
+    uint64_t conv_launches; /* layers timed */
     double conv_flops;     /* algorithmic flops of those launches */
     double select_ms, expand_ms, eval_other_ms, move_ms;
     uint64_t select_launches, expand_launches;
+    double conv_pre_ms;     /* the part of conv_ms spent in the Winograd input transform (C6_PREC_FP32), 0 otherwise */
+    double conv_exec_flops; /* matrix FLOPs those launches EXECUTED (padding rows / tiles included; Winograd: 16 C^2 per tile) */
 } c6_profile;
 int c6_engine_profile_read(c6_engine *e, c6_profile *out, int reset);
 

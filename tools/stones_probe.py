@@ -1,0 +1,22 @@
+"""Measured stones per game for bench.py: complete self-play games of the benchmark's net (random-init weights, Dirichlet noise) at a
+short simulation budget, on the GPU engine.  Writes one JSON line (commit it as profiles/rNN_stones_probe.json).
+    python tools/stones_probe.py [workload=config2] [games=4096] [sims=8] [also_sims=2]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from c6amd_loader import load_package
+
+pkg = load_package()
+name = sys.argv[1] if len(sys.argv) > 1 else "config2"
+games = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+sims = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+also = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+wl = bench.WORKLOADS[name]
+r = bench.stones_probe(pkg, wl, games, sims, pkg.PREC_BF16X3)
+r.update(workload=name, precision="bf16x3 (parity grade: net outputs within 1e-5 of FP32)", board=wl["n"], net_blocks=wl["blocks"], net_channels=wl["channels"])
+if also:      # the game length does not depend on the simulation budget for a random-init net: a second budget shows it
+    r["other_budget"] = bench.stones_probe(pkg, wl, max(games // 4, 64), also, pkg.PREC_BF16X3, seed=8)
+print(json.dumps(r))
