@@ -80,7 +80,37 @@ class TuplePool:
         self.eng_stream = torch.cuda.ExternalStream(eng.stream_ptr(), device=self.dev)
         self.free_ev = [None, None]           # side-stream event after which buffer i may be written again
         self._retired = None
+        self._prewarm()
         eng.swap_tuple_buffer(self.bufs[0].data_ptr(), self.cap, self.counts[0].data_ptr())
+
+    def _prewarm(self):
+        """Every torch op / collective of an exchange once, on dummies, BEFORE the engine plays: on a fresh box the first use of a
+        torch kernel pages its code object in from disk (seconds) and the first RCCL collective builds its channels -- neither
+        belongs into somebody's timed region."""
+        with torch.cuda.stream(self.side):
+            cnt = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            if self.world > 1 and self.backend == "nccl":
+                d = torch.empty(self.world, dtype=torch.int32, device=self.dev)
+                dist.all_gather_into_tensor(d, cnt, group=self.group)
+                p = torch.empty((self.world, self.QUANTUM, self.stride), dtype=torch.uint8, device=self.dev)
+                dist.all_gather_into_tensor(p.view(-1), self.bufs[1][:self.QUANTUM].reshape(-1), group=self.group)
+            else:
+                d = cnt.clone()
+            t = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            t += d.clamp(max=self.cap).sum()
+            d.clamp(max=self.cap).cpu().tolist()
+            self.bufs[1][:self.QUANTUM].unsqueeze(0).clone().cpu()
+            cnt.zero_()
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.eng_stream.wait_event(ev)
+            ev2 = torch.cuda.Event()
+            ev2.record(self.eng_stream)
+            self.side.wait_event(ev2)
+        if self.world > 1 and self.backend != "nccl":
+            c = torch.empty(self.world, dtype=torch.int32)
+            dist.all_gather_into_tensor(c, torch.zeros(1, dtype=torch.int32), group=self.group)
+        torch.cuda.synchronize()
 
     # -- the exchange ------------------------------------------------------------------------------------------
     def exchange(self):

@@ -270,16 +270,22 @@ def main():
         # training tuples: double-buffered torch-owned device buffers, pooled over the ranks on a side stream (shard.TuplePool)
         pool = shard.TuplePool(eng, cap, world, backend=args.backend if world > 1 else "nccl", keep=False)
 
+        trace = os.environ.get("C6_BENCH_TRACE") == "1"
+
         def run_rounds(k):
             # the exchange is pipelined: rounds are enqueued, THEN the buffer retired one interval ago is pooled (the host waits only
             # for its counts, which sit behind work already enqueued) -- no per-round synchronisation of the engine's stream
             done = 0
             while done < k:
                 c = min(gather_every, k - done)
+                ta = time.perf_counter()
                 eng.step(c)
+                tb = time.perf_counter()
                 done += c
                 if world > 1 or done == k:
                     pool.exchange()
+                if trace:
+                    print(f"[trace] rounds {done - c}..{done}: step {1000 * (tb - ta):.1f} ms, exchange {1000 * (time.perf_counter() - tb):.1f} ms", file=sys.stderr, flush=True)
 
         if settle_rounds:
             left = settle_rounds
@@ -296,9 +302,13 @@ def main():
         barrier()
         t0 = time.perf_counter()
         run_rounds(steps)
+        t_enq = time.perf_counter()
         eng.sync()
+        t_sync = time.perf_counter()
         barrier()
         dt = time.perf_counter() - t0
+        if trace:
+            print(f"[trace] timed region: enqueue {t_enq - t0:.3f} s, engine sync {t_sync - t_enq:.3f} s, barrier {t0 + dt - t_sync:.3f} s", file=sys.stderr, flush=True)
         prof = eng.profile_read(reset=True)
         eng.profile(False)
         if world > 1:
