@@ -13,10 +13,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-struct C6HtEntry {       // 16 bytes
+struct C6HtEntry {       // 16 bytes: one load brings everything select needs to know about a child
     unsigned long long key;   // 0 = empty slot
-    uint32_t idx1;            // record index + 1
-    uint32_t pad;
+    uint16_t idx1;            // record index + 1
+    uint16_t visit;           // the record's visit count, saturating at 65535 (then rec_visit is read)
+    float q;                  // the record's q_value
 };
 
 #define C6_MAXD0 64       // initial capacity of the select path kept per search (C6Dev::maxd; grown with the record pool)
@@ -59,6 +60,7 @@ struct C6Dev {
     uint32_t *rec_sig;     // [G][R][4]
     float *rec_prior;      // [G][R][cells]  n_prob of the child at each empty cell
     C6HtEntry *ht;         // [G][H]
+    uint32_t *rec_slot;    // [G][R] table slot of a live record (backup keeps the entry's visit / q in step with the record)
     uint16_t *free_stack;  // [G][R]
     int *free_top;         // [G]
     // per-round leaf exchange
@@ -74,7 +76,8 @@ struct C6Dev {
     float *img_val;        // [G][8]
     float *img_pol;        // [G][8][cells]
     // move exchange
-    int32_t *move_pos;     // [Gpad] -2: not moving, -1: no move (draw), else cell
+    int32_t *move_pos;     // [Gpad] -2: not moving, -1: no move (draw), else cell: pending for K1 / the next round's head
+    int32_t *last_move;    // [Gpad] the same for the caller (c6_engine_last_moves): what the game played during the current step call
     int8_t *move_turn;     // [G]
     // finished games queue
     int *fin_winner, *fin_len;   // [finq_cap]
@@ -98,12 +101,11 @@ struct C6Dev {
 };
 
 // tree_kernels.hip
+void c6_launch_search(const C6Dev &d, int kind, hipStream_t s);      // built-in evaluators: a whole search() per launch
 void c6_launch_select(const C6Dev &d, hipStream_t s);
 void c6_launch_expand(const C6Dev &d, hipStream_t s);
-void c6_launch_eval_builtin(const C6Dev &d, int kind, hipStream_t s);
 void c6_launch_recover(const C6Dev &d, hipStream_t s);
 void c6_launch_augment(const C6Dev &d, float *img_boards, hipStream_t s);
-void c6_launch_move_select(const C6Dev &d, hipStream_t s);
 void c6_launch_post_move(const C6Dev &d, hipStream_t s);
 void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s);
 // record-pool growth (engine.cpp grow_pool): `nw` has the new R / H and freshly allocated, zeroed arrays whose [G][R] prefix was

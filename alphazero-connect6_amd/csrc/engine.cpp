@@ -486,11 +486,11 @@ static int engine_alloc(c6_engine *e) {
     const size_t GR = (size_t)G * d.R;
     ALLOC(d.rec_key, GR); ALLOC(d.rec_visit, GR); ALLOC(d.rec_value, GR); ALLOC(d.rec_qsum, GR); ALLOC(d.rec_q, GR);
     ALLOC(d.rec_level, GR); ALLOC(d.rec_sig, GR * 4); ALLOC(d.rec_prior, GR * cells);
-    ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.free_stack, GR); ALLOC(d.free_top, G);
+    ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.rec_slot, GR); ALLOC(d.free_stack, GR); ALLOC(d.free_top, G);
     ALLOC(d.leaf_board, (size_t)G * d.cellsP); ALLOC(d.leaf_turn, G); ALLOC(d.leaf_kind, G); ALLOC(d.leaf_key, G);
     ALLOC(d.leaf_sig, (size_t)G * 4); ALLOC(d.leaf_level, G); ALLOC(d.path_len, G); ALLOC(d.path_rec, (size_t)G * d.maxd);
     ALLOC(d.eval_value, G); ALLOC(d.eval_prior, (size_t)G * cells);
-    ALLOC(d.move_pos, d.Gpad); ALLOC(d.move_turn, G);
+    ALLOC(d.move_pos, d.Gpad); ALLOC(d.last_move, d.Gpad); ALLOC(d.move_turn, G);
     d.finq_cap = std::max(4 * G, 1024);
     ALLOC(d.fin_winner, d.finq_cap); ALLOC(d.fin_len, d.finq_cap); ALLOC(d.fin_uid, d.finq_cap);
     ALLOC(d.fin_moves, (size_t)d.finq_cap * cells);
@@ -651,8 +651,6 @@ static int evaluate_callback(c6_engine *e) {
 static int evaluate(c6_engine *e) {
     C6Dev &d = e->d;
     switch (e->cfg.evaluator) {
-    case C6_EVAL_RANDOM: c6_launch_eval_builtin(d, 1, e->stream); return C6_OK;
-    case C6_EVAL_UNIFORM: c6_launch_eval_builtin(d, 2, e->stream); return C6_OK;
     case C6_EVAL_NET: {
         if (!e->net.loaded) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_NET but no weights are loaded");
         for (int l0 = 0; l0 < d.G; l0 += e->chunk_leaves) {
@@ -673,24 +671,38 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
     if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
     HIPCHK(hipSetDevice(e->cfg.device));
     C6Dev &d = e->d;
+    const int ev = e->cfg.evaluator;
+    if (ev == C6_EVAL_NET && !e->net.loaded) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_NET but no weights are loaded");
+    bool moved = false;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d.last_move, (int)0xFFFFFFFE, (size_t)d.Gpad, e->stream));      // -2: "did not move in this call"
     for (int r = 0; r < rounds; r++) {
-        { Scoped t(&e->t_select, e->stream, e->profiling); c6_launch_select(d, e->stream); }
-        {
-            Scoped t(&e->t_eval, e->stream, e->profiling);
-            int rc = evaluate(e);
-            if (rc != C6_OK) return rc;
+        if (ev == C6_EVAL_RANDOM || ev == C6_EVAL_UNIFORM) {
+            // one launch per search(): head (last round's move) + select + evaluate + expand / backup + policy()
+            Scoped t(&e->t_select, e->stream, e->profiling);
+            c6_launch_search(d, ev == C6_EVAL_RANDOM ? 1 : 2, e->stream);
+        } else {
+            { Scoped t(&e->t_select, e->stream, e->profiling); c6_launch_select(d, e->stream); }
+            {
+                Scoped t(&e->t_eval, e->stream, e->profiling);
+                int rc = evaluate(e);
+                if (rc != C6_OK) return rc;
+            }
+            { Scoped t(&e->t_expand, e->stream, e->profiling); c6_launch_expand(d, e->stream); }
         }
-        { Scoped t(&e->t_expand, e->stream, e->profiling); c6_launch_expand(d, e->stream); }
         e->rounds++;
         e->round_in_move++;
-        // aligned games all move on the same round; staggered games move a few at a time every round
+        // K1 places the stones of the games whose policy() just ran: aligned games all move on the same round; staggered games
+        // (and games resumed after a pool growth) a few at a time, every round
         if (e->cfg.stagger || e->desync || e->round_in_move >= d.S) {
             Scoped t(&e->t_move, e->stream, e->profiling);
-            c6_launch_move_select(d, e->stream);
             c6_launch_board_step(d.N, d.Gpad, d.board_soa, d.turn, d.remain, d.move_pos, d.winner, d.err, e->stream);
-            c6_launch_post_move(d, e->stream);
+            moved = true;
             if (e->round_in_move >= d.S) e->round_in_move = 0;
         }
+    }
+    if (moved) {      // callers see every applied move finished (root advanced / game queued); inside a call the next round's head does it
+        Scoped t(&e->t_move, e->stream, e->profiling);
+        c6_launch_post_move(d, e->stream);
     }
     HIPCHK(hipGetLastError());
     return C6_OK;
@@ -717,14 +729,14 @@ extern "C" int c6_engine_apply_moves(c6_engine *e, const int32_t *pos) {
     return C6_OK;
 }
 
-// the cells chosen by the engine's last move phase (c6_engine_step): pos[g] = cell, -1 = the policy had no move (the game
-// ended as a draw), -2 = game g did not move.  With c6_engine_apply_moves on a second engine this is MultiPolicy for two
+// the cells the engine's own policy played during the last c6_engine_step call: pos[g] = cell, -1 = the policy had no move (the game
+// ended as a draw), -2 = game g did not move in that call.  With c6_engine_apply_moves on a second engine this is MultiPolicy for two
 // resident nets (net-vs-net evaluation games, policy/multi_policy/mod.rs:61-71).
 extern "C" int c6_engine_last_moves(c6_engine *e, int32_t *pos) {
     if (!e || !pos) return fail(C6_ERR_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(pos, e->d.move_pos, (size_t)e->d.G * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pos, e->d.last_move, (size_t)e->d.G * sizeof(int32_t), hipMemcpyDeviceToHost));
     return C6_OK;
 }
 
@@ -799,6 +811,7 @@ static int grow_pool(c6_engine *e) {
     std::vector<void *> fresh, stale;
     uint16_t *nfs = nullptr;
     C6HtEntry *nht = nullptr;
+    uint32_t *nsl = nullptr;
     int rc;
     if ((rc = grow_array(pool, &nw.rec_prior, G, (size_t)old.R * cells, (size_t)nw.R * cells, fresh, stale)) ||
         (rc = grow_array(pool, &nw.rec_key, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_visit, G, old.R, nw.R, fresh, stale)) ||
@@ -806,21 +819,24 @@ static int grow_pool(c6_engine *e) {
         (rc = grow_array(pool, &nw.rec_q, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_level, G, old.R, nw.R, fresh, stale)) ||
         (rc = grow_array(pool, &nw.rec_sig, G, (size_t)old.R * 4, (size_t)nw.R * 4, fresh, stale)) ||
         (rc = grow_array(pool, &nw.path_rec, G, old.maxd, nw.maxd, fresh, stale)) ||
-        (rc = pool.alloc(&nfs, (size_t)G * nw.R)) || (rc = pool.alloc(&nht, (size_t)G * nw.H))) {
+        (rc = pool.alloc(&nfs, (size_t)G * nw.R)) || (rc = pool.alloc(&nht, (size_t)G * nw.H)) || (rc = pool.alloc(&nsl, (size_t)G * nw.R))) {
         for (void *p : fresh) pool.free_one(p);      // the engine keeps running on the old, untouched pool
         if (nfs) pool.free_one(nfs);
         if (nht) pool.free_one(nht);
+        if (nsl) pool.free_one(nsl);
         e->grow_failed = true;
         return rc;
     }
     // free stack and table are rebuilt from the old ones by the device (c6_grow_fix_kernel)
     nw.free_stack = nfs;
     nw.ht = nht;
+    nw.rec_slot = nsl;
     c6_launch_grow_fix(old, nw, e->stream);
     HIPCHK(hipStreamSynchronize(e->stream));
     for (void *p : stale) pool.free_one(p);
     pool.free_one(old.free_stack);
     pool.free_one(old.ht);
+    pool.free_one(old.rec_slot);
     d = nw;
     e->pool_grows++;
     if (!e->cfg.stagger) e->desync = true;

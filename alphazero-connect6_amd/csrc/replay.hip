@@ -13,16 +13,16 @@
 #define C6_TAG_SAMPLE 5u
 
 struct c6_replay {
-    int n = 0, cells = 0, stride = 0;
+    int n = 0, cells = 0, stride = 0, device = 0;      // device: the one that was current at create; every call selects it
     size_t max_size = 0;
     uint8_t *ring = nullptr;             // [max_size][stride]
     unsigned long long *state = nullptr; // device: [0] = tail, [1] = num_data
 };
 
-extern "C" const char *c6_last_error(void);
-static thread_local std::string r_err;
-static int rfail(int code, const char *msg) { r_err = msg; fprintf(stderr, "libconnect6_amd: %s\n", msg); return code; }
+int c6_set_error(int code, const char *msg);      // engine.cpp: the message c6_last_error() returns
+static int rfail(int code, const char *msg) { return c6_set_error(code, msg); }
 #define RCHK(x) do { if ((x) != hipSuccess) return rfail(C6_ERR_HIP, #x); } while (0)
+#define RDEV(r) RCHK(hipSetDevice((r)->device))
 
 // one workgroup per record: paths[tail] = record; tail = (tail + 1) % max_size; num_data = min(num_data + count, max_size)
 __global__ void c6_replay_push_kernel(uint8_t *ring, unsigned long long *state, unsigned long long max_size, int stride,
@@ -63,7 +63,8 @@ __global__ void c6_replay_sample_kernel(const uint8_t *ring, const unsigned long
     if (threadIdx.x == 0) {
         winners[i] = (float)(int8_t)rec[stride - 1];
         players[i] = (float)(int8_t)rec[stride - 2];
-        poses[i] = (float)*reinterpret_cast<const uint16_t *>(rec + stride - 4);
+        const int pos = (int)*reinterpret_cast<const uint16_t *>(rec + stride - 4);
+        poses[i] = (float)(pos < cells ? pos : cells - 1);      // host-encoded records are not trusted: the trainer indexes the policy with it
     }
 }
 
@@ -73,6 +74,7 @@ extern "C" int c6_replay_create(int n, size_t max_size, c6_replay **out) {
     if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return rfail(C6_ERR_NO_GPU, "no HIP device visible; this library has no CPU fallback");
     c6_replay *r = new c6_replay();
     r->n = n; r->cells = n * n; r->stride = (int)c6_tuple_stride(n); r->max_size = max_size;
+    hipGetDevice(&r->device);
     if (hipMalloc(&r->ring, max_size * (size_t)r->stride) != hipSuccess || hipMalloc(&r->state, 16) != hipSuccess) {
         delete r;
         return rfail(C6_ERR_HIP, "hipMalloc failed");
@@ -84,6 +86,7 @@ extern "C" int c6_replay_create(int n, size_t max_size, c6_replay **out) {
 
 extern "C" void c6_replay_destroy(c6_replay *r) {
     if (!r) return;
+    hipSetDevice(r->device);
     hipDeviceSynchronize();
     hipFree(r->ring);
     hipFree(r->state);
@@ -91,6 +94,7 @@ extern "C" void c6_replay_destroy(c6_replay *r) {
 }
 
 static int push(c6_replay *r, const uint8_t *src_dev, const uint32_t *count_dev, size_t count_host, size_t cap) {
+    RDEV(r);
     const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(cap, 1), 4096);
     hipLaunchKernelGGL(c6_replay_push_kernel, dim3(grid), dim3(128), 0, nullptr, r->ring, r->state, (unsigned long long)r->max_size, r->stride,
                        src_dev, count_dev, (unsigned long long)count_host, (unsigned long long)cap);
@@ -108,6 +112,7 @@ extern "C" int c6_replay_push_dev(c6_replay *r, const void *tuples_dev, const ui
 
 extern "C" int c6_replay_push_host(c6_replay *r, const void *tuples_host, size_t count) {
     if (!r || (!tuples_host && count)) return rfail(C6_ERR_BAD_ARG, "c6_replay_push_host: null argument");
+    RDEV(r);
     // pushes larger than the ring keep the LAST max_size records, like consecutive push_game calls
     const uint8_t *src = reinterpret_cast<const uint8_t *>(tuples_host);
     size_t done = 0;
@@ -127,12 +132,14 @@ extern "C" int c6_replay_push_host(c6_replay *r, const void *tuples_host, size_t
 
 extern "C" int c6_replay_clear(c6_replay *r) {
     if (!r) return rfail(C6_ERR_BAD_ARG, "null replay buffer");
+    RDEV(r);
     RCHK(hipMemset(r->state, 0, 16));
     return C6_OK;
 }
 
 extern "C" int c6_replay_size(c6_replay *r, size_t *num_data, size_t *tail) {
     if (!r) return rfail(C6_ERR_BAD_ARG, "null replay buffer");
+    RDEV(r);
     unsigned long long st[2];
     RCHK(hipMemcpy(st, r->state, 16, hipMemcpyDeviceToHost));
     if (tail) *tail = (size_t)st[0];
@@ -144,6 +151,7 @@ extern "C" int c6_replay_size(c6_replay *r, size_t *num_data, size_t *tail) {
 extern "C" int c6_replay_sample_device(c6_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
                                        float *boards, float *poses, void *stream) {
     if (!r || num_sample < 1 || !winners || !players || !boards || !poses) return rfail(C6_ERR_BAD_ARG, "c6_replay_sample_device: bad argument");
+    RDEV(r);
     unsigned long long st[2] = {0, 0};
     RCHK(hipMemcpy(st, r->state, sizeof(st), hipMemcpyDeviceToHost));
     if (st[1] == 0) return rfail(C6_ERR_BAD_ARG, "c6_replay_sample_device: the buffer is empty");
@@ -156,6 +164,12 @@ extern "C" int c6_replay_board_size(const c6_replay *r) { return r ? r->n : 0; }
 extern "C" int c6_replay_sample(c6_replay *r, int num_sample, uint64_t seed, uint32_t draw_id, float *winners, float *players,
                                 float *boards, float *poses, float *pi) {
     if (!r || num_sample < 1 || !winners || !players || !boards || !poses) return rfail(C6_ERR_BAD_ARG, "c6_replay_sample: bad argument");
+    RDEV(r);
+    {
+        unsigned long long st[2] = {0, 0};
+        RCHK(hipMemcpy(st, r->state, sizeof(st), hipMemcpyDeviceToHost));
+        if (st[1] == 0) return rfail(C6_ERR_BAD_ARG, "c6_replay_sample: the buffer is empty (ReplayBuffer::sample on no data)");
+    }
     const size_t nb = (size_t)num_sample * r->cells;
     float *dw, *dp, *db, *dq, *dpi = nullptr;
     RCHK(hipMalloc(&dw, num_sample * 4)); RCHK(hipMalloc(&dp, num_sample * 4)); RCHK(hipMalloc(&dq, num_sample * 4));

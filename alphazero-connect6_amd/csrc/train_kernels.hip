@@ -468,7 +468,8 @@ __global__ __launch_bounds__(64) void c6t_softmax_loss_kernel(int B, int cells, 
     for (int k = lane; k < cells; k += 64) s += expf(lg[k] - mx);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    const int pos = (int)poses[b];
+    int pos = (int)poses[b];
+    pos = pos < 0 ? 0 : (pos >= cells ? cells - 1 : pos);      // device-resident batches (on_device, step_replay) are not validated on the host
     const float ppos = expf(lg[pos] - mx) / s;
     const float dp = -(1.0f / (float)B) / (ppos + 1e-7f);
     const float dot = dp * ppos;

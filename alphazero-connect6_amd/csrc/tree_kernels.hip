@@ -18,34 +18,67 @@
 //
 // A lane owns cells lane, lane+64, ... (row-major order == child order of the reference, which
 // lists children in `possible` order, simulate/mod.rs:58-69).
+//
+// Launches of a round.  Built-in evaluators: c6_search_kernel (last round's move finished, select, evaluate, expand + backup,
+// policy() -- one launch, the leaf stays in registers) + K1.  Net / callback evaluators: c6_select_kernel (head + select) ->
+// evaluator -> c6_expand_kernel (expand + backup + policy()) + K1.  The move K1 applies is finished (root advanced, pruned,
+// game ended / recycled) at the head of the next round's first kernel, or by c6_post_move_kernel at the end of a step call.
 #include "c6_device.h"
 #include "c6_engine.h"
 
 #define WAVES_PER_BLOCK 4
 
-__device__ __forceinline__ int ht_find(const C6HtEntry *ht, int H, unsigned long long key) {
-    uint32_t slot = (uint32_t)(key ^ (key >> 32)) & (uint32_t)(H - 1);
-    for (int it = 0; it < H; it++) {
-        const C6HtEntry e = ht[slot];
-        if (e.key == key) return (int)e.idx1 - 1;
-        if (e.key == 0ull) return -1;
-        slot = (slot + 1) & (uint32_t)(H - 1);
-    }
-    return -1;
+// ---- the table: board key -> record, with the child statistics select reads riding in the entry ---------------------------
+// C6HtEntry (c6_engine.h) = {key, idx + 1, visit (saturating at 65535), q}: a child's visit count and q_value arrive with the
+// probe that finds it -- one memory round trip per level instead of probe + gather.  The authoritative copies stay in
+// rec_visit / rec_q; expand and backup update both (rec_slot[record] = its table slot).
+
+__device__ __forceinline__ uint32_t ht_home(unsigned long long key, int H) { return (uint32_t)(key ^ (key >> 32)) & (uint32_t)(H - 1); }
+
+// one 16-byte load of an entry
+__device__ __forceinline__ C6HtEntry ht_load(const C6HtEntry *ht, uint32_t slot) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(ht + slot);
+    C6HtEntry e;
+    e.key = ((unsigned long long)v.y << 32) | v.x;
+    e.idx1 = (uint16_t)(v.z & 0xffffu);
+    e.visit = (uint16_t)(v.z >> 16);
+    e.q = __uint_as_float(v.w);
+    return e;
 }
 
-// concurrent insert (distinct keys); returns false if the table is full
-__device__ __forceinline__ bool ht_insert(C6HtEntry *ht, int H, unsigned long long key, int idx) {
-    uint32_t slot = (uint32_t)(key ^ (key >> 32)) & (uint32_t)(H - 1);
+// continue a probe sequence that started with entry `e` at `slot`: true and the entry when `key` is in the table
+__device__ __forceinline__ bool ht_resolve(const C6HtEntry *ht, int H, unsigned long long key, uint32_t slot, C6HtEntry &e) {
+    for (int it = 0; it < H; it++) {
+        if (e.key == key) return true;
+        if (e.key == 0ull) return false;
+        slot = (slot + 1) & (uint32_t)(H - 1);
+        e = ht_load(ht, slot);
+    }
+    return false;
+}
+
+__device__ __forceinline__ int ht_find(const C6HtEntry *ht, int H, unsigned long long key) {
+    const uint32_t slot = ht_home(key, H);
+    C6HtEntry e = ht_load(ht, slot);
+    return ht_resolve(ht, H, key, slot, e) ? (int)e.idx1 - 1 : -1;
+}
+
+__device__ __forceinline__ uint16_t sat16(int v) { return (uint16_t)(v > 65535 ? 65535 : v); }
+
+// concurrent insert (distinct keys); returns the slot, or -1 if the table is full
+__device__ __forceinline__ int ht_insert(C6HtEntry *ht, int H, unsigned long long key, int idx, int visit, float q) {
+    uint32_t slot = ht_home(key, H);
     for (int it = 0; it < H; it++) {
         unsigned long long prev = atomicCAS(&ht[slot].key, 0ull, key);
         if (prev == 0ull || prev == key) {
-            ht[slot].idx1 = (uint32_t)(idx + 1);
-            return true;
+            ht[slot].idx1 = (uint16_t)(idx + 1);
+            ht[slot].visit = sat16(visit);
+            ht[slot].q = q;
+            return (int)slot;
         }
         slot = (slot + 1) & (uint32_t)(H - 1);
     }
-    return false;
+    return -1;
 }
 
 __device__ __forceinline__ void next_turn(int &turn, int &remain) {   // simulate/mod.rs:268-273
@@ -53,19 +86,21 @@ __device__ __forceinline__ void next_turn(int &turn, int &remain) {   // simulat
     if (remain <= 0) { remain = 2; turn = -turn; }
 }
 
+// what select hands to the evaluator / expand: in registers inside the fused search kernel, through the leaf_* arrays otherwise
+template <int J>
+struct C6Leaf {
+    int kind, turn, level, len;
+    unsigned long long key;
+    uint32_t sg0, sg1, sg2, sg3;
+    int my_path;            // lane i < 64: record of the path's i-th step
+    int8_t st[J];           // the leaf position, lane's cells
+};
+
 // ------------------------------------------------------------------------------------------
 // select: walk from the root by PUCT + Dirichlet noise until a node without record (leaf)
 // ------------------------------------------------------------------------------------------
 template <int J>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)) void c6_select_kernel(C6Dev E) {
-    __shared__ double gscratch[WAVES_PER_BLOCK][64 * J];    // c6_wave_gamma hand-back, wave-private
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (g >= E.G) return;
-    if (E.status[g] != C6_ST_PLAYING) {
-        if (lane == 0) E.leaf_kind[g] = C6_LEAF_NONE;
-        return;
-    }
+__device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, double *gscratch, C6Leaf<J> &L) {
     const int cells = E.cells;
     const C6HtEntry *ht = E.ht + (size_t)g * E.H;
     const size_t rbase = (size_t)g * E.R;
@@ -76,15 +111,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     int turn = E.turn[g], remain = E.remain[g], level = E.nstones[g];
     const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.game_uid[g], t = E.nsearch[g];
 
-    int8_t st[J];
 #pragma unroll
     for (int j = 0; j < J; j++) {
         const int c = lane + 64 * j;
-        st[j] = c < cells ? E.root_board[(size_t)g * E.cellsP + c] : (int8_t)2;
+        L.st[j] = c < cells ? E.root_board[(size_t)g * E.cellsP + c] : (int8_t)2;
     }
 
     int d = 0;
     int kind = C6_LEAF_EVAL;
+    L.my_path = 0;
     while (p >= 0) {
         const int nchild = cells - level;
         if (nchild == 0) break;                 // cannot happen: full boards are never records
@@ -92,18 +127,30 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const float *prior = E.rec_prior + (rbase + p) * (size_t)cells;
 
-        int cidx[J], cvis[J];
-        float cq[J], cpr[J];
-        int vs = 0;
+        // all J first probes (and the priors) leave together: one memory round trip per level in the common case
+        unsigned long long ck[J];
+        uint32_t cslot[J];
+        C6HtEntry ce[J];
+        float cpr[J];
 #pragma unroll
         for (int j = 0; j < J; j++) {
             const int c = lane + 64 * j;
-            cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f; cpr[j] = 0.f;
-            if (st[j] == 0) {
-                const int idx = ht_find(ht, E.H, key ^ zk[c]);
-                cidx[j] = idx;
-                if (idx >= 0) { cvis[j] = E.rec_visit[rbase + idx]; cq[j] = E.rec_q[rbase + idx]; }
-                cpr[j] = prior[c];
+            const bool mine = L.st[j] == 0;
+            ck[j] = key ^ zk[mine ? c : 0];
+            cslot[j] = ht_home(ck[j], E.H);
+            ce[j] = ht_load(ht, cslot[j]);
+            cpr[j] = mine ? prior[c] : 0.f;
+        }
+        int cidx[J], cvis[J];
+        float cq[J];
+        int vs = 0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f;
+            if (L.st[j] == 0 && ht_resolve(ht, E.H, ck[j], cslot[j], ce[j])) {
+                cidx[j] = (int)ce[j].idx1 - 1;
+                cvis[j] = ce[j].visit == 65535 ? E.rec_visit[rbase + cidx[j]] : (int)ce[j].visit;
+                cq[j] = ce[j].q;
                 vs += cvis[j];
             }
         }
@@ -112,7 +159,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
         if (nchild == 1) {                       // heuristic, mod.rs:255-258
             int mine = -1;
 #pragma unroll
-            for (int j = 0; j < J; j++) if (st[j] == 0) mine = lane + 64 * j;
+            for (int j = 0; j < J; j++) if (L.st[j] == 0) mine = lane + 64 * j;
             chosen = c6_wave_max_i32(mine);
         } else {
             const float visit_sum = (float)c6_wave_sum_i32(vs);
@@ -120,8 +167,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
             double gam[J], part = 0.0;
             bool need[J];
 #pragma unroll
-            for (int j = 0; j < J; j++) need[j] = st[j] == 0;
-            c6_wave_gamma<J>(need, gam, gscratch[threadIdx.x >> 6], lane, E.alpha, E.gam_d, E.gam_c, k0, k1, t, (uint32_t)d);
+            for (int j = 0; j < J; j++) need[j] = L.st[j] == 0;
+            c6_wave_gamma<J>(need, gam, gscratch, lane, E.alpha, E.gam_d, E.gam_c, k0, k1, t, (uint32_t)d);
 #pragma unroll
             for (int j = 0; j < J; j++) part = part + gam[j];     // cells that need none hold 0.0 (+ 0.0 is exact)
             const double gsum = c6_butterfly_sum(part);
@@ -129,7 +176,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
 #pragma unroll
             for (int j = 0; j < J; j++) {
                 sc[j] = -INFINITY;
-                if (st[j] == 0) {                // mod.rs:265-280
+                if (L.st[j] == 0) {                // mod.rs:265-280
                     const float noise = (float)(gam[j] / gsum);
                     const float visit = (float)cvis[j];
                     const float prob = E.eps * noise + (1.f - E.eps) * cpr[j];
@@ -145,7 +192,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < J; j++) {
-                tie[j] = __ballot(st[j] == 0 && sc[j] == best);
+                tie[j] = __ballot(L.st[j] == 0 && sc[j] == best);
                 cnt += __popcll(tie[j]);
             }
             int pick = 0;
@@ -172,38 +219,28 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
 #pragma unroll
         for (int j = 0; j < J; j++) if (j == cj) child = cidx[j];
         child = __shfl(child, cl, 64);
-        if (lane == 0) E.path_rec[(size_t)g * E.maxd + d] = (uint16_t)p;
+        if (d < 64) { if (lane == d) L.my_path = p; }
+        else if (lane == 0) E.path_rec[(size_t)g * E.maxd + d] = (uint16_t)p;      // beyond 64 steps: through memory
         d++;
         key ^= zk[chosen];
         const uint32_t c1 = (uint32_t)chosen + 1u;
         if (turn == C6_BLACK) { sg0 += c1; sg1 += c1 * c1; } else { sg2 += c1; sg3 += c1 * c1; }
 #pragma unroll
-        for (int j = 0; j < J; j++) if (j == cj && lane == cl) st[j] = (int8_t)turn;
+        for (int j = 0; j < J; j++) if (j == cj && lane == cl) L.st[j] = (int8_t)turn;
         next_turn(turn, remain);
         level++;
         p = child;
     }
     if (kind == C6_LEAF_EVAL && level == cells) kind = C6_LEAF_TERMINAL;   // board full, mod.rs:338
+    L.kind = kind; L.turn = turn; L.level = level; L.len = d; L.key = key;
+    L.sg0 = sg0; L.sg1 = sg1; L.sg2 = sg2; L.sg3 = sg3;
+}
 
-#pragma unroll
-    for (int j = 0; j < J; j++) {
-        const int c = lane + 64 * j;
-        if (c < cells) E.leaf_board[(size_t)g * E.cellsP + c] = st[j];
-    }
+// the game stops (pool / path exhausted: resumable; NaN scores: an error) -- reported through status, never silently
+__device__ __forceinline__ void select_failed(const C6Dev &E, int g, int lane, int kind) {
     if (lane == 0) {
-        if (kind < 0) {   // overflow / NaN: stop this game, reported through status
-            E.status[g] = kind == -2 ? C6_ST_OVERFLOW : C6_ST_ERROR;
-            E.leaf_kind[g] = C6_LEAF_NONE;
-        } else {
-            E.leaf_kind[g] = (int8_t)kind;
-            E.leaf_turn[g] = (int8_t)turn;
-            E.leaf_key[g] = key;
-            E.leaf_sig[g * 4 + 0] = sg0; E.leaf_sig[g * 4 + 1] = sg1; E.leaf_sig[g * 4 + 2] = sg2; E.leaf_sig[g * 4 + 3] = sg3;
-            E.leaf_level[g] = (int16_t)level;
-            E.path_len[g] = d;
-            E.g_select[g] += (unsigned long long)d;      // per-game statistics: no shared-address atomics
-            if ((uint32_t)d > E.g_maxdepth[g]) E.g_maxdepth[g] = (uint32_t)d;
-        }
+        E.status[g] = kind == -2 ? C6_ST_OVERFLOW : C6_ST_ERROR;
+        E.leaf_kind[g] = C6_LEAF_NONE;
     }
 }
 
@@ -233,28 +270,51 @@ __device__ __forceinline__ void recover_wave(int cells, int lane, const int16_t 
     }
 }
 
-// RandomEvaluator (mod.rs:137-169) / uniform evaluator, evaluated on device
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_eval_builtin_kernel(C6Dev E, int kind) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (g >= E.G || E.leaf_kind[g] != C6_LEAF_EVAL) return;
+// RandomEvaluator (mod.rs:137-169) / uniform evaluator, evaluated on device: get_from's tail (recover_way8 + mask) of the lane's
+// own cells, in registers.  Same arithmetic as recover_wave (the summation order of augment.rs:79-88).
+template <int J>
+__device__ __forceinline__ void eval_builtin_regs(const C6Dev &E, int g, int lane, int kind, uint32_t t, const int8_t (&st)[J], float (&pr)[J],
+                                                  float &value) {
     const int cells = E.cells;
-    const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.game_uid[g], t = E.nsearch[g];
-    const int8_t *board = E.leaf_board + (size_t)g * E.cellsP;
-    float *prior = E.eval_prior + (size_t)g * cells;
+    const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.game_uid[g];
     if (kind == 1) {
         auto pf = [&](int k, int cell) -> float {
             const c6_u4 w = c6_philox((uint32_t)(cell >> 2), (uint32_t)k, t, C6_TAG_EVAL_P, k0, k1);
             const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
             return c6_u11(ws[cell & 3]);
         };
-        auto vf = [&](int k) -> float { return c6_u11(c6_philox((uint32_t)k, 0u, t, C6_TAG_EVAL_V, k0, k1).x); };
-        recover_wave(cells, lane, E.rec_map, board, pf, vf, &E.eval_value[g], prior);
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c = lane + 64 * j;
+            pr[j] = 0.f;
+            if (c < cells) {
+                float total = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float a = pf(2 * i, (int)E.rec_map[(2 * i) * cells + c]);
+                    const float b = pf(2 * i + 1, (int)E.rec_map[(2 * i + 1) * cells + c]);
+                    total = total + (a + b);
+                }
+                total = total / 8.f;
+                pr[j] = total * (float)(st[j] == 0);
+            }
+        }
+        float sv = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sv = sv + c6_u11(c6_philox((uint32_t)k, 0u, t, C6_TAG_EVAL_V, k0, k1).x);
+        value = sv / 8.f;
     } else {
         const float u = 1.0f / (float)cells;
-        auto pf = [&](int, int) -> float { return u; };
-        auto vf = [&](int) -> float { return 0.f; };
-        recover_wave(cells, lane, E.rec_map, board, pf, vf, &E.eval_value[g], prior);
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c = lane + 64 * j;
+            float total = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) total = total + (u + u);
+            total = total / 8.f;
+            pr[j] = c < cells ? total * (float)(st[j] == 0) : 0.f;
+        }
+        value = 0.f;
     }
 }
 
@@ -313,51 +373,43 @@ __device__ __forceinline__ int wave_winner(const int8_t *board, int N, int lane)
     return first < cells ? (int)board[first] : 0;
 }
 
-// The kernel is a chain of memory round trips (53 VGPRs, 8 waves per SIMD, 88 % of the wave-cycles waiting), so its shape is
-// dictated by how many of them are serial: everything that depends only on g is loaded up front (one trip), the record scan
-// fetches four 64-record chunks per trip, the free-list pop / record initialisation / table insert overlap the scan's loads,
-// and the backup updates the path's records lane-parallel (they are distinct: levels strictly increase along a path).
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (g >= E.G) return;
+// expand + update for one game.  A chain of memory round trips, so its shape is dictated by how many of them are serial: everything
+// that depends only on g is loaded up front (one trip), the record scan fetches four 64-record chunks per trip, the free-list pop /
+// record initialisation / table insert overlap the scan's loads, and the backup updates the path's records lane-parallel (they are
+// distinct: levels strictly increase along a path).  `prob` = the evaluated prior of the leaf, cells floats (global eval_prior, or
+// the wave's LDS scratch inside the fused search kernel); `board` = the leaf position as bytes (terminal leaves only).
+// Returns true when the game's simulation budget for this move is spent (the caller then runs policy()).
+template <int J>
+__device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, const C6Leaf<J> &L, float evalue, const float *prob, const int8_t *board) {
     const int cells = E.cells;
     const size_t rbase = (size_t)g * E.R;
-    // ---- trip 1: everything addressed by g alone
-    const int kind = E.leaf_kind[g];
-    const int len = E.path_len[g];
-    const int level = E.leaf_level[g];
-    const int turn = E.leaf_turn[g];
+    const int kind = L.kind, len = L.len, level = L.level, turn = L.turn;
+    const unsigned long long key = L.key;
+    // ---- everything addressed by g alone
     const int top = E.free_top[g];
     const int hi0 = E.rec_hi[g];
-    const float evalue = E.eval_value[g];
-    const unsigned long long key = E.leaf_key[g];
-    const uint4 qv = *reinterpret_cast<const uint4 *>(E.leaf_sig + (size_t)g * 4);
     const uint32_t nsearch = E.nsearch[g];
     const int sim_in_move = E.sim_in_move[g];
     const unsigned long long gsims = E.g_sims[g];
     const uint32_t maxrec = E.g_maxrec[g];
-    const int my_path = E.path_rec[(size_t)g * E.maxd + (lane < E.maxd ? lane : 0)];
-    if (kind == C6_LEAF_NONE) return;
     float value;
 
     if (kind == C6_LEAF_TERMINAL) {   // mod.rs:338-348: value by winner, no visit increment, no children
-        const int w = wave_winner(E.leaf_board + (size_t)g * E.cellsP, E.N, lane);
+        const int w = wave_winner(board, E.N, lane);
         const float cost = (float)turn;
         value = w == turn ? cost : (w != 0 ? -cost : 0.f);
     } else {
         // allocate the record of the newly expanded node (every lane reads the same stack slot)
         if (top <= 0) {      // pool exhausted; nothing of this search has been written: resumable after grow_pool
             if (lane == 0) E.status[g] = C6_ST_OVERFLOW;
-            return;
+            return false;
         }
         const int idx = E.free_stack[rbase + top - 1];
         const int hi = idx + 1 > hi0 ? idx + 1 : hi0;
         value = evalue;
-        const float *prob = E.eval_prior + (size_t)g * cells;
         float *prior = E.rec_prior + (rbase + idx) * (size_t)cells;
         for (int c = lane; c < cells; c += 64) prior[c] = prob[c];      // child.n_prob = prob[r][c], mod.rs:370
-        const uint32_t q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
+        const uint32_t q0 = L.sg0, q1 = L.sg1, q2 = L.sg2, q3 = L.sg3;
         // last-writer rule for transposed children (entry().or_insert + n_prob overwrite, mod.rs:366-370):
         // every expanded P on this level with P + i == Q + s sees its child i's prior become prob_Q[s]
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
@@ -387,8 +439,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
                     E.rec_value[rbase + idx] = value;
                     E.rec_qsum[rbase + idx] = 0.f;
                     E.rec_q[rbase + idx] = 0.f;
-                    *reinterpret_cast<uint4 *>(E.rec_sig + (rbase + idx) * 4) = qv;
-                    if (!ht_insert(E.ht + (size_t)g * E.H, E.H, key, idx)) E.status[g] = C6_ST_ERROR;
+                    *reinterpret_cast<uint4 *>(E.rec_sig + (rbase + idx) * 4) = uint4{q0, q1, q2, q3};
+                    const int slot = ht_insert(E.ht + (size_t)g * E.H, E.H, key, idx, 1, 0.f);
+                    if (slot < 0) E.status[g] = C6_ST_ERROR;
+                    else E.rec_slot[rbase + idx] = (uint32_t)slot;
                     if (len == 0) E.root_rec[g] = idx;
                     const uint32_t used = (uint32_t)(E.R - (top - 1));
                     if (used > maxrec) E.g_maxrec[g] = used;
@@ -416,19 +470,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
         if (lane == 0) E.rec_level[rbase + idx] = (int16_t)level;   // after the scan: Q never matches itself
     }
 
-    // update, mod.rs:386-408 (one-level backup): lane i owns the path's i-th record (paths beyond 64 steps: further passes)
+    // update, mod.rs:386-408 (one-level backup): lane i owns the path's i-th record (paths beyond 64 steps: further passes); the
+    // child statistics in the table entry follow the record
+    C6HtEntry *ht = E.ht + (size_t)g * E.H;
     for (int base = 0; base < len; base += 64) {
         const int i = base + lane;
         if (i < len) {
-            const int r = base == 0 ? my_path : (int)E.path_rec[(size_t)g * E.maxd + i];
+            const int r = base == 0 ? L.my_path : (int)E.path_rec[(size_t)g * E.maxd + i];
+            const uint32_t slot = E.rec_slot[rbase + r];
             const int v = E.rec_visit[rbase + r] + 1;
             float qs = E.rec_qsum[rbase + r];
             if (i == len - 1) {      // the leaf's parent receives the value
                 qs = qs + value;
                 E.rec_qsum[rbase + r] = qs;
             }
+            const float qv = qs / (float)v;   // recalc_q :77-79
             E.rec_visit[rbase + r] = v;
-            E.rec_q[rbase + r] = qs / (float)v;   // recalc_q :77-79
+            E.rec_q[rbase + r] = qv;
+            ht[slot].visit = sat16(v);
+            ht[slot].q = qv;
         }
     }
     if (lane == 0) {
@@ -436,20 +496,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
         E.sim_in_move[g] = sim_in_move + 1;
         E.g_sims[g] = gsims + 1ull;
     }
+    return sim_in_move + 1 >= E.S;
 }
 
 // ------------------------------------------------------------------------------------------
-// move: policy() (mod.rs:433-452) for games whose simulation budget is spent
+// move: policy() (mod.rs:433-452) for a game whose simulation budget is spent -> move_pos / move_turn for K1
 // ------------------------------------------------------------------------------------------
 template <int J>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_move_select_kernel(C6Dev E) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (g >= E.G) return;
-    if (E.status[g] != C6_ST_PLAYING || E.sim_in_move[g] < E.S) {
-        if (lane == 0) E.move_pos[g] = -2;
-        return;
-    }
+__device__ __forceinline__ void move_select_wave(const C6Dev &E, int g, int lane) {
     const int cells = E.cells;
     const int p = E.root_rec[g];
     const int level = E.nstones[g];
@@ -468,8 +522,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_move_select_kernel(C6
             const int c = lane + 64 * j;
             cv[j] = -1;
             if (c < cells && board[c] == 0) {
-                const int idx = ht_find(ht, E.H, key ^ zk[c]);
-                cv[j] = idx >= 0 ? E.rec_visit[rbase + idx] : 0;
+                const unsigned long long ck = key ^ zk[c];
+                const uint32_t slot = ht_home(ck, E.H);
+                C6HtEntry e = ht_load(ht, slot);
+                cv[j] = 0;
+                if (ht_resolve(ht, E.H, ck, slot, e)) cv[j] = e.visit == 65535 ? E.rec_visit[rbase + (int)e.idx1 - 1] : (int)e.visit;
                 vs += cv[j];
             }
         }
@@ -515,8 +572,8 @@ __device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane,
         E.rec_level[rbase + r] = -1;
         E.free_stack[rbase + r] = (uint16_t)(E.R - 1 - r);   // pop order 0,1,2,...
     }
-    C6HtEntry *ht = E.ht + (size_t)g * E.H;
-    for (int i = lane; i < E.H; i += 64) { ht[i].key = 0ull; ht[i].idx1 = 0; }
+    uint4 *ht = reinterpret_cast<uint4 *>(E.ht + (size_t)g * E.H);
+    for (int i = lane; i < E.H; i += 64) ht[i] = uint4{0u, 0u, 0u, 0u};
     if (lane == 0) {
         E.turn[g] = C6_BLACK;       // Game::new, game_impl/mod.rs:125-131
         E.remain[g] = 1;
@@ -544,24 +601,29 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_reset_kernel(C6Dev E)
     reset_game_wave(E, g, lane, E.uid_base + (uint32_t)g, 0);
 }
 
-// after K1 placed the stones: advance the root, prune (next(), mod.rs:473-487), finish / recycle games
-template <int J>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6Dev E) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (g >= E.G) return;
-    const int pos = E.move_pos[g];
-    if (pos == -2) {
-        // steady-state mode: a slot whose game stopped in an error state (pool exhausted with no host to grow it, NaN scores)
-        // is abandoned -- counted, never silently -- and starts the next game
-        const int stt = E.status[g];
-        if (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW)) {
-            const uint32_t uid_ = E.game_uid[g];
-            if (lane == 0) atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull);
-            reset_game_wave(E, g, lane, uid_ + E.uid_stride, 0);
+// table of a game rebuilt from its live records (after a prune / a growth): entries carry the records' current statistics;
+// returns (wave-uniform) the record whose key is `find`, or -1
+__device__ __forceinline__ int rebuild_table_wave(const C6Dev &E, int g, int lane, int hi, unsigned long long find) {
+    const size_t rbase = (size_t)g * E.R;
+    C6HtEntry *ht = E.ht + (size_t)g * E.H;
+    uint4 *ht4 = reinterpret_cast<uint4 *>(ht);
+    for (int i = lane; i < E.H; i += 64) ht4[i] = uint4{0u, 0u, 0u, 0u};
+    __threadfence_block();
+    int rr = -1;
+    for (int r = lane; r < hi; r += 64)
+        if (E.rec_level[rbase + r] >= 0) {
+            const unsigned long long k = E.rec_key[rbase + r];
+            const int slot = ht_insert(ht, E.H, k, r, E.rec_visit[rbase + r], E.rec_q[rbase + r]);
+            if (slot >= 0) E.rec_slot[rbase + r] = (uint32_t)slot;
+            if (k == find) rr = r;
         }
-        return;
-    }
+    return c6_wave_max_i32(rr);
+}
+
+// after K1 placed the stone of game g: advance the root, prune (next(), mod.rs:473-487), finish / recycle the game.
+// Called with pos = move_pos[g] != -2; leaves move_pos[g] = -2.
+template <int J>
+__device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, int pos) {
     const int cells = E.cells;
     const size_t rbase = (size_t)g * E.R;
     const int old_level = E.nstones[g];
@@ -570,6 +632,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
     bool finished = false;
     int win = 0;
     int nst = old_level;
+    if (lane == 0) { E.move_pos[g] = -2; E.last_move[g] = pos; }
 
     if (pos < 0) {
         finished = true;                       // policy returned None -> draw, agent_impl/mod.rs:135-137
@@ -617,17 +680,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
             }
             top += __popcll(m);
         }
-        C6HtEntry *ht = E.ht + (size_t)g * E.H;
-        for (int i = lane; i < E.H; i += 64) { ht[i].key = 0ull; ht[i].idx1 = 0; }
         __threadfence_block();
-        int rr = -1;   // record of the new root, if that child was expanded (tree reuse)
-        for (int r = lane; r < hi; r += 64)
-            if (E.rec_level[rbase + r] >= 0) {
-                const unsigned long long k = E.rec_key[rbase + r];
-                ht_insert(ht, E.H, k, r);
-                if (k == new_key) rr = r;
-            }
-        rr = c6_wave_max_i32(rr);
+        const int rr = rebuild_table_wave(E, g, lane, hi, new_key);   // rr: record of the new root, if that child was expanded (tree reuse)
         if (lane == 0) {
             E.free_top[g] = top;
             E.root_rec[g] = rr;
@@ -691,6 +745,133 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
     }
 }
 
+// head of every round for game g: the move K1 applied last round, if any.  Steady-state mode also abandons -- counted, never
+// silently -- a slot whose game stopped in an error state (pool exhausted with no host to grow it, NaN scores).
+template <int J>
+__device__ __forceinline__ void round_head_wave(const C6Dev &E, int g, int lane) {
+    const int pos = E.move_pos[g];
+    if (pos != -2) {
+        post_move_wave<J>(E, g, lane, pos);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the root this wave just wrote is read back below
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return;
+    }
+    const int stt = E.status[g];
+    if (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW)) {
+        const uint32_t uid_ = E.game_uid[g];
+        if (lane == 0) atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull);
+        reset_game_wave(E, g, lane, uid_ + E.uid_stride, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// ---- the kernels of a round -----------------------------------------------------------------------------------------------
+// Built-in evaluators (RandomEvaluator / uniform: BASELINE configs 1 and 5): the whole search() of a game in ONE launch -- last
+// round's move is finished first, then select -> evaluate -> expand / backup -> policy() run in registers; the leaf never
+// travels through memory.  A round is this kernel + K1.
+template <int J, int KIND>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)) void c6_search_kernel(C6Dev E) {
+    __shared__ double gscratch[WAVES_PER_BLOCK][64 * J];    // c6_wave_gamma hand-back, then the leaf's prior / board: wave-private
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + wv;
+    if (g >= E.G) return;
+    round_head_wave<J>(E, g, lane);
+    if (E.status[g] != C6_ST_PLAYING) return;
+    C6Leaf<J> L;
+    const uint32_t t = E.nsearch[g];
+    select_wave<J>(E, g, lane, gscratch[wv], L);
+    if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
+    if (lane == 0) {
+        E.g_select[g] += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
+        if ((uint32_t)L.len > E.g_maxdepth[g]) E.g_maxdepth[g] = (uint32_t)L.len;
+    }
+    float pr[J], value = 0.f;
+    float *probs = reinterpret_cast<float *>(gscratch[wv]);
+    int8_t *lboard = reinterpret_cast<int8_t *>(probs + 64 * J);
+    if (L.kind == C6_LEAF_EVAL) {
+        eval_builtin_regs<J>(E, g, lane, KIND, t, L.st, pr, value);
+#pragma unroll
+        for (int j = 0; j < J; j++) probs[lane + 64 * j] = pr[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < J; j++) lboard[lane + 64 * j] = L.st[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (L.len > 64) __threadfence();      // path steps beyond 64 went through memory
+    if (expand_wave<J>(E, g, lane, L, value, probs, lboard)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // policy() reads the statistics the backup just wrote
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        move_select_wave<J>(E, g, lane);
+    }
+}
+
+// Net / callback evaluators: the evaluator sits between select and expand, so the leaf travels through the leaf_* arrays.
+template <int J>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)) void c6_select_kernel(C6Dev E) {
+    __shared__ double gscratch[WAVES_PER_BLOCK][64 * J];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + wv;
+    if (g >= E.G) return;
+    round_head_wave<J>(E, g, lane);
+    if (E.status[g] != C6_ST_PLAYING) {
+        if (lane == 0) E.leaf_kind[g] = C6_LEAF_NONE;
+        return;
+    }
+    C6Leaf<J> L;
+    select_wave<J>(E, g, lane, gscratch[wv], L);
+    if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int c = lane + 64 * j;
+        if (c < E.cells) E.leaf_board[(size_t)g * E.cellsP + c] = L.st[j];
+    }
+    if (lane < 64 && lane < L.len) E.path_rec[(size_t)g * E.maxd + lane] = (uint16_t)L.my_path;
+    if (lane == 0) {
+        E.leaf_kind[g] = (int8_t)L.kind;
+        E.leaf_turn[g] = (int8_t)L.turn;
+        E.leaf_key[g] = L.key;
+        E.leaf_sig[g * 4 + 0] = L.sg0; E.leaf_sig[g * 4 + 1] = L.sg1; E.leaf_sig[g * 4 + 2] = L.sg2; E.leaf_sig[g * 4 + 3] = L.sg3;
+        E.leaf_level[g] = (int16_t)L.level;
+        E.path_len[g] = L.len;
+        E.g_select[g] += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
+        if ((uint32_t)L.len > E.g_maxdepth[g]) E.g_maxdepth[g] = (uint32_t)L.len;
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G) return;
+    C6Leaf<J> L;
+    L.kind = E.leaf_kind[g];
+    L.len = E.path_len[g];
+    L.level = E.leaf_level[g];
+    L.turn = E.leaf_turn[g];
+    L.key = E.leaf_key[g];
+    const uint4 qv = *reinterpret_cast<const uint4 *>(E.leaf_sig + (size_t)g * 4);
+    L.sg0 = qv.x; L.sg1 = qv.y; L.sg2 = qv.z; L.sg3 = qv.w;
+    L.my_path = E.path_rec[(size_t)g * E.maxd + (lane < E.maxd ? lane : 0)];
+    const float evalue = E.eval_value[g];
+    if (L.kind == C6_LEAF_NONE) return;
+    if (expand_wave<J>(E, g, lane, L, evalue, E.eval_prior + (size_t)g * E.cells, E.leaf_board + (size_t)g * E.cellsP)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        move_select_wave<J>(E, g, lane);
+    }
+}
+
+// the stand-alone forms: flush at the end of c6_engine_step (so that callers see every applied move finished) and
+// c6_engine_apply_moves (stones from outside)
+template <int J>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6Dev E) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= E.G) return;
+    round_head_wave<J>(E, g, lane);
+}
+
 // stagger: pretend game g already spent (g mod S) simulations of its first move
 __global__ void c6_stagger_kernel(C6Dev E) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -711,12 +892,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_grow_fix_kernel(C6Dev
     for (int r = O.R + lane; r < Nw.R; r += 64) Nw.rec_level[nb + r] = -1;
     for (int i = lane; i < add; i += 64) Nw.free_stack[nb + i] = (uint16_t)(Nw.R - 1 - i);       // bottom of the stack: pops O.R, O.R+1, ... last
     for (int i = lane; i < top; i += 64) Nw.free_stack[nb + add + i] = O.free_stack[ob + i];
-    C6HtEntry *ht = Nw.ht + (size_t)g * Nw.H;
-    for (int i = lane; i < Nw.H; i += 64) { ht[i].key = 0ull; ht[i].idx1 = 0; }
     __threadfence_block();
-    const int hi = O.rec_hi[g];
-    for (int r = lane; r < hi; r += 64)
-        if (Nw.rec_level[nb + r] >= 0) ht_insert(ht, Nw.H, Nw.rec_key[nb + r], r);
+    rebuild_table_wave(Nw, g, lane, O.rec_hi[g], 0ull);      // the table at its new size, entries with the records' current statistics
     if (lane == 0) {
         Nw.free_top[g] = top + add;
         if (Nw.status[g] == C6_ST_OVERFLOW) Nw.status[g] = C6_ST_PLAYING;
@@ -761,21 +938,26 @@ static inline int wave_grid(int G) { return (G + WAVES_PER_BLOCK - 1) / WAVES_PE
         else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d); \
         else hipLaunchKernelGGL((KERNEL<6>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);             \
     } while (0)
+#define C6_LAUNCH_JK(KERNEL, K, d, s)                                                                                    \
+    do {                                                                                                                 \
+        const int j_ = ((d).cells + 63) / 64;                                                                            \
+        if (j_ <= 2) hipLaunchKernelGGL((KERNEL<2, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);      \
+        else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d); \
+        else hipLaunchKernelGGL((KERNEL<6, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);             \
+    } while (0)
 
+void c6_launch_search(const C6Dev &d, int kind, hipStream_t s) {      // kind 1: RandomEvaluator, 2: uniform
+    if (kind == 1) C6_LAUNCH_JK(c6_search_kernel, 1, d, s);
+    else C6_LAUNCH_JK(c6_search_kernel, 2, d, s);
+}
 void c6_launch_select(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_select_kernel, d, s); }
-void c6_launch_expand(const C6Dev &d, hipStream_t s) {
-    hipLaunchKernelGGL(c6_expand_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
-}
-void c6_launch_eval_builtin(const C6Dev &d, int kind, hipStream_t s) {
-    hipLaunchKernelGGL(c6_eval_builtin_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d, kind);
-}
+void c6_launch_expand(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_expand_kernel, d, s); }
 void c6_launch_recover(const C6Dev &d, hipStream_t s) {
     hipLaunchKernelGGL(c6_recover_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
 }
 void c6_launch_augment(const C6Dev &d, float *img, hipStream_t s) {
     hipLaunchKernelGGL(c6_augment_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d, img);
 }
-void c6_launch_move_select(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_move_select_kernel, d, s); }
 void c6_launch_post_move(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_post_move_kernel, d, s); }
 void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s) {
     hipLaunchKernelGGL(c6_reset_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);

@@ -121,7 +121,7 @@ def usable_cores():
     return n
 
 
-def stones_probe(pkg, wl, games, sims, precision, seed=7, device=0):
+def stones_probe(pkg, wl, games, sims, precision, seed=7, device=0, progress=False):
     """complete self-play games of the workload's net (same random-init weights, same noise) at `sims` simulations per move: the
     measured game length that turns simulations/s into games/s"""
     import __graft_entry__ as ge
@@ -132,6 +132,13 @@ def stones_probe(pkg, wl, games, sims, precision, seed=7, device=0):
     if ev == pkg.EVAL_NET:
         eng.load_weights(ge.make_random_blob(n, wl["channels"], wl["blocks"], np.random.default_rng(0)))
     t0 = time.perf_counter()
+    if progress:      # long probes report as they go (a silent GPU job is taken to be hung)
+        while True:
+            eng.run(max_rounds=256)
+            st = eng.stats()
+            print(f"[stones_probe] round {st['rounds']}: {st['games_finished']} / {games} games finished, {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+            if st["live_games"] == 0:
+                break
     eng.run()
     dt = time.perf_counter() - t0
     st = eng.stats()

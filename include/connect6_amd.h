@@ -281,7 +281,8 @@ int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *board, int32
  * AlphaZero::next, alphazero_policy/mod.rs:464-489).  An occupied or out-of-range cell makes the game's status an error
  * (the reference: Err -> unwrap() panic). */
 int c6_engine_apply_moves(c6_engine *e, const int32_t *pos);
-/* the cells chosen in the engine's last move phase: pos[g] = cell, -1 = no move (draw), -2 = game g did not move.  Two
+/* the cells the engine's policy played during the last c6_engine_step call: pos[g] = cell, -1 = no move (draw), -2 = game g did not
+ * move in that call (a game moves at most once per num_simulation rounds).  Two
  * engines with different weights, each searching for one colour and receiving the other's stones through
  * c6_engine_apply_moves, are MultiPolicy for resident nets: net-vs-net evaluation games (tools/net_vs_net.py). */
 int c6_engine_last_moves(c6_engine *e, int32_t *pos);

@@ -15,8 +15,8 @@ games = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 sims = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 also = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 wl = bench.WORKLOADS[name]
-r = bench.stones_probe(pkg, wl, games, sims, pkg.PREC_BF16X3)
+r = bench.stones_probe(pkg, wl, games, sims, pkg.PREC_BF16X3, progress=True)
 r.update(workload=name, precision="bf16x3 (parity grade: net outputs within 1e-5 of FP32)", board=wl["n"], net_blocks=wl["blocks"], net_channels=wl["channels"])
-if also:      # the game length does not depend on the simulation budget for a random-init net: a second budget shows it
-    r["other_budget"] = bench.stones_probe(pkg, wl, max(games // 4, 64), also, pkg.PREC_BF16X3, seed=8)
+if also:      # how the game length moves with the simulation budget: further budgets on fewer games
+    r["other_budgets"] = [bench.stones_probe(pkg, wl, 256, b, pkg.PREC_BF16X3, seed=8 + b, progress=True) for b in (2, also)]
 print(json.dumps(r))
