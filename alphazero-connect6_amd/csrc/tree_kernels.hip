@@ -96,26 +96,59 @@ struct C6Leaf {
     int8_t st[J];           // the leaf position, lane's cells
 };
 
+// Everything a search() needs that is addressed by the game alone, fetched as ONE batch of independent loads (the kernels are chains of
+// dependent memory round trips; every scalar loaded where it is first used would be a trip of its own).
+template <int J>
+struct C6GameRegs {
+    unsigned long long key;
+    uint4 sig;
+    int root_rec, turn, remain, level, top, sim_in_move;
+    uint32_t uid, nsearch;
+    int free_idx;           // the record the next expansion takes (free_stack[top - 1]), fetched behind `top`
+    int8_t st[J];           // the root position, lane's cells
+};
+template <int J>
+__device__ __forceinline__ void load_game_regs(const C6Dev &E, int g, int lane, C6GameRegs<J> &R) {
+    R.key = E.root_key[g];
+    R.sig = *reinterpret_cast<const uint4 *>(E.root_sig + (size_t)g * 4);
+    R.root_rec = E.root_rec[g];
+    R.turn = E.turn[g]; R.remain = E.remain[g]; R.level = E.nstones[g];
+    R.uid = E.game_uid[g]; R.nsearch = E.nsearch[g];
+    R.top = E.free_top[g]; R.sim_in_move = E.sim_in_move[g];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int c = lane + 64 * j;
+        R.st[j] = c < E.cells ? E.root_board[(size_t)g * E.cellsP + c] : (int8_t)2;
+    }
+    // wave-uniform values belong in scalar registers (the loads above are vector loads of one address)
+#define C6_SGPR(x) x = __builtin_amdgcn_readfirstlane(x)
+    R.key = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(R.key >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)R.key);
+    R.sig.x = __builtin_amdgcn_readfirstlane(R.sig.x); R.sig.y = __builtin_amdgcn_readfirstlane(R.sig.y);
+    R.sig.z = __builtin_amdgcn_readfirstlane(R.sig.z); R.sig.w = __builtin_amdgcn_readfirstlane(R.sig.w);
+    C6_SGPR(R.root_rec); C6_SGPR(R.turn); C6_SGPR(R.remain); C6_SGPR(R.level); C6_SGPR(R.top); C6_SGPR(R.sim_in_move);
+    R.uid = __builtin_amdgcn_readfirstlane(R.uid); R.nsearch = __builtin_amdgcn_readfirstlane(R.nsearch);
+    R.free_idx = R.top > 0 ? (int)E.free_stack[(size_t)g * E.R + R.top - 1] : -1;      // second trip, overlapped with the first select level
+    C6_SGPR(R.free_idx);
+#undef C6_SGPR
+}
+
 // ------------------------------------------------------------------------------------------
 // select: walk from the root by PUCT + Dirichlet noise until a node without record (leaf)
 // ------------------------------------------------------------------------------------------
 template <int J>
-__device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, double *gscratch, C6Leaf<J> &L) {
+__device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, double *gscratch, const C6GameRegs<J> &R, C6Leaf<J> &L) {
     const int cells = E.cells;
     const C6HtEntry *ht = E.ht + (size_t)g * E.H;
     const size_t rbase = (size_t)g * E.R;
 
-    unsigned long long key = E.root_key[g];
-    uint32_t sg0 = E.root_sig[g * 4 + 0], sg1 = E.root_sig[g * 4 + 1], sg2 = E.root_sig[g * 4 + 2], sg3 = E.root_sig[g * 4 + 3];
-    int p = E.root_rec[g];
-    int turn = E.turn[g], remain = E.remain[g], level = E.nstones[g];
-    const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.game_uid[g], t = E.nsearch[g];
+    unsigned long long key = R.key;
+    uint32_t sg0 = R.sig.x, sg1 = R.sig.y, sg2 = R.sig.z, sg3 = R.sig.w;
+    int p = R.root_rec;
+    int turn = R.turn, remain = R.remain, level = R.level;
+    const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + R.uid, t = R.nsearch;
 
 #pragma unroll
-    for (int j = 0; j < J; j++) {
-        const int c = lane + 64 * j;
-        L.st[j] = c < cells ? E.root_board[(size_t)g * E.cellsP + c] : (int8_t)2;
-    }
+    for (int j = 0; j < J; j++) L.st[j] = R.st[j];
 
     int d = 0;
     int kind = C6_LEAF_EVAL;
@@ -380,19 +413,28 @@ __device__ __forceinline__ int wave_winner(const int8_t *board, int N, int lane)
 // the wave's LDS scratch inside the fused search kernel); `board` = the leaf position as bytes (terminal leaves only).
 // Returns true when the game's simulation budget for this move is spent (the caller then runs policy()).
 template <int J>
-__device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, const C6Leaf<J> &L, float evalue, const float *prob, const int8_t *board) {
+__device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, const C6GameRegs<J> &R, const C6Leaf<J> &L, float evalue, const float *prob,
+                                            const int8_t *board) {
     const int cells = E.cells;
     const size_t rbase = (size_t)g * E.R;
     const int kind = L.kind, len = L.len, level = L.level, turn = L.turn;
     const unsigned long long key = L.key;
-    // ---- everything addressed by g alone
-    const int top = E.free_top[g];
+    const int top = R.top, sim_in_move = R.sim_in_move;
+    const uint32_t nsearch = R.nsearch;
+    float value;
+    // these leave together and come back behind the record scan: the rest of the game's words, and the backup's loads (lane i: the
+    // path's i-th record)
     const int hi0 = E.rec_hi[g];
-    const uint32_t nsearch = E.nsearch[g];
-    const int sim_in_move = E.sim_in_move[g];
     const unsigned long long gsims = E.g_sims[g];
     const uint32_t maxrec = E.g_maxrec[g];
-    float value;
+    uint32_t bk_slot = 0;
+    int bk_visit = 0;
+    float bk_qsum = 0.f;
+    if (lane < len) {
+        bk_slot = E.rec_slot[rbase + L.my_path];
+        bk_visit = E.rec_visit[rbase + L.my_path];
+        bk_qsum = E.rec_qsum[rbase + L.my_path];
+    }
 
     if (kind == C6_LEAF_TERMINAL) {   // mod.rs:338-348: value by winner, no visit increment, no children
         const int w = wave_winner(board, E.N, lane);
@@ -404,7 +446,7 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
             if (lane == 0) E.status[g] = C6_ST_OVERFLOW;
             return false;
         }
-        const int idx = E.free_stack[rbase + top - 1];
+        const int idx = R.free_idx;
         const int hi = idx + 1 > hi0 ? idx + 1 : hi0;
         value = evalue;
         float *prior = E.rec_prior + (rbase + idx) * (size_t)cells;
@@ -477,9 +519,9 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         const int i = base + lane;
         if (i < len) {
             const int r = base == 0 ? L.my_path : (int)E.path_rec[(size_t)g * E.maxd + i];
-            const uint32_t slot = E.rec_slot[rbase + r];
-            const int v = E.rec_visit[rbase + r] + 1;
-            float qs = E.rec_qsum[rbase + r];
+            const uint32_t slot = base == 0 ? bk_slot : E.rec_slot[rbase + r];
+            const int v = (base == 0 ? bk_visit : E.rec_visit[rbase + r]) + 1;
+            float qs = base == 0 ? bk_qsum : E.rec_qsum[rbase + r];
             if (i == len - 1) {      // the leaf's parent receives the value
                 qs = qs + value;
                 E.rec_qsum[rbase + r] = qs;
@@ -776,11 +818,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = blockIdx.x * WAVES_PER_BLOCK + wv;
     if (g >= E.G) return;
-    round_head_wave<J>(E, g, lane);
-    if (E.status[g] != C6_ST_PLAYING) return;
+    // one batch of loads: the two words that decide whether there is a move to finish first, and the game's registers
+    const int pos = E.move_pos[g];
+    int stt = E.status[g];
+    C6GameRegs<J> R;
+    load_game_regs<J>(E, g, lane, R);
+    if (pos != -2 || (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW))) {      // ~1 game in S per round: the slow path reloads
+        round_head_wave<J>(E, g, lane);
+        stt = E.status[g];
+        load_game_regs<J>(E, g, lane, R);
+    }
+    if (stt != C6_ST_PLAYING) return;
     C6Leaf<J> L;
-    const uint32_t t = E.nsearch[g];
-    select_wave<J>(E, g, lane, gscratch[wv], L);
+    select_wave<J>(E, g, lane, gscratch[wv], R, L);
     if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
     if (lane == 0) {
         E.g_select[g] += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
@@ -790,7 +840,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     float *probs = reinterpret_cast<float *>(gscratch[wv]);
     int8_t *lboard = reinterpret_cast<int8_t *>(probs + 64 * J);
     if (L.kind == C6_LEAF_EVAL) {
-        eval_builtin_regs<J>(E, g, lane, KIND, t, L.st, pr, value);
+        eval_builtin_regs<J>(E, g, lane, KIND, R.nsearch, L.st, pr, value);
 #pragma unroll
         for (int j = 0; j < J; j++) probs[lane + 64 * j] = pr[j];
     } else {
@@ -799,7 +849,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (L.len > 64) __threadfence();      // path steps beyond 64 went through memory
-    if (expand_wave<J>(E, g, lane, L, value, probs, lboard)) {
+    if (expand_wave<J>(E, g, lane, R, L, value, probs, lboard)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // policy() reads the statistics the backup just wrote
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         move_select_wave<J>(E, g, lane);
@@ -818,8 +868,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
         if (lane == 0) E.leaf_kind[g] = C6_LEAF_NONE;
         return;
     }
+    C6GameRegs<J> R;
+    load_game_regs<J>(E, g, lane, R);
     C6Leaf<J> L;
-    select_wave<J>(E, g, lane, gscratch[wv], L);
+    select_wave<J>(E, g, lane, gscratch[wv], R, L);
     if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
 #pragma unroll
     for (int j = 0; j < J; j++) {
@@ -854,8 +906,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
     L.sg0 = qv.x; L.sg1 = qv.y; L.sg2 = qv.z; L.sg3 = qv.w;
     L.my_path = E.path_rec[(size_t)g * E.maxd + (lane < E.maxd ? lane : 0)];
     const float evalue = E.eval_value[g];
+    C6GameRegs<J> R;
+    load_game_regs<J>(E, g, lane, R);      // (the root fields go unused here; one loader keeps both paths on the same code)
     if (L.kind == C6_LEAF_NONE) return;
-    if (expand_wave<J>(E, g, lane, L, evalue, E.eval_prior + (size_t)g * E.cells, E.leaf_board + (size_t)g * E.cellsP)) {
+    if (expand_wave<J>(E, g, lane, R, L, evalue, E.eval_prior + (size_t)g * E.cells, E.leaf_board + (size_t)g * E.cellsP)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         move_select_wave<J>(E, g, lane);
