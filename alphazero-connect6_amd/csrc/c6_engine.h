@@ -30,6 +30,42 @@ enum { C6_LEAF_NONE = 0, C6_LEAF_EVAL = 1, C6_LEAF_TERMINAL = 2 };
 enum { C6_CNT_SIMS = 0, C6_CNT_SELECT, C6_CNT_STONES, C6_CNT_FINISHED, C6_CNT_TUPLES, C6_CNT_OVERFLOW, C6_CNT_MAXDEPTH,
        C6_CNT_MAXREC, C6_CNT_LIVE, C6_CNT_FETCHQ, C6_CNT_N };
 
+// Everything a round reads and writes about a game, in ONE 128-byte line: a wave fetches it with a few adjacent loads and lane 0 writes
+// it back into the same line (as ~25 separate arrays every word cost a memory transaction of its own: the tree kernels are bound by
+// small HBM transactions, profiles/r02_tree_traffic.txt).  K1's operands (board_soa, turn, remain, winner, err, move_pos) stay
+// structure-of-arrays over games: K1 reads them with lane == game.
+struct C6GameHdr {
+    unsigned long long root_key;      //   0  Zobrist key of the root position
+    int32_t root_rec;                 //   8  record of the root, -1 = not expanded
+    uint32_t game_uid;                //  12  C6RNG key of the game
+    uint32_t root_sig[4];             //  16  sum / sumsq of (cell + 1) for black, white
+    uint32_t nsearch;                 //  32  searches since the game's start
+    int32_t sim_in_move;              //  36
+    int32_t free_top;                 //  40  free records left
+    int32_t rec_hi;                   //  44  1 + highest record index handed out since the game's reset
+    int16_t nstones;                  //  48
+    int8_t status;                    //  50  C6_ST_*
+    int8_t leaf_kind;                 //  51  C6_LEAF_*
+    uint32_t g_maxdepth, g_maxrec;    //  52  statistics of the game slot
+    int16_t leaf_level;               //  60
+    int8_t leaf_turn, pad0;           //  62
+    unsigned long long g_sims, g_select, g_stones;      //  64
+    unsigned long long leaf_key;      //  88  leaf exchange (select -> evaluator -> expand)
+    uint32_t leaf_sig[4];             //  96
+    int32_t path_len;                 // 112
+    float eval_value;                 // 116
+    uint32_t pad1[2];                 // 120
+};
+static_assert(sizeof(C6GameHdr) == 128, "one line per game");
+
+// the mutable statistics of an expanded node, one 32-byte piece per record (backup touches one sector, not four)
+struct C6RecStat {
+    int32_t visit;
+    float value, qsum, q;
+    uint32_t slot;          // table slot of the record
+    uint32_t pad[3];
+};
+
 struct C6Dev {
     // geometry / hyper-parameters (policy/alphazero_policy/mod.rs:91-96)
     int N, cells, cellsP, G, Gpad, S, R, H, maxd;
@@ -41,37 +77,22 @@ struct C6Dev {
     int8_t *board_soa;     // [cells][Gpad]
     int8_t *turn, *remain; // [Gpad]
     int8_t *winner, *err;  // [Gpad] written by K1
-    int8_t *status;        // [G]
-    int16_t *nstones;      // [G]
-    uint32_t *game_uid, *nsearch;
-    int *sim_in_move;
+    C6GameHdr *hdr;        // [G]
     // root copy for the tree kernels
     int8_t *root_board;    // [G][cellsP]
-    unsigned long long *root_key;
-    uint32_t *root_sig;    // [G][4] = sum/sumsq of (cell+1) for black, white
-    int *root_rec;
     uint16_t *moves;       // [G][cells] cell of stone k
     uint16_t *hist_pi;     // [G][cells][cells] root child visits at move k
     // expanded-node records
     unsigned long long *rec_key; // [G][R]
-    int *rec_visit;
-    float *rec_value, *rec_qsum, *rec_q;
+    C6RecStat *rec_stat;   // [G][R]
     int16_t *rec_level;    // -1 = free
     uint32_t *rec_sig;     // [G][R][4]
     float *rec_prior;      // [G][R][cells]  n_prob of the child at each empty cell
     C6HtEntry *ht;         // [G][H]
-    uint32_t *rec_slot;    // [G][R] table slot of a live record (backup keeps the entry's visit / q in step with the record)
     uint16_t *free_stack;  // [G][R]
-    int *free_top;         // [G]
     // per-round leaf exchange
     int8_t *leaf_board;    // [G][cellsP]
-    int8_t *leaf_turn, *leaf_kind;
-    unsigned long long *leaf_key;
-    uint32_t *leaf_sig;    // [G][4]
-    int16_t *leaf_level;
-    int *path_len;
     uint16_t *path_rec;    // [G][maxd]
-    float *eval_value;     // [G]
     float *eval_prior;     // [G][cells]
     float *img_val;        // [G][8]
     float *img_pol;        // [G][8][cells]
@@ -94,10 +115,6 @@ struct C6Dev {
     const int16_t *aug_map;        // [8][cells] image k, cell c -> source cell of the board
     const int16_t *rec_map;        // [8][cells] image k, output cell c -> cell of image k's policy
     unsigned long long *counters;  // [C6_CNT_N] (rare events only: finished games, tuples, fetch queue)
-    unsigned long long *g_sims, *g_select, *g_stones;   // [G] per-game statistics, reduced on the host
-    uint32_t *g_maxdepth, *g_maxrec;                    // [G]
-    int *rec_hi;                                        // [G] 1 + highest record index ever handed out since the game's reset:
-                                                        // every scan over a game's records stops there (R = 4S + 64 is a bound, not the use)
 };
 
 // tree_kernels.hip
@@ -164,12 +181,12 @@ struct C6NetDev {
     unsigned int *range_flag;
     float range_limit;
 };
-// boards: int8 [nleaf][cellsP]; player int8 [nleaf]; images = 8 (dihedral, aug_map) or 1 (identity).
+// boards: int8 [nleaf][board_stride]; player: int8 of leaf i at player[i * player_stride]; images = 8 (dihedral, aug_map) or 1 (identity).
 // act0/act1/act2: [nleaf*images][cells][C] f32 scratch; vbuf: c6_conv_wino_vbuf_floats(...) floats (C6_CONV_WINO only).
 // Outputs pol [nleaf*images][cells], val [nleaf*images].
 struct C6NetTimers;
 void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t *boards, int board_stride,
-                        const int8_t *player, const int16_t *aug_map, float *act0, float *act1, float *act2, float *vbuf, float *ph,
+                        const int8_t *player, int player_stride, const int16_t *aug_map, float *act0, float *act1, float *act2, float *vbuf, float *ph,
                         float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers);
 void c6_conv_bench_launch(int variant, int C, int N, int nboards, const float *in, const float *w, const float *bias, const float *res,
                           float *out, float *vbuf, int num_cus, hipStream_t s);

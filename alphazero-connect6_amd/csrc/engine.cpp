@@ -427,6 +427,7 @@ struct c6_engine {
     float *img_boards = nullptr;   // device [G][8][cells]
     std::vector<float> h_img, h_pol, h_val, h_cbp, h_cbv;
     std::vector<int8_t> h_kind, h_turn;
+    std::vector<C6GameHdr> h_hdr;      // host copy of the game headers (statistics, states)
     // owned tuple buffer
     uint8_t *own_tuple = nullptr;
     uint32_t *own_tuple_count = nullptr;
@@ -480,22 +481,20 @@ static int engine_alloc(c6_engine *e) {
 
     ALLOC(d.board_soa, (size_t)cells * d.Gpad);
     ALLOC(d.turn, d.Gpad); ALLOC(d.remain, d.Gpad); ALLOC(d.winner, d.Gpad); ALLOC(d.err, d.Gpad);
-    ALLOC(d.status, G); ALLOC(d.nstones, G); ALLOC(d.game_uid, G); ALLOC(d.nsearch, G); ALLOC(d.sim_in_move, G);
-    ALLOC(d.root_board, (size_t)G * d.cellsP); ALLOC(d.root_key, G); ALLOC(d.root_sig, (size_t)G * 4); ALLOC(d.root_rec, G);
+    ALLOC(d.hdr, G);
+    ALLOC(d.root_board, (size_t)G * d.cellsP);
     ALLOC(d.moves, (size_t)G * cells); ALLOC(d.hist_pi, (size_t)G * cells * cells);
     const size_t GR = (size_t)G * d.R;
-    ALLOC(d.rec_key, GR); ALLOC(d.rec_visit, GR); ALLOC(d.rec_value, GR); ALLOC(d.rec_qsum, GR); ALLOC(d.rec_q, GR);
+    ALLOC(d.rec_key, GR); ALLOC(d.rec_stat, GR);
     ALLOC(d.rec_level, GR); ALLOC(d.rec_sig, GR * 4); ALLOC(d.rec_prior, GR * cells);
-    ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.rec_slot, GR); ALLOC(d.free_stack, GR); ALLOC(d.free_top, G);
-    ALLOC(d.leaf_board, (size_t)G * d.cellsP); ALLOC(d.leaf_turn, G); ALLOC(d.leaf_kind, G); ALLOC(d.leaf_key, G);
-    ALLOC(d.leaf_sig, (size_t)G * 4); ALLOC(d.leaf_level, G); ALLOC(d.path_len, G); ALLOC(d.path_rec, (size_t)G * d.maxd);
-    ALLOC(d.eval_value, G); ALLOC(d.eval_prior, (size_t)G * cells);
+    ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.free_stack, GR);
+    ALLOC(d.leaf_board, (size_t)G * d.cellsP); ALLOC(d.path_rec, (size_t)G * d.maxd);
+    ALLOC(d.eval_prior, (size_t)G * cells);
     ALLOC(d.move_pos, d.Gpad); ALLOC(d.last_move, d.Gpad); ALLOC(d.move_turn, G);
     d.finq_cap = std::max(4 * G, 1024);
     ALLOC(d.fin_winner, d.finq_cap); ALLOC(d.fin_len, d.finq_cap); ALLOC(d.fin_uid, d.finq_cap);
     ALLOC(d.fin_moves, (size_t)d.finq_cap * cells);
     ALLOC(d.counters, C6_CNT_N);
-    ALLOC(d.g_sims, G); ALLOC(d.g_select, G); ALLOC(d.g_stones, G); ALLOC(d.g_maxdepth, G); ALLOC(d.g_maxrec, G); ALLOC(d.rec_hi, G);
     d.tuple_stride = (int)c6_tuple_stride(N);
 
     std::vector<unsigned long long> zob;
@@ -621,10 +620,11 @@ static int evaluate_callback(c6_engine *e) {
     c6_launch_augment(d, e->img_boards, e->stream);
     e->h_kind.resize(G); e->h_turn.resize(G);
     e->h_img.resize((size_t)G * 8 * cells); e->h_pol.resize((size_t)G * 8 * cells); e->h_val.resize((size_t)G * 8);
-    HIPCHK(hipMemcpyAsync(e->h_kind.data(), d.leaf_kind, G, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_turn.data(), d.leaf_turn, G, hipMemcpyDeviceToHost, e->stream));
+    e->h_hdr.resize(G);
+    HIPCHK(hipMemcpyAsync(e->h_hdr.data(), d.hdr, (size_t)G * sizeof(C6GameHdr), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(e->h_img.data(), e->img_boards, e->h_img.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    for (int g = 0; g < G; g++) { e->h_kind[g] = e->h_hdr[g].leaf_kind; e->h_turn[g] = e->h_hdr[g].leaf_turn; }
     // the callback takes ONE `player` for all boards (cppeval/mod.rs:8-13): batch per side to move
     for (int player = -1; player <= 1; player += 2) {
         std::vector<int> idx;
@@ -655,7 +655,7 @@ static int evaluate(c6_engine *e) {
         if (!e->net.loaded) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_NET but no weights are loaded");
         for (int l0 = 0; l0 < d.G; l0 += e->chunk_leaves) {
             const int nl = std::min(e->chunk_leaves, d.G - l0);
-            c6_net_forward_dev(e->net.dev, nl, 8, d.leaf_board + (size_t)l0 * d.cellsP, d.cellsP, d.leaf_turn + l0, d.aug_map,
+            c6_net_forward_dev(e->net.dev, nl, 8, d.leaf_board + (size_t)l0 * d.cellsP, d.cellsP, &d.hdr[l0].leaf_turn, (int)sizeof(C6GameHdr), d.aug_map,
                                e->act0, e->act1, e->act2, e->vbuf, e->ph, e->vh, d.img_pol + (size_t)l0 * 8 * d.cells,
                                d.img_val + (size_t)l0 * 8, e->stream, e->timers);
         }
@@ -758,11 +758,11 @@ static int range_status(const NetHost &net) {
 }
 
 static int live_games(c6_engine *e, int *live, int *errors, int *overflow = nullptr) {
-    std::vector<int8_t> st(e->d.G);
-    HIPCHK(hipMemcpyAsync(st.data(), e->d.status, e->d.G, hipMemcpyDeviceToHost, e->stream));
+    e->h_hdr.resize(e->d.G);
+    HIPCHK(hipMemcpyAsync(e->h_hdr.data(), e->d.hdr, (size_t)e->d.G * sizeof(C6GameHdr), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     int l = 0, er = 0, ov = 0;
-    for (int8_t s : st) { l += s == C6_ST_PLAYING; er += s == C6_ST_ERROR; ov += s == C6_ST_OVERFLOW; }
+    for (const C6GameHdr &h : e->h_hdr) { l += h.status == C6_ST_PLAYING; er += h.status == C6_ST_ERROR; ov += h.status == C6_ST_OVERFLOW; }
     *live = l;
     *errors = er + ov;
     if (overflow) *overflow = ov;
@@ -811,32 +811,27 @@ static int grow_pool(c6_engine *e) {
     std::vector<void *> fresh, stale;
     uint16_t *nfs = nullptr;
     C6HtEntry *nht = nullptr;
-    uint32_t *nsl = nullptr;
     int rc;
     if ((rc = grow_array(pool, &nw.rec_prior, G, (size_t)old.R * cells, (size_t)nw.R * cells, fresh, stale)) ||
-        (rc = grow_array(pool, &nw.rec_key, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_visit, G, old.R, nw.R, fresh, stale)) ||
-        (rc = grow_array(pool, &nw.rec_value, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_qsum, G, old.R, nw.R, fresh, stale)) ||
-        (rc = grow_array(pool, &nw.rec_q, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_level, G, old.R, nw.R, fresh, stale)) ||
+        (rc = grow_array(pool, &nw.rec_key, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_stat, G, old.R, nw.R, fresh, stale)) ||
+        (rc = grow_array(pool, &nw.rec_level, G, old.R, nw.R, fresh, stale)) ||
         (rc = grow_array(pool, &nw.rec_sig, G, (size_t)old.R * 4, (size_t)nw.R * 4, fresh, stale)) ||
         (rc = grow_array(pool, &nw.path_rec, G, old.maxd, nw.maxd, fresh, stale)) ||
-        (rc = pool.alloc(&nfs, (size_t)G * nw.R)) || (rc = pool.alloc(&nht, (size_t)G * nw.H)) || (rc = pool.alloc(&nsl, (size_t)G * nw.R))) {
+        (rc = pool.alloc(&nfs, (size_t)G * nw.R)) || (rc = pool.alloc(&nht, (size_t)G * nw.H))) {
         for (void *p : fresh) pool.free_one(p);      // the engine keeps running on the old, untouched pool
         if (nfs) pool.free_one(nfs);
         if (nht) pool.free_one(nht);
-        if (nsl) pool.free_one(nsl);
         e->grow_failed = true;
         return rc;
     }
     // free stack and table are rebuilt from the old ones by the device (c6_grow_fix_kernel)
     nw.free_stack = nfs;
     nw.ht = nht;
-    nw.rec_slot = nsl;
     c6_launch_grow_fix(old, nw, e->stream);
     HIPCHK(hipStreamSynchronize(e->stream));
     for (void *p : stale) pool.free_one(p);
     pool.free_one(old.free_stack);
     pool.free_one(old.ht);
-    pool.free_one(old.rec_slot);
     d = nw;
     e->pool_grows++;
     if (!e->cfg.stagger) e->desync = true;
@@ -849,18 +844,10 @@ static int maintain(c6_engine *e, int overflowed) {
     if (e->grow_failed) return C6_OK;
     bool want = overflowed > 0;
     if (!want) {
-        std::vector<uint32_t> mr(d.G);
-        HIPCHK(hipMemcpy(mr.data(), d.g_maxrec, (size_t)d.G * 4, hipMemcpyDeviceToHost));
-        uint32_t hi = 0;
-        for (uint32_t v : mr) hi = std::max(hi, v);
-        want = (size_t)hi * 4 > (size_t)d.R * 3;
-        if (want) {      // g_maxrec is a high-water mark since the game's reset: grow only if the pool is that full NOW
-            std::vector<int> ft(d.G);
-            HIPCHK(hipMemcpy(ft.data(), d.free_top, (size_t)d.G * 4, hipMemcpyDeviceToHost));
-            int lo = d.R;
-            for (int v : ft) lo = std::min(lo, v);
-            want = (size_t)(d.R - lo) * 4 > (size_t)d.R * 3;
-        }
+        // (live_games has just refreshed e->h_hdr) the fullest pool NOW -- g_maxrec is only a high-water mark since the game's reset
+        int lo = d.R;
+        for (const C6GameHdr &h : e->h_hdr) if (h.status == C6_ST_PLAYING) lo = std::min(lo, (int)h.free_top);
+        want = (size_t)(d.R - lo) * 4 > (size_t)d.R * 3;
     }
     if (!want) return C6_OK;
     int rc = grow_pool(e);
@@ -916,19 +903,11 @@ extern "C" int c6_engine_stats(c6_engine *e, c6_stats *out) {
     int live = 0, errs = 0;
     int rc = live_games(e, &live, &errs);
     if (rc != C6_OK) return rc;
-    const int G = e->d.G;
-    std::vector<unsigned long long> a(G), b(G), s(G);
-    std::vector<uint32_t> md(G), mr(G);
-    HIPCHK(hipMemcpy(a.data(), e->d.g_sims, (size_t)G * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(b.data(), e->d.g_select, (size_t)G * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(s.data(), e->d.g_stones, (size_t)G * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(md.data(), e->d.g_maxdepth, (size_t)G * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(mr.data(), e->d.g_maxrec, (size_t)G * 4, hipMemcpyDeviceToHost));
     c[C6_CNT_SIMS] = c[C6_CNT_SELECT] = c[C6_CNT_STONES] = c[C6_CNT_MAXDEPTH] = c[C6_CNT_MAXREC] = 0;
-    for (int g = 0; g < G; g++) {
-        c[C6_CNT_SIMS] += a[g]; c[C6_CNT_SELECT] += b[g]; c[C6_CNT_STONES] += s[g];
-        c[C6_CNT_MAXDEPTH] = std::max<unsigned long long>(c[C6_CNT_MAXDEPTH], md[g]);
-        c[C6_CNT_MAXREC] = std::max<unsigned long long>(c[C6_CNT_MAXREC], mr[g]);
+    for (const C6GameHdr &h : e->h_hdr) {      // refreshed by live_games above
+        c[C6_CNT_SIMS] += h.g_sims; c[C6_CNT_SELECT] += h.g_select; c[C6_CNT_STONES] += h.g_stones;
+        c[C6_CNT_MAXDEPTH] = std::max<unsigned long long>(c[C6_CNT_MAXDEPTH], h.g_maxdepth);
+        c[C6_CNT_MAXREC] = std::max<unsigned long long>(c[C6_CNT_MAXREC], h.g_maxrec);
     }
     out->rounds = e->rounds;
     out->simulations = c[C6_CNT_SIMS];
@@ -1005,21 +984,21 @@ extern "C" int c6_engine_enable_tuples(c6_engine *e, size_t capacity_records) {
 __global__ void c6_root_probe_kernel(C6Dev E, int g, int32_t *visits, float *q, float *prior, int *root_stats, float *root_f) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int cells = E.cells;
-    const int p = E.root_rec[g];
+    const int p = E.hdr[g].root_rec;
     const size_t rbase = (size_t)g * E.R;
     if (c == 0) {
-        root_stats[0] = p >= 0 ? E.rec_visit[rbase + p] : 0;
-        root_stats[1] = E.R - E.free_top[g];
-        root_f[0] = p >= 0 ? E.rec_value[rbase + p] : 0.f;
-        root_f[1] = p >= 0 ? E.rec_qsum[rbase + p] : 0.f;
-        root_f[2] = p >= 0 ? E.rec_q[rbase + p] : 0.f;
+        root_stats[0] = p >= 0 ? E.rec_stat[rbase + p].visit : 0;
+        root_stats[1] = E.R - E.hdr[g].free_top;
+        root_f[0] = p >= 0 ? E.rec_stat[rbase + p].value : 0.f;
+        root_f[1] = p >= 0 ? E.rec_stat[rbase + p].qsum : 0.f;
+        root_f[2] = p >= 0 ? E.rec_stat[rbase + p].q : 0.f;
     }
     if (c >= cells) return;
     const int8_t v = E.root_board[(size_t)g * E.cellsP + c];
     visits[c] = -1; q[c] = 0.f; prior[c] = 0.f;
     if (v != 0 || p < 0) { if (v == 0) visits[c] = 0; return; }
     const int turn = E.turn[g];
-    const unsigned long long key = E.root_key[g] ^ E.zob[(turn == C6_WHITE ? C6_MAXCELLS : 0) + c];
+    const unsigned long long key = E.hdr[g].root_key ^ E.zob[(turn == C6_WHITE ? C6_MAXCELLS : 0) + c];
     const C6HtEntry *ht = E.ht + (size_t)g * E.H;
     uint32_t slot = (uint32_t)(key ^ (key >> 32)) & (uint32_t)(E.H - 1);
     int idx = -1;
@@ -1029,8 +1008,8 @@ __global__ void c6_root_probe_kernel(C6Dev E, int g, int32_t *visits, float *q, 
         if (en.key == 0ull) break;
         slot = (slot + 1) & (uint32_t)(E.H - 1);
     }
-    visits[c] = idx >= 0 ? E.rec_visit[rbase + idx] : 0;
-    q[c] = idx >= 0 ? E.rec_q[rbase + idx] : 0.f;
+    visits[c] = idx >= 0 ? E.rec_stat[rbase + idx].visit : 0;
+    q[c] = idx >= 0 ? E.rec_stat[rbase + idx].q : 0.f;
     prior[c] = E.rec_prior[(rbase + p) * (size_t)cells + c];
 }
 
@@ -1059,10 +1038,12 @@ extern "C" int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *b
         int8_t t, r, st, w; int16_t ns; uint32_t nsr;
         HIPCHK(hipMemcpy(&t, d.turn + g, 1, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&r, d.remain + g, 1, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&st, d.status + g, 1, hipMemcpyDeviceToHost));
+        C6GameHdr hh;
+        HIPCHK(hipMemcpy(&hh, d.hdr + g, sizeof hh, hipMemcpyDeviceToHost));
+        st = hh.status;
         HIPCHK(hipMemcpy(&w, d.winner + g, 1, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&ns, d.nstones + g, 2, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&nsr, d.nsearch + g, 4, hipMemcpyDeviceToHost));
+        ns = hh.nstones;
+        nsr = hh.nsearch;
         info->turn = t; info->remain = r; info->stones = ns; info->status = st; info->winner = w;
         info->root_visit = rs[0]; info->records_used = rs[1];
         info->root_value = rf[0]; info->root_q_sum = rf[1]; info->root_q_value = rf[2];
@@ -1250,7 +1231,7 @@ extern "C" int c6_net_forward_prec(int n, int C, int blocks, int precision, cons
           *vh = t.get<float>((size_t)num * cells), *dp = t.get<float>((size_t)num * cells), *dv = t.get<float>(num);
     float *vb = nh.dev.variant == C6_CONV_WINO ? t.get<float>(c6_conv_wino_vbuf_floats(C, n, num)) : a0;
     if (!db || !dpl || !dm || !a0 || !a1 || !a2 || !ph || !vh || !dp || !dv || !vb) { nh.pool.release(); return fail(C6_ERR_HIP, "hipMalloc failed"); }
-    c6_net_forward_dev(nh.dev, num, 1, db, cells, dpl, dm, a0, a1, a2, vb, ph, vh, dp, dv, nullptr, nullptr);
+    c6_net_forward_dev(nh.dev, num, 1, db, cells, dpl, 1, dm, a0, a1, a2, vb, ph, vh, dp, dv, nullptr, nullptr);
     hipError_t he = hipDeviceSynchronize();
     if (he == hipSuccess && (rc = range_status(nh)) != C6_OK) { nh.pool.release(); return rc; }
     if (he == hipSuccess) he = hipMemcpy(policy, dp, (size_t)num * cells * 4, hipMemcpyDeviceToHost);

@@ -34,7 +34,7 @@ struct C6NetTimers {
 // stem: dihedral gather (augment_way8, augment.rs:60-73) fused with conv3x3 2->C + folded BN + ReLU
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void c6_stem_kernel(const int8_t *__restrict__ boards, int board_stride,
-                                                     const int8_t *__restrict__ player, const int16_t *__restrict__ aug_map,
+                                                     const int8_t *__restrict__ player, int player_stride, const int16_t *__restrict__ aug_map,
                                                      int images, const float *__restrict__ w /*[9][2][C]*/,
                                                      const float *__restrict__ bias, float *__restrict__ out, int N, int C) {
     __shared__ float pl[21 * 21], bd[21 * 21];
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void c6_stem_kernel(const int8_t *__restrict__
     const size_t leaf = b / images;
     const int k = images == 8 ? (int)(b % 8) : 6;     // image 6 is the identity (four left rotations)
     const int8_t *board = boards + leaf * (size_t)board_stride;
-    const float pv = (float)player[leaf];
+    const float pv = (float)player[leaf * (size_t)player_stride];
     for (int s = threadIdx.x; s < P * P; s += 256) { pl[s] = 0.f; bd[s] = 0.f; }
     __syncthreads();
     for (int c = threadIdx.x; c < cells; c += 256) {
@@ -270,11 +270,11 @@ static hipEvent_t timer_event(C6NetTimers *t) {
 }
 
 void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t *boards, int board_stride,
-                        const int8_t *player, const int16_t *aug_map, float *act0, float *act1, float *act2, float *vbuf, float *ph,
+                        const int8_t *player, int player_stride, const int16_t *aug_map, float *act0, float *act1, float *act2, float *vbuf, float *ph,
                         float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers) {
     const int nb = nleaf * images, cells = net.cells, C = net.C;
     if (nb == 0) return;
-    hipLaunchKernelGGL(c6_stem_kernel, dim3(nb), dim3(256), 0, s, boards, board_stride, player, aug_map, images, net.stem_w,
+    hipLaunchKernelGGL(c6_stem_kernel, dim3(nb), dim3(256), 0, s, boards, board_stride, player, player_stride, aug_map, images, net.stem_w,
                        net.stem_b, act0, net.N, C);
     float *x = act0, *y = act1, *z = act2;
     const bool timed = timers && timers->enabled;

@@ -109,12 +109,12 @@ struct C6GameRegs {
 };
 template <int J>
 __device__ __forceinline__ void load_game_regs(const C6Dev &E, int g, int lane, C6GameRegs<J> &R) {
-    R.key = E.root_key[g];
-    R.sig = *reinterpret_cast<const uint4 *>(E.root_sig + (size_t)g * 4);
-    R.root_rec = E.root_rec[g];
-    R.turn = E.turn[g]; R.remain = E.remain[g]; R.level = E.nstones[g];
-    R.uid = E.game_uid[g]; R.nsearch = E.nsearch[g];
-    R.top = E.free_top[g]; R.sim_in_move = E.sim_in_move[g];
+    R.key = E.hdr[g].root_key;
+    R.sig = *reinterpret_cast<const uint4 *>(E.hdr[g].root_sig);
+    R.root_rec = E.hdr[g].root_rec;
+    R.turn = E.turn[g]; R.remain = E.remain[g]; R.level = E.hdr[g].nstones;
+    R.uid = E.hdr[g].game_uid; R.nsearch = E.hdr[g].nsearch;
+    R.top = E.hdr[g].free_top; R.sim_in_move = E.hdr[g].sim_in_move;
 #pragma unroll
     for (int j = 0; j < J; j++) {
         const int c = lane + 64 * j;
@@ -182,7 +182,7 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
             cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f;
             if (L.st[j] == 0 && ht_resolve(ht, E.H, ck[j], cslot[j], ce[j])) {
                 cidx[j] = (int)ce[j].idx1 - 1;
-                cvis[j] = ce[j].visit == 65535 ? E.rec_visit[rbase + cidx[j]] : (int)ce[j].visit;
+                cvis[j] = ce[j].visit == 65535 ? E.rec_stat[rbase + cidx[j]].visit : (int)ce[j].visit;
                 cq[j] = ce[j].q;
                 vs += cvis[j];
             }
@@ -272,8 +272,8 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
 // the game stops (pool / path exhausted: resumable; NaN scores: an error) -- reported through status, never silently
 __device__ __forceinline__ void select_failed(const C6Dev &E, int g, int lane, int kind) {
     if (lane == 0) {
-        E.status[g] = kind == -2 ? C6_ST_OVERFLOW : C6_ST_ERROR;
-        E.leaf_kind[g] = C6_LEAF_NONE;
+        E.hdr[g].status = kind == -2 ? C6_ST_OVERFLOW : C6_ST_ERROR;
+        E.hdr[g].leaf_kind = C6_LEAF_NONE;
     }
 }
 
@@ -309,7 +309,7 @@ template <int J>
 __device__ __forceinline__ void eval_builtin_regs(const C6Dev &E, int g, int lane, int kind, uint32_t t, const int8_t (&st)[J], float (&pr)[J],
                                                   float &value) {
     const int cells = E.cells;
-    const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.game_uid[g];
+    const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.hdr[g].game_uid;
     if (kind == 1) {
         auto pf = [&](int k, int cell) -> float {
             const c6_u4 w = c6_philox((uint32_t)(cell >> 2), (uint32_t)k, t, C6_TAG_EVAL_P, k0, k1);
@@ -355,13 +355,13 @@ __device__ __forceinline__ void eval_builtin_regs(const C6Dev &E, int g, int lan
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_recover_kernel(C6Dev E) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (g >= E.G || E.leaf_kind[g] != C6_LEAF_EVAL) return;
+    if (g >= E.G || E.hdr[g].leaf_kind != C6_LEAF_EVAL) return;
     const int cells = E.cells;
     const float *pol = E.img_pol + (size_t)g * 8 * cells;
     const float *val = E.img_val + (size_t)g * 8;
     auto pf = [&](int k, int cell) -> float { return pol[k * cells + cell]; };
     auto vf = [&](int k) -> float { return val[k]; };
-    recover_wave(cells, lane, E.rec_map, E.leaf_board + (size_t)g * E.cellsP, pf, vf, &E.eval_value[g],
+    recover_wave(cells, lane, E.rec_map, E.leaf_board + (size_t)g * E.cellsP, pf, vf, &E.hdr[g].eval_value,
                  E.eval_prior + (size_t)g * cells);
 }
 
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_recover_kernel(C6Dev 
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_augment_kernel(C6Dev E, float *img) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (g >= E.G || E.leaf_kind[g] != C6_LEAF_EVAL) return;
+    if (g >= E.G || E.hdr[g].leaf_kind != C6_LEAF_EVAL) return;
     const int cells = E.cells;
     const int8_t *board = E.leaf_board + (size_t)g * E.cellsP;
     for (int k = 0; k < 8; k++)
@@ -424,16 +424,16 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
     float value;
     // these leave together and come back behind the record scan: the rest of the game's words, and the backup's loads (lane i: the
     // path's i-th record)
-    const int hi0 = E.rec_hi[g];
-    const unsigned long long gsims = E.g_sims[g];
-    const uint32_t maxrec = E.g_maxrec[g];
+    const int hi0 = E.hdr[g].rec_hi;
+    const unsigned long long gsims = E.hdr[g].g_sims;
+    const uint32_t maxrec = E.hdr[g].g_maxrec;
     uint32_t bk_slot = 0;
     int bk_visit = 0;
     float bk_qsum = 0.f;
     if (lane < len) {
-        bk_slot = E.rec_slot[rbase + L.my_path];
-        bk_visit = E.rec_visit[rbase + L.my_path];
-        bk_qsum = E.rec_qsum[rbase + L.my_path];
+        bk_slot = E.rec_stat[rbase + L.my_path].slot;
+        bk_visit = E.rec_stat[rbase + L.my_path].visit;
+        bk_qsum = E.rec_stat[rbase + L.my_path].qsum;
     }
 
     if (kind == C6_LEAF_TERMINAL) {   // mod.rs:338-348: value by winner, no visit increment, no children
@@ -443,7 +443,7 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
     } else {
         // allocate the record of the newly expanded node (every lane reads the same stack slot)
         if (top <= 0) {      // pool exhausted; nothing of this search has been written: resumable after grow_pool
-            if (lane == 0) E.status[g] = C6_ST_OVERFLOW;
+            if (lane == 0) E.hdr[g].status = C6_ST_OVERFLOW;
             return false;
         }
         const int idx = R.free_idx;
@@ -474,20 +474,20 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
             if (first_batch) {      // behind the first batch's loads: the new record and its table entry
                 first_batch = false;
                 if (lane == 0) {
-                    E.free_top[g] = top - 1;
-                    if (hi != hi0) E.rec_hi[g] = hi;
+                    E.hdr[g].free_top = top - 1;
+                    if (hi != hi0) E.hdr[g].rec_hi = hi;
                     E.rec_key[rbase + idx] = key;
-                    E.rec_visit[rbase + idx] = 1;          // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
-                    E.rec_value[rbase + idx] = value;
-                    E.rec_qsum[rbase + idx] = 0.f;
-                    E.rec_q[rbase + idx] = 0.f;
+                    E.rec_stat[rbase + idx].visit = 1;          // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
+                    E.rec_stat[rbase + idx].value = value;
+                    E.rec_stat[rbase + idx].qsum = 0.f;
+                    E.rec_stat[rbase + idx].q = 0.f;
                     *reinterpret_cast<uint4 *>(E.rec_sig + (rbase + idx) * 4) = uint4{q0, q1, q2, q3};
                     const int slot = ht_insert(E.ht + (size_t)g * E.H, E.H, key, idx, 1, 0.f);
-                    if (slot < 0) E.status[g] = C6_ST_ERROR;
-                    else E.rec_slot[rbase + idx] = (uint32_t)slot;
-                    if (len == 0) E.root_rec[g] = idx;
+                    if (slot < 0) E.hdr[g].status = C6_ST_ERROR;
+                    else E.rec_stat[rbase + idx].slot = (uint32_t)slot;
+                    if (len == 0) E.hdr[g].root_rec = idx;
                     const uint32_t used = (uint32_t)(E.R - (top - 1));
-                    if (used > maxrec) E.g_maxrec[g] = used;
+                    if (used > maxrec) E.hdr[g].g_maxrec = used;
                 }
             }
 #pragma unroll
@@ -519,24 +519,24 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         const int i = base + lane;
         if (i < len) {
             const int r = base == 0 ? L.my_path : (int)E.path_rec[(size_t)g * E.maxd + i];
-            const uint32_t slot = base == 0 ? bk_slot : E.rec_slot[rbase + r];
-            const int v = (base == 0 ? bk_visit : E.rec_visit[rbase + r]) + 1;
-            float qs = base == 0 ? bk_qsum : E.rec_qsum[rbase + r];
+            const uint32_t slot = base == 0 ? bk_slot : E.rec_stat[rbase + r].slot;
+            const int v = (base == 0 ? bk_visit : E.rec_stat[rbase + r].visit) + 1;
+            float qs = base == 0 ? bk_qsum : E.rec_stat[rbase + r].qsum;
             if (i == len - 1) {      // the leaf's parent receives the value
                 qs = qs + value;
-                E.rec_qsum[rbase + r] = qs;
+                E.rec_stat[rbase + r].qsum = qs;
             }
             const float qv = qs / (float)v;   // recalc_q :77-79
-            E.rec_visit[rbase + r] = v;
-            E.rec_q[rbase + r] = qv;
+            E.rec_stat[rbase + r].visit = v;
+            E.rec_stat[rbase + r].q = qv;
             ht[slot].visit = sat16(v);
             ht[slot].q = qv;
         }
     }
     if (lane == 0) {
-        E.nsearch[g] = nsearch + 1;
-        E.sim_in_move[g] = sim_in_move + 1;
-        E.g_sims[g] = gsims + 1ull;
+        E.hdr[g].nsearch = nsearch + 1;
+        E.hdr[g].sim_in_move = sim_in_move + 1;
+        E.hdr[g].g_sims = gsims + 1ull;
     }
     return sim_in_move + 1 >= E.S;
 }
@@ -547,14 +547,14 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
 template <int J>
 __device__ __forceinline__ void move_select_wave(const C6Dev &E, int g, int lane) {
     const int cells = E.cells;
-    const int p = E.root_rec[g];
-    const int level = E.nstones[g];
+    const int p = E.hdr[g].root_rec;
+    const int level = E.hdr[g].nstones;
     const int turn = E.turn[g];
     int pos = -1;
     if (p >= 0 && level < cells) {
         const C6HtEntry *ht = E.ht + (size_t)g * E.H;
         const size_t rbase = (size_t)g * E.R;
-        const unsigned long long key = E.root_key[g];
+        const unsigned long long key = E.hdr[g].root_key;
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const int8_t *board = E.root_board + (size_t)g * E.cellsP;
         int cv[J];
@@ -568,7 +568,7 @@ __device__ __forceinline__ void move_select_wave(const C6Dev &E, int g, int lane
                 const uint32_t slot = ht_home(ck, E.H);
                 C6HtEntry e = ht_load(ht, slot);
                 cv[j] = 0;
-                if (ht_resolve(ht, E.H, ck, slot, e)) cv[j] = e.visit == 65535 ? E.rec_visit[rbase + (int)e.idx1 - 1] : (int)e.visit;
+                if (ht_resolve(ht, E.H, ck, slot, e)) cv[j] = e.visit == 65535 ? E.rec_stat[rbase + (int)e.idx1 - 1].visit : (int)e.visit;
                 vs += cv[j];
             }
         }
@@ -621,17 +621,17 @@ __device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane,
         E.remain[g] = 1;
         E.winner[g] = 0;
         E.err[g] = 0;
-        E.status[g] = C6_ST_PLAYING;
-        E.nstones[g] = 0;
-        E.game_uid[g] = uid;
-        E.nsearch[g] = 0;
-        E.sim_in_move[g] = presims;
-        E.root_key[g] = C6_EMPTY_BOARD_KEY;
-        E.root_sig[g * 4 + 0] = 0; E.root_sig[g * 4 + 1] = 0; E.root_sig[g * 4 + 2] = 0; E.root_sig[g * 4 + 3] = 0;
-        E.root_rec[g] = -1;
-        E.free_top[g] = E.R;
-        E.rec_hi[g] = 0;
-        E.leaf_kind[g] = C6_LEAF_NONE;
+        E.hdr[g].status = C6_ST_PLAYING;
+        E.hdr[g].nstones = 0;
+        E.hdr[g].game_uid = uid;
+        E.hdr[g].nsearch = 0;
+        E.hdr[g].sim_in_move = presims;
+        E.hdr[g].root_key = C6_EMPTY_BOARD_KEY;
+        E.hdr[g].root_sig[0] = 0; E.hdr[g].root_sig[1] = 0; E.hdr[g].root_sig[2] = 0; E.hdr[g].root_sig[3] = 0;
+        E.hdr[g].root_rec = -1;
+        E.hdr[g].free_top = E.R;
+        E.hdr[g].rec_hi = 0;
+        E.hdr[g].leaf_kind = C6_LEAF_NONE;
         E.move_pos[g] = -2;
     }
 }
@@ -655,8 +655,8 @@ __device__ __forceinline__ int rebuild_table_wave(const C6Dev &E, int g, int lan
     for (int r = lane; r < hi; r += 64)
         if (E.rec_level[rbase + r] >= 0) {
             const unsigned long long k = E.rec_key[rbase + r];
-            const int slot = ht_insert(ht, E.H, k, r, E.rec_visit[rbase + r], E.rec_q[rbase + r]);
-            if (slot >= 0) E.rec_slot[rbase + r] = (uint32_t)slot;
+            const int slot = ht_insert(ht, E.H, k, r, E.rec_stat[rbase + r].visit, E.rec_stat[rbase + r].q);
+            if (slot >= 0) E.rec_stat[rbase + r].slot = (uint32_t)slot;
             if (k == find) rr = r;
         }
     return c6_wave_max_i32(rr);
@@ -668,8 +668,8 @@ template <int J>
 __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, int pos) {
     const int cells = E.cells;
     const size_t rbase = (size_t)g * E.R;
-    const int old_level = E.nstones[g];
-    const unsigned long long old_key = E.root_key[g];
+    const int old_level = E.hdr[g].nstones;
+    const unsigned long long old_key = E.hdr[g].root_key;
     unsigned long long new_key = old_key;
     bool finished = false;
     int win = 0;
@@ -679,7 +679,7 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
     if (pos < 0) {
         finished = true;                       // policy returned None -> draw, agent_impl/mod.rs:135-137
     } else if (E.err[g] != 0) {
-        if (lane == 0) E.status[g] = C6_ST_ERROR;
+        if (lane == 0) E.hdr[g].status = C6_ST_ERROR;
         return;
     } else {
         const int mover = E.move_turn[g];
@@ -689,15 +689,15 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
         new_key = old_key ^ E.zob[(mover == C6_WHITE ? C6_MAXCELLS : 0) + pos];
         if (lane == 0) {
             E.root_board[(size_t)g * E.cellsP + pos] = (int8_t)mover;
-            E.root_key[g] = new_key;
+            E.hdr[g].root_key = new_key;
             const uint32_t c1 = (uint32_t)pos + 1u;
             const int o = mover == C6_BLACK ? 0 : 2;
-            E.root_sig[g * 4 + o] += c1;
-            E.root_sig[g * 4 + o + 1] += c1 * c1;
+            E.hdr[g].root_sig[o] += c1;
+            E.hdr[g].root_sig[o + 1] += c1 * c1;
             E.moves[(size_t)g * cells + old_level] = (uint16_t)pos;
-            E.nstones[g] = (int16_t)nst;
-            E.sim_in_move[g] = 0;
-            E.g_stones[g] += 1ull;
+            E.hdr[g].nstones = (int16_t)nst;
+            E.hdr[g].sim_in_move = 0;
+            E.hdr[g].g_stones += 1ull;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -705,8 +705,8 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
     if (!finished) {
         // prune: nodes of the old root's level are dropped (mod.rs:473-484).  The re-inserted old root
         // (:486) and older levels can never be reached again, so they are dropped too.
-        int top = E.free_top[g];
-        const int hi = E.rec_hi[g];
+        int top = E.hdr[g].free_top;
+        const int hi = E.hdr[g].rec_hi;
         for (int r0 = 0; r0 < hi; r0 += 64) {
             const int r = r0 + lane;
             bool kill = false;
@@ -725,14 +725,14 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
         __threadfence_block();
         const int rr = rebuild_table_wave(E, g, lane, hi, new_key);   // rr: record of the new root, if that child was expanded (tree reuse)
         if (lane == 0) {
-            E.free_top[g] = top;
-            E.root_rec[g] = rr;
+            E.hdr[g].free_top = top;
+            E.hdr[g].root_rec = rr;
         }
         return;
     }
 
     // game over: PlayResult (agent_impl/mod.rs:41-44) + training tuples (state, pi, turn, z)
-    const uint32_t uid = E.game_uid[g];
+    const uint32_t uid = E.hdr[g].game_uid;
     int slot = -1;
     unsigned long long tbase = 0;
     if (lane == 0) {
@@ -782,7 +782,7 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
     if (E.recycle) {
         reset_game_wave(E, g, lane, uid + E.uid_stride, 0);
     } else if (lane == 0) {
-        E.status[g] = C6_ST_FINISHED;
+        E.hdr[g].status = C6_ST_FINISHED;
         E.winner[g] = (int8_t)win;
     }
 }
@@ -798,9 +798,9 @@ __device__ __forceinline__ void round_head_wave(const C6Dev &E, int g, int lane)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return;
     }
-    const int stt = E.status[g];
+    const int stt = E.hdr[g].status;
     if (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW)) {
-        const uint32_t uid_ = E.game_uid[g];
+        const uint32_t uid_ = E.hdr[g].game_uid;
         if (lane == 0) atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull);
         reset_game_wave(E, g, lane, uid_ + E.uid_stride, 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -820,12 +820,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     if (g >= E.G) return;
     // one batch of loads: the two words that decide whether there is a move to finish first, and the game's registers
     const int pos = E.move_pos[g];
-    int stt = E.status[g];
+    int stt = E.hdr[g].status;
     C6GameRegs<J> R;
     load_game_regs<J>(E, g, lane, R);
     if (pos != -2 || (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW))) {      // ~1 game in S per round: the slow path reloads
         round_head_wave<J>(E, g, lane);
-        stt = E.status[g];
+        stt = E.hdr[g].status;
         load_game_regs<J>(E, g, lane, R);
     }
     if (stt != C6_ST_PLAYING) return;
@@ -833,8 +833,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     select_wave<J>(E, g, lane, gscratch[wv], R, L);
     if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
     if (lane == 0) {
-        E.g_select[g] += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
-        if ((uint32_t)L.len > E.g_maxdepth[g]) E.g_maxdepth[g] = (uint32_t)L.len;
+        E.hdr[g].g_select += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
+        if ((uint32_t)L.len > E.hdr[g].g_maxdepth) E.hdr[g].g_maxdepth = (uint32_t)L.len;
     }
     float pr[J], value = 0.f;
     float *probs = reinterpret_cast<float *>(gscratch[wv]);
@@ -864,8 +864,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     const int g = blockIdx.x * WAVES_PER_BLOCK + wv;
     if (g >= E.G) return;
     round_head_wave<J>(E, g, lane);
-    if (E.status[g] != C6_ST_PLAYING) {
-        if (lane == 0) E.leaf_kind[g] = C6_LEAF_NONE;
+    if (E.hdr[g].status != C6_ST_PLAYING) {
+        if (lane == 0) E.hdr[g].leaf_kind = C6_LEAF_NONE;
         return;
     }
     C6GameRegs<J> R;
@@ -880,14 +880,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     }
     if (lane < 64 && lane < L.len) E.path_rec[(size_t)g * E.maxd + lane] = (uint16_t)L.my_path;
     if (lane == 0) {
-        E.leaf_kind[g] = (int8_t)L.kind;
-        E.leaf_turn[g] = (int8_t)L.turn;
-        E.leaf_key[g] = L.key;
-        E.leaf_sig[g * 4 + 0] = L.sg0; E.leaf_sig[g * 4 + 1] = L.sg1; E.leaf_sig[g * 4 + 2] = L.sg2; E.leaf_sig[g * 4 + 3] = L.sg3;
-        E.leaf_level[g] = (int16_t)L.level;
-        E.path_len[g] = L.len;
-        E.g_select[g] += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
-        if ((uint32_t)L.len > E.g_maxdepth[g]) E.g_maxdepth[g] = (uint32_t)L.len;
+        E.hdr[g].leaf_kind = (int8_t)L.kind;
+        E.hdr[g].leaf_turn = (int8_t)L.turn;
+        E.hdr[g].leaf_key = L.key;
+        E.hdr[g].leaf_sig[0] = L.sg0; E.hdr[g].leaf_sig[1] = L.sg1; E.hdr[g].leaf_sig[2] = L.sg2; E.hdr[g].leaf_sig[3] = L.sg3;
+        E.hdr[g].leaf_level = (int16_t)L.level;
+        E.hdr[g].path_len = L.len;
+        E.hdr[g].g_select += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
+        if ((uint32_t)L.len > E.hdr[g].g_maxdepth) E.hdr[g].g_maxdepth = (uint32_t)L.len;
     }
 }
 
@@ -897,15 +897,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= E.G) return;
     C6Leaf<J> L;
-    L.kind = E.leaf_kind[g];
-    L.len = E.path_len[g];
-    L.level = E.leaf_level[g];
-    L.turn = E.leaf_turn[g];
-    L.key = E.leaf_key[g];
-    const uint4 qv = *reinterpret_cast<const uint4 *>(E.leaf_sig + (size_t)g * 4);
+    L.kind = E.hdr[g].leaf_kind;
+    L.len = E.hdr[g].path_len;
+    L.level = E.hdr[g].leaf_level;
+    L.turn = E.hdr[g].leaf_turn;
+    L.key = E.hdr[g].leaf_key;
+    const uint4 qv = *reinterpret_cast<const uint4 *>(E.hdr[g].leaf_sig);
     L.sg0 = qv.x; L.sg1 = qv.y; L.sg2 = qv.z; L.sg3 = qv.w;
     L.my_path = E.path_rec[(size_t)g * E.maxd + (lane < E.maxd ? lane : 0)];
-    const float evalue = E.eval_value[g];
+    const float evalue = E.hdr[g].eval_value;
     C6GameRegs<J> R;
     load_game_regs<J>(E, g, lane, R);      // (the root fields go unused here; one loader keeps both paths on the same code)
     if (L.kind == C6_LEAF_NONE) return;
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_post_move_kernel(C6De
 // stagger: pretend game g already spent (g mod S) simulations of its first move
 __global__ void c6_stagger_kernel(C6Dev E) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < E.G) E.sim_in_move[g] = g % E.S;
+    if (g < E.G) E.hdr[g].sim_in_move = g % E.S;
 }
 
 // ---- record-pool growth ---------------------------------------------------------------------
@@ -942,15 +942,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_grow_fix_kernel(C6Dev
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= Nw.G) return;
     const size_t ob = (size_t)g * O.R, nb = (size_t)g * Nw.R;
-    const int add = Nw.R - O.R, top = O.free_top[g];
+    const int add = Nw.R - O.R, top = O.hdr[g].free_top;
     for (int r = O.R + lane; r < Nw.R; r += 64) Nw.rec_level[nb + r] = -1;
     for (int i = lane; i < add; i += 64) Nw.free_stack[nb + i] = (uint16_t)(Nw.R - 1 - i);       // bottom of the stack: pops O.R, O.R+1, ... last
     for (int i = lane; i < top; i += 64) Nw.free_stack[nb + add + i] = O.free_stack[ob + i];
     __threadfence_block();
-    rebuild_table_wave(Nw, g, lane, O.rec_hi[g], 0ull);      // the table at its new size, entries with the records' current statistics
+    rebuild_table_wave(Nw, g, lane, O.hdr[g].rec_hi, 0ull);      // the table at its new size, entries with the records' current statistics
     if (lane == 0) {
-        Nw.free_top[g] = top + add;
-        if (Nw.status[g] == C6_ST_OVERFLOW) Nw.status[g] = C6_ST_PLAYING;
+        Nw.hdr[g].free_top = top + add;
+        if (Nw.hdr[g].status == C6_ST_OVERFLOW) Nw.hdr[g].status = C6_ST_PLAYING;
     }
 }
 void c6_launch_grow_fix(const C6Dev &old, const C6Dev &nw, hipStream_t s) {
@@ -963,9 +963,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_flush_errors_kernel(C
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= E.G) return;
-    const int stt = E.status[g];
+    const int stt = E.hdr[g].status;
     if (stt != C6_ST_ERROR && stt != C6_ST_OVERFLOW) return;
-    const int nst = E.nstones[g];
+    const int nst = E.hdr[g].nstones;
     int slot = -1;
     if (lane == 0) {
         slot = (int)atomicAdd(&E.counters[C6_CNT_FETCHQ], 1ull);
@@ -973,10 +973,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_flush_errors_kernel(C
     }
     slot = __shfl(slot, 0, 64);
     if (slot < E.finq_cap) {
-        if (lane == 0) { E.fin_winner[slot] = 0; E.fin_len[slot] = nst; E.fin_uid[slot] = E.game_uid[g]; }
+        if (lane == 0) { E.fin_winner[slot] = 0; E.fin_len[slot] = nst; E.fin_uid[slot] = E.hdr[g].game_uid; }
         for (int k = lane; k < nst; k += 64) E.fin_moves[(size_t)slot * E.cells + k] = (int16_t)E.moves[(size_t)g * E.cells + k];
     }
-    if (lane == 0) { E.status[g] = C6_ST_FINISHED; E.winner[g] = 0; }
+    if (lane == 0) { E.hdr[g].status = C6_ST_FINISHED; E.winner[g] = 0; }
 }
 void c6_launch_flush_errors(const C6Dev &d, hipStream_t s) {
     hipLaunchKernelGGL(c6_flush_errors_kernel, dim3((d.G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(64 * WAVES_PER_BLOCK), 0, s, d);

@@ -223,6 +223,8 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="skip the live stones-per-game probe and the steady-state tree measurement")
     ap.add_argument("--probe-games", type=int, default=256)
     ap.add_argument("--gather-every", type=int, default=0, help="rounds between tuple exchanges at N > 1 (0: 1 for net workloads, 64 otherwise)")
+    ap.add_argument("--exchange-always", action="store_true", help="run the tuple exchange every --gather-every rounds at N = 1 too (its cost on one GPU: "
+                    "compare ms_per_step with and without)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to "
                     "exercise the N > 1 path on a 1-GPU box together with C6_BENCH_SHARE_GPU=1)")
     args = ap.parse_args()
@@ -289,7 +291,7 @@ def main():
                 eng.step(c)
                 tb = time.perf_counter()
                 done += c
-                if world > 1 or done == k:
+                if world > 1 or args.exchange_always or done == k:
                     pool.exchange()
                 if trace:
                     print(f"[trace] rounds {done - c}..{done}: step {1000 * (tb - ta):.1f} ms, exchange {1000 * (time.perf_counter() - tb):.1f} ms", file=sys.stderr, flush=True)

@@ -6,11 +6,11 @@
 #   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES ...  -> matrix-core busy cycles, effective clock, LDS conflicts
 # Counter passes carry no trace options (gpurun refuses the combination).  Afterwards, in the build container:
 #   python profiles/summarize.py gpurun_out/prof_<TAG> <TAG>
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="python3 bench.py --no-cpu-baseline"
+B="python3 bench.py --no-cpu-baseline --no-probe"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- $B --steps 2 --warmup 1 > $out/bench_kt.json 2> $out/kt.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B --steps 1 --warmup 1 > $out/bench_pmc1.json 2> $out/pmc1.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B --steps 1 --warmup 1 > $out/bench_pmc2.json 2> $out/pmc2.err
