@@ -16,10 +16,12 @@ A "step" is one simulation ROUND: every live game performs one search() (select 
 backup); game phases are staggered, so each round G/400 games also make their move (policy -> board kernel -> prune / recycle), i.e.
 every step carries the steady-state share of all the work.
     games/sec = simulations/sec / (400 * stones_per_game)
-stones_per_game is MEASURED: complete self-play games of the same net and noise at a short simulation budget (tools/stones_probe.py,
-committed under profiles/, and a smaller live probe in this run) -- a 19x19 game at 400 simulations is ~83 000 rounds, far beyond a
-benchmark of minutes, and its length does not depend on the budget for a random-init net (the probe shows that).  For the tree-only
-workload (config5) games complete inside the timed window and games/sec is counted directly.
+stones_per_game is MEASURED on complete self-play games of the same net and noise (tools/stones_probe.py, results committed under
+profiles/): at the benchmark's own budget of 400 simulations on a small batch, and at 8 simulations on 4096 games; a smaller live probe
+runs here too.  (A 19x19 game at 400 simulations is tens of thousands of rounds: the full-size run cannot finish a game inside a benchmark
+of minutes.  The length DOES depend on the budget, and not monotonically -- 170 stones at 2 simulations, 106 at 8, 92 at 32, 139 at 400 --
+which is why the value measured at 400 is the one used.)  For the tree-only workload (config5) games complete inside the timed window
+and games/sec is counted directly.
 Inputs (game state, trees, weights) are resident in HBM before the timed region.
 """
 import argparse
@@ -92,17 +94,22 @@ def pmc_record(kernel_substr):
     return {}
 
 
-def committed_stones_probe(workload):
-    """profiles/r*_stones_probe.json: complete games of the benchmark's net at a short simulation budget (tools/stones_probe.py)"""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stones_probe.json")))
-    for f in reversed(files):
+def committed_stones_probe(workload, sims=None):
+    """profiles/r*_stones_probe*.json (tools/stones_probe.py): complete games of the benchmark's net.  The probe taken at the workload's
+    own simulation budget wins; otherwise the one with the most games."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stones_probe*.json"))):
         try:
             d = json.load(open(f))
-            if d.get("workload") == workload:
-                return dict(d, file=os.path.basename(f))
         except Exception:
-            pass
-    return None
+            continue
+        if d.get("workload") != workload:
+            continue
+        d = dict(d, file=os.path.basename(f))
+        key = (d.get("num_simulation") == sims, d.get("games", 0))
+        if best is None or key > best[0]:
+            best = (key, d)
+    return best[1] if best else None
 
 
 def usable_cores():
@@ -356,7 +363,7 @@ def main():
         relaxed = measure(pkg.PREC_BF16, args.steps, args.warmup)      # side report only, never `value`
 
     # ---- stones per game: measured --------------------------------------------------------------------------------------
-    probe_file = committed_stones_probe(args.workload if args.workload != "config4" else "config2")
+    probe_file = committed_stones_probe(args.workload if args.workload != "config4" else "config2", S)
     live = None
     if world == 1 and is_net and not args.no_probe:
         live = stones_probe(pkg, wl, args.probe_games, 8, pkg.PREC_BF16X3, device=local_rank)
