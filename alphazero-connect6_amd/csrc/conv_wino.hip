@@ -35,8 +35,15 @@ struct WinoGeom {
     static constexpr int TW = (N + 1) / 2;          // tiles per board side
     static constexpr int T = TW * TW;               // tiles per board (100 / 64 / 25)
     static constexpr int CP = C + 4;                // padded row: conflict-free ds_read_b128 with one tile per lane
-    static constexpr int SLAB = WINO_BT * CP;       // floats of one (block, position) slab
-    static constexpr int NCH = SLAB / 256;          // 1-KiB chunks of a slab (64 (C + 4) 4 B = 256 C + 1024 B: always whole)
+    static constexpr int SLAB = WINO_BT * CP;       // floats of one (block, position) slab IN LDS
+    // V in memory.  C = 256 ("tile-major"): [block][tile 64][position 16][C] -- a tile's 16 positions are one 16-KiB run for the
+    // transform kernel's stores, and a (tile, position) row is exactly one 1-KiB LDS-DMA (64 per position).  Smaller C (a row is less
+    // than a DMA): [block][position 16][tile 64][C + 4], the LDS image itself, copied linearly (SLAB / 256 chunks per position).
+    static constexpr bool TM = C == 256;
+    static constexpr int NCH = TM ? WINO_BT : SLAB / 256;      // DMAs per position
+    static constexpr int POS_STRIDE = TM ? C : SLAB;           // floats between consecutive positions of one tile
+    static constexpr int TILE_STRIDE = TM ? 16 * C : CP;       // floats between consecutive tiles of one position
+    static constexpr size_t BLOCK_FLOATS = TM ? (size_t)WINO_BT * 16 * C : (size_t)16 * SLAB;
     static constexpr int WAVES = C / 32;
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int NG = C / 8;                // 8-channel groups per position
@@ -53,8 +60,8 @@ struct WinoGeom {
 #define WINO_IN_THREADS 320
 template <int C>
 struct WinoInGeom {
-    static constexpr int CS = C < 128 ? C : 128;      // channels per workgroup: a 256-channel board is two work items (45 KB of LDS
-    static constexpr int NS = C / CS;                 // each: three workgroups per CU keep enough loads and stores in flight)
+    static constexpr int CS = C;                      // channels per workgroup (halving it to 128 -- three workgroups per CU -- was slower:
+    static constexpr int NS = C / CS;                 // 19.3 vs 16.8 ms, the 512-byte runs cost more than the extra waves bring)
 };
 template <int C, int N>
 __global__ __launch_bounds__(WINO_IN_THREADS) void c6_wino_in_kernel(const float *__restrict__ in, float *__restrict__ V, int nboards) {
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(WINO_IN_THREADS) void c6_wino_in_kernel(const float
 #pragma unroll 1
             for (int tx = tsub; tx < TW; tx += TPI) {
                 const long t = (long)bd * T + ty * TW + tx;
-                float *vb = V + (size_t)(t / WINO_BT) * 16 * G::SLAB + (size_t)(t % WINO_BT) * CP + c0 + cq * 4;
+                float *vb = V + (size_t)(t / WINO_BT) * G::BLOCK_FLOATS + (size_t)(t % WINO_BT) * G::TILE_STRIDE + c0 + cq * 4;
                 f32x4 d[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; r++)
@@ -126,11 +133,11 @@ __global__ __launch_bounds__(WINO_IN_THREADS) void c6_wino_in_kernel(const float
 #pragma unroll
                 for (int i = 0; i < 4; i++) {                       // (B^T d) B: columns
                     const f32x4 v0 = w[i][0] - w[i][2], v1 = w[i][1] + w[i][2], v2 = w[i][2] - w[i][1], v3 = w[i][1] - w[i][3];
-                    float *o = vb + (size_t)(i * 4) * G::SLAB;
+                    float *o = vb + (size_t)(i * 4) * G::POS_STRIDE;
                     *reinterpret_cast<f32x4 *>(o) = v0;
-                    *reinterpret_cast<f32x4 *>(o + G::SLAB) = v1;
-                    *reinterpret_cast<f32x4 *>(o + 2 * G::SLAB) = v2;
-                    *reinterpret_cast<f32x4 *>(o + 3 * G::SLAB) = v3;
+                    *reinterpret_cast<f32x4 *>(o + G::POS_STRIDE) = v1;
+                    *reinterpret_cast<f32x4 *>(o + 2 * G::POS_STRIDE) = v2;
+                    *reinterpret_cast<f32x4 *>(o + 3 * G::POS_STRIDE) = v3;
                 }
             }
             if (more) {
@@ -147,12 +154,17 @@ __global__ __launch_bounds__(WINO_IN_THREADS) void c6_wino_in_kernel(const float
 
 // the tail of the last block (tiles beyond the batch) is never written by the kernel above: zero it once per launch so that the GEMM
 // multiplies zeros, not stale bits (their products only reach accumulators that are never stored, but NaNs would still be ugly)
-__global__ void c6_wino_tail_kernel(float *__restrict__ V, long total_tiles, int slab, int cp) {
+template <int C, int N>
+__global__ void c6_wino_tail_kernel(float *__restrict__ V, long total_tiles) {
+    using G = WinoGeom<C, N>;
     const long nblocks = (total_tiles + WINO_BT - 1) / WINO_BT;
     const int first = (int)(total_tiles - (nblocks - 1) * WINO_BT);      // valid tiles of the last block
-    const int n = (WINO_BT - first) * cp;
-    float *base = V + (size_t)(nblocks - 1) * 16 * slab + (size_t)first * cp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 16 * n; i += gridDim.x * blockDim.x) base[(size_t)(i / n) * slab + i % n] = 0.f;
+    float *blk = V + (size_t)(nblocks - 1) * G::BLOCK_FLOATS;
+    const int row = G::TM ? C : G::CP, n = (WINO_BT - first) * 16 * row;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = first + i / (16 * row), r = i % (16 * row), p = r / row, c = r % row;
+        blk[(size_t)t * G::TILE_STRIDE + (size_t)p * G::POS_STRIDE + c] = 0.f;
+    }
 }
 
 // ---- GEMM + output transform ---------------------------------------------------------------------------------------
@@ -195,8 +207,8 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
     auto dma_chunk = [&](const float *src, int buf, int c0) {
         int c = c0 * WAVES + wave;
         c = c < NCH ? c : NCH - 1;
-        const float *gp = src + (size_t)c * 256;
-        const int lds_off = (buf * SLAB + c * 256) * 4;
+        const float *gp = src + (size_t)c * (G::TM ? G::TILE_STRIDE : 256);         // tile-major: row of tile c; else the c-th KiB of the slab
+        const int lds_off = (buf * SLAB + c * (G::TM ? CP : 256)) * 4;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lds_off) : "memory");
     };
     auto dma_slab = [&](const float *src, int buf) {
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
         for (int c0 = 0; c0 < ND; c0++) dma_chunk(src, buf, c0);
     };
 
-    dma_slab(V + (size_t)b * 16 * SLAB, 0);
+    dma_slab(V + (size_t)b * G::BLOCK_FLOATS, 0);
     f32x4 ring[8];
 #pragma unroll
     for (int q = 0; q < PF; q++) WINO_ULOAD(ring[q], lane16 + (unsigned)q * 1024u, ubase);
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
             {
                 int nb = p < 15 ? b : b + (int)gridDim.x;
                 nb = nb < nblocks ? nb : b;          // no next block: copy this block's slab 0 again (never read)
-                nsrc = V + ((size_t)nb * 16 + (p < 15 ? p + 1 : 0)) * SLAB;
+                nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)(p < 15 ? p + 1 : 0) * G::POS_STRIDE;
             }
             if (!SPREAD) dma_slab(nsrc, (p + 1) & 1);
             const float *vb = wsm + (p & 1) * SLAB + j * CP + 4 * h;
@@ -391,7 +403,7 @@ void c6_pack_conv_weights_wino(int C, const float *w, float *packed) {
 // floats of the transformed-input scratch for `nboards` boards
 size_t c6_conv_wino_vbuf_floats(int C, int N, int nboards) {
     const long TW = (N + 1) / 2, T = TW * TW, tiles = (long)nboards * T, nblocks = (tiles + WINO_BT - 1) / WINO_BT;
-    return (size_t)nblocks * 16 * WINO_BT * (C + 4);
+    return (size_t)nblocks * (C == 256 ? (size_t)WINO_BT * 16 * C : (size_t)16 * WINO_BT * (C + 4));
 }
 
 template <int C, int N>
@@ -405,7 +417,7 @@ static void launch_wino_in(int nboards, const float *in, float *vbuf, int num_cu
     const int grid_in = items < num_cus * per_cu_in ? items : num_cus * per_cu_in;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino_in_kernel<C, N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)in_smem);
     hipLaunchKernelGGL((c6_wino_in_kernel<C, N>), dim3(grid_in), dim3(WINO_IN_THREADS), in_smem, s, in, vbuf, nboards);
-    if (tiles % WINO_BT) hipLaunchKernelGGL(c6_wino_tail_kernel, dim3(16), dim3(256), 0, s, vbuf, tiles, G::SLAB, G::CP);
+    if (tiles % WINO_BT) hipLaunchKernelGGL((c6_wino_tail_kernel<C, N>), dim3(64), dim3(256), 0, s, vbuf, tiles);
 }
 
 template <int C, int N>

@@ -39,5 +39,5 @@ for sub, name, mul in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0
     for k, c in agg.items():
         if k in res["kernels"] and name in c:
             res["kernels"][k]["hbm_%s_gb" % sub] = mul * sum(c[name]) / len(c[name]) * 1024 / 1e9
-print(json.dumps(res, indent=1))
+s = json.dumps(res, indent=1); open("$out/summary.json", "w").write(s + "\n"); print(s)
 PY
