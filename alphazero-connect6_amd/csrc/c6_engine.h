@@ -8,7 +8,9 @@
 //   * a pool of R "expanded node" records (edge-major: prior[N*N] per record) and an
 //     open-addressed table  board key -> record  (64-bit Zobrist), which together
 //     reproduce the reference's HashMap<u64, Node> (alphazero_policy/mod.rs:186-190)
-//     without materialising the N*N children of every expansion.
+//     without materialising the N*N children of every expansion,
+//   * one tag byte per table slot (the wave holds the whole row in LDS: an absent child costs no memory access) and the
+//     root's children as one contiguous row (rootc).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,6 +20,18 @@ struct C6HtEntry {       // 16 bytes: one load brings everything select needs to
     uint16_t idx1;            // record index + 1
     uint16_t visit;           // the record's visit count, saturating at 65535 (then rec_visit is read)
     float q;                  // the record's q_value
+};
+
+// tag of a key in ht_tag (0 = empty slot): the key's top byte -- independent of the home slot, which uses the low bits
+#define C6_TAG_LDS_MAX 8192      // tables up to this many slots have their tag row in LDS; larger ones are read in memory
+static __host__ __device__ inline uint8_t c6_ht_tag_of(unsigned long long key) { const uint8_t t = (uint8_t)(key >> 56); return t ? t : (uint8_t)1; }
+
+// a child of the root as select reads it: the root is the one node whose children have no other parent on their level (a node's level
+// is its stone count), so this copy can be kept exact -- written when the child is expanded and at every backup through it
+struct C6RootChild {
+    uint16_t idx1;            // record index + 1, 0 = not expanded
+    uint16_t visit;           // saturating at 65535
+    float q;
 };
 
 #define C6_MAXD0 64       // initial capacity of the select path kept per search (C6Dev::maxd; grown with the record pool)
@@ -38,7 +52,8 @@ struct C6GameHdr {
     unsigned long long root_key;      //   0  Zobrist key of the root position
     int32_t root_rec;                 //   8  record of the root, -1 = not expanded
     uint32_t game_uid;                //  12  C6RNG key of the game
-    uint32_t root_sig[4];             //  16  sum / sumsq of (cell + 1) for black, white
+    uint32_t rootc_ok;                //  16  the rootc row holds the current root's children
+    uint32_t pad2[3];
     uint32_t nsearch;                 //  32  searches since the game's start
     int32_t sim_in_move;              //  36
     int32_t free_top;                 //  40  free records left
@@ -51,20 +66,23 @@ struct C6GameHdr {
     int8_t leaf_turn, pad0;           //  62
     unsigned long long g_sims, g_select, g_stones;      //  64
     unsigned long long leaf_key;      //  88  leaf exchange (select -> evaluator -> expand)
-    uint32_t leaf_sig[4];             //  96
+    uint32_t pad3[4];                 //  96
     int32_t path_len;                 // 112
     float eval_value;                 // 116
     uint32_t pad1[2];                 // 120
 };
 static_assert(sizeof(C6GameHdr) == 128, "one line per game");
 
-// the mutable statistics of an expanded node, one 32-byte piece per record (backup touches one sector, not four)
+// an expanded node, one 32-byte piece per record (creation and backup touch one sector); its priors are in rec_prior
 struct C6RecStat {
     int32_t visit;
     float value, qsum, q;
     uint32_t slot;          // table slot of the record
-    uint32_t pad[3];
+    int16_t level;          // stones on the board of the node, -1 = free record
+    uint16_t pad;
+    unsigned long long key; // Zobrist key of the position
 };
+static_assert(sizeof(C6RecStat) == 32, "one sector per record");
 
 struct C6Dev {
     // geometry / hyper-parameters (policy/alphazero_policy/mod.rs:91-96)
@@ -83,16 +101,15 @@ struct C6Dev {
     uint16_t *moves;       // [G][cells] cell of stone k
     uint16_t *hist_pi;     // [G][cells][cells] root child visits at move k
     // expanded-node records
-    unsigned long long *rec_key; // [G][R]
     C6RecStat *rec_stat;   // [G][R]
-    int16_t *rec_level;    // -1 = free
-    uint32_t *rec_sig;     // [G][R][4]
     float *rec_prior;      // [G][R][cells]  n_prob of the child at each empty cell
     C6HtEntry *ht;         // [G][H]
+    uint8_t *ht_tag;       // [G][H] c6_ht_tag_of(key) of the slot's entry, 0 = empty
+    C6RootChild *rootc;    // [G][cellsP] the root's children (valid while hdr.rootc_ok)
     uint16_t *free_stack;  // [G][R]
     // per-round leaf exchange
     int8_t *leaf_board;    // [G][cellsP]
-    uint16_t *path_rec;    // [G][maxd]
+    uint32_t *path_rec;    // [G][maxd] step i of the select path: record | chosen cell << 16
     float *eval_prior;     // [G][cells]
     float *img_val;        // [G][8]
     float *img_pol;        // [G][8][cells]
@@ -118,7 +135,7 @@ struct C6Dev {
 };
 
 // tree_kernels.hip
-void c6_launch_search(const C6Dev &d, int kind, hipStream_t s);      // built-in evaluators: a whole search() per launch
+void c6_launch_search(const C6Dev &d, int kind, int nsims, hipStream_t s);      // built-in evaluators: nsims whole rounds (search + move) of every game per launch
 void c6_launch_select(const C6Dev &d, hipStream_t s);
 void c6_launch_expand(const C6Dev &d, hipStream_t s);
 void c6_launch_recover(const C6Dev &d, hipStream_t s);

@@ -485,9 +485,8 @@ static int engine_alloc(c6_engine *e) {
     ALLOC(d.root_board, (size_t)G * d.cellsP);
     ALLOC(d.moves, (size_t)G * cells); ALLOC(d.hist_pi, (size_t)G * cells * cells);
     const size_t GR = (size_t)G * d.R;
-    ALLOC(d.rec_key, GR); ALLOC(d.rec_stat, GR);
-    ALLOC(d.rec_level, GR); ALLOC(d.rec_sig, GR * 4); ALLOC(d.rec_prior, GR * cells);
-    ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.free_stack, GR);
+    ALLOC(d.rec_stat, GR); ALLOC(d.rec_prior, GR * cells);
+    ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.ht_tag, (size_t)G * d.H); ALLOC(d.rootc, (size_t)G * d.cellsP); ALLOC(d.free_stack, GR);
     ALLOC(d.leaf_board, (size_t)G * d.cellsP); ALLOC(d.path_rec, (size_t)G * d.maxd);
     ALLOC(d.eval_prior, (size_t)G * cells);
     ALLOC(d.move_pos, d.Gpad); ALLOC(d.last_move, d.Gpad); ALLOC(d.move_turn, G);
@@ -667,6 +666,7 @@ static int evaluate(c6_engine *e) {
     }
 }
 
+#define C6_SEARCH_ROUNDS_PER_LAUNCH 16
 extern "C" int c6_engine_step(c6_engine *e, int rounds) {
     if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
     HIPCHK(hipSetDevice(e->cfg.device));
@@ -675,20 +675,27 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
     if (ev == C6_EVAL_NET && !e->net.loaded) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_NET but no weights are loaded");
     bool moved = false;
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d.last_move, (int)0xFFFFFFFE, (size_t)d.Gpad, e->stream));      // -2: "did not move in this call"
-    for (int r = 0; r < rounds; r++) {
-        if (ev == C6_EVAL_RANDOM || ev == C6_EVAL_UNIFORM) {
-            // one launch per search(): head (last round's move) + select + evaluate + expand / backup + policy()
+    if (ev == C6_EVAL_RANDOM || ev == C6_EVAL_UNIFORM) {
+        // built-in evaluators: whole rounds -- search() and, when its budget is spent, the move itself -- inside one kernel, several
+        // rounds of every game per launch (tree_kernels.hip: c6_search_kernel)
+        for (int r = 0; r < rounds;) {
+            const int k = std::min(rounds - r, C6_SEARCH_ROUNDS_PER_LAUNCH);
             Scoped t(&e->t_select, e->stream, e->profiling);
-            c6_launch_search(d, ev == C6_EVAL_RANDOM ? 1 : 2, e->stream);
-        } else {
-            { Scoped t(&e->t_select, e->stream, e->profiling); c6_launch_select(d, e->stream); }
-            {
-                Scoped t(&e->t_eval, e->stream, e->profiling);
-                int rc = evaluate(e);
-                if (rc != C6_OK) return rc;
-            }
-            { Scoped t(&e->t_expand, e->stream, e->profiling); c6_launch_expand(d, e->stream); }
+            c6_launch_search(d, ev == C6_EVAL_RANDOM ? 1 : 2, k, e->stream);
+            r += k;
+            e->rounds += k;
         }
+        HIPCHK(hipGetLastError());
+        return C6_OK;
+    }
+    for (int r = 0; r < rounds; r++) {
+        { Scoped t(&e->t_select, e->stream, e->profiling); c6_launch_select(d, e->stream); }
+        {
+            Scoped t(&e->t_eval, e->stream, e->profiling);
+            int rc = evaluate(e);
+            if (rc != C6_OK) return rc;
+        }
+        { Scoped t(&e->t_expand, e->stream, e->profiling); c6_launch_expand(d, e->stream); }
         e->rounds++;
         e->round_in_move++;
         // K1 places the stones of the games whose policy() just ran: aligned games all move on the same round; staggered games
@@ -811,27 +818,29 @@ static int grow_pool(c6_engine *e) {
     std::vector<void *> fresh, stale;
     uint16_t *nfs = nullptr;
     C6HtEntry *nht = nullptr;
+    uint8_t *ntag = nullptr;
     int rc;
     if ((rc = grow_array(pool, &nw.rec_prior, G, (size_t)old.R * cells, (size_t)nw.R * cells, fresh, stale)) ||
-        (rc = grow_array(pool, &nw.rec_key, G, old.R, nw.R, fresh, stale)) || (rc = grow_array(pool, &nw.rec_stat, G, old.R, nw.R, fresh, stale)) ||
-        (rc = grow_array(pool, &nw.rec_level, G, old.R, nw.R, fresh, stale)) ||
-        (rc = grow_array(pool, &nw.rec_sig, G, (size_t)old.R * 4, (size_t)nw.R * 4, fresh, stale)) ||
+        (rc = grow_array(pool, &nw.rec_stat, G, old.R, nw.R, fresh, stale)) ||
         (rc = grow_array(pool, &nw.path_rec, G, old.maxd, nw.maxd, fresh, stale)) ||
-        (rc = pool.alloc(&nfs, (size_t)G * nw.R)) || (rc = pool.alloc(&nht, (size_t)G * nw.H))) {
+        (rc = pool.alloc(&nfs, (size_t)G * nw.R)) || (rc = pool.alloc(&nht, (size_t)G * nw.H)) || (rc = pool.alloc(&ntag, (size_t)G * nw.H))) {
         for (void *p : fresh) pool.free_one(p);      // the engine keeps running on the old, untouched pool
         if (nfs) pool.free_one(nfs);
         if (nht) pool.free_one(nht);
+        if (ntag) pool.free_one(ntag);
         e->grow_failed = true;
         return rc;
     }
     // free stack and table are rebuilt from the old ones by the device (c6_grow_fix_kernel)
     nw.free_stack = nfs;
     nw.ht = nht;
+    nw.ht_tag = ntag;
     c6_launch_grow_fix(old, nw, e->stream);
     HIPCHK(hipStreamSynchronize(e->stream));
     for (void *p : stale) pool.free_one(p);
     pool.free_one(old.free_stack);
     pool.free_one(old.ht);
+    pool.free_one(old.ht_tag);
     d = nw;
     e->pool_grows++;
     if (!e->cfg.stagger) e->desync = true;

@@ -13,8 +13,18 @@
 // child at that cell, plus a table  Zobrist key -> record  through which a child's shared
 // visit / q_value are found (children reached by different move orders are one node, as in the
 // reference).  The last-writer rule is kept exact: when a node Q is expanded, every expanded node
-// P on the same level with P + i == Q + s (one stone swapped) gets prior_P[i] = prob_Q[s].  Such P
-// are found from per-record (sum, sum of squares) of stone cells per colour, verified by key.
+// P with P + i == Q + s (one stone swapped) gets prior_P[i] = prob_Q[s].  P = Q - i + s holds every
+// stone of the root only if i is one of the stones the select path added to the root -- a P without
+// a root stone can never be reached again, its priors are never read -- so the candidates are
+// (path stones of the mover's colour) x (empty cells of Q), each looked up by key.  Round 1 scanned
+// all records of the game for every expansion (26 bytes per record and two 64-bit divisions).
+//
+// Memory accesses are what a search costs (profiles/r02_tree_traffic.txt), so:
+//  * every table slot has a TAG byte (c6_ht_tag_of); the wave loads the game's whole tag row into LDS
+//    once per search (H bytes, contiguous): looking up an absent child -- most children of most
+//    nodes -- touches no memory, a present one costs its one 16-byte entry, an insert finds its
+//    slot without a probe;
+//  * the root's children, scanned by every search, are kept as one contiguous row (C6RootChild).
 //
 // A lane owns cells lane, lane+64, ... (row-major order == child order of the reference, which
 // lists children in `possible` order, simulate/mod.rs:58-69).
@@ -27,11 +37,17 @@
 #include "c6_engine.h"
 
 #define WAVES_PER_BLOCK 4
+#ifndef C6_OCC2
+#define C6_OCC2 3      // c6_search_kernel<2, .>: at 4 blocks per SIMD it spills 19 registers and is 17 % slower (tools/ab_build_tree.sh -DC6_OCC2=4)
+#endif
+#ifndef C6_OCC4
+#define C6_OCC4 2
+#endif
 
 // ---- the table: board key -> record, with the child statistics select reads riding in the entry ---------------------------
 // C6HtEntry (c6_engine.h) = {key, idx + 1, visit (saturating at 65535), q}: a child's visit count and q_value arrive with the
 // probe that finds it -- one memory round trip per level instead of probe + gather.  The authoritative copies stay in
-// rec_visit / rec_q; expand and backup update both (rec_slot[record] = its table slot).
+// rec_stat; expand and backup update both (rec_stat[record].slot = its table slot).
 
 __device__ __forceinline__ uint32_t ht_home(unsigned long long key, int H) { return (uint32_t)(key ^ (key >> 32)) & (uint32_t)(H - 1); }
 
@@ -45,28 +61,87 @@ __device__ __forceinline__ C6HtEntry ht_load(const C6HtEntry *ht, uint32_t slot)
     e.q = __uint_as_float(v.w);
     return e;
 }
-
-// continue a probe sequence that started with entry `e` at `slot`: true and the entry when `key` is in the table
-__device__ __forceinline__ bool ht_resolve(const C6HtEntry *ht, int H, unsigned long long key, uint32_t slot, C6HtEntry &e) {
-    for (int it = 0; it < H; it++) {
-        if (e.key == key) return true;
-        if (e.key == 0ull) return false;
-        slot = (slot + 1) & (uint32_t)(H - 1);
-        e = ht_load(ht, slot);
-    }
-    return false;
-}
-
-__device__ __forceinline__ int ht_find(const C6HtEntry *ht, int H, unsigned long long key) {
-    const uint32_t slot = ht_home(key, H);
-    C6HtEntry e = ht_load(ht, slot);
-    return ht_resolve(ht, H, key, slot, e) ? (int)e.idx1 - 1 : -1;
+__device__ __forceinline__ void ht_store(C6HtEntry *ht, uint32_t slot, unsigned long long key, int idx, int visit, float q) {
+    const uint32_t v = (uint32_t)(visit > 65535 ? 65535 : visit);
+    *reinterpret_cast<uint4 *>(ht + slot) = uint4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(idx + 1) | (v << 16), __float_as_uint(q)};
 }
 
 __device__ __forceinline__ uint16_t sat16(int v) { return (uint16_t)(v > 65535 ? 65535 : v); }
 
-// concurrent insert (distinct keys); returns the slot, or -1 if the table is full
-__device__ __forceinline__ int ht_insert(C6HtEntry *ht, int H, unsigned long long key, int idx, int visit, float q) {
+// The tag row of the wave's game: in LDS when the table has at most C6_TAG_LDS_MAX slots (l != nullptr), else read in memory.
+// Tags mirror the table exactly: tag 0 <=> empty slot.
+typedef __attribute__((address_space(3))) uint8_t c6_lds_u8;
+struct C6Tags {
+    uint8_t *g;
+    c6_lds_u8 *l;
+    bool lds;
+    uint32_t mask;
+    __device__ __forceinline__ uint8_t at(uint32_t s) const {
+        if (lds) return l[s];
+        return g[s];
+    }
+    __device__ __forceinline__ void set(uint32_t s, uint8_t t) const {
+        if (lds) l[s] = t;
+        g[s] = t;
+    }
+};
+__host__ __device__ __forceinline__ int tag_row_bytes(int H) { return H <= C6_TAG_LDS_MAX ? H : 0; }
+__device__ __forceinline__ void tags_load(const C6Dev &E, int g, int lane, uint8_t *lds, C6Tags &T) {
+    T.g = E.ht_tag + (size_t)g * E.H;
+    T.mask = (uint32_t)(E.H - 1);
+    T.lds = E.H <= C6_TAG_LDS_MAX;
+    T.l = (c6_lds_u8 *)lds;
+    if (T.lds) {
+        typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+        typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(T.g);
+        lds_u32x4 *dst = (lds_u32x4 *)lds;
+        for (int i = lane; i < E.H / 16; i += 64) dst[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+// from `slot` on: the first slot whose tag is t (true) or that is empty (false); `budget` bounds the walk by the table size
+__device__ __forceinline__ bool tag_seek(const C6Tags &T, uint8_t t, uint32_t &slot, int &budget) {
+    while (budget-- > 0) {
+        const uint8_t x = T.at(slot);
+        if (x == t) return true;
+        if (x == 0) return false;
+        slot = (slot + 1) & T.mask;
+    }
+    return false;
+}
+// continue a lookup whose first tag match `slot` has been loaded into `e`: true and the entry when `key` is in the table
+__device__ __forceinline__ bool ht_verify(const C6HtEntry *ht, const C6Tags &T, unsigned long long key, uint8_t t, uint32_t &slot, int &budget, C6HtEntry &e) {
+    while (e.key != key) {      // a different key with the same tag (1 in 255): walk on
+        slot = (slot + 1) & T.mask;
+        if (!tag_seek(T, t, slot, budget)) return false;
+        e = ht_load(ht, slot);
+    }
+    return true;
+}
+__device__ __forceinline__ bool ht_find(const C6HtEntry *ht, const C6Tags &T, unsigned long long key, C6HtEntry &e) {
+    const uint8_t t = c6_ht_tag_of(key);
+    uint32_t slot = ht_home(key, (int)T.mask + 1);
+    int budget = (int)T.mask + 1;
+    if (!tag_seek(T, t, slot, budget)) return false;
+    e = ht_load(ht, slot);
+    return ht_verify(ht, T, key, t, slot, budget, e);
+}
+// insert by the game's one writer (the tags say where the first empty slot is: no probe); returns the slot, -1 = table full
+__device__ __forceinline__ int ht_insert(C6HtEntry *ht, const C6Tags &T, unsigned long long key, int idx, int visit, float q) {
+    uint32_t slot = ht_home(key, (int)T.mask + 1);
+    for (int it = 0; it <= (int)T.mask; it++) {
+        if (T.at(slot) == 0) {
+            ht_store(ht, slot, key, idx, visit, q);
+            T.set(slot, c6_ht_tag_of(key));
+            return (int)slot;
+        }
+        slot = (slot + 1) & T.mask;
+    }
+    return -1;
+}
+// concurrent insert by the lanes of the game's wave (distinct keys) into a table being rebuilt: memory only, no LDS copy
+__device__ __forceinline__ int ht_insert_atomic(C6HtEntry *ht, uint8_t *tag, int H, unsigned long long key, int idx, int visit, float q) {
     uint32_t slot = ht_home(key, H);
     for (int it = 0; it < H; it++) {
         unsigned long long prev = atomicCAS(&ht[slot].key, 0ull, key);
@@ -74,6 +149,7 @@ __device__ __forceinline__ int ht_insert(C6HtEntry *ht, int H, unsigned long lon
             ht[slot].idx1 = (uint16_t)(idx + 1);
             ht[slot].visit = sat16(visit);
             ht[slot].q = q;
+            tag[slot] = c6_ht_tag_of(key);
             return (int)slot;
         }
         slot = (slot + 1) & (uint32_t)(H - 1);
@@ -91,8 +167,7 @@ template <int J>
 struct C6Leaf {
     int kind, turn, level, len;
     unsigned long long key;
-    uint32_t sg0, sg1, sg2, sg3;
-    int my_path;            // lane i < 64: record of the path's i-th step
+    int my_path;            // lane i < 64: record of the path's i-th step | the cell chosen there << 16
     int8_t st[J];           // the leaf position, lane's cells
 };
 
@@ -101,8 +176,7 @@ struct C6Leaf {
 template <int J>
 struct C6GameRegs {
     unsigned long long key;
-    uint4 sig;
-    int root_rec, turn, remain, level, top, sim_in_move;
+    int root_rec, turn, remain, level, top, sim_in_move, rootc_ok;
     uint32_t uid, nsearch;
     int free_idx;           // the record the next expansion takes (free_stack[top - 1]), fetched behind `top`
     int8_t st[J];           // the root position, lane's cells
@@ -110,8 +184,8 @@ struct C6GameRegs {
 template <int J>
 __device__ __forceinline__ void load_game_regs(const C6Dev &E, int g, int lane, C6GameRegs<J> &R) {
     R.key = E.hdr[g].root_key;
-    R.sig = *reinterpret_cast<const uint4 *>(E.hdr[g].root_sig);
     R.root_rec = E.hdr[g].root_rec;
+    R.rootc_ok = (int)E.hdr[g].rootc_ok;
     R.turn = E.turn[g]; R.remain = E.remain[g]; R.level = E.hdr[g].nstones;
     R.uid = E.hdr[g].game_uid; R.nsearch = E.hdr[g].nsearch;
     R.top = E.hdr[g].free_top; R.sim_in_move = E.hdr[g].sim_in_move;
@@ -123,26 +197,29 @@ __device__ __forceinline__ void load_game_regs(const C6Dev &E, int g, int lane, 
     // wave-uniform values belong in scalar registers (the loads above are vector loads of one address)
 #define C6_SGPR(x) x = __builtin_amdgcn_readfirstlane(x)
     R.key = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(R.key >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)R.key);
-    R.sig.x = __builtin_amdgcn_readfirstlane(R.sig.x); R.sig.y = __builtin_amdgcn_readfirstlane(R.sig.y);
-    R.sig.z = __builtin_amdgcn_readfirstlane(R.sig.z); R.sig.w = __builtin_amdgcn_readfirstlane(R.sig.w);
-    C6_SGPR(R.root_rec); C6_SGPR(R.turn); C6_SGPR(R.remain); C6_SGPR(R.level); C6_SGPR(R.top); C6_SGPR(R.sim_in_move);
+    C6_SGPR(R.root_rec); C6_SGPR(R.turn); C6_SGPR(R.remain); C6_SGPR(R.level); C6_SGPR(R.top); C6_SGPR(R.sim_in_move); C6_SGPR(R.rootc_ok);
     R.uid = __builtin_amdgcn_readfirstlane(R.uid); R.nsearch = __builtin_amdgcn_readfirstlane(R.nsearch);
     R.free_idx = R.top > 0 ? (int)E.free_stack[(size_t)g * E.R + R.top - 1] : -1;      // second trip, overlapped with the first select level
     C6_SGPR(R.free_idx);
 #undef C6_SGPR
 }
 
+// colour of the stone the select path places at step m, from the root's (turn, remain): simulate/mod.rs:268-273 unrolled
+__device__ __forceinline__ int path_colour(int root_turn, int root_remain, int m) {
+    if (m < root_remain) return root_turn;
+    return (((m - root_remain) >> 1) & 1) ? root_turn : -root_turn;
+}
+
 // ------------------------------------------------------------------------------------------
 // select: walk from the root by PUCT + Dirichlet noise until a node without record (leaf)
 // ------------------------------------------------------------------------------------------
 template <int J>
-__device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, double *gscratch, const C6GameRegs<J> &R, C6Leaf<J> &L) {
+__device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, double *gscratch, const C6Tags &T, const C6GameRegs<J> &R, C6Leaf<J> &L) {
     const int cells = E.cells;
     const C6HtEntry *ht = E.ht + (size_t)g * E.H;
     const size_t rbase = (size_t)g * E.R;
 
     unsigned long long key = R.key;
-    uint32_t sg0 = R.sig.x, sg1 = R.sig.y, sg2 = R.sig.z, sg3 = R.sig.w;
     int p = R.root_rec;
     int turn = R.turn, remain = R.remain, level = R.level;
     const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + R.uid, t = R.nsearch;
@@ -160,31 +237,71 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const float *prior = E.rec_prior + (rbase + p) * (size_t)cells;
 
-        // all J first probes (and the priors) leave together: one memory round trip per level in the common case
-        unsigned long long ck[J];
-        uint32_t cslot[J];
-        C6HtEntry ce[J];
-        float cpr[J];
-#pragma unroll
-        for (int j = 0; j < J; j++) {
-            const int c = lane + 64 * j;
-            const bool mine = L.st[j] == 0;
-            ck[j] = key ^ zk[mine ? c : 0];
-            cslot[j] = ht_home(ck[j], E.H);
-            ce[j] = ht_load(ht, cslot[j]);
-            cpr[j] = mine ? prior[c] : 0.f;
-        }
         int cidx[J], cvis[J];
-        float cq[J];
+        float cq[J], cpr[J];
         int vs = 0;
+        if (d == 0 && R.rootc_ok) {
+            // the root: its children are one contiguous row
+            const uint2 *rc = reinterpret_cast<const uint2 *>(E.rootc + (size_t)g * E.cellsP);
+            uint2 v[J];
 #pragma unroll
-        for (int j = 0; j < J; j++) {
-            cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f;
-            if (L.st[j] == 0 && ht_resolve(ht, E.H, ck[j], cslot[j], ce[j])) {
-                cidx[j] = (int)ce[j].idx1 - 1;
-                cvis[j] = ce[j].visit == 65535 ? E.rec_stat[rbase + cidx[j]].visit : (int)ce[j].visit;
-                cq[j] = ce[j].q;
-                vs += cvis[j];
+            for (int j = 0; j < J; j++) {
+                const int c = lane + 64 * j;
+                const bool mine = L.st[j] == 0;
+                v[j] = rc[mine ? c : 0];
+                cpr[j] = mine ? prior[c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f;
+                if (L.st[j] == 0 && (v[j].x & 0xffffu) != 0u) {
+                    cidx[j] = (int)(v[j].x & 0xffffu) - 1;
+                    cvis[j] = (v[j].x >> 16) == 65535u ? E.rec_stat[rbase + cidx[j]].visit : (int)(v[j].x >> 16);
+                    cq[j] = __uint_as_float(v[j].y);
+                    vs += cvis[j];
+                }
+            }
+        } else {
+            // tags first (LDS): only children that may be present go to memory, all of the level's loads leave together
+            unsigned long long ck[J];
+            uint32_t cslot[J];
+            int budget[J];
+            bool hit[J];
+            C6HtEntry ce[J];
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c = lane + 64 * j;
+                const bool mine = L.st[j] == 0;
+                ck[j] = key ^ zk[mine ? c : 0];
+                cslot[j] = ht_home(ck[j], E.H);
+                budget[j] = E.H;
+                hit[j] = mine && tag_seek(T, c6_ht_tag_of(ck[j]), cslot[j], budget[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c = lane + 64 * j;
+                if (hit[j]) ce[j] = ht_load(ht, cslot[j]);
+                cpr[j] = L.st[j] == 0 ? prior[c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f;
+                if (hit[j] && ht_verify(ht, T, ck[j], c6_ht_tag_of(ck[j]), cslot[j], budget[j], ce[j])) {
+                    cidx[j] = (int)ce[j].idx1 - 1;
+                    cvis[j] = ce[j].visit == 65535 ? E.rec_stat[rbase + cidx[j]].visit : (int)ce[j].visit;
+                    cq[j] = ce[j].q;
+                    vs += cvis[j];
+                }
+            }
+            if (d == 0) {      // first scan of this root: keep its children as a row for the searches to come
+                C6RootChild *rc = E.rootc + (size_t)g * E.cellsP;
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c = lane + 64 * j;
+                    if (c < cells)
+                        *reinterpret_cast<uint2 *>(rc + c) = uint2{(uint32_t)(cidx[j] + 1) | ((uint32_t)sat16(cvis[j]) << 16), __float_as_uint(cq[j])};
+                }
+                if (lane == 0) E.hdr[g].rootc_ok = 1u;
             }
         }
 
@@ -252,12 +369,11 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
 #pragma unroll
         for (int j = 0; j < J; j++) if (j == cj) child = cidx[j];
         child = __shfl(child, cl, 64);
-        if (d < 64) { if (lane == d) L.my_path = p; }
-        else if (lane == 0) E.path_rec[(size_t)g * E.maxd + d] = (uint16_t)p;      // beyond 64 steps: through memory
+        const int step = p | (chosen << 16);
+        if (d < 64) { if (lane == d) L.my_path = step; }
+        else if (lane == 0) E.path_rec[(size_t)g * E.maxd + d] = (uint32_t)step;      // beyond 64 steps: through memory
         d++;
         key ^= zk[chosen];
-        const uint32_t c1 = (uint32_t)chosen + 1u;
-        if (turn == C6_BLACK) { sg0 += c1; sg1 += c1 * c1; } else { sg2 += c1; sg3 += c1 * c1; }
 #pragma unroll
         for (int j = 0; j < J; j++) if (j == cj && lane == cl) L.st[j] = (int8_t)turn;
         next_turn(turn, remain);
@@ -266,7 +382,6 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
     }
     if (kind == C6_LEAF_EVAL && level == cells) kind = C6_LEAF_TERMINAL;   // board full, mod.rs:338
     L.kind = kind; L.turn = turn; L.level = level; L.len = d; L.key = key;
-    L.sg0 = sg0; L.sg1 = sg1; L.sg2 = sg2; L.sg3 = sg3;
 }
 
 // the game stops (pool / path exhausted: resumable; NaN scores: an error) -- reported through status, never silently
@@ -407,34 +522,37 @@ __device__ __forceinline__ int wave_winner(const int8_t *board, int N, int lane)
 }
 
 // expand + update for one game.  A chain of memory round trips, so its shape is dictated by how many of them are serial: everything
-// that depends only on g is loaded up front (one trip), the record scan fetches four 64-record chunks per trip, the free-list pop /
-// record initialisation / table insert overlap the scan's loads, and the backup updates the path's records lane-parallel (they are
-// distinct: levels strictly increase along a path).  `prob` = the evaluated prior of the leaf, cells floats (global eval_prior, or
-// the wave's LDS scratch inside the fused search kernel); `board` = the leaf position as bytes (terminal leaves only).
+// that depends only on g is loaded up front (one trip), the new record / its table entry (slot found in the LDS tags) and the
+// last-writer candidates go out behind it, and the backup updates the path's records lane-parallel (they are distinct: levels
+// strictly increase along a path).  `prob` = the evaluated prior of the leaf, cells floats (global eval_prior, or the wave's LDS
+// scratch inside the fused search kernel); `board` = the leaf position as bytes (terminal leaves only); L.st = the same in registers.
 // Returns true when the game's simulation budget for this move is spent (the caller then runs policy()).
 template <int J>
-__device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, const C6GameRegs<J> &R, const C6Leaf<J> &L, float evalue, const float *prob,
-                                            const int8_t *board) {
+__device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, const C6Tags &T, const C6GameRegs<J> &R, const C6Leaf<J> &L, float evalue,
+                                            const float *prob, const int8_t *board) {
     const int cells = E.cells;
     const size_t rbase = (size_t)g * E.R;
     const int kind = L.kind, len = L.len, level = L.level, turn = L.turn;
     const unsigned long long key = L.key;
     const int top = R.top, sim_in_move = R.sim_in_move;
     const uint32_t nsearch = R.nsearch;
+    C6HtEntry *ht = E.ht + (size_t)g * E.H;
     float value;
-    // these leave together and come back behind the record scan: the rest of the game's words, and the backup's loads (lane i: the
-    // path's i-th record)
+    // these leave together: the rest of the game's words, and the backup's loads (lane i: the path's i-th record)
     const int hi0 = E.hdr[g].rec_hi;
     const unsigned long long gsims = E.hdr[g].g_sims;
     const uint32_t maxrec = E.hdr[g].g_maxrec;
+    const int my_rec = L.my_path & 0xffff, my_cell = (int)((uint32_t)L.my_path >> 16);
     uint32_t bk_slot = 0;
     int bk_visit = 0;
     float bk_qsum = 0.f;
     if (lane < len) {
-        bk_slot = E.rec_stat[rbase + L.my_path].slot;
-        bk_visit = E.rec_stat[rbase + L.my_path].visit;
-        bk_qsum = E.rec_stat[rbase + L.my_path].qsum;
+        bk_slot = E.rec_stat[rbase + my_rec].slot;
+        bk_visit = E.rec_stat[rbase + my_rec].visit;
+        bk_qsum = E.rec_stat[rbase + my_rec].qsum;
     }
+    const int cell0 = __shfl(my_cell, 0, 64);      // the root's move of this path (len >= 1): its rootc entry follows the child
+    C6RootChild *rootc = E.rootc + (size_t)g * E.cellsP;
 
     if (kind == C6_LEAF_TERMINAL) {   // mod.rs:338-348: value by winner, no visit increment, no children
         const int w = wave_winner(board, E.N, lane);
@@ -451,74 +569,56 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         value = evalue;
         float *prior = E.rec_prior + (rbase + idx) * (size_t)cells;
         for (int c = lane; c < cells; c += 64) prior[c] = prob[c];      // child.n_prob = prob[r][c], mod.rs:370
-        const uint32_t q0 = L.sg0, q1 = L.sg1, q2 = L.sg2, q3 = L.sg3;
-        // last-writer rule for transposed children (entry().or_insert + n_prob overwrite, mod.rs:366-370):
-        // every expanded P on this level with P + i == Q + s sees its child i's prior become prob_Q[s]
+        if (lane == 0) {
+            E.hdr[g].free_top = top - 1;
+            if (hi != hi0) E.hdr[g].rec_hi = hi;
+            const int slot = ht_insert(ht, T, key, idx, 1, 0.f);
+            if (slot < 0) E.hdr[g].status = C6_ST_ERROR;
+            C6RecStat rs;
+            rs.visit = 1;             // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
+            rs.value = value; rs.qsum = 0.f; rs.q = 0.f;
+            rs.slot = (uint32_t)(slot < 0 ? 0 : slot);
+            rs.level = (int16_t)level; rs.pad = 0;
+            rs.key = key;
+            uint4 *dst = reinterpret_cast<uint4 *>(E.rec_stat + rbase + idx);
+            const uint4 *src = reinterpret_cast<const uint4 *>(&rs);
+            dst[0] = src[0]; dst[1] = src[1];
+            if (len == 0) E.hdr[g].root_rec = idx;
+            if (len == 1) *reinterpret_cast<uint2 *>(rootc + cell0) = uint2{(uint32_t)(idx + 1) | (1u << 16), 0u};
+            const uint32_t used = (uint32_t)(E.R - (top - 1));
+            if (used > maxrec) E.hdr[g].g_maxrec = used;
+        }
+        // last-writer rule for transposed children (entry().or_insert + n_prob overwrite, mod.rs:366-370): every expanded P with
+        // P + i == Q + s sees its child i's prior become prob_Q[s].  i: a stone of the mover's colour the path added to the root
+        // (header comment); s: an empty cell of Q; P by key.  The tags answer "absent" for nearly all of them.
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
-        const uint32_t ms = turn == C6_BLACK ? q0 : q2, mq = turn == C6_BLACK ? q1 : q3;   // mover colour sums of Q
-        const uint32_t os = turn == C6_BLACK ? q2 : q0, oq = turn == C6_BLACK ? q3 : q1;
-        constexpr int CH = 4;
-        bool first_batch = true;
-        for (int r0 = 0; r0 < hi; r0 += 64 * CH) {      // records at or above hi were never used: level -1
-            // level, signature and key of 4 x 64 records in flight together (indices clamped: loads stay unconditional)
-            int lv[CH];
-            uint4 sgv[CH];
-            unsigned long long rk[CH];
+        for (int base = 0; base < len; base += 64) {
+            const int m = base + lane;
+            int mcell = my_cell;
+            if (base > 0 && m < len) mcell = (int)(E.path_rec[(size_t)g * E.maxd + m] >> 16);
+            unsigned long long cand = __ballot(m < len && path_colour(R.turn, R.remain, m) == turn);
+            while (cand) {
+                const int src_lane = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const int i = __shfl(mcell, src_lane, 64);
+                const unsigned long long kq = key ^ zk[i];
 #pragma unroll
-            for (int u = 0; u < CH; u++) {
-                const int r = r0 + 64 * u + lane, rc = r < hi ? r : idx;
-                lv[u] = E.rec_level[rbase + rc];
-                sgv[u] = *reinterpret_cast<const uint4 *>(E.rec_sig + (rbase + rc) * 4);
-                rk[u] = E.rec_key[rbase + rc];
-            }
-            if (first_batch) {      // behind the first batch's loads: the new record and its table entry
-                first_batch = false;
-                if (lane == 0) {
-                    E.hdr[g].free_top = top - 1;
-                    if (hi != hi0) E.hdr[g].rec_hi = hi;
-                    E.rec_key[rbase + idx] = key;
-                    E.rec_stat[rbase + idx].visit = 1;          // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
-                    E.rec_stat[rbase + idx].value = value;
-                    E.rec_stat[rbase + idx].qsum = 0.f;
-                    E.rec_stat[rbase + idx].q = 0.f;
-                    *reinterpret_cast<uint4 *>(E.rec_sig + (rbase + idx) * 4) = uint4{q0, q1, q2, q3};
-                    const int slot = ht_insert(E.ht + (size_t)g * E.H, E.H, key, idx, 1, 0.f);
-                    if (slot < 0) E.hdr[g].status = C6_ST_ERROR;
-                    else E.rec_stat[rbase + idx].slot = (uint32_t)slot;
-                    if (len == 0) E.hdr[g].root_rec = idx;
-                    const uint32_t used = (uint32_t)(E.R - (top - 1));
-                    if (used > maxrec) E.hdr[g].g_maxrec = used;
+                for (int j = 0; j < J; j++) {
+                    const int c = lane + 64 * j;
+                    if (L.st[j] != 0) continue;
+                    C6HtEntry e;
+                    if (ht_find(ht, T, kq ^ zk[c], e)) E.rec_prior[(rbase + (size_t)e.idx1 - 1) * (size_t)cells + i] = prob[c];
                 }
             }
-#pragma unroll
-            for (int u = 0; u < CH; u++) {
-                const int r = r0 + 64 * u + lane;
-                if (r >= hi || r == idx || lv[u] != level) continue;
-                const uint32_t sg[4] = {sgv[u].x, sgv[u].y, sgv[u].z, sgv[u].w};
-                const uint32_t pms = turn == C6_BLACK ? sg[0] : sg[2], pmq = turn == C6_BLACK ? sg[1] : sg[3];
-                const uint32_t pos_ = turn == C6_BLACK ? sg[2] : sg[0], poq = turn == C6_BLACK ? sg[3] : sg[1];
-                if (pos_ != os || poq != oq) continue;
-                const long long D1 = (long long)pms - (long long)ms, D2 = (long long)pmq - (long long)mq;   // s1 - i1, s1^2 - i1^2
-                if (D1 == 0 || D2 % D1 != 0) continue;
-                const long long T = D2 / D1;          // s1 + i1
-                if (((T + D1) & 1) != 0) continue;
-                const long long s1 = (T + D1) / 2, i1 = (T - D1) / 2;
-                if (s1 < 1 || i1 < 1 || s1 > cells || i1 > cells) continue;
-                const int s_ = (int)s1 - 1, i = (int)i1 - 1;
-                if (rk[u] != (key ^ zk[i] ^ zk[s_])) continue;
-                E.rec_prior[(rbase + r) * (size_t)cells + i] = prob[s_];
-            }
         }
-        if (lane == 0) E.rec_level[rbase + idx] = (int16_t)level;   // after the scan: Q never matches itself
     }
 
     // update, mod.rs:386-408 (one-level backup): lane i owns the path's i-th record (paths beyond 64 steps: further passes); the
-    // child statistics in the table entry follow the record
-    C6HtEntry *ht = E.ht + (size_t)g * E.H;
+    // child statistics in the table entry -- and in the root's row for the root's child -- follow the record
     for (int base = 0; base < len; base += 64) {
         const int i = base + lane;
         if (i < len) {
-            const int r = base == 0 ? L.my_path : (int)E.path_rec[(size_t)g * E.maxd + i];
+            const int r = base == 0 ? my_rec : (int)(E.path_rec[(size_t)g * E.maxd + i] & 0xffffu);
             const uint32_t slot = base == 0 ? bk_slot : E.rec_stat[rbase + r].slot;
             const int v = (base == 0 ? bk_visit : E.rec_stat[rbase + r].visit) + 1;
             float qs = base == 0 ? bk_qsum : E.rec_stat[rbase + r].qsum;
@@ -531,6 +631,10 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
             E.rec_stat[rbase + r].q = qv;
             ht[slot].visit = sat16(v);
             ht[slot].q = qv;
+            if (i == 1) {
+                rootc[cell0].visit = sat16(v);
+                rootc[cell0].q = qv;
+            }
         }
     }
     if (lane == 0) {
@@ -545,7 +649,7 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
 // move: policy() (mod.rs:433-452) for a game whose simulation budget is spent -> move_pos / move_turn for K1
 // ------------------------------------------------------------------------------------------
 template <int J>
-__device__ __forceinline__ void move_select_wave(const C6Dev &E, int g, int lane) {
+__device__ __forceinline__ int move_select_wave(const C6Dev &E, int g, int lane, const C6Tags &T, bool publish = true) {
     const int cells = E.cells;
     const int p = E.hdr[g].root_rec;
     const int level = E.hdr[g].nstones;
@@ -564,11 +668,9 @@ __device__ __forceinline__ void move_select_wave(const C6Dev &E, int g, int lane
             const int c = lane + 64 * j;
             cv[j] = -1;
             if (c < cells && board[c] == 0) {
-                const unsigned long long ck = key ^ zk[c];
-                const uint32_t slot = ht_home(ck, E.H);
-                C6HtEntry e = ht_load(ht, slot);
+                C6HtEntry e;
                 cv[j] = 0;
-                if (ht_resolve(ht, E.H, ck, slot, e)) cv[j] = e.visit == 65535 ? E.rec_stat[rbase + (int)e.idx1 - 1].visit : (int)e.visit;
+                if (ht_find(ht, T, key ^ zk[c], e)) cv[j] = e.visit == 65535 ? E.rec_stat[rbase + (int)e.idx1 - 1].visit : (int)e.visit;
                 vs += cv[j];
             }
         }
@@ -597,10 +699,11 @@ __device__ __forceinline__ void move_select_wave(const C6Dev &E, int g, int lane
             if (c < cells) pi[c] = (uint16_t)(cv[j] > 0 ? (cv[j] > 65535 ? 65535 : cv[j]) : 0);
         }
     }
-    if (lane == 0) {
+    if (publish && lane == 0) {      // for K1 and the next round's head
         E.move_pos[g] = pos;
         E.move_turn[g] = (int8_t)turn;
     }
+    return pos;
 }
 
 __device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane, uint32_t uid, int presims) {
@@ -611,11 +714,13 @@ __device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane,
     }
     const size_t rbase = (size_t)g * E.R;
     for (int r = lane; r < E.R; r += 64) {
-        E.rec_level[rbase + r] = -1;
+        E.rec_stat[rbase + r].level = -1;
         E.free_stack[rbase + r] = (uint16_t)(E.R - 1 - r);   // pop order 0,1,2,...
     }
     uint4 *ht = reinterpret_cast<uint4 *>(E.ht + (size_t)g * E.H);
     for (int i = lane; i < E.H; i += 64) ht[i] = uint4{0u, 0u, 0u, 0u};
+    uint4 *tg = reinterpret_cast<uint4 *>(E.ht_tag + (size_t)g * E.H);
+    for (int i = lane; i < E.H / 16; i += 64) tg[i] = uint4{0u, 0u, 0u, 0u};
     if (lane == 0) {
         E.turn[g] = C6_BLACK;       // Game::new, game_impl/mod.rs:125-131
         E.remain[g] = 1;
@@ -627,7 +732,7 @@ __device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane,
         E.hdr[g].nsearch = 0;
         E.hdr[g].sim_in_move = presims;
         E.hdr[g].root_key = C6_EMPTY_BOARD_KEY;
-        E.hdr[g].root_sig[0] = 0; E.hdr[g].root_sig[1] = 0; E.hdr[g].root_sig[2] = 0; E.hdr[g].root_sig[3] = 0;
+        E.hdr[g].rootc_ok = 0u;
         E.hdr[g].root_rec = -1;
         E.hdr[g].free_top = E.R;
         E.hdr[g].rec_hi = 0;
@@ -648,24 +753,28 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_reset_kernel(C6Dev E)
 __device__ __forceinline__ int rebuild_table_wave(const C6Dev &E, int g, int lane, int hi, unsigned long long find) {
     const size_t rbase = (size_t)g * E.R;
     C6HtEntry *ht = E.ht + (size_t)g * E.H;
-    uint4 *ht4 = reinterpret_cast<uint4 *>(ht);
+    uint8_t *tag = E.ht_tag + (size_t)g * E.H;
+    uint4 *ht4 = reinterpret_cast<uint4 *>(ht), *tg4 = reinterpret_cast<uint4 *>(tag);
     for (int i = lane; i < E.H; i += 64) ht4[i] = uint4{0u, 0u, 0u, 0u};
+    for (int i = lane; i < E.H / 16; i += 64) tg4[i] = uint4{0u, 0u, 0u, 0u};
     __threadfence_block();
     int rr = -1;
-    for (int r = lane; r < hi; r += 64)
-        if (E.rec_level[rbase + r] >= 0) {
-            const unsigned long long k = E.rec_key[rbase + r];
-            const int slot = ht_insert(ht, E.H, k, r, E.rec_stat[rbase + r].visit, E.rec_stat[rbase + r].q);
+    for (int r = lane; r < hi; r += 64) {
+        const C6RecStat rs = E.rec_stat[rbase + r];
+        if (rs.level >= 0) {
+            const int slot = ht_insert_atomic(ht, tag, E.H, rs.key, r, rs.visit, rs.q);
             if (slot >= 0) E.rec_stat[rbase + r].slot = (uint32_t)slot;
-            if (k == find) rr = r;
+            if (rs.key == find) rr = r;
         }
+    }
     return c6_wave_max_i32(rr);
 }
 
-// after K1 placed the stone of game g: advance the root, prune (next(), mod.rs:473-487), finish / recycle the game.
-// Called with pos = move_pos[g] != -2; leaves move_pos[g] = -2.
+// after the stone of game g was placed (by K1, or by the search kernel itself): advance the root, prune (next(), mod.rs:473-487),
+// finish / recycle the game.  pos = the cell (-1: the policy had no move), mover / win / err = who placed it and what Game::set +
+// search_winner said; leaves move_pos[g] = -2.
 template <int J>
-__device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, int pos) {
+__device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, int pos, int mover, int win_in, int err) {
     const int cells = E.cells;
     const size_t rbase = (size_t)g * E.R;
     const int old_level = E.hdr[g].nstones;
@@ -678,22 +787,18 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
 
     if (pos < 0) {
         finished = true;                       // policy returned None -> draw, agent_impl/mod.rs:135-137
-    } else if (E.err[g] != 0) {
+    } else if (err != 0) {
         if (lane == 0) E.hdr[g].status = C6_ST_ERROR;
         return;
     } else {
-        const int mover = E.move_turn[g];
         nst = old_level + 1;
-        win = E.winner[g];
+        win = win_in;
         finished = win != 0;                   // agent_impl/mod.rs:167-171
         new_key = old_key ^ E.zob[(mover == C6_WHITE ? C6_MAXCELLS : 0) + pos];
         if (lane == 0) {
             E.root_board[(size_t)g * E.cellsP + pos] = (int8_t)mover;
             E.hdr[g].root_key = new_key;
-            const uint32_t c1 = (uint32_t)pos + 1u;
-            const int o = mover == C6_BLACK ? 0 : 2;
-            E.hdr[g].root_sig[o] += c1;
-            E.hdr[g].root_sig[o + 1] += c1 * c1;
+            E.hdr[g].rootc_ok = 0u;      // the next select scans the new root's children and writes their row
             E.moves[(size_t)g * cells + old_level] = (uint16_t)pos;
             E.hdr[g].nstones = (int16_t)nst;
             E.hdr[g].sim_in_move = 0;
@@ -711,14 +816,14 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
             const int r = r0 + lane;
             bool kill = false;
             if (r < hi) {
-                const int lv = E.rec_level[rbase + r];
+                const int lv = E.rec_stat[rbase + r].level;
                 kill = lv >= 0 && lv <= old_level;
             }
             const unsigned long long m = __ballot(kill);
             if (kill) {
                 const int off = __popcll(m & ((1ull << lane) - 1ull));
                 E.free_stack[rbase + top + off] = (uint16_t)r;
-                E.rec_level[rbase + r] = -1;
+                E.rec_stat[rbase + r].level = -1;
             }
             top += __popcll(m);
         }
@@ -793,7 +898,9 @@ template <int J>
 __device__ __forceinline__ void round_head_wave(const C6Dev &E, int g, int lane) {
     const int pos = E.move_pos[g];
     if (pos != -2) {
-        post_move_wave<J>(E, g, lane, pos);
+        int mover = 0, win = 0, err = 0;
+        if (pos >= 0) { mover = E.move_turn[g]; win = E.winner[g]; err = E.err[g]; }
+        post_move_wave<J>(E, g, lane, pos, mover, win, err);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the root this wave just wrote is read back below
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return;
@@ -808,51 +915,113 @@ __device__ __forceinline__ void round_head_wave(const C6Dev &E, int g, int lane)
     }
 }
 
+// The rare paths of the search kernel (a move: one round in S; a stone from outside) as real functions that read the engine
+// descriptor from a copy in LDS: inlined, their ~20 extra pointers stayed live in scalar registers across the whole kernel, which
+// then spilled 113-192 SGPRs and up to 90 VGPRs in its hot loop.
+template <int J>
+__device__ __noinline__ void round_head_call(const C6Dev *Es, int g, int lane) { round_head_wave<J>(*Es, g, lane); }
+// policy() (mod.rs:433-452), then Game::set + search_winner (game_impl/mod.rs:148-169) on the root position, then next()
+template <int J>
+__device__ __noinline__ void move_call(const C6Dev *Es, int g, int lane, uint8_t *tag_row, int8_t *lboard) {
+    const C6Dev &E = *Es;
+    C6Tags T;
+    T.g = E.ht_tag + (size_t)g * E.H; T.mask = (uint32_t)(E.H - 1); T.lds = E.H <= C6_TAG_LDS_MAX; T.l = (c6_lds_u8 *)tag_row;
+    const int pos = move_select_wave<J>(E, g, lane, T, false);
+    const int mover = E.turn[g];
+    int win = 0;
+    if (pos >= 0) {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c = lane + 64 * j;
+            lboard[c] = c == pos ? (int8_t)mover : (c < E.cells ? E.root_board[(size_t)g * E.cellsP + c] : (int8_t)0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        win = wave_winner(lboard, E.N, lane);
+        if (lane == 0) {      // K1's operands follow (canonical state: c6_engine_boards, apply_moves, the other kernels)
+            E.board_soa[(size_t)pos * E.Gpad + g] = (int8_t)mover;
+            int nt = mover, nr = E.remain[g];
+            next_turn(nt, nr);
+            E.turn[g] = (int8_t)nt;
+            E.remain[g] = (int8_t)nr;
+            E.winner[g] = (int8_t)win;
+        }
+    }
+    post_move_wave<J>(E, g, lane, pos, mover, win, 0);
+}
+
 // ---- the kernels of a round -----------------------------------------------------------------------------------------------
-// Built-in evaluators (RandomEvaluator / uniform: BASELINE configs 1 and 5): the whole search() of a game in ONE launch -- last
-// round's move is finished first, then select -> evaluate -> expand / backup -> policy() run in registers; the leaf never
-// travels through memory.  A round is this kernel + K1.
+// Built-in evaluators (RandomEvaluator / uniform: BASELINE configs 1 and 5): `nsims` whole rounds of a game in ONE launch.  A round =
+// search() -- select -> evaluate -> expand / backup in registers, the leaf never travels through memory -- and, when the move's
+// simulation budget is spent, policy() + Game::set + search_winner + next() (prune / finish / recycle) by the same wave: no K1
+// launch, no hand-over through move_pos.  Games do not interact, so a wave runs its game's rounds back to back: from the second
+// one on, the game's header, tag row, root row and root priors come out of the L2 instead of HBM.
 template <int J, int KIND>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)) void c6_search_kernel(C6Dev E) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? C6_OCC4 : 2)) void c6_search_kernel(C6Dev E, int nsims) {
     __shared__ double gscratch[WAVES_PER_BLOCK][64 * J];    // c6_wave_gamma hand-back, then the leaf's prior / board: wave-private
+    __shared__ C6Dev Es;                                    // the descriptor for the rare paths (round_head_call / move_call)
+    extern __shared__ __align__(16) uint8_t c6_tag_lds[];   // [WAVES_PER_BLOCK][tag_row_bytes(H)] the games' tag rows
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = blockIdx.x * WAVES_PER_BLOCK + wv;
+    {   // E is the kernel's first argument: copied word by word from the kernarg segment (through registers it would cost ~100 SGPRs)
+        static_assert(sizeof(C6Dev) % 4 == 0, "copied as dwords");
+        typedef __attribute__((address_space(4))) const uint32_t c6_const_u32;
+        c6_const_u32 *ka = (c6_const_u32 *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&Es);
+        for (int i = threadIdx.x; i < (int)(sizeof(C6Dev) / 4); i += 64 * WAVES_PER_BLOCK) dst[i] = ka[i];
+    }
+    __syncthreads();
     if (g >= E.G) return;
-    // one batch of loads: the two words that decide whether there is a move to finish first, and the game's registers
-    const int pos = E.move_pos[g];
+    // one batch of loads: the two words that decide whether there is a move to finish first (a stone from outside,
+    // c6_engine_apply_moves; a game abandoned in steady-state mode), and the game's registers
+    const int pos0 = E.move_pos[g];
     int stt = E.hdr[g].status;
     C6GameRegs<J> R;
     load_game_regs<J>(E, g, lane, R);
-    if (pos != -2 || (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW))) {      // ~1 game in S per round: the slow path reloads
-        round_head_wave<J>(E, g, lane);
+    if (pos0 != -2 || (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW))) {
+        round_head_call<J>(&Es, g, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         stt = E.hdr[g].status;
         load_game_regs<J>(E, g, lane, R);
     }
     if (stt != C6_ST_PLAYING) return;
-    C6Leaf<J> L;
-    select_wave<J>(E, g, lane, gscratch[wv], R, L);
-    if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
-    if (lane == 0) {
-        E.hdr[g].g_select += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
-        if ((uint32_t)L.len > E.hdr[g].g_maxdepth) E.hdr[g].g_maxdepth = (uint32_t)L.len;
-    }
-    float pr[J], value = 0.f;
+    C6Tags T;
+    uint8_t *tag_row = c6_tag_lds + (size_t)wv * tag_row_bytes(E.H);
+    tags_load(E, g, lane, tag_row, T);
     float *probs = reinterpret_cast<float *>(gscratch[wv]);
     int8_t *lboard = reinterpret_cast<int8_t *>(probs + 64 * J);
-    if (L.kind == C6_LEAF_EVAL) {
-        eval_builtin_regs<J>(E, g, lane, KIND, R.nsearch, L.st, pr, value);
+    for (int it = 0;;) {
+        C6Leaf<J> L;
+        select_wave<J>(E, g, lane, gscratch[wv], T, R, L);
+        if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
+        if (lane == 0) {
+            E.hdr[g].g_select += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
+            if ((uint32_t)L.len > E.hdr[g].g_maxdepth) E.hdr[g].g_maxdepth = (uint32_t)L.len;
+        }
+        float pr[J], value = 0.f;
+        if (L.kind == C6_LEAF_EVAL) {
+            eval_builtin_regs<J>(E, g, lane, KIND, R.nsearch, L.st, pr, value);
 #pragma unroll
-        for (int j = 0; j < J; j++) probs[lane + 64 * j] = pr[j];
-    } else {
+            for (int j = 0; j < J; j++) probs[lane + 64 * j] = pr[j];
+        } else {
 #pragma unroll
-        for (int j = 0; j < J; j++) lboard[lane + 64 * j] = L.st[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (L.len > 64) __threadfence();      // path steps beyond 64 went through memory
-    if (expand_wave<J>(E, g, lane, R, L, value, probs, lboard)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // policy() reads the statistics the backup just wrote
+            for (int j = 0; j < J; j++) lboard[lane + 64 * j] = L.st[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (L.len > 64) __threadfence();      // path steps beyond 64 went through memory
+        const bool spent = expand_wave<J>(E, g, lane, T, R, L, value, probs, lboard);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // what this round wrote is read back below / by the next round
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        move_select_wave<J>(E, g, lane);
+        if (spent) {
+            move_call<J>(&Es, g, lane, tag_row, lboard);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (++it >= nsims) break;
+        // the next round of the same game: its state as this wave left it
+        if (E.hdr[g].status != C6_ST_PLAYING) break;
+        load_game_regs<J>(E, g, lane, R);
+        if (spent) tags_load(E, g, lane, tag_row, T);      // the table was rebuilt
     }
 }
 
@@ -860,6 +1029,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
 template <int J>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)) void c6_select_kernel(C6Dev E) {
     __shared__ double gscratch[WAVES_PER_BLOCK][64 * J];
+    extern __shared__ __align__(16) uint8_t c6_tag_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = blockIdx.x * WAVES_PER_BLOCK + wv;
     if (g >= E.G) return;
@@ -870,20 +1040,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     }
     C6GameRegs<J> R;
     load_game_regs<J>(E, g, lane, R);
+    C6Tags T;
+    tags_load(E, g, lane, c6_tag_lds + (size_t)wv * tag_row_bytes(E.H), T);
     C6Leaf<J> L;
-    select_wave<J>(E, g, lane, gscratch[wv], R, L);
+    select_wave<J>(E, g, lane, gscratch[wv], T, R, L);
     if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
 #pragma unroll
     for (int j = 0; j < J; j++) {
         const int c = lane + 64 * j;
         if (c < E.cells) E.leaf_board[(size_t)g * E.cellsP + c] = L.st[j];
     }
-    if (lane < 64 && lane < L.len) E.path_rec[(size_t)g * E.maxd + lane] = (uint16_t)L.my_path;
+    if (lane < 64 && lane < L.len) E.path_rec[(size_t)g * E.maxd + lane] = (uint32_t)L.my_path;
     if (lane == 0) {
         E.hdr[g].leaf_kind = (int8_t)L.kind;
         E.hdr[g].leaf_turn = (int8_t)L.turn;
         E.hdr[g].leaf_key = L.key;
-        E.hdr[g].leaf_sig[0] = L.sg0; E.hdr[g].leaf_sig[1] = L.sg1; E.hdr[g].leaf_sig[2] = L.sg2; E.hdr[g].leaf_sig[3] = L.sg3;
         E.hdr[g].leaf_level = (int16_t)L.level;
         E.hdr[g].path_len = L.len;
         E.hdr[g].g_select += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
@@ -893,8 +1064,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
 
 template <int J>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    extern __shared__ __align__(16) uint8_t c6_tag_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = blockIdx.x * WAVES_PER_BLOCK + wv;
     if (g >= E.G) return;
     C6Leaf<J> L;
     L.kind = E.hdr[g].leaf_kind;
@@ -902,17 +1074,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
     L.level = E.hdr[g].leaf_level;
     L.turn = E.hdr[g].leaf_turn;
     L.key = E.hdr[g].leaf_key;
-    const uint4 qv = *reinterpret_cast<const uint4 *>(E.hdr[g].leaf_sig);
-    L.sg0 = qv.x; L.sg1 = qv.y; L.sg2 = qv.z; L.sg3 = qv.w;
-    L.my_path = E.path_rec[(size_t)g * E.maxd + (lane < E.maxd ? lane : 0)];
+    L.my_path = (int)E.path_rec[(size_t)g * E.maxd + (lane < E.maxd ? lane : 0)];
     const float evalue = E.hdr[g].eval_value;
     C6GameRegs<J> R;
-    load_game_regs<J>(E, g, lane, R);      // (the root fields go unused here; one loader keeps both paths on the same code)
+    load_game_regs<J>(E, g, lane, R);      // (some root fields go unused here; one loader keeps both paths on the same code)
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int c = lane + 64 * j;
+        L.st[j] = c < E.cells ? E.leaf_board[(size_t)g * E.cellsP + c] : (int8_t)2;
+    }
     if (L.kind == C6_LEAF_NONE) return;
-    if (expand_wave<J>(E, g, lane, R, L, evalue, E.eval_prior + (size_t)g * E.cells, E.leaf_board + (size_t)g * E.cellsP)) {
+    C6Tags T;
+    tags_load(E, g, lane, c6_tag_lds + (size_t)wv * tag_row_bytes(E.H), T);
+    if (expand_wave<J>(E, g, lane, T, R, L, evalue, E.eval_prior + (size_t)g * E.cells, E.leaf_board + (size_t)g * E.cellsP)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        move_select_wave<J>(E, g, lane);
+        move_select_wave<J>(E, g, lane, T);
     }
 }
 
@@ -943,7 +1120,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_grow_fix_kernel(C6Dev
     if (g >= Nw.G) return;
     const size_t ob = (size_t)g * O.R, nb = (size_t)g * Nw.R;
     const int add = Nw.R - O.R, top = O.hdr[g].free_top;
-    for (int r = O.R + lane; r < Nw.R; r += 64) Nw.rec_level[nb + r] = -1;
+    for (int r = O.R + lane; r < Nw.R; r += 64) Nw.rec_stat[nb + r].level = -1;
     for (int i = lane; i < add; i += 64) Nw.free_stack[nb + i] = (uint16_t)(Nw.R - 1 - i);       // bottom of the stack: pops O.R, O.R+1, ... last
     for (int i = lane; i < top; i += 64) Nw.free_stack[nb + add + i] = O.free_stack[ob + i];
     __threadfence_block();
@@ -983,26 +1160,27 @@ void c6_launch_flush_errors(const C6Dev &d, hipStream_t s) {
 }
 
 static inline int wave_grid(int G) { return (G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }
+static inline size_t tag_lds(const C6Dev &d) { return (size_t)WAVES_PER_BLOCK * tag_row_bytes(d.H); }      // dynamic LDS of the kernels that hold tag rows
 
 // J = cells owned by one lane: 2 (9x9), 4 (15x15), 6 (19x19)
 #define C6_LAUNCH_J(KERNEL, d, s)                                                                                     \
     do {                                                                                                              \
         const int j_ = ((d).cells + 63) / 64;                                                                         \
-        if (j_ <= 2) hipLaunchKernelGGL((KERNEL<2>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);      \
-        else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d); \
-        else hipLaunchKernelGGL((KERNEL<6>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);             \
+        if (j_ <= 2) hipLaunchKernelGGL((KERNEL<2>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d);      \
+        else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d); \
+        else hipLaunchKernelGGL((KERNEL<6>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d);             \
     } while (0)
-#define C6_LAUNCH_JK(KERNEL, K, d, s)                                                                                    \
-    do {                                                                                                                 \
-        const int j_ = ((d).cells + 63) / 64;                                                                            \
-        if (j_ <= 2) hipLaunchKernelGGL((KERNEL<2, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);      \
-        else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d); \
-        else hipLaunchKernelGGL((KERNEL<6, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);             \
+#define C6_LAUNCH_JK(KERNEL, K, d, n, s)                                                                                       \
+    do {                                                                                                                        \
+        const int j_ = ((d).cells + 63) / 64;                                                                                   \
+        if (j_ <= 2) hipLaunchKernelGGL((KERNEL<2, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d, n);      \
+        else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d, n); \
+        else hipLaunchKernelGGL((KERNEL<6, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d, n);             \
     } while (0)
 
-void c6_launch_search(const C6Dev &d, int kind, hipStream_t s) {      // kind 1: RandomEvaluator, 2: uniform
-    if (kind == 1) C6_LAUNCH_JK(c6_search_kernel, 1, d, s);
-    else C6_LAUNCH_JK(c6_search_kernel, 2, d, s);
+void c6_launch_search(const C6Dev &d, int kind, int nsims, hipStream_t s) {      // kind 1: RandomEvaluator, 2: uniform
+    if (kind == 1) C6_LAUNCH_JK(c6_search_kernel, 1, d, nsims, s);
+    else C6_LAUNCH_JK(c6_search_kernel, 2, d, nsims, s);
 }
 void c6_launch_select(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_select_kernel, d, s); }
 void c6_launch_expand(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_expand_kernel, d, s); }
