@@ -80,7 +80,7 @@ class Profile(C.Structure):
     _fields_ = [("conv_ms", C.c_double), ("conv_launches", C.c_uint64), ("conv_flops", C.c_double), ("select_ms", C.c_double),
                 ("expand_ms", C.c_double), ("eval_other_ms", C.c_double), ("move_ms", C.c_double),
                 ("select_launches", C.c_uint64), ("expand_launches", C.c_uint64), ("conv_pre_ms", C.c_double),
-                ("conv_exec_flops", C.c_double)]
+                ("conv_exec_flops", C.c_double), ("conv_post_ms", C.c_double)]
 
 
 class RolloutInfo(C.Structure):

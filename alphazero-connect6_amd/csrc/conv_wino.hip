@@ -377,11 +377,18 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-size_t c6_conv_packed_wino_floats(int C) { return (size_t)16 * C * C; }
+// C = 256 runs the F(4x4, 3x3) form (conv_wino4.hip); C6_WINO_F2=1 keeps F(2x2) there too (A/B measurements, profiles/r02_wino_f4.txt)
+#include <cstdlib>
+static bool wino4(int C) {
+    static const bool f2 = [] { const char *e = getenv("C6_WINO_F2"); return e && e[0] == '1'; }();
+    return C == 256 && !f2;
+}
+size_t c6_conv_packed_wino_floats(int C) { return wino4(C) ? c6_conv_packed_wino4_floats(C) : (size_t)16 * C * C; }
 
 // w: folded OIHW [C][C][3][3] -> U = G g G^T (double, rounded once) packed [wave][pos = 4i + j][group u][lane][r]:
 //    U_pos[cout = 32 wave + (lane & 31)][cin = 8u + 4(lane >> 5) + r]
 void c6_pack_conv_weights_wino(int C, const float *w, float *packed) {
+    if (wino4(C)) { c6_pack_conv_weights_wino4(C, w, packed); return; }
     static const double Gm[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
     const int WAVES = C / 32, NG = C / 8;
     for (int wv = 0; wv < WAVES; wv++)
@@ -402,6 +409,7 @@ void c6_pack_conv_weights_wino(int C, const float *w, float *packed) {
 
 // floats of the transformed-input scratch for `nboards` boards
 size_t c6_conv_wino_vbuf_floats(int C, int N, int nboards) {
+    if (wino4(C)) return c6_conv_wino4_vbuf_floats(C, N, nboards);
     const long TW = (N + 1) / 2, T = TW * TW, tiles = (long)nboards * T, nblocks = (tiles + WINO_BT - 1) / WINO_BT;
     return (size_t)nblocks * (C == 256 ? (size_t)WINO_BT * 16 * C : (size_t)16 * WINO_BT * (C + 4));
 }
@@ -438,26 +446,37 @@ static void launch_wino_gemm(int nboards, const float *vbuf, const float *wp, co
 // step 1 of a layer: activations -> transformed tiles in vbuf
 bool c6_conv_wino_transform(int C, int N, int nboards, const float *in, float *vbuf, int num_cus, hipStream_t s) {
     if (nboards <= 0) return true;
+    if (wino4(C)) return c6_conv_wino4_dispatch(C, N, nboards, in, nullptr, nullptr, nullptr, nullptr, vbuf, num_cus, s, 1, 1);
 #define WINOCASE(CC, NN) if (C == CC && N == NN) { launch_wino_in<CC, NN>(nboards, in, vbuf, num_cus, s); return true; }
     WINO_ALL(WINOCASE)
 #undef WINOCASE
     return false;
 }
-// step 2: the 16 GEMMs + output transform + bias / residual / ReLU
+// step 2: the 16 GEMMs + output transform + bias / residual / ReLU (F(4x4): the 36 GEMMs, their results into vbuf's second half)
 bool c6_conv_wino_gemm(int C, int N, int nboards, const float *vbuf, const float *wp, const float *bias, const float *res, float *out, int num_cus,
                        hipStream_t s, int relu) {
     if (nboards <= 0) return true;
+    if (wino4(C)) return c6_conv_wino4_dispatch(C, N, nboards, nullptr, wp, nullptr, nullptr, nullptr, const_cast<float *>(vbuf), num_cus, s, relu, 2);
 #define WINOCASE(CC, NN) if (C == CC && N == NN) { launch_wino_gemm<CC, NN>(nboards, vbuf, wp, bias, res, out, num_cus, relu, s); return true; }
     WINO_ALL(WINOCASE)
 #undef WINOCASE
     return false;
 }
+// step 3, F(4x4) only (false: the form in use has none): output transform + bias / residual / ReLU
+bool c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *out, int num_cus, hipStream_t s, int relu) {
+    if (!wino4(C)) return false;
+    if (nboards <= 0) return true;
+    return c6_conv_wino4_dispatch(C, N, nboards, nullptr, nullptr, bias, res, out, vbuf, num_cus, s, relu, 4);
+}
 bool c6_conv_wino_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            float *vbuf, int num_cus, hipStream_t s, int relu) {
-    return c6_conv_wino_transform(C, N, nboards, in, vbuf, num_cus, s) && c6_conv_wino_gemm(C, N, nboards, vbuf, wp, bias, res, out, num_cus, s, relu);
+    if (!c6_conv_wino_transform(C, N, nboards, in, vbuf, num_cus, s) || !c6_conv_wino_gemm(C, N, nboards, vbuf, wp, bias, res, out, num_cus, s, relu)) return false;
+    c6_conv_wino_out(C, N, nboards, vbuf, bias, res, out, num_cus, s, relu);
+    return true;
 }
 // matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 16 positions x C x C MACs)
 double c6_conv_wino_exec_flops(int C, int N, int nboards) {
+    if (wino4(C)) return c6_conv_wino4_exec_flops(C, N, nboards);
     const long TW = (N + 1) / 2, tiles = (long)nboards * TW * TW, nblocks = (tiles + WINO_BT - 1) / WINO_BT;
     return 2.0 * 16.0 * (double)nblocks * WINO_BT * (double)C * C;
 }

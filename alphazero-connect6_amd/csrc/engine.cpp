@@ -18,7 +18,8 @@ struct C6NetTimers;
 C6NetTimers *c6_timers_new();
 void c6_timers_free(C6NetTimers *t);
 void c6_timers_enable(C6NetTimers *t, bool on);
-void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches, double *flops, double *pre_ms, double *exec_flops, bool reset);
+void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches, double *flops, double *pre_ms, double *exec_flops, double *post_ms,
+                       bool reset);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) {
@@ -1073,7 +1074,7 @@ extern "C" int c6_engine_profile_read(c6_engine *e, c6_profile *out, int reset) 
     HIPCHK(hipStreamSynchronize(e->stream));
     memset(out, 0, sizeof *out);
     unsigned long long n = 0;
-    c6_timers_collect(e->timers, &out->conv_ms, &n, &out->conv_flops, &out->conv_pre_ms, &out->conv_exec_flops, reset != 0);
+    c6_timers_collect(e->timers, &out->conv_ms, &n, &out->conv_flops, &out->conv_pre_ms, &out->conv_exec_flops, &out->conv_post_ms, reset != 0);
     out->conv_launches = n;
     e->t_select.collect(); e->t_expand.collect(); e->t_eval.collect(); e->t_move.collect();
     out->select_ms = e->t_select.ms; out->select_launches = e->t_select.n;

@@ -23,7 +23,8 @@ struct C6NetTimers {
     bool enabled = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv;   // one pair per conv layer (all its kernels)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pre;    // Winograd: the input-transform kernel of that layer
-    double pre_ms = 0.0, exec_flops = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> post;   // Winograd F(4x4): its output-transform kernel
+    double pre_ms = 0.0, post_ms = 0.0, exec_flops = 0.0;
     std::vector<hipEvent_t> pool;
     double conv_flops = 0.0;
     double acc_ms = 0.0;
@@ -297,6 +298,17 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                     timers->exec_flops += c6_conv_wino_exec_flops(C, net.N, nb);
                 }
                 c6_conv_wino_gemm(C, net.N, nb, vbuf, net.conv_ww + (size_t)l * c6_conv_packed_wino_floats(C), cb, cres, cout, net.num_cus, s, 1);
+                hipEvent_t eg = nullptr;
+                if (timed) { eg = timer_event(timers); hipEventRecord(eg, s); }
+                const bool has_out = c6_conv_wino_out(C, net.N, nb, vbuf, cb, cres, cout, net.num_cus, s, 1);
+                if (timed) {
+                    if (has_out) {
+                        hipEvent_t eo = timer_event(timers);
+                        hipEventRecord(eo, s);
+                        timers->post.emplace_back(eg, eo);
+                    } else
+                        timers->pool.push_back(eg);
+                }
             }
             else if (net.variant == C6_CONV_F32N)
                 c6_conv_f32n_dispatch(C, net.N, nb, cin, net.conv_w5 + (size_t)l * c6_conv_packed_f32n_floats(C), cb, cres, cout, net.num_cus, s);
@@ -341,12 +353,23 @@ void c6_timers_free(C6NetTimers *t) {
     if (!t) return;
     for (auto &p : t->conv) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : t->pre) hipEventDestroy(p.second);      // .first is shared with the layer's pair
+    for (auto &p : t->post) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto e : t->pool) hipEventDestroy(e);
     delete t;
 }
 void c6_timers_enable(C6NetTimers *t, bool on) { t->enabled = on; }
 // drains finished event pairs; returns (ms, launches, algorithmic flops) and the Winograd extras (input-transform ms, executed flops)
-void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches, double *flops, double *pre_ms, double *exec_flops, bool reset) {
+void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches, double *flops, double *pre_ms, double *exec_flops, double *post_ms,
+                       bool reset) {
+    for (auto &p : t->post) {
+        float m = 0.f;
+        hipEventSynchronize(p.second);
+        hipEventElapsedTime(&m, p.first, p.second);
+        t->post_ms += m;
+        t->pool.push_back(p.first);
+        t->pool.push_back(p.second);
+    }
+    t->post.clear();
     for (auto &p : t->pre) {      // before the layer pairs: they recycle the shared start events
         float m = 0.f;
         hipEventSynchronize(p.second);
@@ -369,8 +392,9 @@ void c6_timers_collect(C6NetTimers *t, double *ms, unsigned long long *launches,
     *launches = t->acc_n;
     *flops = t->conv_flops;
     *pre_ms = t->pre_ms;
+    *post_ms = t->post_ms;
     *exec_flops = t->exec_flops;
-    if (reset) { t->acc_ms = 0; t->acc_n = 0; t->conv_flops = 0; t->pre_ms = 0; t->exec_flops = 0; }
+    if (reset) { t->acc_ms = 0; t->acc_n = 0; t->conv_flops = 0; t->pre_ms = 0; t->post_ms = 0; t->exec_flops = 0; }
 }
 
 // range guard, second half: max |activation| of each board of a sample (one workgroup per board; see c6_engine.h)

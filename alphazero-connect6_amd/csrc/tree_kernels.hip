@@ -592,6 +592,19 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         // P + i == Q + s sees its child i's prior become prob_Q[s].  i: a stone of the mover's colour the path added to the root
         // (header comment); s: an empty cell of Q; P by key.  The tags answer "absent" for nearly all of them.
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
+        if (len == 1) {
+            // Q is a child of the root: i can only be the root's move, the P are the root's other expanded children -- its row has them
+            if (R.turn == turn) {
+                const uint2 *rc = reinterpret_cast<const uint2 *>(rootc);
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c = lane + 64 * j;
+                    if (L.st[j] != 0) continue;
+                    const uint32_t pi1 = rc[c].x & 0xffffu;
+                    if (pi1 != 0u) E.rec_prior[(rbase + (size_t)pi1 - 1) * (size_t)cells + cell0] = prob[c];
+                }
+            }
+        } else
         for (int base = 0; base < len; base += 64) {
             const int m = base + lane;
             int mcell = my_cell;

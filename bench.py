@@ -8,7 +8,7 @@ Workload at every N (weak scaling: per-GPU work fixed): BASELINE.json configs[1]
 simulations/move, random-init policy/value net with "4 blocks" = stem + 3 residual blocks, C = 256.
 
 `value` runs on the REFERENCE's arithmetic: f32 operands, f32 products, f32 accumulate (AlphaZero/cpp_weighted/model.hpp:52-95 is an f32
-net) -- `--precision fp32`, the library default: Winograd F(2x2,3x3) on the FP32 matrix cores.  The same f32 arithmetic as a direct
+net) -- `--precision fp32`, the library default: Winograd F(4x4,3x3) on the FP32 matrix cores.  The same f32 arithmetic as a direct
 convolution (`fp32_direct_path`) and the reduced-operand arithmetics (`bf16x3_path`, `f16f8_path`, `relaxed_bf16_path`) are measured in
 the same run at N = 1 and reported BESIDE it, never as `value`.
 
@@ -49,8 +49,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, description)
-    "fp32": ("c6_wino_gemm_kernel<256, 19>", "FP32 Winograd F(2x2,3x3): 16 GEMMs per 64-tile block on v_mfma_f32_32x32x2_f32 + fused output transform; "
-             "c6_wino_in_kernel (input transform, HBM bound) runs in front of it"),
+    "fp32": ("c6_wino4_gemm_kernel<19>", "FP32 Winograd F(4x4,3x3): the 36 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32; "
+             "c6_wino4_in_kernel / c6_wino4_out_kernel (input / output transform, HBM bound) run in front of and behind it"),
     "fp32_direct": ("c6_conv3x3_f32n_kernel<256, 19>", "FP32 direct implicit GEMM, v_mfma_f32_32x32x2_f32"),
     "bf16x3": ("c6_conv3x3_b3s_kernel<256, 19, true, false>", "split-bf16 implicit GEMM, v_mfma_f32_16x16x32_bf16, 3 MFMAs per product"),
     "f16f8": ("c6_conv3x3_m8_kernel<256, 19, false>", "fp16 main term + MX-fp8 cross terms, v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4"),
@@ -344,7 +344,7 @@ def main():
         return r
 
     PRECS = {"fp32": pkg.PREC_FP32, "fp32_direct": pkg.PREC_FP32_DIRECT, "bf16x3": pkg.PREC_BF16X3, "f16f8": pkg.PREC_F16F8}
-    DTYPES = {"fp32": "f32 (f32 operands, f32 products, f32 accumulate on v_mfma_f32_32x32x2_f32; Winograd F(2x2,3x3) form)",
+    DTYPES = {"fp32": "f32 (f32 operands, f32 products, f32 accumulate on v_mfma_f32_32x32x2_f32; Winograd F(4x4,3x3) form)",
               "fp32_direct": "f32 (the same arithmetic as a direct implicit GEMM)",
               "bf16x3": "bf16x3 (f32 operands split hi+mid in bf16, 3 bf16 MFMAs per product, f32 accumulate; net outputs within 1e-5)",
               "f16f8": "f16+f8 (f32 operands split hi+lo in fp16: x_hi*w_hi on fp16 MFMAs, cross terms on MX-scaled fp8 MFMAs, f32 accumulate; net outputs "
@@ -399,7 +399,7 @@ def main():
         def conv_roofline(m, name):
             prof, dt_ = m["prof"], m["dt"]
             kern, desc = KERNELS[name]
-            gemm_ms = prof["conv_ms"] - prof["conv_pre_ms"]
+            gemm_ms = prof["conv_ms"] - prof["conv_pre_ms"] - prof.get("conv_post_ms", 0.0)
             peak = PEAK_FP32_MFMA_TFLOPS if name.startswith("fp32") else PEAK_BF16_MFMA_TFLOPS
             L = max(prof["conv_launches"], 1)
             ach = prof["conv_flops"] / (gemm_ms * 1e-3) / 1e12      # algorithmic (direct-convolution) FLOPs over the dominant kernel's time
@@ -411,11 +411,18 @@ def main():
                  "executed_mfma_tflops": prof["conv_exec_flops"] / (gemm_ms * 1e-3) / 1e12, "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt_)}
             r["frac_executed"] = r["executed_mfma_tflops"] / peak
             if name == "fp32":
-                r["note"] = ("frac = ALGORITHMIC FLOP/s (2*9*C^2*N^2 per board and layer, SURVEY 8d) / dense FP32-MFMA peak; Winograd executes 2.03x fewer "
-                             "matrix FLOPs than that count, so frac can exceed 1 -- frac_executed is the matrix-pipe utilisation")
-                r["input_transform"] = {"kernel": "c6_wino_in_kernel<256, 19> (HBM bound)", "avg_launch_ms": prof["conv_pre_ms"] / L,
-                                        "algorithmic_bytes_per_launch": (n * n * wl["channels"] * 4 + 16 * ((n + 1) // 2) ** 2 * (wl["channels"] + 4) * 4) * min(G * 8, 32768),
-                                        "traffic": pmc_record("c6_wino_in_kernel").get("hbm_bytes_per_launch") if std else None}
+                r["note"] = ("frac = ALGORITHMIC FLOP/s (2*9*C^2*N^2 per board and layer, SURVEY 8d) / dense FP32-MFMA peak; Winograd F(4x4,3x3) executes 3.6x "
+                             "fewer matrix FLOPs than that count (900 products per channel pair and board instead of 3249), so frac exceeds 1 -- "
+                             "frac_executed is the matrix-pipe utilisation; the two transforms are HBM-bound kernels of their own, reported beside it")
+                nbd, Cc, tiles = min(G * 8, 32768), wl["channels"], ((n + 3) // 4) ** 2
+                r["input_transform"] = {"kernel": "c6_wino4_in_kernel<19> (HBM bound)", "avg_launch_ms": prof["conv_pre_ms"] / L,
+                                        "algorithmic_bytes_per_launch": (n * n + 36 * tiles) * Cc * 4 * nbd,
+                                        "traffic": pmc_record("c6_wino4_in_kernel").get("hbm_bytes_per_launch") if std else None}
+                r["input_transform"]["achieved_gbs"] = r["input_transform"]["algorithmic_bytes_per_launch"] / max(r["input_transform"]["avg_launch_ms"], 1e-9) / 1e6
+                r["output_transform"] = {"kernel": "c6_wino4_out_kernel<19> (HBM bound)", "avg_launch_ms": prof.get("conv_post_ms", 0.0) / L,
+                                         "algorithmic_bytes_per_launch": (36 * tiles + 1.5 * n * n) * Cc * 4 * nbd,      # M in, residual on every second layer, activations out
+                                         "traffic": pmc_record("c6_wino4_out_kernel").get("hbm_bytes_per_launch") if std else None}
+                r["output_transform"]["achieved_gbs"] = r["output_transform"]["algorithmic_bytes_per_launch"] / max(r["output_transform"]["avg_launch_ms"], 1e-9) / 1e6
                 r["conv_layer_tflops_algorithmic"] = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
             if name == "bf16x3":
                 r.update(mfma_flops_per_algorithmic_flop=3, executed_mfma_tflops=3 * ach, frac_executed=3 * ach / peak)
@@ -488,7 +495,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "c6_select_kernel + c6_expand_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_sim": bytes_sim,
                                "avg_launch_ms": tree_ms / max(prof["select_launches"], 1)}
-        out["phase_ms"] = {k: head["prof"][k] for k in ("conv_ms", "conv_pre_ms", "select_ms", "expand_ms", "eval_other_ms", "move_ms")}
+        out["phase_ms"] = {k: head["prof"][k] for k in ("conv_ms", "conv_pre_ms", "conv_post_ms", "select_ms", "expand_ms", "eval_other_ms", "move_ms")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, stones, args.cpu_seconds)
         print(json.dumps(out))

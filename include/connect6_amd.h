@@ -297,7 +297,8 @@ typedef struct c6_profile {
     double select_ms, expand_ms, eval_other_ms, move_ms;
     uint64_t select_launches, expand_launches;
     double conv_pre_ms;     /* the part of conv_ms spent in the Winograd input transform (C6_PREC_FP32), 0 otherwise */
-    double conv_exec_flops; /* matrix FLOPs those launches EXECUTED (padding rows / tiles included; Winograd: 16 C^2 per tile) */
+    double conv_exec_flops; /* matrix FLOPs those launches EXECUTED (padding rows / tiles included; Winograd: 16 or 36 C^2 per tile) */
+    double conv_post_ms;    /* the part of conv_ms spent in the Winograd F(4x4) output transform (C6_PREC_FP32 at 256 channels), 0 otherwise */
 } c6_profile;
 int c6_engine_profile_read(c6_engine *e, c6_profile *out, int reset);
 
