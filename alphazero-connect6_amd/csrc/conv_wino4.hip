@@ -7,7 +7,7 @@
 // matrix FLOPs than the direct form.  The price: a tile has 16 outputs per (tile, cout), so the output transform cannot be
 // accumulated in registers position by position as conv_wino.hip does (16 x 8192 accumulators per wave) -- the 36 products go
 // to memory and a third kernel applies A^T . A.  Three launches per layer:
-//   c6_wino4_in_kernel    activations NHWC -> V[block][tile 64][pos 36][C]      HBM bound: reads 1x, writes 36/16 x the activations
+//   c6_wino4_in_kernel    activations NHWC -> V[block][tile 64][pos 36][C]      HBM bound: reads 1x (+ patch overlap from the caches), writes 36/16 x the activations
 //   c6_wino4_gemm_kernel  M[block][tile][pos][cout] = sum_cin U_pos[cout][cin] V[block][tile][pos][cin]: conv_wino.hip's schedule
 //                         (persistent workgroups, wave w owns couts [32w, 32w+32) x 64 tiles, weights L2 -> VGPR through a ring of
 //                         8 groups, V slabs by LDS-DMA one position ahead, one barrier per position) without the accumulators: the
@@ -23,7 +23,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define W4_BT 64        // tiles per block
 #define W4_NP 36        // positions of a 6x6 patch
-#define W4_PF 7         // weight groups in flight ahead of the one being multiplied (ring of 8)
+#ifndef W4_PF
+#define W4_PF 7         // weight groups in flight ahead of the one being multiplied (ring of W4_PF + 1: 8 or 16)
+#endif
 #define W4_C 256
 
 template <int N>
@@ -45,11 +47,6 @@ struct W4Geom {
 __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __builtin_elementwise_fma(f32x4{a, a, a, a}, x, y); }
 
 // ---- input transform: B^T d B, B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] ----
-// One workgroup per board at a time; the board's rows pass through a rolling 6-row window in LDS (row y in slot (y + 1) mod 6,
-// columns x = -1 .. 4 TW with a zero halo): every activation is read from HBM once.  Per tile row the four new rows are prefetched
-// into registers while the tiles of the current row are transformed -- 64 lanes per tile, each 4 channels; a result row i of the
-// patch is formed from the window (B^T's rows have 3-4 non-zeros) and leaves as six 1-KiB runs.
-#define W4_IN_THREADS 320
 // row i of B^T applied along the first index of x[6]
 #define W4_BT_ROW(i, x0, x1, x2, x3, x4, x5)                                                          \
     ((i) == 0 ? w4_fma(4.f, x0, w4_fma(-5.f, x2, x4))                                                 \
@@ -58,96 +55,45 @@ __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __bu
    : (i) == 3 ? w4_fma(2.f, (x3) - (x1), (x4) - (x2))                                                \
    : (i) == 4 ? w4_fma(2.f, (x1) - (x3), (x4) - (x2))                                                \
               : w4_fma(4.f, x1, w4_fma(-5.f, x3, x5)))
+// One wave per tile at a time, lane = 4 channels: the 36 pixels of the patch straight from memory (1-KiB runs; the 2-pixel overlap
+// of neighbouring patches is served by the caches -- 2.25 loads per activation, 13.3 GB fetched from HBM for 12.1 GB of
+// activations), both passes in place in the 36 registers, 36 x 1 KiB stored as one run.  (A rolling 6-row window in LDS, the form
+// conv_wino.hip's F(2x2) transform takes, read every activation once and was slower: 8.0 vs 7.7 ms.)
 template <int N>
-__global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int nboards) {
+__global__ __launch_bounds__(256) void c6_wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, long total_tiles) {
     using G = W4Geom<N>;
-    constexpr int C = G::C, LPT = C / 4, TPI = W4_IN_THREADS / LPT, T = G::T, TW = G::TW, COLS = 4 * TW + 2;
-    constexpr int ROWF = COLS * C;
-    constexpr int NPF = (4 * N * LPT + W4_IN_THREADS - 1) / W4_IN_THREADS;      // prefetch items (f32x4) per thread and step
-    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C]
-    const int tid = threadIdx.x, cq = tid % LPT, tsub = tid / LPT;
+    constexpr int C = G::C, T = G::T, TW = G::TW;
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = tid; k < 6 * ROWF / 4; k += W4_IN_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
-    // item k of a load of rows y0 .. y0 + nr - 1: row y0 + k / (N LPT), pixel (k / LPT) % N, channel quad k % LPT
-    auto item_src = [&](const float *ib, int y0, int nr, int k, bool &ok) -> const float * {
-        const int r = k / (N * LPT), px = (k / LPT) % N, q = k % LPT, y = y0 + r;
-        ok = k < nr * N * LPT && y >= 0 && y < N;
-        return ib + (size_t)((ok ? y : 0) * N + px) * C + q * 4;
-    };
-    auto item_dst = [&](int y0, int k) -> float * {
-        const int r = k / (N * LPT), px = (k / LPT) % N, q = k % LPT, y = y0 + r;
-        return win + ((y + 1) % 6) * ROWF + (px + 1) * C + q * 4;
-    };
 #pragma unroll 1
-    for (int bd = blockIdx.x; bd < nboards; bd += gridDim.x) {
-        const float *ib = in + (size_t)bd * (N * N) * C;
-        __syncthreads();                                            // the previous board's last reads (and the zero fill)
-        // rows -1 .. 4 of the first tile row: -1, 0 and 1 .. 4
-#pragma unroll 1
-        for (int part = 0; part < 2; part++) {
-            const int y0 = part == 0 ? -1 : 1, nr = part == 0 ? 2 : 4;
+    for (long t = wave0; t < total_tiles; t += nwaves) {
+        const long bd = t / T;
+        const int tt = (int)(t - bd * T), ty = tt / TW, tx = tt - ty * TW;
+        const float *ib = in + (size_t)bd * (N * N) * C + lane * 4;
+        f32x4 d[6][6];
 #pragma unroll
-            for (int i = 0; i < NPF; i++) {
-                const int k = tid + i * W4_IN_THREADS;
-                bool ok;
-                const float *sp = item_src(ib, y0, nr, k, ok);
-                const f32x4 v = ok ? *reinterpret_cast<const f32x4 *>(sp) : zero4;
-                if (k < nr * N * LPT) *reinterpret_cast<f32x4 *>(item_dst(y0, k)) = v;
+        for (int a = 0; a < 6; a++) {
+            const int y = 4 * ty - 1 + a;
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const int x = 4 * tx - 1 + b;
+                const bool ok = y >= 0 && y < N && x >= 0 && x < N;
+                d[a][b] = ok ? *reinterpret_cast<const f32x4 *>(ib + (size_t)(y * N + x) * C) : zero4;
             }
         }
-#pragma unroll 1
-        for (int ty = 0; ty < TW; ty++) {
-            __syncthreads();                                        // rows 4 ty - 1 .. 4 ty + 4 are in the window
-            f32x4 pf[NPF];
-            const bool more = ty + 1 < TW;
-            if (more) {
 #pragma unroll
-                for (int i = 0; i < NPF; i++) {
-                    bool ok;
-                    const float *sp = item_src(ib, 4 * ty + 5, 4, tid + i * W4_IN_THREADS, ok);
-                    pf[i] = ok ? *reinterpret_cast<const f32x4 *>(sp) : zero4;
-                }
-            }
-#pragma unroll 1
-            for (int tx = tsub; tx < TW; tx += TPI) {
-                const long t = (long)bd * T + ty * TW + tx;
-                float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + cq * 4;
-                // window slot of patch row a (board row 4 ty - 1 + a) and the patch's first column
-                const float *wc = win + (4 * tx) * C + cq * 4;
-                int slot[6];
+        for (int b = 0; b < 6; b++) {      // B^T d: along the rows index, column by column, in place
+            const f32x4 x0 = d[0][b], x1 = d[1][b], x2 = d[2][b], x3 = d[3][b], x4 = d[4][b], x5 = d[5][b];
 #pragma unroll
-                for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
+            for (int i = 0; i < 6; i++) d[i][b] = W4_BT_ROW(i, x0, x1, x2, x3, x4, x5);
+        }
+        float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + lane * 4;
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    // w[b] = sum_a B^T[i][a] d[a][b]
-                    f32x4 w[6];
+        for (int i = 0; i < 6; i++) {      // (B^T d) B, row by row, and out
+            const f32x4 x0 = d[i][0], x1 = d[i][1], x2 = d[i][2], x3 = d[i][3], x4 = d[i][4], x5 = d[i][5];
 #pragma unroll
-                    for (int b = 0; b < 6; b++) {
-                        const float *col = wc + b * C;
-#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
-                        if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
-                        else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
-                        else {
-                            const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
-                            w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
-                        }
-#undef W4_D
-                    }
-                    float *o = vb + (size_t)(i * 6) * G::POS_STRIDE;
-#pragma unroll
-                    for (int jj = 0; jj < 6; jj++)
-                        *reinterpret_cast<f32x4 *>(o + jj * G::POS_STRIDE) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
-                    __builtin_amdgcn_sched_barrier(0);      // one patch row at a time: interleaved, the six rows' window reads spill
-                }
-            }
-            if (more) {
-                __syncthreads();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more: their slots take rows 4 ty + 5 .. 4 ty + 8
-#pragma unroll
-                for (int i = 0; i < NPF; i++) {
-                    const int k = tid + i * W4_IN_THREADS;
-                    if (k < 4 * N * LPT) *reinterpret_cast<f32x4 *>(item_dst(4 * ty + 5, k)) = pf[i];
-                }
-            }
+            for (int jj = 0; jj < 6; jj++) *reinterpret_cast<f32x4 *>(vb + (size_t)(i * 6 + jj) * G::POS_STRIDE) = W4_BT_ROW(jj, x0, x1, x2, x3, x4, x5);
         }
     }
 }
@@ -167,15 +113,30 @@ __global__ void c6_wino4_tail_kernel(float *__restrict__ V, long total_tiles) {
 // Vector-memory operations of the main loop retire IN ORDER on one counter (loads, LDS-DMAs and stores alike), so they are
 // issued by hand and every wait names exactly the operations younger than the weight group it needs (conv_wino.hip).  Schedule of
 // a position (NG = 32 groups of 8 input channels): group k < 8 issues slab DMA k of the next position behind its weight wait;
-// group 8 issues the 8 stores of the PREVIOUS position's results (kept aside in 32 registers); every group requests the weights of
-// group + 7 first.  Younger than the weights of group i when they are waited for:
+// groups 8, 10, .. 22 issue one each of the 8 stores of the PREVIOUS position's results (kept aside in 32 registers; a store is 64
+// lanes x 16 bytes to 64 different lines: all eight in one group cost 1 ms of 31; re-ordering them through LDS so that a store
+// covers 8 whole lines gained nothing more, and neither did a ring of 16 -- what remains against the kernel without its stores,
+// 2 ms, is the doubled HBM traffic itself, profiles/r02_wino_f4.txt); every group requests the weights of group + 7 first.  Younger than the weights of group i when they are waited for:
+#ifndef W4_ST_FIRST
+#define W4_ST_FIRST 8       // store k of a position goes out in group W4_ST_FIRST + W4_ST_STEP * k
+#define W4_ST_STEP 2
+#endif
+constexpr int w4_store_group(int k) { return W4_ST_FIRST + W4_ST_STEP * k; }
+constexpr int w4_store_of(int g) {      // the store issued in group g, or -1
+    for (int k = 0; k < 8; k++)
+        if (w4_store_group(k) == g) return k;
+    return -1;
+}
 constexpr int w4_wait(int i) {
     const int nd = 8;
     const int lo = i - W4_PF > 0 ? i - W4_PF : 0, hi = (nd - 1 < i - 1) ? nd - 1 : i - 1;
     const int dmas = hi >= lo ? hi - lo + 1 : 0;
-    const int stores = (i > 8 && i - W4_PF <= 8) ? 8 : 0;      // the stores went out in group 8, behind the request of group 8 + 7
+    int stores = 0;      // issued behind the weight wait of their group: before wait(i) iff group < i, younger than request(i) iff group >= i - PF
+    for (int k = 0; k < 8; k++)
+        if (w4_store_group(k) < i && w4_store_group(k) >= i - W4_PF) stores++;
     return W4_PF + dmas + stores;
 }
+static_assert(w4_store_group(7) < 32 - W4_PF, "the stores of a position are all older than the requests that are waited for in the next one");
 #define W4_ULOAD(dst, voff, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define W4_UWAIT(dst, n) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dst) : "n"(n) : "memory")
 #define W4_STORE(voff, data, base, imm) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #imm ::"v"(voff), "v"(data), "s"(base) : "memory")
@@ -187,7 +148,8 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
     constexpr int C = G::C, CP = G::CP, SLAB = G::SLAB, WAVES = G::WAVES, NG = G::NG, PF = W4_PF;
     constexpr int NGT = W4_NP * NG;                  // weight groups of a whole block
     constexpr int ND = W4_BT / WAVES;                // slab DMAs per wave and position
-    static_assert(PF == 7 && NG == 32 && ND == 8, "ring of 8 weight groups, 7 in flight; 8 DMAs and 8 stores per position");
+    static_assert((PF == 7 || PF == 15) && NG == 32 && ND == 8, "ring of 8 / 16 weight groups; 8 DMAs and 8 stores per position");
+    constexpr int RM = PF;                           // ring index mask (ring size PF + 1, a power of two)
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -209,84 +171,103 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
 
 #pragma unroll
     for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * G::BLOCK_FLOATS, 0, c0);
-    f32x4 ring[8];
+    // The FP32 matrix instructions run on the lanes of the vector ALU (their peak IS the vector FP32 peak; a kernel of plain
+    // vector instructions beside this one on another stream makes no progress at all): every vector instruction in the loop is
+    // matrix time lost.  So: the weight stream advances a SCALAR pointer (the lane offset never changes), the tile fragments
+    // alternate between two register sets instead of being copied, a position's accumulators start from the instruction's
+    // zero operand, and two accumulator sets alternate between positions -- the set of the previous position is stored while
+    // this one accumulates -- instead of being copied aside.
+    f32x4 ring[PF + 1];
+    const float *uptr = ubase;
+    int gi = 0;
+#define W4_UNEXT()                                                       \
+    {                                                                    \
+        gi += 1; uptr += 256;                                            \
+        if (gi == NGT) { gi = 0; uptr = ubase; }                         \
+    }
 #pragma unroll
-    for (int q = 0; q < PF; q++) W4_ULOAD(ring[q], lane16 + (unsigned)q * 1024u, ubase);
-    int gi = PF;
+    for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W4_UNEXT() }
 
     // results of the previous position, on their way to memory; the very first "previous position" is this block's position 0
     // itself (zeros now, overwritten by the real results one position later: same wave, same addresses, in order)
-    f32x16 s0, s1;
-#pragma unroll
-    for (int v = 0; v < 16; v++) { s0[v] = 0.f; s1[v] = 0.f; }
+    f32x16 mA0, mA1, mB0, mB1;
+    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    mB0 = z16; mB1 = z16;
     const float *sdst = Mo + (size_t)b * G::BLOCK_FLOATS;
+
+#define W4_GROUP(q, u, NWAIT, DMA, ST, BUF, ACC0, ACC1, SH0, SH1)                                                \
+            {                                                                                                    \
+                W4_ULOAD(ring[((q) + PF) & RM], lane16, uptr);                                                   \
+                W4_UNEXT()                                                                                       \
+                if ((u) + 1 < NG) {                                                                              \
+                    va[((u) + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(vb + 8 * ((u) + 1));                 \
+                    va[((u) + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP + 8 * ((u) + 1));       \
+                }                                                                                                \
+                W4_UWAIT(ring[(q)], NWAIT);                                                                      \
+                const f32x4 w = ring[(q)];                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : ACC0, 0, 0, 0); \
+                ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : ACC1, 0, 0, 0); \
+                if ((DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (BUF) ^ 1, (DMA));                                 \
+                if ((ST) >= 0) {      /* store (ST): quad (ST) & 3 of tile half (ST) >> 2 of the previous position */ \
+                    const f32x16 &sv = (ST) < 4 ? SH0 : SH1;                                                     \
+                    const f32x4 a = {sv[4 * ((ST) & 3)], sv[4 * ((ST) & 3) + 1], sv[4 * ((ST) & 3) + 2], sv[4 * ((ST) & 3) + 3]}; \
+                    if (((ST) & 3) == 0) W4_STORE((ST) < 4 ? moff0 : moff1, a, sdst, 0);                         \
+                    else if (((ST) & 3) == 1) W4_STORE((ST) < 4 ? moff0 : moff1, a, sdst, 32);                   \
+                    else if (((ST) & 3) == 2) W4_STORE((ST) < 4 ? moff0 : moff1, a, sdst, 64);                   \
+                    else W4_STORE((ST) < 4 ? moff0 : moff1, a, sdst, 96);                                        \
+                    asm volatile("s_nop 1" ::: "memory");                                                        \
+                }                                                                                                \
+                _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                  \
+                    ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], ACC0, 0, 0, 0);         \
+                    ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], ACC1, 0, 0, 0);         \
+                }                                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+            }
+#define WG_(i, BUF, A0, A1, S0, S1) W4_GROUP((i) & RM, (i), w4_wait(i), (i), w4_store_of(i), BUF, A0, A1, S0, S1)
+    // one position: slab in LDS buffer BUF (= position & 1), accumulating into ACC, storing SH (the previous position's results)
+#define W4_POSITION(pp, BUF, A0, A1, S0, S1)                                                                     \
+        {                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");      /* slab pp has landed (and older stores) */ \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            const float *nsrc;                                                                                   \
+            {                                                                                                    \
+                int nb = (pp) < W4_NP - 1 ? b : b + (int)gridDim.x;                                              \
+                nb = nb < nblocks ? nb : b;          /* no next block: copy this block's slab 0 again (never read) */ \
+                nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)((pp) < W4_NP - 1 ? (pp) + 1 : 0) * G::POS_STRIDE; \
+            }                                                                                                    \
+            const float *vb = wsm + (BUF) * SLAB + j * CP + 4 * h;                                               \
+            f32x4 va[2][2];                                                                                      \
+            va[0][0] = *reinterpret_cast<const f32x4 *>(vb);                                                     \
+            va[0][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP);                                           \
+            WG_(0, BUF, A0, A1, S0, S1) WG_(1, BUF, A0, A1, S0, S1) WG_(2, BUF, A0, A1, S0, S1) WG_(3, BUF, A0, A1, S0, S1)         \
+            WG_(4, BUF, A0, A1, S0, S1) WG_(5, BUF, A0, A1, S0, S1) WG_(6, BUF, A0, A1, S0, S1) WG_(7, BUF, A0, A1, S0, S1)         \
+            WG_(8, BUF, A0, A1, S0, S1) WG_(9, BUF, A0, A1, S0, S1) WG_(10, BUF, A0, A1, S0, S1) WG_(11, BUF, A0, A1, S0, S1)       \
+            WG_(12, BUF, A0, A1, S0, S1) WG_(13, BUF, A0, A1, S0, S1) WG_(14, BUF, A0, A1, S0, S1) WG_(15, BUF, A0, A1, S0, S1)     \
+            WG_(16, BUF, A0, A1, S0, S1) WG_(17, BUF, A0, A1, S0, S1) WG_(18, BUF, A0, A1, S0, S1) WG_(19, BUF, A0, A1, S0, S1)     \
+            WG_(20, BUF, A0, A1, S0, S1) WG_(21, BUF, A0, A1, S0, S1) WG_(22, BUF, A0, A1, S0, S1) WG_(23, BUF, A0, A1, S0, S1)     \
+            WG_(24, BUF, A0, A1, S0, S1) WG_(25, BUF, A0, A1, S0, S1) WG_(26, BUF, A0, A1, S0, S1) WG_(27, BUF, A0, A1, S0, S1)     \
+            WG_(28, BUF, A0, A1, S0, S1) WG_(29, BUF, A0, A1, S0, S1) WG_(30, BUF, A0, A1, S0, S1) WG_(31, BUF, A0, A1, S0, S1)     \
+            sdst = Mo + (size_t)b * G::BLOCK_FLOATS + (size_t)(pp) * G::POS_STRIDE;      /* where ACC goes, one position later */ \
+        }
 
 #pragma unroll 1
     for (; b < nblocks; b += gridDim.x) {
 #pragma unroll 1
-        for (int p = 0; p < W4_NP; p++) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");      // slab p has landed (and the stores of two positions ago)
-            __builtin_amdgcn_s_barrier();
-            const float *nsrc;
-            {
-                int nb = p < W4_NP - 1 ? b : b + (int)gridDim.x;
-                nb = nb < nblocks ? nb : b;          // no next block: copy this block's slab 0 again (never read)
-                nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)(p < W4_NP - 1 ? p + 1 : 0) * G::POS_STRIDE;
-            }
-            const float *vb = wsm + (p & 1) * SLAB + j * CP + 4 * h;
-            f32x16 m0, m1;
-#pragma unroll
-            for (int v = 0; v < 16; v++) { m0[v] = 0.f; m1[v] = 0.f; }
-            f32x4 va0 = *reinterpret_cast<const f32x4 *>(vb), va1 = *reinterpret_cast<const f32x4 *>(vb + 32 * CP), vn0, vn1;
-#define W4_GROUP(q, u, NWAIT, DMA, ST)                                                                           \
-            {                                                                                                    \
-                W4_ULOAD(ring[((q) + PF) & 7], lane16 + (unsigned)gi * 1024u, ubase);                            \
-                gi = gi + 1 == NGT ? 0 : gi + 1;                                                                 \
-                vn0 = *reinterpret_cast<const f32x4 *>(vb + 8 * ((u) + 1 < NG ? (u) + 1 : (u)));                 \
-                vn1 = *reinterpret_cast<const f32x4 *>(vb + 32 * CP + 8 * ((u) + 1 < NG ? (u) + 1 : (u)));       \
-                W4_UWAIT(ring[(q)], NWAIT);                                                                      \
-                const f32x4 w = ring[(q)];                                                                       \
-                __builtin_amdgcn_sched_barrier(0);                                                               \
-                m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va0[0], m0, 0, 0, 0);                            \
-                m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va1[0], m1, 0, 0, 0);                            \
-                if ((DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (p + 1) & 1, (DMA));                               \
-                if (ST) {                                                                                        \
-                    const f32x4 a0 = {s0[0], s0[1], s0[2], s0[3]}, a1 = {s0[4], s0[5], s0[6], s0[7]};            \
-                    const f32x4 a2 = {s0[8], s0[9], s0[10], s0[11]}, a3 = {s0[12], s0[13], s0[14], s0[15]};      \
-                    const f32x4 b0 = {s1[0], s1[1], s1[2], s1[3]}, b1 = {s1[4], s1[5], s1[6], s1[7]};            \
-                    const f32x4 b2 = {s1[8], s1[9], s1[10], s1[11]}, b3 = {s1[12], s1[13], s1[14], s1[15]};      \
-                    W4_STORE(moff0, a0, sdst, 0); W4_STORE(moff0, a1, sdst, 32);                                 \
-                    W4_STORE(moff0, a2, sdst, 64); W4_STORE(moff0, a3, sdst, 96);                                \
-                    W4_STORE(moff1, b0, sdst, 0); W4_STORE(moff1, b1, sdst, 32);                                 \
-                    W4_STORE(moff1, b2, sdst, 64); W4_STORE(moff1, b3, sdst, 96);                                \
-                    asm volatile("s_nop 1" ::: "memory");                                                        \
-                }                                                                                                \
-                _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                  \
-                    m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va0[r], m0, 0, 0, 0);                        \
-                    m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va1[r], m1, 0, 0, 0);                        \
-                }                                                                                                \
-                __builtin_amdgcn_sched_barrier(0);                                                               \
-                va0 = vn0; va1 = vn1;                                                                            \
-            }
-#define WG_(i) W4_GROUP((i) & 7, (i), w4_wait(i), (i), (i) == 8)
-            WG_(0) WG_(1) WG_(2) WG_(3) WG_(4) WG_(5) WG_(6) WG_(7) WG_(8) WG_(9) WG_(10) WG_(11) WG_(12) WG_(13) WG_(14) WG_(15)
-#undef WG_
-#pragma unroll 1
-            for (int u0 = 16; u0 < NG; u0 += 8) {
-                W4_GROUP(0, u0, PF, -1, false) W4_GROUP(1, u0 + 1, PF, -1, false) W4_GROUP(2, u0 + 2, PF, -1, false) W4_GROUP(3, u0 + 3, PF, -1, false)
-                W4_GROUP(4, u0 + 4, PF, -1, false) W4_GROUP(5, u0 + 5, PF, -1, false) W4_GROUP(6, u0 + 6, PF, -1, false) W4_GROUP(7, u0 + 7, PF, -1, false)
-            }
-#undef W4_GROUP
-            // this position's results aside: stored in group 8 of the next position
-            s0 = m0; s1 = m1;
-            sdst = Mo + (size_t)b * G::BLOCK_FLOATS + (size_t)p * G::POS_STRIDE;
+        for (int p = 0; p < W4_NP; p += 2) {
+            W4_POSITION(p, 0, mA0, mA1, mB0, mB1)
+            W4_POSITION(p + 1, 1, mB0, mB1, mA0, mA1)
         }
     }
-    {
-        const f32x4 a0 = {s0[0], s0[1], s0[2], s0[3]}, a1 = {s0[4], s0[5], s0[6], s0[7]};
-        const f32x4 a2 = {s0[8], s0[9], s0[10], s0[11]}, a3 = {s0[12], s0[13], s0[14], s0[15]};
-        const f32x4 b0 = {s1[0], s1[1], s1[2], s1[3]}, b1 = {s1[4], s1[5], s1[6], s1[7]};
-        const f32x4 b2 = {s1[8], s1[9], s1[10], s1[11]}, b3 = {s1[12], s1[13], s1[14], s1[15]};
+#undef W4_POSITION
+#undef WG_
+#undef W4_GROUP
+#undef W4_UNEXT
+    {      // the last position's results (an odd position: set B)
+        const f32x4 a0 = {mB0[0], mB0[1], mB0[2], mB0[3]}, a1 = {mB0[4], mB0[5], mB0[6], mB0[7]};
+        const f32x4 a2 = {mB0[8], mB0[9], mB0[10], mB0[11]}, a3 = {mB0[12], mB0[13], mB0[14], mB0[15]};
+        const f32x4 b0 = {mB1[0], mB1[1], mB1[2], mB1[3]}, b1 = {mB1[4], mB1[5], mB1[6], mB1[7]};
+        const f32x4 b2 = {mB1[8], mB1[9], mB1[10], mB1[11]}, b3 = {mB1[12], mB1[13], mB1[14], mB1[15]};
         W4_STORE(moff0, a0, sdst, 0); W4_STORE(moff0, a1, sdst, 32); W4_STORE(moff0, a2, sdst, 64); W4_STORE(moff0, a3, sdst, 96);
         W4_STORE(moff1, b0, sdst, 0); W4_STORE(moff1, b1, sdst, 32); W4_STORE(moff1, b2, sdst, 64); W4_STORE(moff1, b3, sdst, 96);
     }
@@ -388,16 +369,16 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     const int nblocks = (int)((tiles + W4_BT - 1) / W4_BT);
     float *Vb = vbuf, *Mb = vbuf + w4_half_floats(N, nboards);
     if (steps & 1) {
-        constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
-        const int grid_in = nboards < num_cus ? nboards : num_cus;
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino4_in_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)in_smem);
-        hipLaunchKernelGGL((c6_wino4_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, in, Vb, nboards);
+        const long want = (tiles + 3) / 4;
+        const int grid_in = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
+        hipLaunchKernelGGL((c6_wino4_in_kernel<N>), dim3(grid_in), dim3(256), 0, s, in, Vb, tiles);
         if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
     }
     if (steps & 2) {
         const size_t smem = G::LDS_BYTES;
         const int grid = nblocks < num_cus ? nblocks : num_cus;
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)attr_once;      // once per process: the call is not asynchronous
         hipLaunchKernelGGL((c6_wino4_gemm_kernel<N>), dim3(grid), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks);
     }
     if (steps & 4) {

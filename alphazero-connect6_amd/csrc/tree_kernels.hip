@@ -38,7 +38,7 @@
 
 #define WAVES_PER_BLOCK 4
 #ifndef C6_OCC2
-#define C6_OCC2 3      // c6_search_kernel<2, .>: at 4 blocks per SIMD it spills 19 registers and is 17 % slower (tools/ab_build_tree.sh -DC6_OCC2=4)
+#define C6_OCC2 3      // c6_search_kernel<2, .>: at 4 blocks per SIMD it spills 19 registers and is 17 % slower (tools/ab_build.sh -DC6_OCC2=4)
 #endif
 #ifndef C6_OCC4
 #define C6_OCC4 2
