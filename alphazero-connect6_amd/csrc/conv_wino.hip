@@ -1,4 +1,7 @@
-// conv_wino.hip -- FP32 3x3 convolution by Winograd F(2x2, 3x3) on the FP32 matrix cores (v_mfma_f32_32x32x2_f32).
+// conv_wino.hip -- FP32 3x3 convolution by Winograd F(2x2, 3x3) on the FP32 matrix cores (v_mfma_f32_32x32x2_f32), for towers of
+// 64 and 128 channels; 256 channels (the benchmark's tower) run the F(4x4, 3x3) form of conv_wino4.hip, to which the host
+// functions at the end of this file forward.  (F(2x2) at 256 channels, with the transformed input tile-major as in conv_wino4.hip:
+// transform 12.0 ms + GEMM 53.0 ms = 64.3 ms per 32768-board layer against 46 ms, profiles/r02_wino_f2_prof.json.)
 //
 // Same layer as c6_conv3x3_f32n_kernel (conv3x3 C -> C, pad 1, + folded-BN bias (+ residual) + ReLU;
 // AlphaZero/cpp_weighted/model.hpp:61-78), same f32 arithmetic (f32 operands, exact f32 products, f32 accumulate), 2.03x fewer
@@ -17,7 +20,7 @@
 //         Schedule = the f32n one: persistent workgroups; wave w owns output channels [32w, 32w + 32) for all 64 tiles of the
 //         block, so its transformed weights are private and stream L2 -> VGPR three 8-channel groups ahead (no weight staging
 //         in LDS); V_p (64 x (C + 4) floats) lands in LDS by LDS-DMA as a linear copy one position ahead, double-buffered;
-//         ONE barrier per position (2 x 32 MFMAs x 64 cycles per wave between barriers at C = 256).
+//         ONE barrier per position.
 //         Weights are the MFMA A operand (D = U x V): a lane's accumulators are 16-byte NHWC runs of one tile.
 // MFMA operand mapping (as in conv_f32n.hip): one ds_read_b128 gives lane (tile j, h) channels 8u + 4h .. + 3 of group u; MFMA r
 // of the group contracts the channel pair (8u + r, 8u + 4 + r); weight lane (cout i, h) holds U_p[i][8u + 4h + r].
@@ -35,15 +38,11 @@ struct WinoGeom {
     static constexpr int TW = (N + 1) / 2;          // tiles per board side
     static constexpr int T = TW * TW;               // tiles per board (100 / 64 / 25)
     static constexpr int CP = C + 4;                // padded row: conflict-free ds_read_b128 with one tile per lane
-    static constexpr int SLAB = WINO_BT * CP;       // floats of one (block, position) slab IN LDS
-    // V in memory.  C = 256 ("tile-major"): [block][tile 64][position 16][C] -- a tile's 16 positions are one 16-KiB run for the
-    // transform kernel's stores, and a (tile, position) row is exactly one 1-KiB LDS-DMA (64 per position).  Smaller C (a row is less
-    // than a DMA): [block][position 16][tile 64][C + 4], the LDS image itself, copied linearly (SLAB / 256 chunks per position).
-    static constexpr bool TM = C == 256;
-    static constexpr int NCH = TM ? WINO_BT : SLAB / 256;      // DMAs per position
-    static constexpr int POS_STRIDE = TM ? C : SLAB;           // floats between consecutive positions of one tile
-    static constexpr int TILE_STRIDE = TM ? 16 * C : CP;       // floats between consecutive tiles of one position
-    static constexpr size_t BLOCK_FLOATS = TM ? (size_t)WINO_BT * 16 * C : (size_t)16 * SLAB;
+    static constexpr int SLAB = WINO_BT * CP;       // floats of one (block, position) slab: V in memory is [block][position 16][tile 64][C + 4],
+    static constexpr int NCH = SLAB / 256;          // the LDS image itself, copied linearly in 1-KiB chunks
+    static constexpr int POS_STRIDE = SLAB;         // floats between consecutive positions of one tile
+    static constexpr int TILE_STRIDE = CP;          // floats between consecutive tiles of one position
+    static constexpr size_t BLOCK_FLOATS = (size_t)16 * SLAB;
     static constexpr int WAVES = C / 32;
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int NG = C / 8;                // 8-channel groups per position
@@ -56,7 +55,7 @@ struct WinoGeom {
 // patches (the first form of this kernel gathered the patches straight from memory: 35 GB fetched for 12 GB of activations at
 // 32 768 boards, profiles/r02_wino_prof_v1.json).  Per tile row: the two new rows are prefetched into registers while the tiles
 // of the current row are transformed (C / 4 lanes per tile, each 4 channels: B^T d B is 32 + 32 adds on f32x4) and stored --
-// 16 positions x one 1-KiB run per tile at C = 256.
+// 16 positions x one (C + 4)-float row per tile.
 #define WINO_IN_THREADS 320
 template <int C>
 struct WinoInGeom {
@@ -160,7 +159,7 @@ __global__ void c6_wino_tail_kernel(float *__restrict__ V, long total_tiles) {
     const long nblocks = (total_tiles + WINO_BT - 1) / WINO_BT;
     const int first = (int)(total_tiles - (nblocks - 1) * WINO_BT);      // valid tiles of the last block
     float *blk = V + (size_t)(nblocks - 1) * G::BLOCK_FLOATS;
-    const int row = G::TM ? C : G::CP, n = (WINO_BT - first) * 16 * row;
+    const int row = G::CP, n = (WINO_BT - first) * 16 * row;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int t = first + i / (16 * row), r = i % (16 * row), p = r / row, c = r % row;
         blk[(size_t)t * G::TILE_STRIDE + (size_t)p * G::POS_STRIDE + c] = 0.f;
@@ -207,8 +206,8 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
     auto dma_chunk = [&](const float *src, int buf, int c0) {
         int c = c0 * WAVES + wave;
         c = c < NCH ? c : NCH - 1;
-        const float *gp = src + (size_t)c * (G::TM ? G::TILE_STRIDE : 256);         // tile-major: row of tile c; else the c-th KiB of the slab
-        const int lds_off = (buf * SLAB + c * (G::TM ? CP : 256)) * 4;
+        const float *gp = src + (size_t)c * 256;
+        const int lds_off = (buf * SLAB + c * 256) * 4;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lds_off) : "memory");
     };
     auto dma_slab = [&](const float *src, int buf) {
@@ -377,12 +376,8 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_wino_gemm_kernel(const float
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-// C = 256 runs the F(4x4, 3x3) form (conv_wino4.hip); C6_WINO_F2=1 keeps F(2x2) there too (A/B measurements, profiles/r02_wino_f4.txt)
-#include <cstdlib>
-static bool wino4(int C) {
-    static const bool f2 = [] { const char *e = getenv("C6_WINO_F2"); return e && e[0] == '1'; }();
-    return C == 256 && !f2;
-}
+// C = 256 runs the F(4x4, 3x3) form (conv_wino4.hip)
+static bool wino4(int C) { return C == 256; }
 size_t c6_conv_packed_wino_floats(int C) { return wino4(C) ? c6_conv_packed_wino4_floats(C) : (size_t)16 * C * C; }
 
 // w: folded OIHW [C][C][3][3] -> U = G g G^T (double, rounded once) packed [wave][pos = 4i + j][group u][lane][r]:
@@ -411,7 +406,7 @@ void c6_pack_conv_weights_wino(int C, const float *w, float *packed) {
 size_t c6_conv_wino_vbuf_floats(int C, int N, int nboards) {
     if (wino4(C)) return c6_conv_wino4_vbuf_floats(C, N, nboards);
     const long TW = (N + 1) / 2, T = TW * TW, tiles = (long)nboards * T, nblocks = (tiles + WINO_BT - 1) / WINO_BT;
-    return (size_t)nblocks * (C == 256 ? (size_t)WINO_BT * 16 * C : (size_t)16 * WINO_BT * (C + 4));
+    return (size_t)nblocks * 16 * WINO_BT * (C + 4);
 }
 
 template <int C, int N>
@@ -442,7 +437,7 @@ static void launch_wino_gemm(int nboards, const float *vbuf, const float *wp, co
     hipLaunchKernelGGL((c6_wino_gemm_kernel<C, N>), dim3(grid), dim3(G::THREADS), smem, s, vbuf, wp, bias, res, out, tiles, nblocks, relu);
 }
 
-#define WINO_ALL(M) M(256, 19) M(256, 15) M(256, 9) M(128, 19) M(128, 15) M(128, 9) M(64, 19) M(64, 15) M(64, 9)
+#define WINO_ALL(M) M(128, 19) M(128, 15) M(128, 9) M(64, 19) M(64, 15) M(64, 9)
 // step 1 of a layer: activations -> transformed tiles in vbuf
 bool c6_conv_wino_transform(int C, int N, int nboards, const float *in, float *vbuf, int num_cus, hipStream_t s) {
     if (nboards <= 0) return true;

@@ -7,7 +7,7 @@
 // matrix FLOPs than the direct form.  The price: a tile has 16 outputs per (tile, cout), so the output transform cannot be
 // accumulated in registers position by position as conv_wino.hip does (16 x 8192 accumulators per wave) -- the 36 products go
 // to memory and a third kernel applies A^T . A.  Three launches per layer:
-//   c6_wino4_in_kernel    activations NHWC -> V[block][tile 64][pos 36][C]      HBM bound: reads 1x (+ patch overlap from the caches), writes 36/16 x the activations
+//   c6_wino4_in_kernel    activations NHWC -> V[block][tile 64][pos 36][C]      HBM bound: reads 1x, writes 36/16 x the activations
 //   c6_wino4_gemm_kernel  M[block][tile][pos][cout] = sum_cin U_pos[cout][cin] V[block][tile][pos][cin]: conv_wino.hip's schedule
 //                         (persistent workgroups, wave w owns couts [32w, 32w+32) x 64 tiles, weights L2 -> VGPR through a ring of
 //                         8 groups, V slabs by LDS-DMA one position ahead, one barrier per position) without the accumulators: the
@@ -47,6 +47,13 @@ struct W4Geom {
 __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __builtin_elementwise_fma(f32x4{a, a, a, a}, x, y); }
 
 // ---- input transform: B^T d B, B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] ----
+// One workgroup per board at a time; the board's rows pass through a rolling 6-row window in LDS (row y in slot (y + 1) mod 6,
+// columns x = -1 .. 4 TW with a zero halo): every activation is read from HBM once.  Per tile row the four new rows are prefetched
+// into registers while the tiles of the current row are transformed -- 64 lanes per tile, each 4 channels; a result row i of the
+// patch is formed from the window (B^T's rows have 3-4 non-zeros) and leaves as six 1-KiB runs.  (An LDS-free form -- a wave per tile,
+// the 36 pixels straight from memory, the patches' overlap left to the caches -- fetched 21 GB instead of 13 for the 12 GB of
+// activations and took 9.0-9.6 ms instead of 8.0 at 32 768 boards, however its tiles were dealt to the waves.)
+#define W4_IN_THREADS 320
 // row i of B^T applied along the first index of x[6]
 #define W4_BT_ROW(i, x0, x1, x2, x3, x4, x5)                                                          \
     ((i) == 0 ? w4_fma(4.f, x0, w4_fma(-5.f, x2, x4))                                                 \
@@ -55,45 +62,96 @@ __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __bu
    : (i) == 3 ? w4_fma(2.f, (x3) - (x1), (x4) - (x2))                                                \
    : (i) == 4 ? w4_fma(2.f, (x1) - (x3), (x4) - (x2))                                                \
               : w4_fma(4.f, x1, w4_fma(-5.f, x3, x5)))
-// One wave per tile at a time, lane = 4 channels: the 36 pixels of the patch straight from memory (1-KiB runs; the 2-pixel overlap
-// of neighbouring patches is served by the caches -- 2.25 loads per activation, 13.3 GB fetched from HBM for 12.1 GB of
-// activations), both passes in place in the 36 registers, 36 x 1 KiB stored as one run.  (A rolling 6-row window in LDS, the form
-// conv_wino.hip's F(2x2) transform takes, read every activation once and was slower: 8.0 vs 7.7 ms.)
 template <int N>
-__global__ __launch_bounds__(256) void c6_wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, long total_tiles) {
+__global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int nboards) {
     using G = W4Geom<N>;
-    constexpr int C = G::C, T = G::T, TW = G::TW;
-    const int lane = threadIdx.x & 63;
-    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    constexpr int C = G::C, LPT = C / 4, TPI = W4_IN_THREADS / LPT, T = G::T, TW = G::TW, COLS = 4 * TW + 2;
+    constexpr int ROWF = COLS * C;
+    constexpr int NPF = (4 * N * LPT + W4_IN_THREADS - 1) / W4_IN_THREADS;      // prefetch items (f32x4) per thread and step
+    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C]
+    const int tid = threadIdx.x, cq = tid % LPT, tsub = tid / LPT;
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = tid; k < 6 * ROWF / 4; k += W4_IN_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
+    // item k of a load of rows y0 .. y0 + nr - 1: row y0 + k / (N LPT), pixel (k / LPT) % N, channel quad k % LPT
+    auto item_src = [&](const float *ib, int y0, int nr, int k, bool &ok) -> const float * {
+        const int r = k / (N * LPT), px = (k / LPT) % N, q = k % LPT, y = y0 + r;
+        ok = k < nr * N * LPT && y >= 0 && y < N;
+        return ib + (size_t)((ok ? y : 0) * N + px) * C + q * 4;
+    };
+    auto item_dst = [&](int y0, int k) -> float * {
+        const int r = k / (N * LPT), px = (k / LPT) % N, q = k % LPT, y = y0 + r;
+        return win + ((y + 1) % 6) * ROWF + (px + 1) * C + q * 4;
+    };
 #pragma unroll 1
-    for (long t = wave0; t < total_tiles; t += nwaves) {
-        const long bd = t / T;
-        const int tt = (int)(t - bd * T), ty = tt / TW, tx = tt - ty * TW;
-        const float *ib = in + (size_t)bd * (N * N) * C + lane * 4;
-        f32x4 d[6][6];
+    for (int bd = blockIdx.x; bd < nboards; bd += gridDim.x) {
+        const float *ib = in + (size_t)bd * (N * N) * C;
+        __syncthreads();                                            // the previous board's last reads (and the zero fill)
+        // rows -1 .. 4 of the first tile row: -1, 0 and 1 .. 4
+#pragma unroll 1
+        for (int part = 0; part < 2; part++) {
+            const int y0 = part == 0 ? -1 : 1, nr = part == 0 ? 2 : 4;
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-            const int y = 4 * ty - 1 + a;
-#pragma unroll
-            for (int b = 0; b < 6; b++) {
-                const int x = 4 * tx - 1 + b;
-                const bool ok = y >= 0 && y < N && x >= 0 && x < N;
-                d[a][b] = ok ? *reinterpret_cast<const f32x4 *>(ib + (size_t)(y * N + x) * C) : zero4;
+            for (int i = 0; i < NPF; i++) {
+                const int k = tid + i * W4_IN_THREADS;
+                bool ok;
+                const float *sp = item_src(ib, y0, nr, k, ok);
+                const f32x4 v = ok ? *reinterpret_cast<const f32x4 *>(sp) : zero4;
+                if (k < nr * N * LPT) *reinterpret_cast<f32x4 *>(item_dst(y0, k)) = v;
             }
         }
+#pragma unroll 1
+        for (int ty = 0; ty < TW; ty++) {
+            __syncthreads();                                        // rows 4 ty - 1 .. 4 ty + 4 are in the window
+            f32x4 pf[NPF];
+            const bool more = ty + 1 < TW;
+            if (more) {
 #pragma unroll
-        for (int b = 0; b < 6; b++) {      // B^T d: along the rows index, column by column, in place
-            const f32x4 x0 = d[0][b], x1 = d[1][b], x2 = d[2][b], x3 = d[3][b], x4 = d[4][b], x5 = d[5][b];
+                for (int i = 0; i < NPF; i++) {
+                    bool ok;
+                    const float *sp = item_src(ib, 4 * ty + 5, 4, tid + i * W4_IN_THREADS, ok);
+                    pf[i] = ok ? *reinterpret_cast<const f32x4 *>(sp) : zero4;
+                }
+            }
+#pragma unroll 1
+            for (int tx = tsub; tx < TW; tx += TPI) {
+                const long t = (long)bd * T + ty * TW + tx;
+                float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + cq * 4;
+                // window slot of patch row a (board row 4 ty - 1 + a) and the patch's first column
+                const float *wc = win + (4 * tx) * C + cq * 4;
+                int slot[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) d[i][b] = W4_BT_ROW(i, x0, x1, x2, x3, x4, x5);
-        }
-        float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + lane * 4;
+                for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {      // (B^T d) B, row by row, and out
-            const f32x4 x0 = d[i][0], x1 = d[i][1], x2 = d[i][2], x3 = d[i][3], x4 = d[i][4], x5 = d[i][5];
+                for (int i = 0; i < 6; i++) {
+                    // w[b] = sum_a B^T[i][a] d[a][b]
+                    f32x4 w[6];
 #pragma unroll
-            for (int jj = 0; jj < 6; jj++) *reinterpret_cast<f32x4 *>(vb + (size_t)(i * 6 + jj) * G::POS_STRIDE) = W4_BT_ROW(jj, x0, x1, x2, x3, x4, x5);
+                    for (int b = 0; b < 6; b++) {
+                        const float *col = wc + b * C;
+#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
+                        if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
+                        else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
+                        else {
+                            const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
+                            w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
+                        }
+#undef W4_D
+                    }
+                    float *o = vb + (size_t)(i * 6) * G::POS_STRIDE;
+#pragma unroll
+                    for (int jj = 0; jj < 6; jj++)
+                        *reinterpret_cast<f32x4 *>(o + jj * G::POS_STRIDE) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
+                    __builtin_amdgcn_sched_barrier(0);      // one patch row at a time: interleaved, the six rows' window reads spill
+                }
+            }
+            if (more) {
+                __syncthreads();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more: their slots take rows 4 ty + 5 .. 4 ty + 8
+#pragma unroll
+                for (int i = 0; i < NPF; i++) {
+                    const int k = tid + i * W4_IN_THREADS;
+                    if (k < 4 * N * LPT) *reinterpret_cast<f32x4 *>(item_dst(4 * ty + 5, k)) = pf[i];
+                }
+            }
         }
     }
 }
@@ -369,9 +427,11 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     const int nblocks = (int)((tiles + W4_BT - 1) / W4_BT);
     float *Vb = vbuf, *Mb = vbuf + w4_half_floats(N, nboards);
     if (steps & 1) {
-        const long want = (tiles + 3) / 4;
-        const int grid_in = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
-        hipLaunchKernelGGL((c6_wino4_in_kernel<N>), dim3(grid_in), dim3(256), 0, s, in, Vb, tiles);
+        constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
+        const int grid_in = nboards < num_cus ? nboards : num_cus;
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino4_in_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)in_smem);
+        (void)attr_once;
+        hipLaunchKernelGGL((c6_wino4_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, in, Vb, nboards);
         if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
     }
     if (steps & 2) {
