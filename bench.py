@@ -376,8 +376,14 @@ def main():
         else:
             stones, stones_src = wl["stones_prior"], "PRIOR (SURVEY 8d: uniform-random play), no measurement available in this run"
     else:
-        stones = head["stones_in_window"] / max(head["games_in_window"], 1) if head["games_in_window"] else wl["stones_prior"]
-        stones_src = "counted in the timed window" if head["games_in_window"] else "PRIOR: no game finished in the window"
+        # tree-only workload: complete games are cheap -- play a batch to the end (no recycling: every game counts, short and long alike).
+        # The ratio stones / finished games inside a timed window is NOT the game length while the games' phases are still correlated
+        # (all slots started together: 45 in a window one game length after the start, against 65.5 for complete games)
+        live = stones_probe(pkg, wl, min(G, 8192), S, 0, device=local_rank) if rank == 0 or world == 1 else None
+        if live:
+            stones, stones_src = live["stones_per_game"], f"measured in this run: {live['games']} complete games on the engine (same evaluator, same noise), mean length"
+        else:
+            stones, stones_src = wl["stones_prior"], "PRIOR (other ranks use rank 0's line)"
 
     # ---- steady state of the tree kernels at this workload's geometry (N = 1) ---------------------------------------------
     tree_steady = None
@@ -460,9 +466,10 @@ def main():
                        "exchanges": head["exchanges"], "payload_gathers": head["payload_gathers"]},
         }
         if not is_net and head["games_in_window"]:
-            out["value"] = head["games_in_window"] * world / head["dt"] if world == 1 else games_s
-            out["games_per_s_counted"] = head["games_in_window"] / head["dt"]
-            out["games_per_s_from_sims"] = games_s
+            # `value` = simulations/s / (S * mean length of complete games).  The completions counted in the window are reported
+            # beside it: they converge to `value` only once the slots' game phases have decorrelated (many game lengths)
+            out["games_per_s_counted_in_window"] = head["games_in_window"] / head["dt"]
+            out["stones_per_finished_game_in_window"] = head["stones_in_window"] / head["games_in_window"]
         if live:
             out["config"]["stones_per_game_live_probe"] = live
         if is_net and head["prof"]["conv_launches"]:
@@ -492,9 +499,13 @@ def main():
             tree_ms = prof["select_ms"] + prof["expand_ms"]
             bytes_sim = (12.0 * d + 13.0) * n * n
             ach = bytes_sim * G * args.steps / max(tree_ms * 1e-3, 1e-9) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "c6_select_kernel + c6_expand_kernel", "achieved": ach, "peak": PEAK_HBM_GBS,
+            out["roofline"] = {"bound": "hbm", "kernel": "c6_search_kernel<2, 2> (a whole round -- search, and the move when its budget is spent -- per game and wave; "
+                                                          "up to 16 rounds of every game per launch)", "achieved": ach, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_sim": bytes_sim,
-                               "avg_launch_ms": tree_ms / max(prof["select_launches"], 1)}
+                               "avg_launch_ms": tree_ms / max(prof["select_launches"], 1), "rounds_per_launch": args.steps / max(prof["select_launches"], 1),
+                               "note": "algorithmic bytes (SURVEY 8d: (12 d + 13) N^2 per simulation) over the kernel's time; the kernel is bound by the vector "
+                                       "ALU (the Gamma sampler of the Dirichlet noise is half of it) and by small HBM transactions, not by streaming bandwidth: "
+                                       "profiles/r02_tree_ablation.txt"}
         out["phase_ms"] = {k: head["prof"][k] for k in ("conv_ms", "conv_pre_ms", "conv_post_ms", "select_ms", "expand_ms", "eval_other_ms", "move_ms")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, stones, args.cpu_seconds)

@@ -54,6 +54,9 @@ t0 = time.time()
 th = [threading.Thread(target=worker) for _ in range(cores)]
 for t in th:
     t.start()
+while any(t.is_alive() for t in th):      # a heartbeat: a job that prints nothing for minutes is taken to be hung
+    time.sleep(30)
+    print(f"[cpu_baseline_full] {time.time() - t0:.0f} s: {sum(played)} of {ngames * moves} moves played", file=sys.stderr, flush=True)
 for t in th:
     t.join()
 dt = time.time() - t0
