@@ -379,11 +379,11 @@ def main():
         # tree-only workload: complete games are cheap -- play a batch to the end (no recycling: every game counts, short and long alike).
         # The ratio stones / finished games inside a timed window is NOT the game length while the games' phases are still correlated
         # (all slots started together: 45 in a window one game length after the start, against 65.5 for complete games)
-        live = stones_probe(pkg, wl, min(G, 8192), S, 0, device=local_rank) if rank == 0 or world == 1 else None
+        live = stones_probe(pkg, wl, min(G, 8192), S, 0, device=local_rank) if (rank == 0 or world == 1) and not args.no_probe else None
         if live:
             stones, stones_src = live["stones_per_game"], f"measured in this run: {live['games']} complete games on the engine (same evaluator, same noise), mean length"
         else:
-            stones, stones_src = wl["stones_prior"], "PRIOR (other ranks use rank 0's line)"
+            stones, stones_src = wl["stones_prior"], "PRIOR (--no-probe, or a rank other than 0)"
 
     # ---- steady state of the tree kernels at this workload's geometry (N = 1) ---------------------------------------------
     tree_steady = None
