@@ -24,7 +24,7 @@ BLACK, NONE, WHITE = -1, 0, 1
 EVAL_RANDOM, EVAL_UNIFORM, EVAL_NET, EVAL_CALLBACK = 1, 2, 3, 4
 OK, ERR_NO_GPU, ERR_BAD_ARG, ERR_OVERFLOW, ERR_HIP, ERR_INVALID_POSITION, ERR_ALREADY_SET = range(7)
 # arithmetic of the 3x3 convolutions (include/connect6_amd.h C6_PREC_*).  DEFAULT = FP32: f32 like the reference net, evaluated as
-# Winograd F(2x2,3x3) on the FP32 matrix cores; FP32_DIRECT: the same arithmetic as a direct implicit GEMM
+# Winograd F(4x4,3x3) (256 channels) / F(2x2,3x3) (64, 128) on the FP32 matrix cores; FP32_DIRECT: the same arithmetic as a direct implicit GEMM
 PREC_DEFAULT, PREC_FP32, PREC_BF16X3, PREC_BF16 = 0, 1, 3, 4      # PREC_BF16: relaxed tolerance (~1e-3), not parity grade
 PREC_F16F8 = 5      # opt-in: fp16 main term + MX-fp8 cross terms, bounded range (guarded: C6_ERR_RANGE)
 PREC_FP32_DIRECT = 6

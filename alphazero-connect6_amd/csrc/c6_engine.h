@@ -166,7 +166,7 @@ enum {
     C6_CONV_B3S = 7,    // c6_conv3x3_b3s_kernel: split bf16 (3 bf16 MFMAs per product), C6_PREC_BF16X3
     C6_CONV_BF16 = 8,   // the same kernel with plain bf16 products: relaxed tolerance, C6_PREC_BF16
     C6_CONV_M8 = 9,     // c6_conv3x3_m8_kernel: fp16 main term + MX-fp8 cross terms, C6_PREC_F16F8
-    C6_CONV_WINO = 10   // c6_wino_in_kernel + c6_wino_gemm_kernel: FP32 Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, C6_PREC_FP32 (default)
+    C6_CONV_WINO = 10   // FP32 Winograd on v_mfma_f32_32x32x2_f32, C6_PREC_FP32 (default): c6_wino4_* (F(4x4,3x3), C = 256), c6_wino_* (F(2x2,3x3), C < 256)
 };
 struct C6NetDev {
     int N, cells, C, blocks;
@@ -207,7 +207,7 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                         float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers);
 void c6_conv_bench_launch(int variant, int C, int N, int nboards, const float *in, const float *w, const float *bias, const float *res,
                           float *out, float *vbuf, int num_cus, hipStream_t s);
-// FP32 Winograd F(2x2,3x3) (conv_wino.hip)
+// FP32 Winograd (conv_wino.hip: F(2x2,3x3) and the dispatch by channel count)
 size_t c6_conv_packed_wino_floats(int C);
 void c6_pack_conv_weights_wino(int C, const float *w_oihw_folded, float *packed);
 size_t c6_conv_wino_vbuf_floats(int C, int N, int nboards);

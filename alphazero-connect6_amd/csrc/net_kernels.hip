@@ -6,7 +6,7 @@
 //   conv1x1 C->1, BatchNorm over the N^2 features, ReLU, Linear(N^2->256), ReLU, Linear(256->1), tanh
 //   (:86-92).  BatchNorm is eval-mode and folded into the preceding convolution on the host.
 //
-// The 3x3 convolutions are >99.9 % of the FLOPs; their kernels live in conv_wino.hip (FP32 Winograd F(2x2,3x3), the default),
+// The 3x3 convolutions are >99.9 % of the FLOPs; their kernels live in conv_wino4.hip / conv_wino.hip (FP32 Winograd F(4x4,3x3) at 256 channels / F(2x2,3x3) below: the default),
 // conv_f32n.hip (FP32 direct), conv_bf16x3.hip (split bf16) and conv_m8.hip (fp16 + MX-fp8).  This file holds the stem, the
 // heads and the forward driver.  Activations are NHWC ([board][pixel][C]).
 #include <cstdlib>
