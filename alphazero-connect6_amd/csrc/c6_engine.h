@@ -217,13 +217,23 @@ bool c6_conv_wino_transform(int C, int N, int nboards, const float *in, float *v
 bool c6_conv_wino_gemm(int C, int N, int nboards, const float *vbuf, const float *wp, const float *bias, const float *res, float *out, int num_cus,
                        hipStream_t s, int relu = 1);
 double c6_conv_wino_exec_flops(int C, int N, int nboards);
-bool c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *out, int num_cus, hipStream_t s, int relu = 1);
+// the heads' 1x1 filters applied by the tower's last output transform (conv_wino4.hip): w = [3][C] (policy rows 0-1, value), outputs ph / vh
+// as c6_head_conv_kernel writes them; the layer's activations are then not stored
+struct C6HeadFuse {
+    const float *w, *pc_b;
+    float vc_b;
+    const float *vn_scale, *vn_shift;
+    float *ph, *vh;
+};
+// returns 0: this form has no separate output transform; 1: done; 2: done and the heads' filters applied (heads != nullptr, F(4x4) only)
+int c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *out, int num_cus, hipStream_t s, int relu = 1,
+                     const C6HeadFuse *heads = nullptr);
 // FP32 Winograd F(4x4,3x3), C = 256 (conv_wino4.hip): what the functions above run at C = 256
 size_t c6_conv_packed_wino4_floats(int C);
 void c6_pack_conv_weights_wino4(int C, const float *w_oihw_folded, float *packed);
 size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards);
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps);
+                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads = nullptr);
 double c6_conv_wino4_exec_flops(int C, int N, int nboards);
 // FP32 direct (conv_f32n.hip)
 size_t c6_conv_packed_f32n_floats(int C);

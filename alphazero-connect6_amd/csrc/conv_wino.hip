@@ -457,11 +457,12 @@ bool c6_conv_wino_gemm(int C, int N, int nboards, const float *vbuf, const float
 #undef WINOCASE
     return false;
 }
-// step 3, F(4x4) only (false: the form in use has none): output transform + bias / residual / ReLU
-bool c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *out, int num_cus, hipStream_t s, int relu) {
-    if (!wino4(C)) return false;
-    if (nboards <= 0) return true;
-    return c6_conv_wino4_dispatch(C, N, nboards, nullptr, nullptr, bias, res, out, vbuf, num_cus, s, relu, 4);
+// step 3, F(4x4) only (0: the form in use has none): output transform + bias / residual / ReLU (2: and the heads' 1x1 filters)
+int c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *out, int num_cus, hipStream_t s, int relu,
+                     const C6HeadFuse *heads) {
+    if (!wino4(C)) return 0;
+    if (nboards > 0) c6_conv_wino4_dispatch(C, N, nboards, nullptr, nullptr, bias, res, out, vbuf, num_cus, s, relu, 4, heads);
+    return heads ? 2 : 1;
 }
 bool c6_conv_wino_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            float *vbuf, int num_cus, hipStream_t s, int relu) {

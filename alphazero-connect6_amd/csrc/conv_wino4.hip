@@ -334,16 +334,34 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
 
 // ---- output transform: A^T M A, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1], + bias (+ residual), ReLU ----
 // One wave per tile at a time, lane = 4 channels: the tile's 36 x 1 KiB of M are one contiguous run; the 4x4 pixels leave as
-// 1-KiB NHWC runs (pixels beyond the board edge are dropped).
-template <int N>
+// 1-KiB NHWC runs (pixels beyond the board edge are dropped).  HEADS (the tower's last layer): the activations are consumed here --
+// the heads' three 1x1 filters (policy conv C -> 2 + folded BN + ReLU, value conv C -> 1 + BatchNorm1d over cells + ReLU;
+// model.hpp:80-92, c6_head_conv_kernel) are applied to every pixel (a wave sum per filter) and nothing else is written: 12 GB of
+// activations neither stored nor read back.
+__device__ __forceinline__ float w4_wave_sum(float v) {
+    v += c6_dpp_f32<C6_DPP_XOR1>(v);
+    v += c6_dpp_f32<C6_DPP_XOR2>(v);
+    v += c6_dpp_f32<C6_DPP_HALF_MIRROR>(v);
+    v += c6_dpp_f32<C6_DPP_MIRROR>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+template <int N, bool HEADS>
 __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
-                                                           float *__restrict__ out, long total_tiles, int relu) {
+                                                           float *__restrict__ out, long total_tiles, int relu, C6HeadFuse hd) {
     using G = W4Geom<N>;
     constexpr int C = G::C, T = G::T, TW = G::TW;
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
     const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float floor_ = relu ? 0.f : -INFINITY;
+    f32x4 hw0 = bi, hw1 = bi, hw2 = bi;
+    if (HEADS) {
+        hw0 = *reinterpret_cast<const f32x4 *>(hd.w + lane * 4);
+        hw1 = *reinterpret_cast<const f32x4 *>(hd.w + C + lane * 4);
+        hw2 = *reinterpret_cast<const f32x4 *>(hd.w + 2 * C + lane * 4);
+    }
 #pragma unroll 1
     for (long t = wave0; t < total_tiles; t += nwaves) {
         const float *mb = M + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + lane * 4;
@@ -362,6 +380,11 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
             tc[2][jj] = w4_fma(4.f, s34, s12);
             tc[3][jj] = w4_fma(8.f, d34, d12) + m[5];
         }
+        float hs[4][4][3];      // HEADS: this lane's share of the three filters' sums at the tile's 16 pixels
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) { hs[a][bb][0] = 0.f; hs[a][bb][1] = 0.f; hs[a][bb][2] = 0.f; }
 #pragma unroll
         for (int a = 0; a < 4; a++) {
             const int py = 4 * ty + a;
@@ -376,12 +399,47 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
             for (int bb = 0; bb < 4; bb++) {
                 const int px = 4 * tx + bb;
                 if (px >= N) continue;
-                const size_t o = ((size_t)bd * (N * N) + (size_t)(py * N + px)) * C + lane * 4;
+                const int p = py * N + px;
+                const size_t o = ((size_t)bd * (N * N) + (size_t)p) * C + lane * 4;
                 f32x4 v = y[bb] + bi;
                 if (res) v = v + *reinterpret_cast<const f32x4 *>(res + o);
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = v[r] > floor_ ? v[r] : floor_;
-                *reinterpret_cast<f32x4 *>(out + o) = v;
+                if (!HEADS) {
+                    *reinterpret_cast<f32x4 *>(out + o) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        hs[a][bb][0] = __builtin_fmaf(v[r], hw0[r], hs[a][bb][0]);
+                        hs[a][bb][1] = __builtin_fmaf(v[r], hw1[r], hs[a][bb][1]);
+                        hs[a][bb][2] = __builtin_fmaf(v[r], hw2[r], hs[a][bb][2]);
+                    }
+                }
+            }
+        }
+        if (HEADS) {
+            // 48 independent wave sums (16 pixels x 3 filters), issued together so that their dependent steps interleave
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++)
+#pragma unroll
+                    for (int f = 0; f < 3; f++) hs[a][bb][f] = w4_wave_sum(hs[a][bb][f]);
+            // every lane has all 48 sums: lane l < 16 writes pixel l of the tile (three 16-lane stores instead of 48 one-lane ones)
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++)
+                    if (lane == a * 4 + bb) { m0 = hs[a][bb][0]; m1 = hs[a][bb][1]; m2 = hs[a][bb][2]; }
+            const int py = 4 * ty + (lane >> 2), px = 4 * tx + (lane & 3);
+            if (lane < 16 && py < N && px < N) {
+                const int p = py * N + px;
+                const float y0 = m0 + hd.pc_b[0], y1 = m1 + hd.pc_b[1];
+                hd.ph[(size_t)bd * (2 * N * N) + p] = y0 > 0.f ? y0 : 0.f;             // flatten is channel-major (NCHW view)
+                hd.ph[(size_t)bd * (2 * N * N) + N * N + p] = y1 > 0.f ? y1 : 0.f;
+                const float vv = (m2 + hd.vc_b) * hd.vn_scale[p] + hd.vn_shift[p];
+                hd.vh[(size_t)bd * (N * N) + p] = vv > 0.f ? vv : 0.f;
             }
         }
     }
@@ -421,7 +479,7 @@ size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards) { return C == W4_C ?
 
 template <int N>
 static void launch_w4(int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out, float *vbuf, int num_cus,
-                      int relu, int steps, hipStream_t s) {
+                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads) {
     using G = W4Geom<N>;
     const long tiles = (long)nboards * G::T;
     const int nblocks = (int)((tiles + W4_BT - 1) / W4_BT);
@@ -444,18 +502,19 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     if (steps & 4) {
         const long want = (tiles + 3) / 4;
         const int grid_out = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
-        hipLaunchKernelGGL((c6_wino4_out_kernel<N>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu);
+        if (heads) hipLaunchKernelGGL((c6_wino4_out_kernel<N, true>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, *heads);
+        else hipLaunchKernelGGL((c6_wino4_out_kernel<N, false>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, C6HeadFuse{});
     }
 }
 
 // steps: bit 0 input transform, bit 1 GEMMs, bit 2 output transform (7 = the layer)
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps) {
+                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads) {
     if (C != W4_C) return false;
     if (nboards <= 0) return true;
-    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s); return true; }
-    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s); return true; }
-    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s); return true; }
+    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads); return true; }
+    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads); return true; }
+    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads); return true; }
     return false;
 }
 // matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 positions x C x C MACs)

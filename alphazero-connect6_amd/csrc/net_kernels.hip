@@ -280,7 +280,7 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
     float *x = act0, *y = act1, *z = act2;
     const bool timed = timers && timers->enabled;
     static const bool fuse_heads = [] { const char *e = getenv("C6_HEAD_FUSE"); return !(e && e[0] == '0'); }();   // A/B switch
-    bool head_fused = false;
+    bool head_fused = false, heads_done = false;
     for (int i = 0; i < net.blocks - 1; i++) {     // res_block, model.hpp:61-78
         for (int half = 0; half < 2; half++) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -300,7 +300,12 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                 c6_conv_wino_gemm(C, net.N, nb, vbuf, net.conv_ww + (size_t)l * c6_conv_packed_wino_floats(C), cb, cres, cout, net.num_cus, s, 1);
                 hipEvent_t eg = nullptr;
                 if (timed) { eg = timer_event(timers); hipEventRecord(eg, s); }
-                const bool has_out = c6_conv_wino_out(C, net.N, nb, vbuf, cb, cres, cout, net.num_cus, s, 1);
+                // the tower's last output transform applies the heads' 1x1 filters itself (F(4x4) form) and stores no activations
+                const bool last = l == 2 * (net.blocks - 1) - 1;
+                const C6HeadFuse hf{net.head_w, net.pc_b, net.vc_b, net.vn_scale, net.vn_shift, ph, vh};
+                const int out_rc = c6_conv_wino_out(C, net.N, nb, vbuf, cb, cres, cout, net.num_cus, s, 1, last && fuse_heads ? &hf : nullptr);
+                const bool has_out = out_rc != 0;
+                if (out_rc == 2) heads_done = true;
                 if (timed) {
                     if (has_out) {
                         hipEvent_t eo = timer_event(timers);
@@ -333,7 +338,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
         }
         float *t = x; x = z; z = t;
     }
-    if (head_fused)
+    if (heads_done) {
+    } else if (head_fused)
         hipLaunchKernelGGL(c6_head_reduce_kernel, dim3((unsigned)(((size_t)nb * cells + 255) / 256)), dim3(256), 0, s, x, net.pc_b, net.vc_b,
                            net.vn_scale, net.vn_shift, ph, vh, net.N, C / 32, c6_conv_b3s_head_rows(net.N), nb);
     else
