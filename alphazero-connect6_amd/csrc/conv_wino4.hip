@@ -52,7 +52,8 @@ __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __bu
 // into registers while the tiles of the current row are transformed -- 64 lanes per tile, each 4 channels; a result row i of the
 // patch is formed from the window (B^T's rows have 3-4 non-zeros) and leaves as six 1-KiB runs.  (An LDS-free form -- a wave per tile,
 // the 36 pixels straight from memory, the patches' overlap left to the caches -- fetched 21 GB instead of 13 for the 12 GB of
-// activations and took 9.0-9.6 ms instead of 8.0 at 32 768 boards, however its tiles were dealt to the waves.)
+// activations and took 8.9-9.6 ms instead of 8.0 at 32 768 boards, however its tiles were dealt to the waves: a tile per wave from a
+// global queue, a tile row of a board per workgroup, a whole board per workgroup.)
 #define W4_IN_THREADS 320
 // row i of B^T applied along the first index of x[6]
 #define W4_BT_ROW(i, x0, x1, x2, x3, x4, x5)                                                          \
