@@ -228,6 +228,7 @@ struct C6HeadFuse {
 // returns 0: this form has no separate output transform; 1: done; 2: done and the heads' filters applied (heads != nullptr, F(4x4) only)
 int c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *out, int num_cus, hipStream_t s, int relu = 1,
                      const C6HeadFuse *heads = nullptr);
+bool c6_conv_wino_mid(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *act, int num_cus, hipStream_t s);
 // FP32 Winograd F(4x4,3x3), C = 256 (conv_wino4.hip): what the functions above run at C = 256
 size_t c6_conv_packed_wino4_floats(int C);
 void c6_pack_conv_weights_wino4(int C, const float *w_oihw_folded, float *packed);

@@ -464,6 +464,13 @@ int c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, 
     if (nboards > 0) c6_conv_wino4_dispatch(C, N, nboards, nullptr, nullptr, bias, res, out, vbuf, num_cus, s, relu, 4, heads);
     return heads ? 2 : 1;
 }
+// F(4x4) only: the output transform of a layer + the input transform of the layer that reads it, as one kernel; the activations between
+// them are stored only if `act` is given (a block's output, the next block's residual); false: not available for this shape
+bool c6_conv_wino_mid(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *act, int num_cus, hipStream_t s) {
+    if (!wino4(C)) return false;
+    if (nboards <= 0) return true;
+    return c6_conv_wino4_dispatch(C, N, nboards, nullptr, nullptr, bias, res, act, vbuf, num_cus, s, 1, 16);
+}
 bool c6_conv_wino_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            float *vbuf, int num_cus, hipStream_t s, int relu) {
     if (!c6_conv_wino_transform(C, N, nboards, in, vbuf, num_cus, s) || !c6_conv_wino_gemm(C, N, nboards, vbuf, wp, bias, res, out, num_cus, s, relu)) return false;

@@ -446,6 +446,117 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
     }
 }
 
+// ---- output transform of one layer + input transform of the next, in one pass ------------------------------------------
+// Between the two convolutions of a residual block the activations have one reader: written by the first layer's output transform
+// (12 GB per 32 768 boards) only to be read back by the second layer's input transform.  This kernel goes from M of layer l to V of
+// layer l + 1 with the activations passing through LDS: one workgroup per board at a time, wave = tile column, lane = 4 channels.
+// Step t: (a) the wave turns its tile (t, tx) of M into 4x4 pixels (A^T M A + bias, ReLU) and puts the FIRST of their rows, board
+// row 4t, into the rolling 6-row window of c6_wino4_in_kernel; (b) the window now holds rows 4t - 5 .. 4t: the patch rows of tile
+// row t - 1, whose B^T d B goes out as the next layer's V; (c) pixel rows 4t + 1 .. 4t + 3, kept in registers meanwhile, take the
+// slots of the rows (b) read last.  HBM: M in, V out -- 60 GB instead of 84 for the pair of kernels it replaces.
+template <int N>
+__global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const float *__restrict__ M, const float *__restrict__ bias,
+                                                                          const float *__restrict__ res, float *__restrict__ act,
+                                                                          float *__restrict__ V, int nboards) {
+    using G = W4Geom<N>;
+    constexpr int C = G::C, T = G::T, TW = G::TW, COLS = 4 * TW + 2, ROWF = COLS * C, NT = 64 * TW;
+    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C]
+    const int tid = threadIdx.x, lane = tid & 63, tx = tid >> 6;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + lane * 4) : zero4;
+    for (int k = tid; k < 6 * ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
+    float *wpix = win + (4 * tx + 1) * C + lane * 4;       // window column of this wave's first pixel column (board column 4 tx)
+#pragma unroll 1
+    for (int bd = blockIdx.x; bd < nboards; bd += gridDim.x) {
+        __syncthreads();                                    // the previous board's last window reads (and the zero fill)
+        for (int k = tid; k < ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // slot 0 = board row -1
+#pragma unroll 1
+        for (int t = 0; t <= TW; t++) {
+            f32x4 keep[3][4];
+            if (t < TW) {
+                const long tt = (long)bd * T + t * TW + tx;
+                const float *mb = M + (size_t)(tt / W4_BT) * G::BLOCK_FLOATS + (size_t)(tt % W4_BT) * G::TILE_STRIDE + lane * 4;
+                f32x4 tc[4][6];
+#pragma unroll
+                for (int jj = 0; jj < 6; jj++) {
+                    f32x4 m[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) m[i] = *reinterpret_cast<const f32x4 *>(mb + (size_t)(i * 6 + jj) * C);
+                    const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                    tc[0][jj] = m[0] + s12 + s34;
+                    tc[1][jj] = w4_fma(2.f, d34, d12);
+                    tc[2][jj] = w4_fma(4.f, s34, s12);
+                    tc[3][jj] = w4_fma(8.f, d34, d12) + m[5];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const int py = 4 * t + a;
+                    const f32x4 s12 = tc[a][1] + tc[a][2], d12 = tc[a][1] - tc[a][2], s34 = tc[a][3] + tc[a][4], d34 = tc[a][3] - tc[a][4];
+                    f32x4 y[4];
+                    y[0] = tc[a][0] + s12 + s34;
+                    y[1] = w4_fma(2.f, d34, d12);
+                    y[2] = w4_fma(4.f, s34, s12);
+                    y[3] = w4_fma(8.f, d34, d12) + tc[a][5];
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++) {
+                        f32x4 v = y[bb] + bi;
+                        const bool inb = py < N && 4 * tx + bb < N;
+                        const size_t o = ((size_t)bd * (N * N) + (size_t)((inb ? py : 0) * N + (inb ? 4 * tx + bb : 0))) * C + lane * 4;
+                        if (res && inb) v = v + *reinterpret_cast<const f32x4 *>(res + o);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                        if (!inb) v = zero4;                             // beyond the board: the next layer's zero padding
+                        else if (act) *reinterpret_cast<f32x4 *>(act + o) = v;      // a block's output is also the next block's residual
+                        if (a == 0) *reinterpret_cast<f32x4 *>(wpix + ((py + 1) % 6) * ROWF + bb * C) = v;
+                        else keep[a - 1][bb] = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) *reinterpret_cast<f32x4 *>(wpix + ((4 * t + 1) % 6) * ROWF + bb * C) = zero4;      // row 4 TW: below the board
+            }
+            __syncthreads();                                // board rows 4t - 5 .. 4t are in the window
+            if (t >= 1) {
+                const int ty = t - 1;
+                const long tt = (long)bd * T + ty * TW + tx;
+                float *vb = V + (size_t)(tt / W4_BT) * G::BLOCK_FLOATS + (size_t)(tt % W4_BT) * G::TILE_STRIDE + lane * 4;
+                const float *wc = win + (4 * tx) * C + lane * 4;
+                int slot[6];
+#pragma unroll
+                for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    f32x4 w[6];
+#pragma unroll
+                    for (int b = 0; b < 6; b++) {
+                        const float *col = wc + b * C;
+#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
+                        if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
+                        else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
+                        else {
+                            const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
+                            w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
+                        }
+#undef W4_D
+                    }
+                    float *o = vb + (size_t)(i * 6) * G::POS_STRIDE;
+#pragma unroll
+                    for (int jj = 0; jj < 6; jj++)
+                        *reinterpret_cast<f32x4 *>(o + jj * G::POS_STRIDE) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();                                // rows 4t - 5 .. 4t - 3 are read no more: their slots take rows 4t + 1 .. 4t + 3
+            if (t < TW) {
+#pragma unroll
+                for (int a = 1; a < 4; a++)
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++) *reinterpret_cast<f32x4 *>(wpix + ((4 * t + a + 1) % 6) * ROWF + bb * C) = keep[a - 1][bb];
+            }
+        }
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 size_t c6_conv_packed_wino4_floats(int C) { return (size_t)W4_NP * C * C; }
 
@@ -500,6 +611,14 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
         (void)attr_once;      // once per process: the call is not asynchronous
         hipLaunchKernelGGL((c6_wino4_gemm_kernel<N>), dim3(grid), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks);
     }
+    if (steps & 16) {      // output transform of this layer (bias, residual if any, ReLU; activations stored if `out`) + input transform of the next: M -> V
+        constexpr size_t mid_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
+        const int grid_mid = nboards < num_cus ? nboards : num_cus;
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino4_mid_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_smem);
+        (void)attr_once;
+        hipLaunchKernelGGL((c6_wino4_mid_kernel<N>), dim3(grid_mid), dim3(64 * G::TW), mid_smem, s, Mb, bias, res, out, Vb, nboards);
+        if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
+    }
     if (steps & 4) {
         const long want = (tiles + 3) / 4;
         const int grid_out = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
@@ -508,7 +627,7 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     }
 }
 
-// steps: bit 0 input transform, bit 1 GEMMs, bit 2 output transform (7 = the layer)
+// steps: bit 0 input transform, bit 1 GEMMs, bit 2 output transform (7 = the layer); bit 4: output transform fused with the NEXT layer's input transform
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                             float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads) {
     if (C != W4_C) return false;

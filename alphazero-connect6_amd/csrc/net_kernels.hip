@@ -280,7 +280,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
     float *x = act0, *y = act1, *z = act2;
     const bool timed = timers && timers->enabled;
     static const bool fuse_heads = [] { const char *e = getenv("C6_HEAD_FUSE"); return !(e && e[0] == '0'); }();   // A/B switch
-    bool head_fused = false, heads_done = false;
+    static const bool fuse_mid = [] { const char *e = getenv("C6_WINO_MID"); return !(e && e[0] == '0'); }();       // A/B switch
+    bool head_fused = false, heads_done = false, v_ready = false;
     for (int i = 0; i < net.blocks - 1; i++) {     // res_block, model.hpp:61-78
         for (int half = 0; half < 2; half++) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -290,7 +291,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
             float *cout = half == 0 ? y : z;
             const float *cb = net.conv_b + (size_t)l * C;
             if (net.variant == C6_CONV_WINO) {
-                c6_conv_wino_transform(C, net.N, nb, cin, vbuf, net.num_cus, s);
+                if (!v_ready) c6_conv_wino_transform(C, net.N, nb, cin, vbuf, net.num_cus, s);      // else: the previous layer's fused transform left V
+                v_ready = false;
                 if (timed) {
                     hipEvent_t em = timer_event(timers);
                     hipEventRecord(em, s);
@@ -300,12 +302,23 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                 c6_conv_wino_gemm(C, net.N, nb, vbuf, net.conv_ww + (size_t)l * c6_conv_packed_wino_floats(C), cb, cres, cout, net.num_cus, s, 1);
                 hipEvent_t eg = nullptr;
                 if (timed) { eg = timer_event(timers); hipEventRecord(eg, s); }
-                // the tower's last output transform applies the heads' 1x1 filters itself (F(4x4) form) and stores no activations
-                const bool last = l == 2 * (net.blocks - 1) - 1;
-                const C6HeadFuse hf{net.head_w, net.pc_b, net.vc_b, net.vn_scale, net.vn_shift, ph, vh};
-                const int out_rc = c6_conv_wino_out(C, net.N, nb, vbuf, cb, cres, cout, net.num_cus, s, 1, last && fuse_heads ? &hf : nullptr);
-                const bool has_out = out_rc != 0;
-                if (out_rc == 2) heads_done = true;
+                // first convolution of a block (no residual, one reader): its output transform and the next layer's input transform
+                // are one kernel and the activations between them are never stored (F(4x4) form)
+                bool has_out = false;
+                const bool last_layer = l == 2 * (net.blocks - 1) - 1;
+                static const int mid_mode = [] { const char *e = getenv("C6_WINO_MID"); return e ? atoi(e) : 2; }();      // 0 off, 1 inside blocks, 2 also across blocks
+                if (fuse_mid && !last_layer && (half == 0 || mid_mode >= 2) &&
+                    c6_conv_wino_mid(C, net.N, nb, vbuf, cb, half == 0 ? nullptr : cres, half == 0 ? nullptr : cout, net.num_cus, s)) {
+                    v_ready = true;
+                    has_out = true;
+                } else {
+                    // the tower's last output transform applies the heads' 1x1 filters itself (F(4x4) form) and stores no activations
+                    const bool last = l == 2 * (net.blocks - 1) - 1;
+                    const C6HeadFuse hf{net.head_w, net.pc_b, net.vc_b, net.vn_scale, net.vn_shift, ph, vh};
+                    const int out_rc = c6_conv_wino_out(C, net.N, nb, vbuf, cb, cres, cout, net.num_cus, s, 1, last && fuse_heads ? &hf : nullptr);
+                    has_out = out_rc != 0;
+                    if (out_rc == 2) heads_done = true;
+                }
                 if (timed) {
                     if (has_out) {
                         hipEvent_t eo = timer_event(timers);

@@ -50,7 +50,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, de
 PEAK_HBM_GBS = 8000.0
 KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, description)
     "fp32": ("c6_wino4_gemm_kernel<19>", "FP32 Winograd F(4x4,3x3): the 36 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32; "
-             "c6_wino4_in_kernel / c6_wino4_out_kernel (input / output transform, HBM bound) run in front of and behind it"),
+             "the transforms between the layers' GEMMs are HBM-bound kernels of their own (c6_wino4_mid_kernel: output transform of a layer + "
+             "input transform of the next)"),
     "fp32_direct": ("c6_conv3x3_f32n_kernel<256, 19>", "FP32 direct implicit GEMM, v_mfma_f32_32x32x2_f32"),
     "bf16x3": ("c6_conv3x3_b3s_kernel<256, 19, true, false>", "split-bf16 implicit GEMM, v_mfma_f32_16x16x32_bf16, 3 MFMAs per product"),
     "f16f8": ("c6_conv3x3_m8_kernel<256, 19, false>", "fp16 main term + MX-fp8 cross terms, v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4"),
@@ -421,14 +422,17 @@ def main():
                              "fewer matrix FLOPs than that count (900 products per channel pair and board instead of 3249), so frac exceeds 1 -- "
                              "frac_executed is the matrix-pipe utilisation; the two transforms are HBM-bound kernels of their own, reported beside it")
                 nbd, Cc, tiles = min(G * 8, 32768), wl["channels"], ((n + 3) // 4) ** 2
-                r["input_transform"] = {"kernel": "c6_wino4_in_kernel<19> (HBM bound)", "avg_launch_ms": prof["conv_pre_ms"] / L,
-                                        "algorithmic_bytes_per_launch": (n * n + 36 * tiles) * Cc * 4 * nbd,
-                                        "traffic": pmc_record("c6_wino4_in_kernel").get("hbm_bytes_per_launch") if std else None}
-                r["input_transform"]["achieved_gbs"] = r["input_transform"]["algorithmic_bytes_per_launch"] / max(r["input_transform"]["avg_launch_ms"], 1e-9) / 1e6
-                r["output_transform"] = {"kernel": "c6_wino4_out_kernel<19> (HBM bound)", "avg_launch_ms": prof.get("conv_post_ms", 0.0) / L,
-                                         "algorithmic_bytes_per_launch": (36 * tiles + 1.5 * n * n) * Cc * 4 * nbd,      # M in, residual on every second layer, activations out
-                                         "traffic": pmc_record("c6_wino4_out_kernel").get("hbm_bytes_per_launch") if std else None}
-                r["output_transform"]["achieved_gbs"] = r["output_transform"]["algorithmic_bytes_per_launch"] / max(r["output_transform"]["avg_launch_ms"], 1e-9) / 1e6
+                # between the GEMM kernels: one input transform in front of the tower, then ONE kernel per layer boundary (output transform of
+                # layer l + input transform of layer l + 1; the activations between the two convolutions of a block are never stored), and
+                # the last output transform, which applies the heads' 1x1 filters.  HBM-bound kernels.
+                nl = 2 * (wl["blocks"] - 1)
+                act_b, vm_b = n * n * Cc * 4 * nbd, 36 * tiles * Cc * 4 * nbd
+                tr_bytes = (act_b + vm_b) + (nl // 2) * (2 * vm_b) + (nl // 2 - 1) * (2 * vm_b + 2 * act_b) + (vm_b + act_b)
+                tr_ms = (prof["conv_pre_ms"] + prof.get("conv_post_ms", 0.0)) / L
+                r["transforms"] = {"kernels": "c6_wino4_in_kernel<19> (first layer), c6_wino4_mid_kernel<19> (between layers), c6_wino4_out_kernel<19, true> (last layer + heads): HBM bound",
+                                   "avg_ms_per_layer": tr_ms, "algorithmic_bytes_per_layer": tr_bytes / nl,
+                                   "achieved_gbs": tr_bytes / nl / max(tr_ms, 1e-9) / 1e6,
+                                   "traffic_mid_kernel": pmc_record("c6_wino4_mid_kernel").get("hbm_bytes_per_launch") if std else None}
                 r["conv_layer_tflops_algorithmic"] = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
             if name == "bf16x3":
                 r.update(mfma_flops_per_algorithmic_flop=3, executed_mfma_tflops=3 * ach, frac_executed=3 * ach / peak)
