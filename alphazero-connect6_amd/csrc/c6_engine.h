@@ -232,6 +232,7 @@ bool c6_conv_wino_mid(int C, int N, int nboards, float *vbuf, const float *bias,
 // FP32 Winograd F(4x4,3x3), C = 256 (conv_wino4.hip): what the functions above run at C = 256
 size_t c6_conv_packed_wino4_floats(int C);
 void c6_pack_conv_weights_wino4(int C, const float *w_oihw_folded, float *packed);
+void c6_pack_conv_weights_wino4_dev(int C, const float *w_oihw_dev, float *packed_dev, int transpose_flip, hipStream_t s);
 size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards);
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                             float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads = nullptr);

@@ -582,6 +582,34 @@ void c6_pack_conv_weights_wino4(int C, const float *w, float *packed) {
                 }
 }
 
+// the same packing on the device, from weights that change every training step (trainer.cpp); transpose_flip: the layer of the
+// input gradient, w'[ci][co][2 - a][2 - b]
+__global__ void c6_pack_wino4_kernel(int C, const float *__restrict__ w, float *__restrict__ packed, int transpose_flip) {
+    const double Gm[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const int NG = C / 8;
+    const size_t total = (size_t)W4_NP * C * C;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t q = e;
+        const int r = (int)(q % 4); q /= 4;
+        const int lane = (int)(q % 64); q /= 64;
+        const int u = (int)(q % NG); q /= NG;
+        const int pos = (int)(q % W4_NP); q /= W4_NP;
+        const int wv = (int)q;
+        const int co = wv * 32 + (lane & 31), ci = 8 * u + 4 * (lane >> 5) + r, i = pos / 6, jj = pos % 6;
+        const float *g = transpose_flip ? w + ((size_t)ci * C + co) * 9 : w + ((size_t)co * C + ci) * 9;
+        double sum = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) sum += Gm[i][a] * (double)g[transpose_flip ? 8 - (a * 3 + b) : a * 3 + b] * Gm[jj][b];
+        packed[e] = (float)sum;
+    }
+}
+void c6_pack_conv_weights_wino4_dev(int C, const float *w_oihw_dev, float *packed_dev, int transpose_flip, hipStream_t s) {
+    hipLaunchKernelGGL(c6_pack_wino4_kernel, dim3(1024), dim3(256), 0, s, C, w_oihw_dev, packed_dev, transpose_flip);
+}
+
 // floats of the scratch for `nboards` boards: V and M, one behind the other
 static size_t w4_half_floats(int N, int nboards) {
     const long TW = (N + 3) / 4, tiles = (long)nboards * TW * TW, nblocks = (tiles + W4_BT - 1) / W4_BT;
