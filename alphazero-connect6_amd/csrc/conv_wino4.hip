@@ -6,13 +6,17 @@
 // 25 tiles x 36 positions = 900 products per (cin, cout) and 19x19 board instead of 1600 for F(2x2) and 3249 direct: 3.6x fewer
 // matrix FLOPs than the direct form.  The price: a tile has 16 outputs per (tile, cout), so the output transform cannot be
 // accumulated in registers position by position as conv_wino.hip does (16 x 8192 accumulators per wave) -- the 36 products go
-// to memory and a third kernel applies A^T . A.  Three launches per layer:
-//   c6_wino4_in_kernel    activations NHWC -> V[block][tile 64][pos 36][C]      HBM bound: reads 1x, writes 36/16 x the activations
+// to memory and a transform kernel applies A^T . A.  The kernels:
 //   c6_wino4_gemm_kernel  M[block][tile][pos][cout] = sum_cin U_pos[cout][cin] V[block][tile][pos][cin]: conv_wino.hip's schedule
 //                         (persistent workgroups, wave w owns couts [32w, 32w+32) x 64 tiles, weights L2 -> VGPR through a ring of
-//                         8 groups, V slabs by LDS-DMA one position ahead, one barrier per position) without the accumulators: the
-//                         32 result registers of a position are copied aside and stored during the next one
-//   c6_wino4_out_kernel   A^T M A + bias (+ residual), ReLU -> activations NHWC    HBM bound: reads 36/16 x + 1x, writes 1x
+//                         8 groups, V slabs by LDS-DMA one position ahead, one barrier per position) without the accumulators and
+//                         without a single vector instruction in its loop; two accumulator sets alternate between positions, the
+//                         previous position's set is stored while this one accumulates.  MFMA bound, at the part's power limit
+//   c6_wino4_in_kernel    activations NHWC -> V[block][tile 64][pos 36][C]      HBM bound: reads 1x, writes 36/16 x the activations
+//   c6_wino4_out_kernel   A^T M A + bias (+ residual), ReLU -> activations NHWC  HBM bound: reads 36/16 x + 1x, writes 1x;
+//                         as the tower's last kernel it applies the heads' 1x1 filters instead of storing activations
+//   c6_wino4_mid_kernel   out of layer l + in of layer l + 1 in one pass through an LDS window: what runs between two GEMM kernels
+//                         inside the net (in / out are left with the tower's first and last layer, and with a layer on its own)
 // Rounding: a layer's error is ~6x that of the direct f32 kernel (2.4e-6 rms of activations of order 1); over the benchmark's net
 // the outputs move by < 1e-7 (tests/test_gpu_net.py holds every arithmetic to 1e-5 against the oracle and a float64 PyTorch model).
 #include "c6_device.h"
