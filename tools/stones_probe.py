@@ -1,6 +1,6 @@
 """Measured stones per game for bench.py: complete self-play games of the benchmark's net (random-init weights, Dirichlet noise) at a
 short simulation budget, on the GPU engine.  Writes one JSON line (commit it as profiles/rNN_stones_probe.json).
-    python tools/stones_probe.py [workload=config2] [games=4096] [sims=8] [also_sims=2]"""
+    python tools/stones_probe.py [workload=config2] [games=4096] [sims=8] [also_sims=0] [seed=7]"""
 import json
 import os
 import sys
@@ -14,8 +14,10 @@ name = sys.argv[1] if len(sys.argv) > 1 else "config2"
 games = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 sims = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 also = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+seed = int(sys.argv[5]) if len(sys.argv) > 5 else 7
 wl = bench.WORKLOADS[name]
-r = bench.stones_probe(pkg, wl, games, sims, pkg.PREC_BF16X3, progress=True)
+r = bench.stones_probe(pkg, wl, games, sims, pkg.PREC_BF16X3, seed=seed, progress=True)
+r["seed"] = seed
 r.update(workload=name, precision="bf16x3 (parity grade: net outputs within 1e-5 of FP32)", board=wl["n"], net_blocks=wl["blocks"], net_channels=wl["channels"])
 if also:      # how the game length moves with the simulation budget: further budgets on fewer games
     r["other_budgets"] = [bench.stones_probe(pkg, wl, 256, b, pkg.PREC_BF16X3, seed=8 + b, progress=True) for b in (2, also)]
