@@ -621,6 +621,18 @@ static size_t w4_half_floats(int N, int nboards) {
 }
 size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards) { return C == W4_C ? 2 * w4_half_floats(N, nboards) : 0; }
 
+// the dynamic-LDS limit of a kernel, raised once per (kernel, device) instead of at every launch
+#include <mutex>
+#include <set>
+#include <utility>
+static void w4_smem_once(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({fn, dev}).second) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 template <int N>
 static void launch_w4(int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out, float *vbuf, int num_cus,
                       int relu, int steps, hipStream_t s, const C6HeadFuse *heads) {
@@ -631,23 +643,20 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     if (steps & 1) {
         constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
         const int grid_in = nboards < num_cus ? nboards : num_cus;
-        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino4_in_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)in_smem);
-        (void)attr_once;
+        w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_in_kernel<N>), (int)in_smem);
         hipLaunchKernelGGL((c6_wino4_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, in, Vb, nboards);
         if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
     }
     if (steps & 2) {
         const size_t smem = G::LDS_BYTES;
         const int grid = nblocks < num_cus ? nblocks : num_cus;
-        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)attr_once;      // once per process: the call is not asynchronous
+        w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N>), (int)smem);
         hipLaunchKernelGGL((c6_wino4_gemm_kernel<N>), dim3(grid), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks);
     }
     if (steps & 16) {      // output transform of this layer (bias, residual if any, ReLU; activations stored if `out`) + input transform of the next: M -> V
         constexpr size_t mid_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
         const int grid_mid = nboards < num_cus ? nboards : num_cus;
-        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wino4_mid_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_smem);
-        (void)attr_once;
+        w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_mid_kernel<N>), (int)mid_smem);
         hipLaunchKernelGGL((c6_wino4_mid_kernel<N>), dim3(grid_mid), dim3(64 * G::TW), mid_smem, s, Mb, bias, res, out, Vb, nboards);
         if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
     }

@@ -4,7 +4,8 @@
   32-bit row descriptors of the default kernel (board_kernel.hip): same bits as the default kernel and as the oracle
   (game_impl/mod.rs:148-169, search_winner/mod.rs:201-246);
 * C6_HEAD_FUSE=0 -- the evaluator with a separate 1x1 head convolution instead of the partial sums the tower's last
-  convolution leaves behind (net_kernels.hip): same outputs within float summation order (model.hpp:80-92).
+  convolution leaves behind (net_kernels.hip): same outputs within float summation order (model.hpp:80-92);
+* C6_WINO_MID=0 -- the FP32 Winograd tower without the fused boundary kernel (conv_wino4.hip).
 """
 import os
 import subprocess
@@ -81,3 +82,23 @@ def test_unfused_heads_match():
     net = o.Net(n, C, blocks, blob)
     rpol, rval = net.forward(-1.0, nb.astype(np.float32))
     assert np.abs(pol - rpol).max() < 1e-5 and np.abs(val - rval).max() < 1e-5
+
+
+def test_winograd_separate_transform_kernels_match():
+    """C6_WINO_MID=0 C6_HEAD_FUSE=0 -- the FP32 Winograd F(4x4) tower with one input-transform and one output-transform kernel per
+    layer and a separate head convolution, instead of the fused boundary kernel and the heads' filters in the last output transform
+    (conv_wino4.hip): the same arithmetic in another order of kernels (model.hpp:61-92)."""
+    need_gpu()
+    import __graft_entry__ as ge
+    n, C, blocks = 19, 256, 3
+    rng = np.random.default_rng(6)
+    blob = ge.make_random_blob(n, C, blocks, rng)
+    nb = rng.integers(-1, 2, size=(70, n * n)).astype(np.int8)
+    player = np.full(70, 1, np.int8)
+    pol, val = pkg.net_forward(n, C, blocks, blob, nb, player)
+    other = run_child({"C6_WINO_MID": "0", "C6_HEAD_FUSE": "0"}, n=n, C=C, blocks=blocks, blob=blob, nb=nb, player=player)
+    assert np.abs(other["pol"] - pol).max() < 1e-6 and np.abs(other["val"] - val).max() < 1e-5
+    net = o.Net(n, C, blocks, blob)
+    for i in (0, 1, 35, 69):
+        rpol, rval = net.forward(1.0, nb[i].astype(np.float32))
+        assert np.abs(pol[i] - rpol).max() < 1e-5 and abs(val[i] - rval) < 1e-5
