@@ -217,6 +217,17 @@ bool c6_conv_wino_transform(int C, int N, int nboards, const float *in, float *v
 bool c6_conv_wino_gemm(int C, int N, int nboards, const float *vbuf, const float *wp, const float *bias, const float *res, float *out, int num_cus,
                        hipStream_t s, int relu = 1);
 double c6_conv_wino_exec_flops(int C, int N, int nboards);
+// the stem (dihedral gather + conv 2 -> C + folded BN + ReLU, c6_stem_kernel) as an INPUT of the Winograd kernels: the first layer's input
+// transform computes it on the fly and the boundary kernel that needs it as a residual computes it again -- its activations are never stored
+struct C6StemSrc {
+    const int8_t *boards;
+    int board_stride;
+    const int8_t *player;
+    int player_stride;
+    const int16_t *aug_map;
+    int images;
+    const float *w, *bias;      // [9][2][C], [C]
+};
 // the heads' 1x1 filters applied by the tower's last output transform (conv_wino4.hip): w = [3][C] (policy rows 0-1, value), outputs ph / vh
 // as c6_head_conv_kernel writes them; the layer's activations are then not stored
 struct C6HeadFuse {
@@ -228,14 +239,18 @@ struct C6HeadFuse {
 // returns 0: this form has no separate output transform; 1: done; 2: done and the heads' filters applied (heads != nullptr, F(4x4) only)
 int c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *out, int num_cus, hipStream_t s, int relu = 1,
                      const C6HeadFuse *heads = nullptr);
-bool c6_conv_wino_mid(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *act, int num_cus, hipStream_t s);
+bool c6_conv_wino_mid(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *act, int num_cus, hipStream_t s,
+                      const C6StemSrc *res_stem = nullptr);
+// F(4x4) only: the first layer's input transform straight from the boards (the stem computed on the fly); false: not available
+bool c6_conv_wino_stem_transform(int C, int N, int nboards, const C6StemSrc &stem, float *vbuf, int num_cus, hipStream_t s);
 // FP32 Winograd F(4x4,3x3), C = 256 (conv_wino4.hip): what the functions above run at C = 256
 size_t c6_conv_packed_wino4_floats(int C);
 void c6_pack_conv_weights_wino4(int C, const float *w_oihw_folded, float *packed);
 void c6_pack_conv_weights_wino4_dev(int C, const float *w_oihw_dev, float *packed_dev, int transpose_flip, hipStream_t s);
 size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards);
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads = nullptr);
+                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads = nullptr,
+                            const C6StemSrc *stem = nullptr);
 double c6_conv_wino4_exec_flops(int C, int N, int nboards);
 // FP32 direct (conv_f32n.hip)
 size_t c6_conv_packed_f32n_floats(int C);

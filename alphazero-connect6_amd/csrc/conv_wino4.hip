@@ -161,6 +161,118 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float 
     }
 }
 
+// ---- the stem as an input ---------------------------------------------------------------------------------------------
+// conv 2 -> C (+ folded BN, ReLU) on the planes [player broadcast, board image] (model.hpp:56-59, c6_stem_kernel) at pixel (y, x)
+// for 4 channels: 18 multiply-adds per channel, in c6_stem_kernel's order.  bd = the board image as floats on the (N+2)-wide zero-haloed
+// grid, wt(t, plane) = the lane's 4 weights of tap t.  Cheap enough to be COMPUTED wherever the stem's activations are needed
+// (the first layer's input transform, the residual of the first block) instead of being written and read back: 36 GB per forward pass.
+template <int N, typename WT>
+__device__ __forceinline__ f32x4 w4_stem_pixel(const float *bd, float pv, int y, int x, f32x4 bias, WT wt) {
+    constexpr int P = N + 2;
+    f32x4 acc = bias;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const float plv = (yy >= 0 && yy < N && xx >= 0 && xx < N) ? pv : 0.f;      // the player plane is zero padded like the board
+        const float bdv = bd[(yy + 1) * P + xx + 1];
+        const f32x4 w0 = wt(t, 0), w1 = wt(t, 1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            acc[r] = __builtin_fmaf(w0[r], plv, acc[r]);
+            acc[r] = __builtin_fmaf(w1[r], bdv, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
+    return acc;
+}
+// board image k of leaf b / images as floats on the zero-haloed grid (augment_way8, augment.rs:60-73: the stem's gather)
+template <int N>
+__device__ __forceinline__ float w4_stem_plane(const C6StemSrc &S, long b, float *bd, int tid, int nthreads) {
+    constexpr int P = N + 2, cells = N * N;
+    const long leaf = b / S.images;
+    const int k = S.images == 8 ? (int)(b % 8) : 6;      // image 6 is the identity
+    const int8_t *board = S.boards + leaf * (size_t)S.board_stride;
+    for (int c = tid; c < cells; c += nthreads) bd[(c / N + 1) * P + c % N + 1] = (float)board[S.aug_map[k * cells + c]];
+    return (float)S.player[leaf * (size_t)S.player_stride];
+}
+
+// c6_wino4_in_kernel with the window rows computed from the board instead of loaded
+template <int N>
+__global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemSrc S, float *__restrict__ V, int nboards) {
+    using G = W4Geom<N>;
+    constexpr int C = G::C, LPT = C / 4, TPI = W4_IN_THREADS / LPT, T = G::T, TW = G::TW, COLS = 4 * TW + 2, P = N + 2;
+    constexpr int ROWF = COLS * C;
+    static_assert(W4_IN_THREADS % LPT == 0, "a thread keeps its channel quad");
+    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] + the board plane [P][P]
+    float *bd = win + 6 * ROWF;
+    const int tid = threadIdx.x, cq = tid % LPT, tsub = tid / LPT;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = tid; k < 6 * ROWF / 4; k += W4_IN_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
+    for (int k = tid; k < P * P; k += W4_IN_THREADS) bd[k] = 0.f;
+    f32x4 sw[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        sw[t][0] = *reinterpret_cast<const f32x4 *>(S.w + (t * 2 + 0) * C + cq * 4);
+        sw[t][1] = *reinterpret_cast<const f32x4 *>(S.w + (t * 2 + 1) * C + cq * 4);
+    }
+    const f32x4 sb = *reinterpret_cast<const f32x4 *>(S.bias + cq * 4);
+    float pv = 0.f;
+    // rows y0 .. y0 + nr - 1 of the stem's output into the window (rows outside the board are zeros)
+    auto fill = [&](int y0, int nr) {
+        for (int k = tid; k < nr * N * LPT; k += W4_IN_THREADS) {
+            const int r = k / (N * LPT), px = (k / LPT) % N, y = y0 + r;
+            const f32x4 v = (y >= 0 && y < N) ? w4_stem_pixel<N>(bd, pv, y, px, sb, [&](int t, int pl) { return sw[t][pl]; }) : zero4;
+            *reinterpret_cast<f32x4 *>(win + ((y + 1) % 6) * ROWF + (px + 1) * C + cq * 4) = v;
+        }
+    };
+#pragma unroll 1
+    for (int b = blockIdx.x; b < nboards; b += gridDim.x) {
+        __syncthreads();                                            // the previous board's last reads (and the zero fills)
+        pv = w4_stem_plane<N>(S, b, bd, tid, W4_IN_THREADS);
+        __syncthreads();
+        fill(-1, 6);
+#pragma unroll 1
+        for (int ty = 0; ty < TW; ty++) {
+            __syncthreads();                                        // rows 4 ty - 1 .. 4 ty + 4 are in the window
+#pragma unroll 1
+            for (int tx = tsub; tx < TW; tx += TPI) {
+                const long t = (long)b * T + ty * TW + tx;
+                float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + cq * 4;
+                const float *wc = win + (4 * tx) * C + cq * 4;
+                int slot[6];
+#pragma unroll
+                for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    f32x4 w[6];
+#pragma unroll
+                    for (int bb = 0; bb < 6; bb++) {
+                        const float *col = wc + bb * C;
+#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
+                        if (i == 0) w[bb] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
+                        else if (i == 5) w[bb] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
+                        else {
+                            const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
+                            w[bb] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
+                        }
+#undef W4_D
+                    }
+                    float *o = vb + (size_t)(i * 6) * G::POS_STRIDE;
+#pragma unroll
+                    for (int jj = 0; jj < 6; jj++)
+                        *reinterpret_cast<f32x4 *>(o + jj * G::POS_STRIDE) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (ty + 1 < TW) {
+                __syncthreads();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more
+                fill(4 * ty + 5, 4);
+            }
+        }
+    }
+}
+
 // the tail of the last block (tiles beyond the batch) is never written by the kernel above: zero it once per launch
 template <int N>
 __global__ void c6_wino4_tail_kernel(float *__restrict__ V, long total_tiles) {
@@ -458,10 +570,11 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
 // row 4t, into the rolling 6-row window of c6_wino4_in_kernel; (b) the window now holds rows 4t - 5 .. 4t: the patch rows of tile
 // row t - 1, whose B^T d B goes out as the next layer's V; (c) pixel rows 4t + 1 .. 4t + 3, kept in registers meanwhile, take the
 // slots of the rows (b) read last.  HBM: M in, V out -- 60 GB instead of 84 for the pair of kernels it replaces.
-template <int N>
+// RS: the residual is the STEM's output, computed here from the board (w4_stem_pixel; weights and board plane in LDS behind the window)
+template <int N, bool RS>
 __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const float *__restrict__ M, const float *__restrict__ bias,
                                                                           const float *__restrict__ res, float *__restrict__ act,
-                                                                          float *__restrict__ V, int nboards) {
+                                                                          float *__restrict__ V, int nboards, C6StemSrc S) {
     using G = W4Geom<N>;
     constexpr int C = G::C, T = G::T, TW = G::TW, COLS = 4 * TW + 2, ROWF = COLS * C, NT = 64 * TW;
     extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C]
@@ -470,10 +583,22 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
     const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + lane * 4) : zero4;
     for (int k = tid; k < 6 * ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
     float *wpix = win + (4 * tx + 1) * C + lane * 4;       // window column of this wave's first pixel column (board column 4 tx)
+    float *swl = win + 6 * ROWF, *bdp = swl + 18 * C;     // RS: the stem's weights [9][2][C] and the board plane [(N+2)^2]
+    f32x4 sb = zero4;
+    float pv = 0.f;
+    if (RS) {
+        for (int k = tid; k < 18 * C / 4; k += NT) reinterpret_cast<f32x4 *>(swl)[k] = reinterpret_cast<const f32x4 *>(S.w)[k];
+        for (int k = tid; k < (N + 2) * (N + 2); k += NT) bdp[k] = 0.f;
+        sb = *reinterpret_cast<const f32x4 *>(S.bias + lane * 4);
+    }
 #pragma unroll 1
     for (int bd = blockIdx.x; bd < nboards; bd += gridDim.x) {
         __syncthreads();                                    // the previous board's last window reads (and the zero fill)
         for (int k = tid; k < ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // slot 0 = board row -1
+        if (RS) {
+            pv = w4_stem_plane<N>(S, bd, bdp, tid, NT);
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int t = 0; t <= TW; t++) {
             f32x4 keep[3][4];
@@ -506,7 +631,9 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
                         f32x4 v = y[bb] + bi;
                         const bool inb = py < N && 4 * tx + bb < N;
                         const size_t o = ((size_t)bd * (N * N) + (size_t)((inb ? py : 0) * N + (inb ? 4 * tx + bb : 0))) * C + lane * 4;
-                        if (res && inb) v = v + *reinterpret_cast<const f32x4 *>(res + o);
+                        if (RS) {
+                            if (inb) v = v + w4_stem_pixel<N>(bdp, pv, py, 4 * tx + bb, sb, [&](int t, int pl) { return *reinterpret_cast<const f32x4 *>(swl + (t * 2 + pl) * C + lane * 4); });
+                        } else if (res && inb) v = v + *reinterpret_cast<const f32x4 *>(res + o);
 #pragma unroll
                         for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : 0.f;
                         if (!inb) v = zero4;                             // beyond the board: the next layer's zero padding
@@ -635,12 +762,18 @@ static void w4_smem_once(const void *fn, int bytes) {
 }
 template <int N>
 static void launch_w4(int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out, float *vbuf, int num_cus,
-                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads) {
+                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads, const C6StemSrc *stem) {
     using G = W4Geom<N>;
     const long tiles = (long)nboards * G::T;
     const int nblocks = (int)((tiles + W4_BT - 1) / W4_BT);
     float *Vb = vbuf, *Mb = vbuf + w4_half_floats(N, nboards);
-    if (steps & 1) {
+    if ((steps & 1) && stem) {      // the first layer: window rows computed from the boards
+        constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
+        const int grid_in = nboards < num_cus ? nboards : num_cus;
+        w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_stem_in_kernel<N>), (int)in_smem);
+        hipLaunchKernelGGL((c6_wino4_stem_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, *stem, Vb, nboards);
+        if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
+    } else if (steps & 1) {
         constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
         const int grid_in = nboards < num_cus ? nboards : num_cus;
         w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_in_kernel<N>), (int)in_smem);
@@ -655,9 +788,15 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     }
     if (steps & 16) {      // output transform of this layer (bias, residual if any, ReLU; activations stored if `out`) + input transform of the next: M -> V
         constexpr size_t mid_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
+        constexpr size_t rs_smem = mid_smem + (size_t)18 * W4_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
         const int grid_mid = nboards < num_cus ? nboards : num_cus;
-        w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_mid_kernel<N>), (int)mid_smem);
-        hipLaunchKernelGGL((c6_wino4_mid_kernel<N>), dim3(grid_mid), dim3(64 * G::TW), mid_smem, s, Mb, bias, res, out, Vb, nboards);
+        if (stem) {      // the residual is the stem's output, recomputed from the boards
+            w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_mid_kernel<N, true>), (int)rs_smem);
+            hipLaunchKernelGGL((c6_wino4_mid_kernel<N, true>), dim3(grid_mid), dim3(64 * G::TW), rs_smem, s, Mb, bias, res, out, Vb, nboards, *stem);
+        } else {
+            w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_mid_kernel<N, false>), (int)mid_smem);
+            hipLaunchKernelGGL((c6_wino4_mid_kernel<N, false>), dim3(grid_mid), dim3(64 * G::TW), mid_smem, s, Mb, bias, res, out, Vb, nboards, C6StemSrc{});
+        }
         if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
     }
     if (steps & 4) {
@@ -670,12 +809,12 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
 
 // steps: bit 0 input transform, bit 1 GEMMs, bit 2 output transform (7 = the layer); bit 4: output transform fused with the NEXT layer's input transform
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads) {
+                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads, const C6StemSrc *stem) {
     if (C != W4_C) return false;
     if (nboards <= 0) return true;
-    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads); return true; }
-    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads); return true; }
-    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads); return true; }
+    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem); return true; }
+    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem); return true; }
+    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem); return true; }
     return false;
 }
 // matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 positions x C x C MACs)

@@ -275,13 +275,21 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                         float *vh, float *pol, float *val, hipStream_t s, C6NetTimers *timers) {
     const int nb = nleaf * images, cells = net.cells, C = net.C;
     if (nb == 0) return;
-    hipLaunchKernelGGL(c6_stem_kernel, dim3(nb), dim3(256), 0, s, boards, board_stride, player, player_stride, aug_map, images, net.stem_w,
-                       net.stem_b, act0, net.N, C);
     float *x = act0, *y = act1, *z = act2;
     const bool timed = timers && timers->enabled;
     static const bool fuse_heads = [] { const char *e = getenv("C6_HEAD_FUSE"); return !(e && e[0] == '0'); }();   // A/B switch
     static const bool fuse_mid = [] { const char *e = getenv("C6_WINO_MID"); return !(e && e[0] == '0'); }();       // A/B switch
+    static const bool fuse_stem = [] { const char *e = getenv("C6_WINO_STEM"); return !(e && e[0] == '0'); }();     // A/B switch
     bool head_fused = false, heads_done = false, v_ready = false;
+    // FP32 Winograd F(4x4) with at least two residual blocks: the stem's activations are never stored -- the first layer's input transform
+    // computes them from the boards, and so does the boundary kernel behind the first block, which needs them as its residual
+    const C6StemSrc stem_src{boards, board_stride, player, player_stride, aug_map, images, net.stem_w, net.stem_b};
+    bool stem_inline = false;
+    static const int mid_mode0 = [] { const char *e = getenv("C6_WINO_MID"); return e ? atoi(e) : 2; }();      // the boundary kernel across blocks must be on
+    if (net.variant == C6_CONV_WINO && fuse_stem && mid_mode0 >= 2 && net.blocks - 1 >= 2 && c6_conv_wino4_vbuf_floats(C, net.N, 1) > 0) stem_inline = true;
+    if (!stem_inline)
+        hipLaunchKernelGGL(c6_stem_kernel, dim3(nb), dim3(256), 0, s, boards, board_stride, player, player_stride, aug_map, images, net.stem_w,
+                           net.stem_b, act0, net.N, C);
     for (int i = 0; i < net.blocks - 1; i++) {     // res_block, model.hpp:61-78
         for (int half = 0; half < 2; half++) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -291,7 +299,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
             float *cout = half == 0 ? y : z;
             const float *cb = net.conv_b + (size_t)l * C;
             if (net.variant == C6_CONV_WINO) {
-                if (!v_ready) c6_conv_wino_transform(C, net.N, nb, cin, vbuf, net.num_cus, s);      // else: the previous layer's fused transform left V
+                if (l == 0 && stem_inline) c6_conv_wino_stem_transform(C, net.N, nb, stem_src, vbuf, net.num_cus, s);      // straight from the boards
+                else if (!v_ready) c6_conv_wino_transform(C, net.N, nb, cin, vbuf, net.num_cus, s);      // else: the previous layer's fused transform left V
                 v_ready = false;
                 if (timed) {
                     hipEvent_t em = timer_event(timers);
@@ -308,7 +317,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                 const bool last_layer = l == 2 * (net.blocks - 1) - 1;
                 static const int mid_mode = [] { const char *e = getenv("C6_WINO_MID"); return e ? atoi(e) : 2; }();      // 0 off, 1 inside blocks, 2 also across blocks
                 if (fuse_mid && !last_layer && (half == 0 || mid_mode >= 2) &&
-                    c6_conv_wino_mid(C, net.N, nb, vbuf, cb, half == 0 ? nullptr : cres, half == 0 ? nullptr : cout, net.num_cus, s)) {
+                    c6_conv_wino_mid(C, net.N, nb, vbuf, cb, half == 0 ? nullptr : cres, half == 0 ? nullptr : cout, net.num_cus, s,
+                                     stem_inline && l == 1 ? &stem_src : nullptr)) {
                     v_ready = true;
                     has_out = true;
                 } else {

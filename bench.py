@@ -427,12 +427,15 @@ def main():
                 # the last output transform, which applies the heads' 1x1 filters.  HBM-bound kernels.
                 nl = 2 * (wl["blocks"] - 1)
                 act_b, vm_b = n * n * Cc * 4 * nbd, 36 * tiles * Cc * 4 * nbd
-                tr_bytes = (act_b + vm_b) + (nl // 2) * (2 * vm_b) + (nl // 2 - 1) * (2 * vm_b + 2 * act_b) + (vm_b + act_b)
+                # first layer: V written from the boards (the stem is computed, not read); inside a block: M in, V out; across blocks: M + residual
+                # in, activations + V out -- except behind the first block, whose residual (the stem) is computed too; last layer: M + residual in
+                tr_bytes = vm_b + (nl // 2) * (2 * vm_b) + (nl // 2 - 1) * (2 * vm_b + 2 * act_b) - act_b + (vm_b + act_b)
                 tr_ms = (prof["conv_pre_ms"] + prof.get("conv_post_ms", 0.0)) / L
-                r["transforms"] = {"kernels": "c6_wino4_in_kernel<19> (first layer), c6_wino4_mid_kernel<19> (between layers), c6_wino4_out_kernel<19, true> (last layer + heads): HBM bound",
+                r["transforms"] = {"kernels": "c6_wino4_stem_in_kernel<19> (first layer: stem + input transform), c6_wino4_mid_kernel<19> (between layers), "
+                                              "c6_wino4_out_kernel<19, true> (last layer + heads): HBM bound",
                                    "avg_ms_per_layer": tr_ms, "algorithmic_bytes_per_layer": tr_bytes / nl,
                                    "achieved_gbs": tr_bytes / nl / max(tr_ms, 1e-9) / 1e6,
-                                   "traffic_mid_kernel": pmc_record("c6_wino4_mid_kernel").get("hbm_bytes_per_launch") if std else None}
+                                   "traffic_mid_kernel": pmc_record("c6_wino4_mid_kernel<19, false>").get("hbm_bytes_per_launch") if std else None}
                 r["conv_layer_tflops_algorithmic"] = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
             if name == "bf16x3":
                 r.update(mfma_flops_per_algorithmic_flop=3, executed_mfma_tflops=3 * ach, frac_executed=3 * ach / peak)

@@ -5,7 +5,9 @@
   (game_impl/mod.rs:148-169, search_winner/mod.rs:201-246);
 * C6_HEAD_FUSE=0 -- the evaluator with a separate 1x1 head convolution instead of the partial sums the tower's last
   convolution leaves behind (net_kernels.hip): same outputs within float summation order (model.hpp:80-92);
-* C6_WINO_MID=0 -- the FP32 Winograd tower without the fused boundary kernel (conv_wino4.hip).
+* C6_WINO_MID=0 -- the FP32 Winograd tower without the fused boundary kernel (conv_wino4.hip);
+* C6_WINO_STEM=0 -- the same tower with the stem as a kernel of its own (its activations written and read back) instead of being
+  computed inside the first input transform and the first block's boundary kernel.
 """
 import os
 import subprocess
@@ -97,6 +99,8 @@ def test_winograd_separate_transform_kernels_match():
     player = np.full(70, 1, np.int8)
     pol, val = pkg.net_forward(n, C, blocks, blob, nb, player)
     other = run_child({"C6_WINO_MID": "0", "C6_HEAD_FUSE": "0"}, n=n, C=C, blocks=blocks, blob=blob, nb=nb, player=player)
+    assert np.abs(other["pol"] - pol).max() < 1e-6 and np.abs(other["val"] - val).max() < 1e-5
+    other = run_child({"C6_WINO_STEM": "0"}, n=n, C=C, blocks=blocks, blob=blob, nb=nb, player=player)      # the stem as its own kernel
     assert np.abs(other["pol"] - pol).max() < 1e-6 and np.abs(other["val"] - val).max() < 1e-5
     net = o.Net(n, C, blocks, blob)
     for i in (0, 1, 35, 69):
