@@ -241,8 +241,9 @@ int c6_conv_wino_out(int C, int N, int nboards, float *vbuf, const float *bias, 
                      const C6HeadFuse *heads = nullptr);
 bool c6_conv_wino_mid(int C, int N, int nboards, float *vbuf, const float *bias, const float *res, float *act, int num_cus, hipStream_t s,
                       const C6StemSrc *res_stem = nullptr);
-// F(4x4) only: the first layer's input transform straight from the boards (the stem computed on the fly); false: not available
-bool c6_conv_wino_stem_transform(int C, int N, int nboards, const C6StemSrc &stem, float *vbuf, int num_cus, hipStream_t s);
+// F(4x4) only: the first layer's input transform straight from the boards (the stem computed on the fly; its activations stored only
+// if `act` is given); false: not available
+bool c6_conv_wino_stem_transform(int C, int N, int nboards, const C6StemSrc &stem, float *vbuf, float *act, int num_cus, hipStream_t s);
 // FP32 Winograd F(4x4,3x3), C = 256 (conv_wino4.hip): what the functions above run at C = 256
 size_t c6_conv_packed_wino4_floats(int C);
 void c6_pack_conv_weights_wino4(int C, const float *w_oihw_folded, float *packed);

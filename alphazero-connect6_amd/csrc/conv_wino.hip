@@ -472,10 +472,10 @@ bool c6_conv_wino_mid(int C, int N, int nboards, float *vbuf, const float *bias,
     if (nboards <= 0) return true;
     return c6_conv_wino4_dispatch(C, N, nboards, nullptr, nullptr, bias, res, act, vbuf, num_cus, s, 1, 16, nullptr, res_stem);
 }
-bool c6_conv_wino_stem_transform(int C, int N, int nboards, const C6StemSrc &stem, float *vbuf, int num_cus, hipStream_t s) {
+bool c6_conv_wino_stem_transform(int C, int N, int nboards, const C6StemSrc &stem, float *vbuf, float *act, int num_cus, hipStream_t s) {
     if (!wino4(C)) return false;
     if (nboards <= 0) return true;
-    return c6_conv_wino4_dispatch(C, N, nboards, nullptr, nullptr, nullptr, nullptr, nullptr, vbuf, num_cus, s, 1, 1, nullptr, &stem);
+    return c6_conv_wino4_dispatch(C, N, nboards, nullptr, nullptr, nullptr, nullptr, act, vbuf, num_cus, s, 1, 1, nullptr, &stem);
 }
 bool c6_conv_wino_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                            float *vbuf, int num_cus, hipStream_t s, int relu) {

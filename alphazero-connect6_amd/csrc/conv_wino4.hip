@@ -199,7 +199,7 @@ __device__ __forceinline__ float w4_stem_plane(const C6StemSrc &S, long b, float
 
 // c6_wino4_in_kernel with the window rows computed from the board instead of loaded
 template <int N>
-__global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemSrc S, float *__restrict__ V, int nboards) {
+__global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemSrc S, float *__restrict__ V, float *__restrict__ act, int nboards) {
     using G = W4Geom<N>;
     constexpr int C = G::C, LPT = C / 4, TPI = W4_IN_THREADS / LPT, T = G::T, TW = G::TW, COLS = 4 * TW + 2, P = N + 2;
     constexpr int ROWF = COLS * C;
@@ -218,18 +218,22 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemS
     }
     const f32x4 sb = *reinterpret_cast<const f32x4 *>(S.bias + cq * 4);
     float pv = 0.f;
-    // rows y0 .. y0 + nr - 1 of the stem's output into the window (rows outside the board are zeros)
+    float *ab = act;
+    // rows y0 .. y0 + nr - 1 of the stem's output into the window (rows outside the board are zeros) and, if asked for, to memory
     auto fill = [&](int y0, int nr) {
         for (int k = tid; k < nr * N * LPT; k += W4_IN_THREADS) {
             const int r = k / (N * LPT), px = (k / LPT) % N, y = y0 + r;
-            const f32x4 v = (y >= 0 && y < N) ? w4_stem_pixel<N>(bd, pv, y, px, sb, [&](int t, int pl) { return sw[t][pl]; }) : zero4;
+            const bool inb = y >= 0 && y < N;
+            const f32x4 v = inb ? w4_stem_pixel<N>(bd, pv, y, px, sb, [&](int t, int pl) { return sw[t][pl]; }) : zero4;
             *reinterpret_cast<f32x4 *>(win + ((y + 1) % 6) * ROWF + (px + 1) * C + cq * 4) = v;
+            if (act && inb) *reinterpret_cast<f32x4 *>(ab + (size_t)(y * N + px) * C + cq * 4) = v;
         }
     };
 #pragma unroll 1
     for (int b = blockIdx.x; b < nboards; b += gridDim.x) {
         __syncthreads();                                            // the previous board's last reads (and the zero fills)
         pv = w4_stem_plane<N>(S, b, bd, tid, W4_IN_THREADS);
+        ab = act + (size_t)b * (N * N) * C;
         __syncthreads();
         fill(-1, 6);
 #pragma unroll 1
@@ -771,7 +775,7 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
         constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
         const int grid_in = nboards < num_cus ? nboards : num_cus;
         w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_stem_in_kernel<N>), (int)in_smem);
-        hipLaunchKernelGGL((c6_wino4_stem_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, *stem, Vb, nboards);
+        hipLaunchKernelGGL((c6_wino4_stem_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, *stem, Vb, out, nboards);
         if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
     } else if (steps & 1) {
         constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;

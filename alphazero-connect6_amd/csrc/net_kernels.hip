@@ -279,7 +279,8 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
     const bool timed = timers && timers->enabled;
     static const bool fuse_heads = [] { const char *e = getenv("C6_HEAD_FUSE"); return !(e && e[0] == '0'); }();   // A/B switch
     static const bool fuse_mid = [] { const char *e = getenv("C6_WINO_MID"); return !(e && e[0] == '0'); }();       // A/B switch
-    static const bool fuse_stem = [] { const char *e = getenv("C6_WINO_STEM"); return !(e && e[0] == '0'); }();     // A/B switch
+    static const int stem_mode = [] { const char *e = getenv("C6_WINO_STEM"); return e ? atoi(e) : 1; }();      // A/B switch: 0 the stem as a kernel of its own,
+    const bool fuse_stem = stem_mode != 0;                     // 1 never stored (computed twice), 2 computed by the first input transform and stored for the residual
     bool head_fused = false, heads_done = false, v_ready = false;
     // FP32 Winograd F(4x4) with at least two residual blocks: the stem's activations are never stored -- the first layer's input transform
     // computes them from the boards, and so does the boundary kernel behind the first block, which needs them as its residual
@@ -299,7 +300,7 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
             float *cout = half == 0 ? y : z;
             const float *cb = net.conv_b + (size_t)l * C;
             if (net.variant == C6_CONV_WINO) {
-                if (l == 0 && stem_inline) c6_conv_wino_stem_transform(C, net.N, nb, stem_src, vbuf, net.num_cus, s);      // straight from the boards
+                if (l == 0 && stem_inline) c6_conv_wino_stem_transform(C, net.N, nb, stem_src, vbuf, stem_mode == 2 ? x : nullptr, net.num_cus, s);      // straight from the boards
                 else if (!v_ready) c6_conv_wino_transform(C, net.N, nb, cin, vbuf, net.num_cus, s);      // else: the previous layer's fused transform left V
                 v_ready = false;
                 if (timed) {
@@ -318,7 +319,7 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                 static const int mid_mode = [] { const char *e = getenv("C6_WINO_MID"); return e ? atoi(e) : 2; }();      // 0 off, 1 inside blocks, 2 also across blocks
                 if (fuse_mid && !last_layer && (half == 0 || mid_mode >= 2) &&
                     c6_conv_wino_mid(C, net.N, nb, vbuf, cb, half == 0 ? nullptr : cres, half == 0 ? nullptr : cout, net.num_cus, s,
-                                     stem_inline && l == 1 ? &stem_src : nullptr)) {
+                                     stem_inline && stem_mode != 2 && l == 1 ? &stem_src : nullptr)) {
                     v_ready = true;
                     has_out = true;
                 } else {
