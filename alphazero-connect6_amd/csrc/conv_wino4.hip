@@ -5,15 +5,15 @@
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A      (points 0, +-1, +-2, inf: Lavin & Gray's matrices)
 // 25 tiles x 36 positions = 900 products per (cin, cout) and 19x19 board instead of 1600 for F(2x2) and 3249 direct: 3.6x fewer
 // matrix FLOPs than the direct form.  The price: a tile has 16 outputs per (tile, cout), so the output transform cannot be
-// accumulated in registers position by position as conv_wino.hip does (16 x 8192 accumulators per wave) -- the 36 products go
-// to memory and a transform kernel applies A^T . A.  The kernels:
-//   c6_wino4_gemm_kernel  M[block][tile][pos][cout] = sum_cin U_pos[cout][cin] V[block][tile][pos][cin]: conv_wino.hip's schedule
-//                         (persistent workgroups, wave w owns couts [32w, 32w+32) x 64 tiles, weights L2 -> VGPR through a ring of
-//                         8 groups, V slabs by LDS-DMA one position ahead, one barrier per position) without the accumulators and
-//                         without a single vector instruction in its loop; two accumulator sets alternate between positions, the
-//                         previous position's set is stored while this one accumulates.  MFMA bound, at the part's power limit
+// accumulated in registers position by position as conv_wino.hip does (16 x 8192 accumulators per wave).  Its column half can, one
+// patch row at a time: 24 row sums Z per (tile, cout) go to memory and a boundary kernel applies the row half.  The kernels:
+//   c6_wino4_gemm_kernel  Z[block][tile][row i][b][cout] = sum_j A^T[b][j] sum_cin U_ij[cout][cin] V[block][tile][ij][cin]:
+//                         conv_wino.hip's schedule (persistent workgroups, wave w owns couts [32w, 32w+32) x 64 tiles, weights L2 ->
+//                         VGPR through a ring of 8 groups, V slabs by LDS-DMA one position ahead, one barrier per position); positions
+//                         j = 0 and j = 5 of a row accumulate straight into Z, j = 1 .. 4 aside + a few packed vector instructions;
+//                         a row's Z is stored while the next row accumulates.  MFMA bound, at the part's power limit
 //   c6_wino4_in_kernel    activations NHWC -> V[block][tile 64][pos 36][C]      HBM bound: reads 1x, writes 36/16 x the activations
-//   c6_wino4_out_kernel   A^T M A + bias (+ residual), ReLU -> activations NHWC  HBM bound: reads 36/16 x + 1x, writes 1x;
+//   c6_wino4_out_kernel   A^T Z + bias (+ residual), ReLU -> activations NHWC   HBM bound: reads 24/16 x + 1x, writes 1x;
 //                         as the tower's last kernel it applies the heads' 1x1 filters instead of storing activations
 //   c6_wino4_mid_kernel   out of layer l + in of layer l + 1 in one pass through an LDS window: what runs between two GEMM kernels
 //                         inside the net (in / out are left with the tower's first and last layer, and with a layer on its own)
@@ -39,7 +39,7 @@ struct W4Geom {
     static constexpr int T = TW * TW;
     static constexpr int CP = C + 4;                // LDS row: conflict-free ds_read_b128 with one tile per lane
     static constexpr int SLAB = W4_BT * CP;         // floats of one (block, position) slab in LDS
-    static constexpr int POS_STRIDE = C;            // V / M in memory: [block][tile][pos][C]
+    static constexpr int POS_STRIDE = C;            // V in memory: [block][tile][pos][C]; Z: [block][tile][row 6][b 4][C]
     static constexpr int TILE_STRIDE = W4_NP * C;
     static constexpr size_t BLOCK_FLOATS = (size_t)W4_BT * W4_NP * C;
     static constexpr int WAVES = C / 32;
@@ -288,47 +288,54 @@ __global__ void c6_wino4_tail_kernel(float *__restrict__ V, long total_tiles) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) blk[i] = 0.f;
 }
 
-// ---- the 36 GEMMs of a block -------------------------------------------------------------------------------------------
-// Vector-memory operations of the main loop retire IN ORDER on one counter (loads, LDS-DMAs and stores alike), so they are
-// issued by hand and every wait names exactly the operations younger than the weight group it needs (conv_wino.hip).  Schedule of
-// a position (NG = 32 groups of 8 input channels): group k < 8 issues slab DMA k of the next position behind its weight wait;
-// groups 8, 10, .. 22 issue one each of the 8 stores of the PREVIOUS position's results (kept aside in 32 registers; a store is 64
-// lanes x 16 bytes to 64 different lines: all eight in one group cost 1 ms of 31; re-ordering them through LDS so that a store
-// covers 8 whole lines gained nothing more, and neither did a ring of 16 -- what remains against the kernel without its stores,
-// 2 ms, is the doubled HBM traffic itself, profiles/r02_wino_f4.txt); every group requests the weights of group + 7 first.  Younger than the weights of group i when they are waited for:
-#ifndef W4_ST_FIRST
-#define W4_ST_FIRST 8       // store k of a position goes out in group W4_ST_FIRST + W4_ST_STEP * k
-#define W4_ST_STEP 2
-#endif
-constexpr int w4_store_group(int k) { return W4_ST_FIRST + W4_ST_STEP * k; }
-constexpr int w4_store_of(int g) {      // the store issued in group g, or -1
-    for (int k = 0; k < 8; k++)
-        if (w4_store_group(k) == g) return k;
-    return -1;
-}
-constexpr int w4_wait(int i) {
-    const int nd = 8;
-    const int lo = i - W4_PF > 0 ? i - W4_PF : 0, hi = (nd - 1 < i - 1) ? nd - 1 : i - 1;
-    const int dmas = hi >= lo ? hi - lo + 1 : 0;
-    int stores = 0;      // issued behind the weight wait of their group: before wait(i) iff group < i, younger than request(i) iff group >= i - PF
-    for (int k = 0; k < 8; k++)
-        if (w4_store_group(k) < i && w4_store_group(k) >= i - W4_PF) stores++;
-    return W4_PF + dmas + stores;
-}
-static_assert(w4_store_group(7) < 32 - W4_PF, "the stores of a position are all older than the requests that are waited for in the next one");
+// ---- the 36 GEMMs of a block, with the column half of the output transform ("Z rows") ---------------------------------------
+// Per block of 64 tiles and position p = (i, j) the GEMM  M[cout][tile] = sum_cin U_p[cout][cin] V_p[cin][tile]  on 32x32x2 MFMAs:
+// persistent workgroups of 8 waves; wave w owns couts [32w, 32w + 32) x 64 tiles, so its transformed weights are private and stream
+// L2 -> VGPR as one linear 1-KiB-per-group sequence 7 groups ahead (ring of 8; 16 changed nothing); V_p (64 tile rows of 1 KiB) lands in
+// LDS by LDS-DMA one position ahead, double-buffered, rows padded to C + 4 floats (conflict-free ds_read_b128); one barrier per position.
+//  * Vector-memory operations retire IN ORDER on one counter (loads, LDS-DMAs and stores alike), and the compiler's own s_waitcnt
+//    counts do not see inline-asm operations: all of the loop's are issued by hand and every wait names exactly the operations younger
+//    than the weight group it needs (w4_wait): the 7 groups behind it, the slab DMAs (group k < 8 issues DMA k of the next position) and
+//    the result stores issued since (one per group, groups 8 .. 23 of the positions that store).
+//  * The FP32 matrix instructions run on the lanes of the vector ALU (their peak IS the vector FP32 peak; a kernel of plain vector
+//    instructions beside this one on another stream makes no progress at all): every vector instruction in the loop is matrix time
+//    lost.  The weight stream advances a SCALAR pointer, the tile fragments alternate between two register sets instead of being
+//    copied, accumulators start from the instruction's zero operand.  (With ~350 register copies / address adds per position the matrix
+//    pipes were busy 0.864 at 2.20 GHz, without them 0.968 at 2.07: the part is at its power limit for this instruction mix.)
+//  * Y = A^T M A, and the positions of a patch row i arrive one after the other: Z_i[b] = sum_j M[i][j] A^T[b][j] (b = 0 .. 3) is
+//    accumulated in registers -- one row at a time, 4 x 32 registers -- and 24 instead of 36 values per (tile, cout) go to memory: a third
+//    less for this kernel to write and for the boundary kernel behind it to read.  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0;
+//    0 1 -1 8 -8 1]: position j = 0 accumulates straight into Z_0 and j = 5 straight into Z_3 (no vector instruction); j = 1 .. 4
+//    accumulate aside and cost 40 packed vector instructions per position on average -- the one exception to the rule above: +1.5 % on
+//    this kernel, -19 % on the boundary kernels (same box, in the engine: 248.4 -> 236.8 ms per round).  Stores: Z_0, Z_1 during position
+//    j = 5 of their row, Z_2, Z_3 during j = 0 of the next.  Result: Zo[block][tile 64][row i 6][b 4][C].
 #define W4_ULOAD(dst, voff, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define W4_UWAIT(dst, n) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dst) : "n"(n) : "memory")
 #define W4_STORE(voff, data, base, imm) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #imm ::"v"(voff), "v"(data), "s"(base) : "memory")
+constexpr int w4_store_group(int k) { return 8 + k; }      // store k (0 .. 15) of a storing position goes out in group 8 + k
+constexpr int w4_wait(int i, bool stores) {
+    const int nd = 8;
+    const int lo = i - W4_PF > 0 ? i - W4_PF : 0, hi = (nd - 1 < i - 1) ? nd - 1 : i - 1;
+    const int dmas = hi >= lo ? hi - lo + 1 : 0;
+    int st = 0;
+    if (stores)
+        for (int k = 0; k < 16; k++)
+            if (w4_store_group(k) < i && w4_store_group(k) >= i - W4_PF) st++;
+    return W4_PF + dmas + st;
+}
+static_assert(w4_store_group(15) < 32 - W4_PF, "a position's stores are older than every request that is waited for in the next one");
 
 template <int N>
 __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
-                                                                        float *__restrict__ Mo, int nblocks) {
+                                                                         float *__restrict__ Zo, int nblocks) {
     using G = W4Geom<N>;
     constexpr int C = G::C, CP = G::CP, SLAB = G::SLAB, WAVES = G::WAVES, NG = G::NG, PF = W4_PF;
-    constexpr int NGT = W4_NP * NG;                  // weight groups of a whole block
-    constexpr int ND = W4_BT / WAVES;                // slab DMAs per wave and position
-    static_assert((PF == 7 || PF == 15) && NG == 32 && ND == 8, "ring of 8 / 16 weight groups; 8 DMAs and 8 stores per position");
-    constexpr int RM = PF;                           // ring index mask (ring size PF + 1, a power of two)
+    constexpr int NGT = W4_NP * NG;
+    constexpr int ND = W4_BT / WAVES;
+    static_assert(PF == 7 && NG == 32 && ND == 8, "ring of 8 weight groups; 8 DMAs per position");
+    constexpr int RM = PF;
+    constexpr int ZTILE = 24 * C;                    // floats of a tile in Zo
+    constexpr size_t ZBLOCK = (size_t)W4_BT * ZTILE;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -338,24 +345,16 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
 
     const float *ubase = U + (size_t)wave * NGT * 256;
     const unsigned lane16 = (unsigned)lane * 16u;
-    // the (tile j, position 0, couts n4 ..) corner of this lane in a block of M, bytes; tile half 1 is 32 tiles further
-    const unsigned moff0 = (unsigned)(((size_t)j * G::TILE_STRIDE + n4) * 4), moff1 = moff0 + (unsigned)((size_t)32 * G::TILE_STRIDE * 4);
+    const unsigned zoff0 = (unsigned)(((size_t)j * ZTILE + n4) * 4), zoff1 = zoff0 + (unsigned)((size_t)32 * ZTILE * 4);
 
     auto dma_chunk = [&](const float *src, int buf, int c0) {
-        const int c = c0 * WAVES + wave;            // tile c of the block: its row of this position
+        const int c = c0 * WAVES + wave;
         const float *gp = src + (size_t)c * G::TILE_STRIDE;
         const int lds_off = (buf * SLAB + c * CP) * 4;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lds_off) : "memory");
     };
-
 #pragma unroll
     for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * G::BLOCK_FLOATS, 0, c0);
-    // The FP32 matrix instructions run on the lanes of the vector ALU (their peak IS the vector FP32 peak; a kernel of plain
-    // vector instructions beside this one on another stream makes no progress at all): every vector instruction in the loop is
-    // matrix time lost.  So: the weight stream advances a SCALAR pointer (the lane offset never changes), the tile fragments
-    // alternate between two register sets instead of being copied, a position's accumulators start from the instruction's
-    // zero operand, and two accumulator sets alternate between positions -- the set of the previous position is stored while
-    // this one accumulates -- instead of being copied aside.
     f32x4 ring[PF + 1];
     const float *uptr = ubase;
     int gi = 0;
@@ -367,14 +366,27 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
 #pragma unroll
     for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W4_UNEXT() }
 
-    // results of the previous position, on their way to memory; the very first "previous position" is this block's position 0
-    // itself (zeros now, overwritten by the real results one position later: same wave, same addresses, in order)
-    f32x16 mA0, mA1, mB0, mB1;
+    // z[b][tile half]; the very first "previous row" is this block's row 0 itself (zeros, overwritten one row later)
+    f32x16 z00, z01, z10, z11, z20, z21, z30, z31, m0, m1;
     const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    mB0 = z16; mB1 = z16;
-    const float *sdst = Mo + (size_t)b * G::BLOCK_FLOATS;
+    z20 = z16; z21 = z16; z30 = z16; z31 = z16;
+    const float *zprev = Zo + (size_t)b * ZBLOCK;          // row base of the row whose Z_2, Z_3 are still to be stored
+    const float *zcur = zprev;                              // row base of the row being accumulated
 
-#define W4_GROUP(q, u, NWAIT, DMA, ST, BUF, ACC0, ACC1, SH0, SH1)                                                \
+    // store k (0 .. 15) of a storing position: two Z sets, each 2 tile halves x 4 quads
+#define W4Z_STORE1(SET0, SET1, BIDX, DST, k)                                                                     \
+    {                                                                                                            \
+        const f32x16 &sv = ((k) & 4) ? SET1 : SET0;                                                              \
+        const f32x4 a = {sv[4 * ((k) & 3)], sv[4 * ((k) & 3) + 1], sv[4 * ((k) & 3) + 2], sv[4 * ((k) & 3) + 3]}; \
+        const float *d_ = (DST) + (size_t)(BIDX) * C;                                                            \
+        if (((k) & 3) == 0) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 0);                                       \
+        else if (((k) & 3) == 1) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 32);                                 \
+        else if (((k) & 3) == 2) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 64);                                 \
+        else W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 96);                                                     \
+        asm volatile("s_nop 1" ::: "memory");                                                                    \
+    }
+    // JJ = position's column j: 0 accumulates into z0 from zero, 5 into z3 on top of it, 1 .. 4 into m from zero
+#define W4Z_GROUP(q, u, NWAIT, DMA, JJ, BUF)                                                                     \
             {                                                                                                    \
                 W4_ULOAD(ring[((q) + PF) & RM], lane16, uptr);                                                   \
                 W4_UNEXT()                                                                                       \
@@ -385,71 +397,108 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
                 W4_UWAIT(ring[(q)], NWAIT);                                                                      \
                 const f32x4 w = ring[(q)];                                                                       \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
-                ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : ACC0, 0, 0, 0); \
-                ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : ACC1, 0, 0, 0); \
+                if ((JJ) == 0) {                                                                                 \
+                    z00 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : z00, 0, 0, 0); \
+                    z01 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : z01, 0, 0, 0); \
+                } else if ((JJ) == 5) {                                                                          \
+                    z30 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], z30, 0, 0, 0);           \
+                    z31 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], z31, 0, 0, 0);           \
+                } else {                                                                                         \
+                    m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : m0, 0, 0, 0); \
+                    m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : m1, 0, 0, 0); \
+                }                                                                                                \
                 if ((DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (BUF) ^ 1, (DMA));                                 \
-                if ((ST) >= 0) {      /* store (ST): quad (ST) & 3 of tile half (ST) >> 2 of the previous position */ \
-                    const f32x16 &sv = (ST) < 4 ? SH0 : SH1;                                                     \
-                    const f32x4 a = {sv[4 * ((ST) & 3)], sv[4 * ((ST) & 3) + 1], sv[4 * ((ST) & 3) + 2], sv[4 * ((ST) & 3) + 3]}; \
-                    if (((ST) & 3) == 0) W4_STORE((ST) < 4 ? moff0 : moff1, a, sdst, 0);                         \
-                    else if (((ST) & 3) == 1) W4_STORE((ST) < 4 ? moff0 : moff1, a, sdst, 32);                   \
-                    else if (((ST) & 3) == 2) W4_STORE((ST) < 4 ? moff0 : moff1, a, sdst, 64);                   \
-                    else W4_STORE((ST) < 4 ? moff0 : moff1, a, sdst, 96);                                        \
-                    asm volatile("s_nop 1" ::: "memory");                                                        \
+                if ((JJ) == 5 && (u) >= 8 && (u) < 24) {      /* Z_0, Z_1 of this row */                          \
+                    if ((u) < 16) W4Z_STORE1(z00, z01, 0, zcur, (u) - 8)                                         \
+                    else W4Z_STORE1(z10, z11, 1, zcur, (u) - 16)                                                 \
+                }                                                                                                \
+                if ((JJ) == 0 && (u) >= 8 && (u) < 24) {      /* Z_2, Z_3 of the previous row */                  \
+                    if ((u) < 16) W4Z_STORE1(z20, z21, 2, zprev, (u) - 8)                                        \
+                    else W4Z_STORE1(z30, z31, 3, zprev, (u) - 16)                                                \
                 }                                                                                                \
                 _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                  \
-                    ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], ACC0, 0, 0, 0);         \
-                    ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], ACC1, 0, 0, 0);         \
+                    if ((JJ) == 0) {                                                                             \
+                        z00 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], z00, 0, 0, 0);       \
+                        z01 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], z01, 0, 0, 0);       \
+                    } else if ((JJ) == 5) {                                                                      \
+                        z30 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], z30, 0, 0, 0);       \
+                        z31 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], z31, 0, 0, 0);       \
+                    } else {                                                                                     \
+                        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], m0, 0, 0, 0);         \
+                        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], m1, 0, 0, 0);         \
+                    }                                                                                            \
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }
-#define WG_(i, BUF, A0, A1, S0, S1) W4_GROUP((i) & RM, (i), w4_wait(i), (i), w4_store_of(i), BUF, A0, A1, S0, S1)
-    // one position: slab in LDS buffer BUF (= position & 1), accumulating into ACC, storing SH (the previous position's results)
-#define W4_POSITION(pp, BUF, A0, A1, S0, S1)                                                                     \
+#define WGZ_(i, JJ, BUF) W4Z_GROUP((i) & RM, (i), w4_wait((i), (JJ) == 0 || (JJ) == 5), (i), JJ, BUF)
+    // one position (row i_, column JJ): slab in LDS buffer JJ & 1
+#define W4Z_POSITION(i_, JJ)                                                                                     \
         {                                                                                                        \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");      /* slab pp has landed (and older stores) */ \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");                                            \
             __builtin_amdgcn_s_barrier();                                                                        \
             const float *nsrc;                                                                                   \
             {                                                                                                    \
-                int nb = (pp) < W4_NP - 1 ? b : b + (int)gridDim.x;                                              \
-                nb = nb < nblocks ? nb : b;          /* no next block: copy this block's slab 0 again (never read) */ \
-                nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)((pp) < W4_NP - 1 ? (pp) + 1 : 0) * G::POS_STRIDE; \
+                const int pp = 6 * (i_) + (JJ);                                                                  \
+                int nb = pp < W4_NP - 1 ? b : b + (int)gridDim.x;                                                \
+                nb = nb < nblocks ? nb : b;                                                                      \
+                nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)(pp < W4_NP - 1 ? pp + 1 : 0) * G::POS_STRIDE; \
             }                                                                                                    \
-            const float *vb = wsm + (BUF) * SLAB + j * CP + 4 * h;                                               \
+            const float *vb = wsm + ((JJ) & 1) * SLAB + j * CP + 4 * h;                                          \
             f32x4 va[2][2];                                                                                      \
             va[0][0] = *reinterpret_cast<const f32x4 *>(vb);                                                     \
             va[0][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP);                                           \
-            WG_(0, BUF, A0, A1, S0, S1) WG_(1, BUF, A0, A1, S0, S1) WG_(2, BUF, A0, A1, S0, S1) WG_(3, BUF, A0, A1, S0, S1)         \
-            WG_(4, BUF, A0, A1, S0, S1) WG_(5, BUF, A0, A1, S0, S1) WG_(6, BUF, A0, A1, S0, S1) WG_(7, BUF, A0, A1, S0, S1)         \
-            WG_(8, BUF, A0, A1, S0, S1) WG_(9, BUF, A0, A1, S0, S1) WG_(10, BUF, A0, A1, S0, S1) WG_(11, BUF, A0, A1, S0, S1)       \
-            WG_(12, BUF, A0, A1, S0, S1) WG_(13, BUF, A0, A1, S0, S1) WG_(14, BUF, A0, A1, S0, S1) WG_(15, BUF, A0, A1, S0, S1)     \
-            WG_(16, BUF, A0, A1, S0, S1) WG_(17, BUF, A0, A1, S0, S1) WG_(18, BUF, A0, A1, S0, S1) WG_(19, BUF, A0, A1, S0, S1)     \
-            WG_(20, BUF, A0, A1, S0, S1) WG_(21, BUF, A0, A1, S0, S1) WG_(22, BUF, A0, A1, S0, S1) WG_(23, BUF, A0, A1, S0, S1)     \
-            WG_(24, BUF, A0, A1, S0, S1) WG_(25, BUF, A0, A1, S0, S1) WG_(26, BUF, A0, A1, S0, S1) WG_(27, BUF, A0, A1, S0, S1)     \
-            WG_(28, BUF, A0, A1, S0, S1) WG_(29, BUF, A0, A1, S0, S1) WG_(30, BUF, A0, A1, S0, S1) WG_(31, BUF, A0, A1, S0, S1)     \
-            sdst = Mo + (size_t)b * G::BLOCK_FLOATS + (size_t)(pp) * G::POS_STRIDE;      /* where ACC goes, one position later */ \
+            WGZ_(0, JJ, (JJ) & 1) WGZ_(1, JJ, (JJ) & 1) WGZ_(2, JJ, (JJ) & 1) WGZ_(3, JJ, (JJ) & 1)                     \
+            WGZ_(4, JJ, (JJ) & 1) WGZ_(5, JJ, (JJ) & 1) WGZ_(6, JJ, (JJ) & 1) WGZ_(7, JJ, (JJ) & 1)                     \
+            WGZ_(8, JJ, (JJ) & 1) WGZ_(9, JJ, (JJ) & 1) WGZ_(10, JJ, (JJ) & 1) WGZ_(11, JJ, (JJ) & 1)                   \
+            WGZ_(12, JJ, (JJ) & 1) WGZ_(13, JJ, (JJ) & 1) WGZ_(14, JJ, (JJ) & 1) WGZ_(15, JJ, (JJ) & 1)                 \
+            WGZ_(16, JJ, (JJ) & 1) WGZ_(17, JJ, (JJ) & 1) WGZ_(18, JJ, (JJ) & 1) WGZ_(19, JJ, (JJ) & 1)                 \
+            WGZ_(20, JJ, (JJ) & 1) WGZ_(21, JJ, (JJ) & 1) WGZ_(22, JJ, (JJ) & 1) WGZ_(23, JJ, (JJ) & 1)                 \
+            WGZ_(24, JJ, (JJ) & 1) WGZ_(25, JJ, (JJ) & 1) WGZ_(26, JJ, (JJ) & 1) WGZ_(27, JJ, (JJ) & 1)                 \
+            WGZ_(28, JJ, (JJ) & 1) WGZ_(29, JJ, (JJ) & 1) WGZ_(30, JJ, (JJ) & 1) WGZ_(31, JJ, (JJ) & 1)                 \
+        }
+    // the vector part: Z_b += A^T[b][JJ] * M for the columns that accumulate aside (A^T[.][1..4] = (1,1,1,1), (1,-1,1,-1), (1,2,4,8), (1,-2,4,-8))
+#define W4Z_UPDATE(JJ)                                                                                           \
+        _Pragma("unroll") for (int v = 0; v < 16; v++) {                                                         \
+            z00[v] += m0[v]; z01[v] += m1[v];                                                                    \
+            if ((JJ) == 1) { z10[v] = m0[v]; z11[v] = m1[v]; z20[v] = m0[v]; z21[v] = m1[v]; z30[v] = m0[v]; z31[v] = m1[v]; } \
+            if ((JJ) == 2) { z10[v] -= m0[v]; z11[v] -= m1[v]; z20[v] += m0[v]; z21[v] += m1[v]; z30[v] -= m0[v]; z31[v] -= m1[v]; } \
+            if ((JJ) == 3) {                                                                                     \
+                z10[v] = __builtin_fmaf(2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(2.f, m1[v], z11[v]);        \
+                z20[v] = __builtin_fmaf(4.f, m0[v], z20[v]); z21[v] = __builtin_fmaf(4.f, m1[v], z21[v]);        \
+                z30[v] = __builtin_fmaf(8.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(8.f, m1[v], z31[v]);        \
+            }                                                                                                    \
+            if ((JJ) == 4) {                                                                                     \
+                z10[v] = __builtin_fmaf(-2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(-2.f, m1[v], z11[v]);      \
+                z20[v] = __builtin_fmaf(4.f, m0[v], z20[v]); z21[v] = __builtin_fmaf(4.f, m1[v], z21[v]);        \
+                z30[v] = __builtin_fmaf(-8.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(-8.f, m1[v], z31[v]);      \
+            }                                                                                                    \
         }
 
 #pragma unroll 1
     for (; b < nblocks; b += gridDim.x) {
 #pragma unroll 1
-        for (int p = 0; p < W4_NP; p += 2) {
-            W4_POSITION(p, 0, mA0, mA1, mB0, mB1)
-            W4_POSITION(p + 1, 1, mB0, mB1, mA0, mA1)
+        for (int i = 0; i < 6; i++) {
+            zcur = Zo + (size_t)b * ZBLOCK + (size_t)i * (4 * C);
+            W4Z_POSITION(i, 0)            // (stores Z_2, Z_3 of the previous row to zprev)
+            W4Z_POSITION(i, 1) W4Z_UPDATE(1)
+            W4Z_POSITION(i, 2) W4Z_UPDATE(2)
+            W4Z_POSITION(i, 3) W4Z_UPDATE(3)
+            W4Z_POSITION(i, 4) W4Z_UPDATE(4)
+            W4Z_POSITION(i, 5)            // (stores Z_0, Z_1 of this row to zcur)
+            zprev = zcur;
         }
     }
-#undef W4_POSITION
-#undef WG_
-#undef W4_GROUP
+    // the last row's Z_2, Z_3
+#pragma unroll
+    for (int k = 0; k < 8; k++) W4Z_STORE1(z20, z21, 2, zprev, k)
+#pragma unroll
+    for (int k = 0; k < 8; k++) W4Z_STORE1(z30, z31, 3, zprev, k)
+#undef W4Z_UPDATE
+#undef W4Z_POSITION
+#undef WGZ_
+#undef W4Z_GROUP
+#undef W4Z_STORE1
 #undef W4_UNEXT
-    {      // the last position's results (an odd position: set B)
-        const f32x4 a0 = {mB0[0], mB0[1], mB0[2], mB0[3]}, a1 = {mB0[4], mB0[5], mB0[6], mB0[7]};
-        const f32x4 a2 = {mB0[8], mB0[9], mB0[10], mB0[11]}, a3 = {mB0[12], mB0[13], mB0[14], mB0[15]};
-        const f32x4 b0 = {mB1[0], mB1[1], mB1[2], mB1[3]}, b1 = {mB1[4], mB1[5], mB1[6], mB1[7]};
-        const f32x4 b2 = {mB1[8], mB1[9], mB1[10], mB1[11]}, b3 = {mB1[12], mB1[13], mB1[14], mB1[15]};
-        W4_STORE(moff0, a0, sdst, 0); W4_STORE(moff0, a1, sdst, 32); W4_STORE(moff0, a2, sdst, 64); W4_STORE(moff0, a3, sdst, 96);
-        W4_STORE(moff1, b0, sdst, 0); W4_STORE(moff1, b1, sdst, 32); W4_STORE(moff1, b2, sdst, 64); W4_STORE(moff1, b3, sdst, 96);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -468,6 +517,23 @@ __device__ __forceinline__ float w4_wave_sum(float v) {
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return (r0 + r1) + (r2 + r3);
 }
+// the 4x4 outputs of a tile (before bias) for this lane's 4 channels from the GEMM kernel's 24 row sums Z_i[b]: A^T Z, the row half of
+// the output transform; zb = the lane's corner of the tile in Z
+#define W4_ZTILE(C) (24 * (C))
+template <int C>
+__device__ __forceinline__ void w4_tile_outputs(const float *zb, f32x4 (&y)[4][4]) {
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        f32x4 z[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) z[i] = *reinterpret_cast<const f32x4 *>(zb + (size_t)(i * 4 + b) * C);
+        const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
+        y[0][b] = z[0] + s12 + s34;
+        y[1][b] = w4_fma(2.f, d34, d12);
+        y[2][b] = w4_fma(4.f, s34, s12);
+        y[3][b] = w4_fma(8.f, d34, d12) + z[5];
+    }
+}
 template <int N, bool HEADS>
 __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
                                                            float *__restrict__ out, long total_tiles, int relu, C6HeadFuse hd) {
@@ -485,22 +551,11 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
     }
 #pragma unroll 1
     for (long t = wave0; t < total_tiles; t += nwaves) {
-        const float *mb = M + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + lane * 4;
+        const float *mb = M + ((size_t)(t / W4_BT) * W4_BT + (size_t)(t % W4_BT)) * W4_ZTILE(C) + lane * 4;
         const long bd = t / T;
         const int tt = (int)(t - bd * T), ty = tt / TW, tx = tt - ty * TW;
-        // tcol[a][jj] = sum_i A^T[a][i] M[i][jj]
-        f32x4 tc[4][6];
-#pragma unroll
-        for (int jj = 0; jj < 6; jj++) {
-            f32x4 m[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) m[i] = *reinterpret_cast<const f32x4 *>(mb + (size_t)(i * 6 + jj) * C);
-            const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            tc[0][jj] = m[0] + s12 + s34;
-            tc[1][jj] = w4_fma(2.f, d34, d12);
-            tc[2][jj] = w4_fma(4.f, s34, s12);
-            tc[3][jj] = w4_fma(8.f, d34, d12) + m[5];
-        }
+        f32x4 yv[4][4];
+        w4_tile_outputs<C>(mb, yv);
         float hs[4][4][3];      // HEADS: this lane's share of the three filters' sums at the tile's 16 pixels
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -510,19 +565,13 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
         for (int a = 0; a < 4; a++) {
             const int py = 4 * ty + a;
             if (py >= N) continue;
-            const f32x4 s12 = tc[a][1] + tc[a][2], d12 = tc[a][1] - tc[a][2], s34 = tc[a][3] + tc[a][4], d34 = tc[a][3] - tc[a][4];
-            f32x4 y[4];
-            y[0] = tc[a][0] + s12 + s34;
-            y[1] = w4_fma(2.f, d34, d12);
-            y[2] = w4_fma(4.f, s34, s12);
-            y[3] = w4_fma(8.f, d34, d12) + tc[a][5];
 #pragma unroll
             for (int bb = 0; bb < 4; bb++) {
                 const int px = 4 * tx + bb;
                 if (px >= N) continue;
                 const int p = py * N + px;
                 const size_t o = ((size_t)bd * (N * N) + (size_t)p) * C + lane * 4;
-                f32x4 v = y[bb] + bi;
+                f32x4 v = yv[a][bb] + bi;
                 if (res) v = v + *reinterpret_cast<const f32x4 *>(res + o);
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = v[r] > floor_ ? v[r] : floor_;
@@ -608,31 +657,15 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
             f32x4 keep[3][4];
             if (t < TW) {
                 const long tt = (long)bd * T + t * TW + tx;
-                const float *mb = M + (size_t)(tt / W4_BT) * G::BLOCK_FLOATS + (size_t)(tt % W4_BT) * G::TILE_STRIDE + lane * 4;
-                f32x4 tc[4][6];
-#pragma unroll
-                for (int jj = 0; jj < 6; jj++) {
-                    f32x4 m[6];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) m[i] = *reinterpret_cast<const f32x4 *>(mb + (size_t)(i * 6 + jj) * C);
-                    const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-                    tc[0][jj] = m[0] + s12 + s34;
-                    tc[1][jj] = w4_fma(2.f, d34, d12);
-                    tc[2][jj] = w4_fma(4.f, s34, s12);
-                    tc[3][jj] = w4_fma(8.f, d34, d12) + m[5];
-                }
+                const float *mb = M + ((size_t)(tt / W4_BT) * W4_BT + (size_t)(tt % W4_BT)) * W4_ZTILE(C) + lane * 4;
+                f32x4 yv[4][4];
+                w4_tile_outputs<C>(mb, yv);
 #pragma unroll
                 for (int a = 0; a < 4; a++) {
                     const int py = 4 * t + a;
-                    const f32x4 s12 = tc[a][1] + tc[a][2], d12 = tc[a][1] - tc[a][2], s34 = tc[a][3] + tc[a][4], d34 = tc[a][3] - tc[a][4];
-                    f32x4 y[4];
-                    y[0] = tc[a][0] + s12 + s34;
-                    y[1] = w4_fma(2.f, d34, d12);
-                    y[2] = w4_fma(4.f, s34, s12);
-                    y[3] = w4_fma(8.f, d34, d12) + tc[a][5];
 #pragma unroll
                     for (int bb = 0; bb < 4; bb++) {
-                        f32x4 v = y[bb] + bi;
+                        f32x4 v = yv[a][bb] + bi;
                         const bool inb = py < N && 4 * tx + bb < N;
                         const size_t o = ((size_t)bd * (N * N) + (size_t)((inb ? py : 0) * N + (inb ? 4 * tx + bb : 0))) * C + lane * 4;
                         if (RS) {

@@ -49,7 +49,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, description)
-    "fp32": ("c6_wino4_gemm_kernel<19>", "FP32 Winograd F(4x4,3x3): the 36 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32; "
+    "fp32": ("c6_wino4_gemm_kernel<19>", "FP32 Winograd F(4x4,3x3): the 36 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, column half of the "
+             "output transform accumulated in registers; "
              "the transforms between the layers' GEMMs are HBM-bound kernels of their own (c6_wino4_mid_kernel: output transform of a layer + "
              "input transform of the next)"),
     "fp32_direct": ("c6_conv3x3_f32n_kernel<256, 19>", "FP32 direct implicit GEMM, v_mfma_f32_32x32x2_f32"),
@@ -426,10 +427,12 @@ def main():
                 # layer l + input transform of layer l + 1; the activations between the two convolutions of a block are never stored), and
                 # the last output transform, which applies the heads' 1x1 filters.  HBM-bound kernels.
                 nl = 2 * (wl["blocks"] - 1)
-                act_b, vm_b = n * n * Cc * 4 * nbd, 36 * tiles * Cc * 4 * nbd
-                # first layer: V written from the boards (the stem is computed, not read); inside a block: M in, V out; across blocks: M + residual
-                # in, activations + V out -- except behind the first block, whose residual (the stem) is computed too; last layer: M + residual in
-                tr_bytes = vm_b + (nl // 2) * (2 * vm_b) + (nl // 2 - 1) * (2 * vm_b + 2 * act_b) - act_b + (vm_b + act_b)
+                act_b, v_b, z_b = n * n * Cc * 4 * nbd, 36 * tiles * Cc * 4 * nbd, 24 * tiles * Cc * 4 * nbd
+                # V: the 36 transformed positions of a tile, GEMM input; Z: the 24 row sums the GEMM kernel leaves (column half of the output
+                # transform applied in its registers).  First layer: V written from the boards (the stem is computed, not read); inside a block:
+                # Z in, V out; across blocks: Z + residual in, activations + V out -- except behind the first block, whose residual (the stem) is
+                # computed too; last layer: Z + residual in
+                tr_bytes = v_b + (nl // 2) * (z_b + v_b) + (nl // 2 - 1) * (z_b + v_b + 2 * act_b) - act_b + (z_b + act_b)
                 tr_ms = (prof["conv_pre_ms"] + prof.get("conv_post_ms", 0.0)) / L
                 r["transforms"] = {"kernels": "c6_wino4_stem_in_kernel<19> (first layer: stem + input transform), c6_wino4_mid_kernel<19> (between layers), "
                                               "c6_wino4_out_kernel<19, true> (last layer + heads): HBM bound",
