@@ -46,6 +46,43 @@ struct W4Geom {
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int NG = C / 8;
     static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 4;
+    // Mixed tiling: when N = 4 (TW - 1) + 3 (19, 15) the last tile row / column has 3 output rows / columns, and F(3,3) -- 5 patch rows /
+    // columns, points 0, +-1, 2, inf -- covers them with 30 instead of 36 positions per tile: 846 instead of 900 positions per 19x19 board.
+    // Three classes of tiles, each in its own region of V / Z so that a GEMM block is of one class:
+    //   A   ty, tx < TW - 1          F(4) x F(4), 36 positions  p = 6 i + j
+    //   B   tx = TW - 1, ty < TW - 1  F(4) vertically, F(3) horizontally: 6 x 5 positions, stored TRANSPOSED, p = 6 j + i (j < 5)
+    //   B'  ty = TW - 1              F(3) vertically, F(4) horizontally: 5 x 6 positions, p = 6 i + j (i < 5); the corner tile is of this class
+    // so that for every class the 6-long direction runs inside a "row" of positions: the GEMM kernel's register half of the output
+    // transform is the same F(4) A^T everywhere, and B / B' blocks simply have 5 rows.
+    static constexpr bool MIX = (N % 4 == 3);
+    static constexpr int NA = MIX ? (TW - 1) * (TW - 1) : T, NB = MIX ? TW - 1 : 0, NBP = MIX ? TW : 0;      // tiles of a board per class
+};
+#define W4_CLS_A 0
+#define W4_CLS_B 1
+#define W4_CLS_BP 2
+#define W4_NP_EDGE 30   // positions of a B / B' tile
+// blocks of the three regions for `nboards` boards
+template <int N>
+struct W4Map {
+    long blkB, blkBP, nblocks;      // first block of region B, of region B', and the number of blocks
+    __host__ __device__ explicit W4Map(long nboards) {
+        using G = W4Geom<N>;
+        blkB = (nboards * G::NA + W4_BT - 1) / W4_BT;
+        blkBP = blkB + (nboards * G::NB + W4_BT - 1) / W4_BT;
+        nblocks = blkBP + (nboards * G::NBP + W4_BT - 1) / W4_BT;
+    }
+    __device__ __forceinline__ static int cls(int ty, int tx) {
+        using G = W4Geom<N>;
+        return !G::MIX ? W4_CLS_A : ty == G::TW - 1 ? W4_CLS_BP : tx == G::TW - 1 ? W4_CLS_B : W4_CLS_A;
+    }
+    // the tile's slot: block slot / 64, tile slot % 64 of the block
+    __device__ __forceinline__ long slot(long bd, int ty, int tx) const {
+        using G = W4Geom<N>;
+        if (!G::MIX) return bd * G::T + ty * G::TW + tx;
+        if (ty == G::TW - 1) return blkBP * W4_BT + bd * G::NBP + tx;
+        if (tx == G::TW - 1) return blkB * W4_BT + bd * G::NB + ty;
+        return bd * G::NA + ty * (G::TW - 1) + tx;
+    }
 };
 
 __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __builtin_elementwise_fma(f32x4{a, a, a, a}, x, y); }
@@ -67,6 +104,77 @@ __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __bu
    : (i) == 3 ? w4_fma(2.f, (x3) - (x1), (x4) - (x2))                                                \
    : (i) == 4 ? w4_fma(2.f, (x1) - (x3), (x4) - (x2))                                                \
               : w4_fma(4.f, x1, w4_fma(-5.f, x3, x5)))
+// row i of F(3,3)'s B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1] applied along the first index of x[5]
+#define W4_BT3_ROW(i, x0, x1, x2, x3, x4)                                                             \
+    ((i) == 0 ? w4_fma(2.f, (x0) - (x2), (x3) - (x1))                                                 \
+   : (i) == 1 ? w4_fma(-2.f, x1, (x3) - (x2))                                                         \
+   : (i) == 2 ? w4_fma(2.f, x1, w4_fma(-3.f, x2, x3))                                                 \
+   : (i) == 3 ? (x3) - (x1)                                                                           \
+              : w4_fma(2.f, (x1) - (x3), (x4) - (x2)))
+// B^T d B of one patch -> the tile's positions in V.  The patch's rows lie in the window slots slot[0 .. 5] (float offsets), wc = its
+// first column at this lane's channels, vb = the tile in V at this lane's channels.  One patch row at a time: interleaved, the six
+// rows' window reads spill.  cls is uniform over the wave.
+template <int C>
+__device__ __forceinline__ void w4_patch_transform(const float *wc, const int (&slot)[6], float *vb, int cls) {
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
+    if (cls == W4_CLS_A) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            f32x4 w[6];      // w[b] = sum_a B^T[i][a] d[a][b]
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const float *col = wc + b * C;
+                if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
+                else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
+                else {
+                    const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
+                    w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++) *reinterpret_cast<f32x4 *>(vb + (size_t)(i * 6 + jj) * C) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (cls == W4_CLS_BP) {      // 5 patch rows (F(3) vertically) x 6 columns
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            f32x4 w[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const float *col = wc + b * C;
+                if (i == 0) w[b] = W4_BT3_ROW(0, W4_D(0), W4_D(1), W4_D(2), W4_D(3), zero4);
+                else if (i == 4) w[b] = W4_BT3_ROW(4, zero4, W4_D(1), W4_D(2), W4_D(3), W4_D(4));
+                else {
+                    const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3);
+                    w[b] = W4_BT3_ROW(i, zero4, d1, d2, d3, zero4);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++) *reinterpret_cast<f32x4 *>(vb + (size_t)(i * 6 + jj) * C) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {                            // 6 patch rows x 5 columns (F(3) horizontally), positions stored transposed
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            f32x4 w[5];
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+                const float *col = wc + b * C;
+                if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
+                else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
+                else {
+                    const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
+                    w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 5; jj++) *reinterpret_cast<f32x4 *>(vb + (size_t)(jj * 6 + i) * C) = W4_BT3_ROW(jj, w[0], w[1], w[2], w[3], w[4]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef W4_D
+}
 template <int N>
 __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int nboards) {
     using G = W4Geom<N>;
@@ -75,6 +183,7 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float 
     constexpr int NPF = (4 * N * LPT + W4_IN_THREADS - 1) / W4_IN_THREADS;      // prefetch items (f32x4) per thread and step
     extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C]
     const int tid = threadIdx.x, cq = tid % LPT, tsub = tid / LPT;
+    const W4Map<N> map(nboards);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = tid; k < 6 * ROWF / 4; k += W4_IN_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
     // item k of a load of rows y0 .. y0 + nr - 1: row y0 + k / (N LPT), pixel (k / LPT) % N, channel quad k % LPT
@@ -119,35 +228,14 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float 
             }
 #pragma unroll 1
             for (int tx = tsub; tx < TW; tx += TPI) {
-                const long t = (long)bd * T + ty * TW + tx;
+                const long t = map.slot(bd, ty, tx);
                 float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + cq * 4;
                 // window slot of patch row a (board row 4 ty - 1 + a) and the patch's first column
                 const float *wc = win + (4 * tx) * C + cq * 4;
                 int slot[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    // w[b] = sum_a B^T[i][a] d[a][b]
-                    f32x4 w[6];
-#pragma unroll
-                    for (int b = 0; b < 6; b++) {
-                        const float *col = wc + b * C;
-#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
-                        if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
-                        else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
-                        else {
-                            const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
-                            w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
-                        }
-#undef W4_D
-                    }
-                    float *o = vb + (size_t)(i * 6) * G::POS_STRIDE;
-#pragma unroll
-                    for (int jj = 0; jj < 6; jj++)
-                        *reinterpret_cast<f32x4 *>(o + jj * G::POS_STRIDE) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
-                    __builtin_amdgcn_sched_barrier(0);      // one patch row at a time: interleaved, the six rows' window reads spill
-                }
+                w4_patch_transform<C>(wc, slot, vb, W4Map<N>::cls(ty, tx));
             }
             if (more) {
                 __syncthreads();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more: their slots take rows 4 ty + 5 .. 4 ty + 8
@@ -207,6 +295,7 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemS
     extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] + the board plane [P][P]
     float *bd = win + 6 * ROWF;
     const int tid = threadIdx.x, cq = tid % LPT, tsub = tid / LPT;
+    const W4Map<N> map(nboards);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = tid; k < 6 * ROWF / 4; k += W4_IN_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
     for (int k = tid; k < P * P; k += W4_IN_THREADS) bd[k] = 0.f;
@@ -241,33 +330,13 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemS
             __syncthreads();                                        // rows 4 ty - 1 .. 4 ty + 4 are in the window
 #pragma unroll 1
             for (int tx = tsub; tx < TW; tx += TPI) {
-                const long t = (long)b * T + ty * TW + tx;
+                const long t = map.slot(b, ty, tx);
                 float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + cq * 4;
                 const float *wc = win + (4 * tx) * C + cq * 4;
                 int slot[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    f32x4 w[6];
-#pragma unroll
-                    for (int bb = 0; bb < 6; bb++) {
-                        const float *col = wc + bb * C;
-#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
-                        if (i == 0) w[bb] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
-                        else if (i == 5) w[bb] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
-                        else {
-                            const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
-                            w[bb] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
-                        }
-#undef W4_D
-                    }
-                    float *o = vb + (size_t)(i * 6) * G::POS_STRIDE;
-#pragma unroll
-                    for (int jj = 0; jj < 6; jj++)
-                        *reinterpret_cast<f32x4 *>(o + jj * G::POS_STRIDE) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                w4_patch_transform<C>(wc, slot, vb, W4Map<N>::cls(ty, tx));
             }
             if (ty + 1 < TW) {
                 __syncthreads();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more
@@ -277,15 +346,24 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemS
     }
 }
 
-// the tail of the last block (tiles beyond the batch) is never written by the kernel above: zero it once per launch
+// the tail of a region's last block (tiles beyond the batch) is never written by the kernels above: zero it once per launch
 template <int N>
-__global__ void c6_wino4_tail_kernel(float *__restrict__ V, long total_tiles) {
+__global__ void c6_wino4_tail_kernel(float *__restrict__ V, int nboards) {
     using G = W4Geom<N>;
-    const long nblocks = (total_tiles + W4_BT - 1) / W4_BT;
-    const int first = (int)(total_tiles - (nblocks - 1) * W4_BT);
-    float *blk = V + (size_t)(nblocks - 1) * G::BLOCK_FLOATS + (size_t)first * G::TILE_STRIDE;
-    const size_t n = (size_t)(W4_BT - first) * G::TILE_STRIDE;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) blk[i] = 0.f;
+    const W4Map<N> map(nboards);
+    const long first_blk[3] = {0, map.blkB, map.blkBP}, count[3] = {(long)nboards * G::NA, (long)nboards * G::NB, (long)nboards * G::NBP};
+    for (int r = 0; r < 3; r++) {
+        const int used = (int)(count[r] % W4_BT);
+        if (used == 0) continue;
+        float *blk = V + (size_t)(first_blk[r] + count[r] / W4_BT) * G::BLOCK_FLOATS + (size_t)used * G::TILE_STRIDE;
+        const size_t n = (size_t)(W4_BT - used) * G::TILE_STRIDE;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) blk[i] = 0.f;
+    }
+}
+template <int N>
+static bool w4_has_tail(int nboards) {
+    using G = W4Geom<N>;
+    return ((long)nboards * G::NA) % W4_BT || ((long)nboards * G::NB) % W4_BT || ((long)nboards * G::NBP) % W4_BT;
 }
 
 // ---- the 36 GEMMs of a block, with the column half of the output transform ("Z rows") ---------------------------------------
@@ -327,10 +405,9 @@ static_assert(w4_store_group(15) < 32 - W4_PF, "a position's stores are older th
 
 template <int N>
 __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
-                                                                         float *__restrict__ Zo, int nblocks) {
+                                                                         float *__restrict__ Zo, int nblocks, int blkB, int blkBP) {
     using G = W4Geom<N>;
     constexpr int C = G::C, CP = G::CP, SLAB = G::SLAB, WAVES = G::WAVES, NG = G::NG, PF = W4_PF;
-    constexpr int NGT = W4_NP * NG;
     constexpr int ND = W4_BT / WAVES;
     static_assert(PF == 7 && NG == 32 && ND == 8, "ring of 8 weight groups; 8 DMAs per position");
     constexpr int RM = PF;
@@ -343,7 +420,13 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
     int b = blockIdx.x;
     if (b >= nblocks) return;
 
-    const float *ubase = U + (size_t)wave * NGT * 256;
+    // blocks [0, blkB) are of class A (6 rows of positions, weight set 0), [blkB, blkBP) of class B, [blkBP, nblocks) of class B' (5 rows,
+    // weight sets at 36 C^2 and 66 C^2); a set is packed [wave][position][group][lane][4]
+    auto rows_of = [&](int blk) { return blk < blkB ? 6 : 5; };
+    auto wbase_of = [&](int blk) {
+        return blk < blkB ? U + (size_t)wave * (W4_NP * NG * 256)
+                          : U + (size_t)(blk < blkBP ? W4_NP : W4_NP + W4_NP_EDGE) * C * C + (size_t)wave * (W4_NP_EDGE * NG * 256);
+    };
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned zoff0 = (unsigned)(((size_t)j * ZTILE + n4) * 4), zoff1 = zoff0 + (unsigned)((size_t)32 * ZTILE * 4);
 
@@ -356,12 +439,18 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
 #pragma unroll
     for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * G::BLOCK_FLOATS, 0, c0);
     f32x4 ring[PF + 1];
-    const float *uptr = ubase;
+    int ub = b, ungt = rows_of(b) * 6 * NG;      // the weight stream runs ahead of the multiplications: its own block and group counters
+    const float *uptr = wbase_of(b);
     int gi = 0;
 #define W4_UNEXT()                                                       \
     {                                                                    \
         gi += 1; uptr += 256;                                            \
-        if (gi == NGT) { gi = 0; uptr = ubase; }                         \
+        if (gi == ungt) {                                                \
+            gi = 0;                                                      \
+            ub = ub + (int)gridDim.x < nblocks ? ub + (int)gridDim.x : ub; \
+            ungt = rows_of(ub) * 6 * NG;                                 \
+            uptr = wbase_of(ub);                                         \
+        }                                                                \
     }
 #pragma unroll
     for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W4_UNEXT() }
@@ -439,9 +528,9 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
             const float *nsrc;                                                                                   \
             {                                                                                                    \
                 const int pp = 6 * (i_) + (JJ);                                                                  \
-                int nb = pp < W4_NP - 1 ? b : b + (int)gridDim.x;                                                \
+                int nb = pp < 6 * R - 1 ? b : b + (int)gridDim.x;                                                \
                 nb = nb < nblocks ? nb : b;                                                                      \
-                nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)(pp < W4_NP - 1 ? pp + 1 : 0) * G::POS_STRIDE; \
+                nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)(pp < 6 * R - 1 ? pp + 1 : 0) * G::POS_STRIDE; \
             }                                                                                                    \
             const float *vb = wsm + ((JJ) & 1) * SLAB + j * CP + 4 * h;                                          \
             f32x4 va[2][2];                                                                                      \
@@ -476,8 +565,9 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
 
 #pragma unroll 1
     for (; b < nblocks; b += gridDim.x) {
+        const int R = rows_of(b);
 #pragma unroll 1
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < R; i++) {
             zcur = Zo + (size_t)b * ZBLOCK + (size_t)i * (4 * C);
             W4Z_POSITION(i, 0)            // (stores Z_2, Z_3 of the previous row to zprev)
             W4Z_POSITION(i, 1) W4Z_UPDATE(1)
@@ -517,21 +607,46 @@ __device__ __forceinline__ float w4_wave_sum(float v) {
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return (r0 + r1) + (r2 + r3);
 }
-// the 4x4 outputs of a tile (before bias) for this lane's 4 channels from the GEMM kernel's 24 row sums Z_i[b]: A^T Z, the row half of
-// the output transform; zb = the lane's corner of the tile in Z
+// the 4x4 outputs of a tile (before bias) for this lane's 4 channels from the GEMM kernel's row sums Z_i[b]: the other half of the
+// output transform; zb = the lane's corner of the tile in Z.  Class A: A^T Z with F(4)'s A^T over 6 rows.  Class B': F(3)'s
+// A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1] over 5 rows -> output rows 0 .. 2.  Class B (stored transposed: Z's row index is the patch
+// COLUMN j, b the output ROW): the same over j -> output columns 0 .. 2.  The fourth row / column of an edge tile lies beyond the board.
 #define W4_ZTILE(C) (24 * (C))
 template <int C>
-__device__ __forceinline__ void w4_tile_outputs(const float *zb, f32x4 (&y)[4][4]) {
+__device__ __forceinline__ void w4_tile_outputs(const float *zb, f32x4 (&y)[4][4], int cls) {
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cls == W4_CLS_A) {
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        f32x4 z[6];
+        for (int b = 0; b < 4; b++) {
+            f32x4 z[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) z[i] = *reinterpret_cast<const f32x4 *>(zb + (size_t)(i * 4 + b) * C);
-        const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
-        y[0][b] = z[0] + s12 + s34;
-        y[1][b] = w4_fma(2.f, d34, d12);
-        y[2][b] = w4_fma(4.f, s34, s12);
-        y[3][b] = w4_fma(8.f, d34, d12) + z[5];
+            for (int i = 0; i < 6; i++) z[i] = *reinterpret_cast<const f32x4 *>(zb + (size_t)(i * 4 + b) * C);
+            const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
+            y[0][b] = z[0] + s12 + s34;
+            y[1][b] = w4_fma(2.f, d34, d12);
+            y[2][b] = w4_fma(4.f, s34, s12);
+            y[3][b] = w4_fma(8.f, d34, d12) + z[5];
+        }
+    } else {
+        f32x4 e[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const f32x4 z0 = *reinterpret_cast<const f32x4 *>(zb + (size_t)(0 * 4 + b) * C), z1 = *reinterpret_cast<const f32x4 *>(zb + (size_t)(1 * 4 + b) * C),
+                        z2 = *reinterpret_cast<const f32x4 *>(zb + (size_t)(2 * 4 + b) * C), z3 = *reinterpret_cast<const f32x4 *>(zb + (size_t)(3 * 4 + b) * C),
+                        z4 = *reinterpret_cast<const f32x4 *>(zb + (size_t)(4 * 4 + b) * C);
+            const f32x4 s12 = z1 + z2, d12 = z1 - z2;
+            e[0][b] = z0 + s12 + z3;
+            e[1][b] = w4_fma(2.f, z3, d12);
+            e[2][b] = w4_fma(4.f, z3, s12) + z4;
+        }
+        const bool tr = cls == W4_CLS_B;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const f32x4 rowwise = a < 3 ? e[a < 3 ? a : 0][b] : zero4, colwise = b < 3 ? e[b < 3 ? b : 0][a] : zero4;
+                y[a][b] = tr ? colwise : rowwise;
+            }
     }
 }
 template <int N, bool HEADS>
@@ -549,13 +664,14 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
         hw1 = *reinterpret_cast<const f32x4 *>(hd.w + C + lane * 4);
         hw2 = *reinterpret_cast<const f32x4 *>(hd.w + 2 * C + lane * 4);
     }
+    const W4Map<N> map(total_tiles / T);
 #pragma unroll 1
     for (long t = wave0; t < total_tiles; t += nwaves) {
-        const float *mb = M + ((size_t)(t / W4_BT) * W4_BT + (size_t)(t % W4_BT)) * W4_ZTILE(C) + lane * 4;
         const long bd = t / T;
         const int tt = (int)(t - bd * T), ty = tt / TW, tx = tt - ty * TW;
+        const float *mb = M + (size_t)map.slot(bd, ty, tx) * W4_ZTILE(C) + lane * 4;
         f32x4 yv[4][4];
-        w4_tile_outputs<C>(mb, yv);
+        w4_tile_outputs<C>(mb, yv, W4Map<N>::cls(ty, tx));
         float hs[4][4][3];      // HEADS: this lane's share of the three filters' sums at the tile's 16 pixels
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -632,6 +748,7 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
     constexpr int C = G::C, T = G::T, TW = G::TW, COLS = 4 * TW + 2, ROWF = COLS * C, NT = 64 * TW;
     extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C]
     const int tid = threadIdx.x, lane = tid & 63, tx = tid >> 6;
+    const W4Map<N> map(nboards);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + lane * 4) : zero4;
     for (int k = tid; k < 6 * ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
@@ -656,10 +773,9 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
         for (int t = 0; t <= TW; t++) {
             f32x4 keep[3][4];
             if (t < TW) {
-                const long tt = (long)bd * T + t * TW + tx;
-                const float *mb = M + ((size_t)(tt / W4_BT) * W4_BT + (size_t)(tt % W4_BT)) * W4_ZTILE(C) + lane * 4;
+                const float *mb = M + (size_t)map.slot(bd, t, tx) * W4_ZTILE(C) + lane * 4;
                 f32x4 yv[4][4];
-                w4_tile_outputs<C>(mb, yv);
+                w4_tile_outputs<C>(mb, yv, W4Map<N>::cls(t, tx));
 #pragma unroll
                 for (int a = 0; a < 4; a++) {
                     const int py = 4 * t + a;
@@ -686,33 +802,13 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
             __syncthreads();                                // board rows 4t - 5 .. 4t are in the window
             if (t >= 1) {
                 const int ty = t - 1;
-                const long tt = (long)bd * T + ty * TW + tx;
+                const long tt = map.slot(bd, ty, tx);
                 float *vb = V + (size_t)(tt / W4_BT) * G::BLOCK_FLOATS + (size_t)(tt % W4_BT) * G::TILE_STRIDE + lane * 4;
                 const float *wc = win + (4 * tx) * C + lane * 4;
                 int slot[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    f32x4 w[6];
-#pragma unroll
-                    for (int b = 0; b < 6; b++) {
-                        const float *col = wc + b * C;
-#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
-                        if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
-                        else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
-                        else {
-                            const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
-                            w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
-                        }
-#undef W4_D
-                    }
-                    float *o = vb + (size_t)(i * 6) * G::POS_STRIDE;
-#pragma unroll
-                    for (int jj = 0; jj < 6; jj++)
-                        *reinterpret_cast<f32x4 *>(o + jj * G::POS_STRIDE) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                w4_patch_transform<C>(wc, slot, vb, W4Map<N>::cls(ty, tx));
             }
             __syncthreads();                                // rows 4t - 5 .. 4t - 3 are read no more: their slots take rows 4t + 1 .. 4t + 3
             if (t < TW) {
@@ -726,63 +822,65 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-size_t c6_conv_packed_wino4_floats(int C) { return (size_t)W4_NP * C * C; }
+size_t c6_conv_packed_wino4_floats(int C) { return (size_t)(W4_NP + 2 * W4_NP_EDGE) * C * C; }
 
-// w: folded OIHW [C][C][3][3] -> U = G g G^T (double, rounded once) packed [wave][pos = 6i + j][group u][lane][r]:
-//    U_pos[cout = 32 wave + (lane & 31)][cin = 8u + 4(lane >> 5) + r]
+// Transformed weights U = G_v g G_h^T (double, rounded once), three sets one behind the other (W4Geom): class A (36 positions p = 6 i + j:
+// F(4)'s G both ways), class B (30 positions p = 6 j + i: G4 vertically, F(3)'s G horizontally), class B' (30 positions p = 6 i + j: G3
+// vertically, G4 horizontally).  A set is packed [wave][position][group u][lane][r]: U_p[cout = 32 wave + (lane & 31)][cin = 8u + 4(lane >> 5) + r].
+// g: the 9 taps of (cout, cin); flip: the input-gradient layer's taps w'[2 - a][2 - b]
+__host__ __device__ inline double w4_u_element(int set, int pos, const float *g, bool flip) {
+    const double G4[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const double G3[5][3] = {{1.0 / 2, 0.0, 0.0}, {-1.0 / 2, -1.0 / 2, -1.0 / 2}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
+    const int p = pos / 6, q = pos % 6;
+    const double *gv = set == 0 ? G4[p] : set == 1 ? G4[q] : G3[p];      // the row of G on the vertical side
+    const double *gh = set == 0 ? G4[q] : set == 1 ? G3[p] : G4[q];      // ... and on the horizontal side
+    double sum = 0.0;
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) sum += gv[a] * (double)g[flip ? 8 - (a * 3 + b) : a * 3 + b] * gh[b];
+    return sum;
+}
+// element e of the packed array -> (set, position, cout, cin)
+__host__ __device__ inline void w4_u_index(int C, size_t e, int &set, int &pos, int &co, int &ci) {
+    const size_t cc = (size_t)C * C;
+    set = e < W4_NP * cc ? 0 : e < (W4_NP + W4_NP_EDGE) * cc ? 1 : 2;
+    const int npos = set == 0 ? W4_NP : W4_NP_EDGE, NG = C / 8;
+    size_t q = e - (set == 0 ? 0 : set == 1 ? W4_NP * cc : (W4_NP + W4_NP_EDGE) * cc);
+    const int r = (int)(q % 4); q /= 4;
+    const int lane = (int)(q % 64); q /= 64;
+    const int u = (int)(q % NG); q /= NG;
+    pos = (int)(q % npos); q /= npos;
+    co = (int)q * 32 + (lane & 31);
+    ci = 8 * u + 4 * (lane >> 5) + r;
+}
+// w: folded OIHW [C][C][3][3]
 void c6_pack_conv_weights_wino4(int C, const float *w, float *packed) {
-    static const double Gm[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-    const int WAVES = C / 32, NG = C / 8;
-    for (int wv = 0; wv < WAVES; wv++)
-        for (int lane = 0; lane < 64; lane++)
-            for (int u = 0; u < NG; u++)
-                for (int r = 0; r < 4; r++) {
-                    const int co = wv * 32 + (lane & 31), ci = 8 * u + 4 * (lane >> 5) + r;
-                    const float *g = w + ((size_t)co * C + ci) * 9;
-                    for (int i = 0; i < 6; i++)
-                        for (int jj = 0; jj < 6; jj++) {
-                            double s = 0.0;
-                            for (int a = 0; a < 3; a++)
-                                for (int b = 0; b < 3; b++) s += Gm[i][a] * (double)g[a * 3 + b] * Gm[jj][b];
-                            packed[((((size_t)wv * W4_NP + (i * 6 + jj)) * NG + u) * 64 + lane) * 4 + r] = (float)s;
-                        }
-                }
+    const size_t total = c6_conv_packed_wino4_floats(C);
+    for (size_t e = 0; e < total; e++) {
+        int set, pos, co, ci;
+        w4_u_index(C, e, set, pos, co, ci);
+        packed[e] = (float)w4_u_element(set, pos, w + ((size_t)co * C + ci) * 9, false);
+    }
 }
 
 // the same packing on the device, from weights that change every training step (trainer.cpp); transpose_flip: the layer of the
 // input gradient, w'[ci][co][2 - a][2 - b]
 __global__ void c6_pack_wino4_kernel(int C, const float *__restrict__ w, float *__restrict__ packed, int transpose_flip) {
-    const double Gm[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-    const int NG = C / 8;
-    const size_t total = (size_t)W4_NP * C * C;
+    const size_t total = (size_t)(W4_NP + 2 * W4_NP_EDGE) * C * C;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        size_t q = e;
-        const int r = (int)(q % 4); q /= 4;
-        const int lane = (int)(q % 64); q /= 64;
-        const int u = (int)(q % NG); q /= NG;
-        const int pos = (int)(q % W4_NP); q /= W4_NP;
-        const int wv = (int)q;
-        const int co = wv * 32 + (lane & 31), ci = 8 * u + 4 * (lane >> 5) + r, i = pos / 6, jj = pos % 6;
+        int set, pos, co, ci;
+        w4_u_index(C, e, set, pos, co, ci);
         const float *g = transpose_flip ? w + ((size_t)ci * C + co) * 9 : w + ((size_t)co * C + ci) * 9;
-        double sum = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) sum += Gm[i][a] * (double)g[transpose_flip ? 8 - (a * 3 + b) : a * 3 + b] * Gm[jj][b];
-        packed[e] = (float)sum;
+        packed[e] = (float)w4_u_element(set, pos, g, transpose_flip != 0);
     }
 }
 void c6_pack_conv_weights_wino4_dev(int C, const float *w_oihw_dev, float *packed_dev, int transpose_flip, hipStream_t s) {
     hipLaunchKernelGGL(c6_pack_wino4_kernel, dim3(1024), dim3(256), 0, s, C, w_oihw_dev, packed_dev, transpose_flip);
 }
 
-// floats of the scratch for `nboards` boards: V and M, one behind the other
-static size_t w4_half_floats(int N, int nboards) {
-    const long TW = (N + 3) / 4, tiles = (long)nboards * TW * TW, nblocks = (tiles + W4_BT - 1) / W4_BT;
-    return (size_t)nblocks * W4_BT * W4_NP * W4_C;
-}
+// floats of the scratch for `nboards` boards: V and Z, one behind the other (Z uses 24 / 36 of its half)
+static long w4_nblocks(int N, int nboards) { return N == 19 ? W4Map<19>(nboards).nblocks : N == 15 ? W4Map<15>(nboards).nblocks : W4Map<9>(nboards).nblocks; }
+static size_t w4_half_floats(int N, int nboards) { return (size_t)w4_nblocks(N, nboards) * W4_BT * W4_NP * W4_C; }
 size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards) { return C == W4_C ? 2 * w4_half_floats(N, nboards) : 0; }
 
 // the dynamic-LDS limit of a kernel, raised once per (kernel, device) instead of at every launch
@@ -802,26 +900,28 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
                       int relu, int steps, hipStream_t s, const C6HeadFuse *heads, const C6StemSrc *stem) {
     using G = W4Geom<N>;
     const long tiles = (long)nboards * G::T;
-    const int nblocks = (int)((tiles + W4_BT - 1) / W4_BT);
+    const W4Map<N> map(nboards);
+    const int nblocks = (int)map.nblocks;
+    const bool tail = w4_has_tail<N>(nboards);
     float *Vb = vbuf, *Mb = vbuf + w4_half_floats(N, nboards);
     if ((steps & 1) && stem) {      // the first layer: window rows computed from the boards
         constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
         const int grid_in = nboards < num_cus ? nboards : num_cus;
         w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_stem_in_kernel<N>), (int)in_smem);
         hipLaunchKernelGGL((c6_wino4_stem_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, *stem, Vb, out, nboards);
-        if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
+        if (tail) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, nboards);
     } else if (steps & 1) {
         constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
         const int grid_in = nboards < num_cus ? nboards : num_cus;
         w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_in_kernel<N>), (int)in_smem);
         hipLaunchKernelGGL((c6_wino4_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, in, Vb, nboards);
-        if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
+        if (tail) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, nboards);
     }
     if (steps & 2) {
         const size_t smem = G::LDS_BYTES;
         const int grid = nblocks < num_cus ? nblocks : num_cus;
         w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N>), (int)smem);
-        hipLaunchKernelGGL((c6_wino4_gemm_kernel<N>), dim3(grid), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks);
+        hipLaunchKernelGGL((c6_wino4_gemm_kernel<N>), dim3(grid), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP);
     }
     if (steps & 16) {      // output transform of this layer (bias, residual if any, ReLU; activations stored if `out`) + input transform of the next: M -> V
         constexpr size_t mid_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;
@@ -834,7 +934,7 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
             w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_mid_kernel<N, false>), (int)mid_smem);
             hipLaunchKernelGGL((c6_wino4_mid_kernel<N, false>), dim3(grid_mid), dim3(64 * G::TW), mid_smem, s, Mb, bias, res, out, Vb, nboards, C6StemSrc{});
         }
-        if (tiles % W4_BT) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, tiles);
+        if (tail) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, nboards);
     }
     if (steps & 4) {
         const long want = (tiles + 3) / 4;
@@ -854,8 +954,12 @@ bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const fl
     if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem); return true; }
     return false;
 }
-// matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 positions x C x C MACs)
+// matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 or 30 positions x C x C MACs)
+template <int N>
+static double w4_exec_flops(int C, int nboards) {
+    const W4Map<N> m(nboards);
+    return 2.0 * ((double)W4_NP * m.blkB + (double)W4_NP_EDGE * (m.nblocks - m.blkB)) * W4_BT * (double)C * C;
+}
 double c6_conv_wino4_exec_flops(int C, int N, int nboards) {
-    const long TW = (N + 3) / 4, tiles = (long)nboards * TW * TW, nblocks = (tiles + W4_BT - 1) / W4_BT;
-    return 2.0 * W4_NP * (double)nblocks * W4_BT * (double)C * C;
+    return N == 19 ? w4_exec_flops<19>(C, nboards) : N == 15 ? w4_exec_flops<15>(C, nboards) : w4_exec_flops<9>(C, nboards);
 }

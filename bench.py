@@ -49,7 +49,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, description)
-    "fp32": ("c6_wino4_gemm_kernel<19>", "FP32 Winograd F(4x4,3x3): the 36 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, column half of the "
+    "fp32": ("c6_wino4_gemm_kernel<19>", "FP32 Winograd F(4x4,3x3) (F(3,3) in the last tile row / column): the 36 / 30 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, column half of the "
              "output transform accumulated in registers; "
              "the transforms between the layers' GEMMs are HBM-bound kernels of their own (c6_wino4_mid_kernel: output transform of a layer + "
              "input transform of the next)"),
@@ -419,15 +419,17 @@ def main():
                  "executed_mfma_tflops": prof["conv_exec_flops"] / (gemm_ms * 1e-3) / 1e12, "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt_)}
             r["frac_executed"] = r["executed_mfma_tflops"] / peak
             if name == "fp32":
-                r["note"] = ("frac = ALGORITHMIC FLOP/s (2*9*C^2*N^2 per board and layer, SURVEY 8d) / dense FP32-MFMA peak; Winograd F(4x4,3x3) executes 3.6x "
-                             "fewer matrix FLOPs than that count (900 products per channel pair and board instead of 3249), so frac exceeds 1 -- "
+                r["note"] = ("frac = ALGORITHMIC FLOP/s (2*9*C^2*N^2 per board and layer, SURVEY 8d) / dense FP32-MFMA peak; Winograd F(4x4,3x3) with F(3,3) edge tiles executes 3.8x "
+                             "fewer matrix FLOPs than that count (846 products per channel pair and board instead of 3249), so frac exceeds 1 -- "
                              "frac_executed is the matrix-pipe utilisation; the two transforms are HBM-bound kernels of their own, reported beside it")
                 nbd, Cc, tiles = min(G * 8, 32768), wl["channels"], ((n + 3) // 4) ** 2
                 # between the GEMM kernels: one input transform in front of the tower, then ONE kernel per layer boundary (output transform of
                 # layer l + input transform of layer l + 1; the activations between the two convolutions of a block are never stored), and
                 # the last output transform, which applies the heads' 1x1 filters.  HBM-bound kernels.
                 nl = 2 * (wl["blocks"] - 1)
-                act_b, v_b, z_b = n * n * Cc * 4 * nbd, 36 * tiles * Cc * 4 * nbd, 24 * tiles * Cc * 4 * nbd
+                tw = (n + 3) // 4
+                edge = 2 * tw - 1 if n % 4 == 3 else 0      # mixed tiling: the last tile row / column is F(3,3) in one direction, 30 positions / 20 row sums
+                act_b, v_b, z_b = n * n * Cc * 4 * nbd, (36 * (tiles - edge) + 30 * edge) * Cc * 4 * nbd, (24 * (tiles - edge) + 20 * edge) * Cc * 4 * nbd
                 # V: the 36 transformed positions of a tile, GEMM input; Z: the 24 row sums the GEMM kernel leaves (column half of the output
                 # transform applied in its registers).  First layer: V written from the boards (the stem is computed, not read); inside a block:
                 # Z in, V out; across blocks: Z + residual in, activations + V out -- except behind the first block, whose residual (the stem) is
