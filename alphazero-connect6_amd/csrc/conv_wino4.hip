@@ -3,8 +3,8 @@
 // Same layer and the same f32 arithmetic as conv_wino.hip (conv3x3 C -> C, pad 1, + folded-BN bias (+ residual) + ReLU;
 // AlphaZero/cpp_weighted/model.hpp:61-78; f32 operands, exact f32 products, f32 accumulate), with 6x6 patches / 4x4 outputs:
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A      (points 0, +-1, +-2, inf: Lavin & Gray's matrices)
-// 25 tiles x 36 positions = 900 products per (cin, cout) and 19x19 board instead of 1600 for F(2x2) and 3249 direct -- 846 with F(3,3)
-// along the short side of the last tile row and column (W4Geom::MIX): 3.8x fewer matrix FLOPs than the direct form.  The price: a tile has 16 outputs per (tile, cout), so the output transform cannot be
+// 25 tiles x 36 positions = 900 products per (cin, cout) and 19x19 board instead of 1600 for F(2x2) and 3249 direct: 3.6x fewer
+// matrix FLOPs than the direct form.  The price: a tile has 16 outputs per (tile, cout), so the output transform cannot be
 // accumulated in registers position by position as conv_wino.hip does (16 x 8192 accumulators per wave).  Its column half can, one
 // patch row at a time: 24 row sums Z per (tile, cout) go to memory and a boundary kernel applies the row half.  The kernels:
 //   c6_wino4_gemm_kernel  Z[block][tile][row i][b][cout] = sum_j A^T[b][j] sum_cin U_ij[cout][cin] V[block][tile][ij][cin]:
