@@ -3,8 +3,8 @@
 // Same layer and the same f32 arithmetic as conv_wino.hip (conv3x3 C -> C, pad 1, + folded-BN bias (+ residual) + ReLU;
 // AlphaZero/cpp_weighted/model.hpp:61-78; f32 operands, exact f32 products, f32 accumulate), with 6x6 patches / 4x4 outputs:
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A      (points 0, +-1, +-2, inf: Lavin & Gray's matrices)
-// 25 tiles x 36 positions = 900 products per (cin, cout) and 19x19 board instead of 1600 for F(2x2) and 3249 direct: 3.6x fewer
-// matrix FLOPs than the direct form.  The price: a tile has 16 outputs per (tile, cout), so the output transform cannot be
+// 25 tiles x 36 positions = 900 products per (cin, cout) and 19x19 board instead of 1600 for F(2x2) and 3249 direct -- 846 with F(3,3)
+// along the short side of the last tile row and column (W4Geom::MIX): 3.8x fewer matrix FLOPs than the direct form.  The price: a tile has 16 outputs per (tile, cout), so the output transform cannot be
 // accumulated in registers position by position as conv_wino.hip does (16 x 8192 accumulators per wave).  Its column half can, one
 // patch row at a time: 24 row sums Z per (tile, cout) go to memory and a boundary kernel applies the row half.  The kernels:
 //   c6_wino4_gemm_kernel  Z[block][tile][row i][b][cout] = sum_j A^T[b][j] sum_cin U_ij[cout][cin] V[block][tile][ij][cin]:
@@ -85,7 +85,9 @@ struct W4Map {
     }
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __builtin_elementwise_fma(f32x4{a, a, a, a}, x, y); }
+__device__ __forceinline__ f32x2 w4_fma(float a, f32x2 x, f32x2 y) { return __builtin_elementwise_fma(f32x2{a, a}, x, y); }
 
 // ---- input transform: B^T d B, B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] ----
 // One workgroup per board at a time; the board's rows pass through a rolling 6-row window in LDS (row y in slot (y + 1) mod 6,
@@ -112,68 +114,60 @@ __device__ __forceinline__ f32x4 w4_fma(float a, f32x4 x, f32x4 y) { return __bu
    : (i) == 3 ? (x3) - (x1)                                                                           \
               : w4_fma(2.f, (x1) - (x3), (x4) - (x2)))
 // B^T d B of one patch -> the tile's positions in V.  The patch's rows lie in the window slots slot[0 .. 5] (float offsets), wc = its
-// first column at this lane's channels, vb = the tile in V at this lane's channels.  One patch row at a time: interleaved, the six
-// rows' window reads spill.  cls is uniform over the wave.
+// first column (channel 0), vt = the tile in V (channel 0).  A lane transforms 4 channels as two passes of 2 -- channels 2 lane, 2 lane + 1
+// of each half of C -- so that the whole patch of a pass fits in registers (36 x 2) and every window value is read from LDS ONCE: formed
+// one patch row at a time from the window (4 channels per lane, 132 reads of 16 bytes per tile) the LDS reads alone were a third of
+// the kernels' time.  A pass reads and stores 512 contiguous bytes per wave instruction.  cls is uniform over the wave.
 template <int C>
-__device__ __forceinline__ void w4_patch_transform(const float *wc, const int (&slot)[6], float *vb, int cls) {
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#define W4_D(a) (*reinterpret_cast<const f32x4 *>(col + slot[a]))
-    if (cls == W4_CLS_A) {
+__device__ __forceinline__ void w4_patch_transform(const float *wc, const int (&slot)[6], float *vt, int lane, int cls) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            f32x4 w[6];      // w[b] = sum_a B^T[i][a] d[a][b]
-#pragma unroll
-            for (int b = 0; b < 6; b++) {
-                const float *col = wc + b * C;
-                if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
-                else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
-                else {
-                    const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
-                    w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < 6; jj++) *reinterpret_cast<f32x4 *>(vb + (size_t)(i * 6 + jj) * C) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else if (cls == W4_CLS_BP) {      // 5 patch rows (F(3) vertically) x 6 columns
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            f32x4 w[6];
+    for (int h = 0; h < 2; h++) {
+        const int co = h * (C / 2) + lane * 2;
+        const float *wl = wc + co;
+        float *vl = vt + co;
+#define W4_D(a, b) (*reinterpret_cast<const f32x2 *>(wl + slot[a] + (b) * C))
+#define W4_VST(pos, val) *reinterpret_cast<f32x2 *>(vl + (size_t)(pos) * C) = (val)
+        if (cls == W4_CLS_A) {
+            f32x2 t[6][6];      // t[i][b] = sum_a B^T[i][a] d[a][b]
 #pragma unroll
             for (int b = 0; b < 6; b++) {
-                const float *col = wc + b * C;
-                if (i == 0) w[b] = W4_BT3_ROW(0, W4_D(0), W4_D(1), W4_D(2), W4_D(3), zero4);
-                else if (i == 4) w[b] = W4_BT3_ROW(4, zero4, W4_D(1), W4_D(2), W4_D(3), W4_D(4));
-                else {
-                    const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3);
-                    w[b] = W4_BT3_ROW(i, zero4, d1, d2, d3, zero4);
-                }
+                const f32x2 d0 = W4_D(0, b), d1 = W4_D(1, b), d2 = W4_D(2, b), d3 = W4_D(3, b), d4 = W4_D(4, b), d5 = W4_D(5, b);
+#pragma unroll
+                for (int i = 0; i < 6; i++) t[i][b] = W4_BT_ROW(i, d0, d1, d2, d3, d4, d5);
             }
 #pragma unroll
-            for (int jj = 0; jj < 6; jj++) *reinterpret_cast<f32x4 *>(vb + (size_t)(i * 6 + jj) * C) = W4_BT_ROW(jj, w[0], w[1], w[2], w[3], w[4], w[5]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {                            // 6 patch rows x 5 columns (F(3) horizontally), positions stored transposed
+            for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            f32x4 w[5];
+                for (int jj = 0; jj < 6; jj++) W4_VST(i * 6 + jj, W4_BT_ROW(jj, t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5]));
+        } else if (cls == W4_CLS_BP) {      // 5 patch rows (F(3) vertically) x 6 columns
+            f32x2 t[5][6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const f32x2 d0 = W4_D(0, b), d1 = W4_D(1, b), d2 = W4_D(2, b), d3 = W4_D(3, b), d4 = W4_D(4, b);
+#pragma unroll
+                for (int i = 0; i < 5; i++) t[i][b] = W4_BT3_ROW(i, d0, d1, d2, d3, d4);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int jj = 0; jj < 6; jj++) W4_VST(i * 6 + jj, W4_BT_ROW(jj, t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5]));
+        } else {                            // 6 patch rows x 5 columns (F(3) horizontally), positions stored transposed
+            f32x2 t[6][5];
 #pragma unroll
             for (int b = 0; b < 5; b++) {
-                const float *col = wc + b * C;
-                if (i == 0) w[b] = w4_fma(4.f, W4_D(0), w4_fma(-5.f, W4_D(2), W4_D(4)));
-                else if (i == 5) w[b] = w4_fma(4.f, W4_D(1), w4_fma(-5.f, W4_D(3), W4_D(5)));
-                else {
-                    const f32x4 d1 = W4_D(1), d2 = W4_D(2), d3 = W4_D(3), d4 = W4_D(4);
-                    w[b] = W4_BT_ROW(i, zero4, d1, d2, d3, d4, zero4);
-                }
+                const f32x2 d0 = W4_D(0, b), d1 = W4_D(1, b), d2 = W4_D(2, b), d3 = W4_D(3, b), d4 = W4_D(4, b), d5 = W4_D(5, b);
+#pragma unroll
+                for (int i = 0; i < 6; i++) t[i][b] = W4_BT_ROW(i, d0, d1, d2, d3, d4, d5);
             }
 #pragma unroll
-            for (int jj = 0; jj < 5; jj++) *reinterpret_cast<f32x4 *>(vb + (size_t)(jj * 6 + i) * C) = W4_BT3_ROW(jj, w[0], w[1], w[2], w[3], w[4]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int jj = 0; jj < 5; jj++) W4_VST(jj * 6 + i, W4_BT3_ROW(jj, t[i][0], t[i][1], t[i][2], t[i][3], t[i][4]));
         }
-    }
 #undef W4_D
+#undef W4_VST
+        __builtin_amdgcn_sched_barrier(0);      // one pass at a time
+    }
 }
 template <int N>
 __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float *__restrict__ in, float *__restrict__ V, int nboards) {
@@ -229,13 +223,13 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float 
 #pragma unroll 1
             for (int tx = tsub; tx < TW; tx += TPI) {
                 const long t = map.slot(bd, ty, tx);
-                float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + cq * 4;
+                float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE;
                 // window slot of patch row a (board row 4 ty - 1 + a) and the patch's first column
-                const float *wc = win + (4 * tx) * C + cq * 4;
+                const float *wc = win + (4 * tx) * C;
                 int slot[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
-                w4_patch_transform<C>(wc, slot, vb, W4Map<N>::cls(ty, tx));
+                w4_patch_transform<C>(wc, slot, vb, cq, W4Map<N>::cls(ty, tx));
             }
             if (more) {
                 __syncthreads();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more: their slots take rows 4 ty + 5 .. 4 ty + 8
@@ -331,12 +325,12 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemS
 #pragma unroll 1
             for (int tx = tsub; tx < TW; tx += TPI) {
                 const long t = map.slot(b, ty, tx);
-                float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE + cq * 4;
-                const float *wc = win + (4 * tx) * C + cq * 4;
+                float *vb = V + (size_t)(t / W4_BT) * G::BLOCK_FLOATS + (size_t)(t % W4_BT) * G::TILE_STRIDE;
+                const float *wc = win + (4 * tx) * C;
                 int slot[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
-                w4_patch_transform<C>(wc, slot, vb, W4Map<N>::cls(ty, tx));
+                w4_patch_transform<C>(wc, slot, vb, cq, W4Map<N>::cls(ty, tx));
             }
             if (ty + 1 < TW) {
                 __syncthreads();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more
@@ -803,12 +797,12 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
             if (t >= 1) {
                 const int ty = t - 1;
                 const long tt = map.slot(bd, ty, tx);
-                float *vb = V + (size_t)(tt / W4_BT) * G::BLOCK_FLOATS + (size_t)(tt % W4_BT) * G::TILE_STRIDE + lane * 4;
-                const float *wc = win + (4 * tx) * C + lane * 4;
+                float *vb = V + (size_t)(tt / W4_BT) * G::BLOCK_FLOATS + (size_t)(tt % W4_BT) * G::TILE_STRIDE;
+                const float *wc = win + (4 * tx) * C;
                 int slot[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * ROWF;
-                w4_patch_transform<C>(wc, slot, vb, W4Map<N>::cls(ty, tx));
+                w4_patch_transform<C>(wc, slot, vb, lane, W4Map<N>::cls(ty, tx));
             }
             __syncthreads();                                // rows 4t - 5 .. 4t - 3 are read no more: their slots take rows 4t + 1 .. 4t + 3
             if (t < TW) {
