@@ -32,7 +32,11 @@ PRECISIONS = [pytest.param(1, id="fp32-winograd"), pytest.param(6, id="fp32-dire
                                             (19, 256, 2, 300), (15, 128, 3, 300), (9, 64, 2, 700),
                                             # Winograd F(4x4) (C = 256) at the other board sizes: 4x4 / 3x3 tiles per board, partial edge tiles,
                                             # 64-tile blocks that end inside a board and a last block that is not full
-                                            (15, 256, 2, 7), (15, 256, 3, 150), (9, 256, 2, 100)])
+                                            (15, 256, 2, 7), (15, 256, 3, 150), (9, 256, 2, 100),
+                                            # mixed tiling (19 = 4+4+4+4+3, 15 = 4+4+4+3): F(3,3) edge tiles live in regions of their own, each
+                                            # with a last block of its own -- one board (every region a partial block), 13 boards (208 / 52 / 65
+                                            # tiles: region B under one block), 65 boards of 15x15 (585 / 195 / 260)
+                                            (19, 256, 2, 1), (19, 256, 3, 13), (15, 256, 2, 65)])
 def test_net_forward_vs_oracle(n, C, blocks, num, prec):
     need_gpu()
     rng = np.random.default_rng(n * 1000 + C)
