@@ -957,3 +957,217 @@ static double w4_exec_flops(int C, int nboards) {
 double c6_conv_wino4_exec_flops(int C, int N, int nboards) {
     return N == 19 ? w4_exec_flops<19>(C, nboards) : N == 15 ? w4_exec_flops<15>(C, nboards) : w4_exec_flops<9>(C, nboards);
 }
+
+// ---- weight gradient in the Winograd domain (the trainer's FP32 path, trainer.cpp) -----------------------------------------------
+// Y = A^T [U .* V] A per tile, so  dU_p[co][ci] = sum over tiles (A dY A^T)_p[co] V_p[ci]  and  dg = G_v^T dU G_h: the 3x3 filter's gradient from
+// 846 (19x19) / 529 (15x15) products per board and channel pair instead of 9 N^2 -- 3.8x fewer matrix FLOPs than the direct
+// form (c6_wgrad_kernel, train_kernels.hip), in f32 like it.  Three kernels behind the input transform of x (c6_wino4_in_kernel):
+//   c6_wino4_dyt_kernel    dY (NHWC) -> D = A dY A^T in V's layout (regions, classes and the transposed class B as for V)
+//   c6_wino4_wgrad_kernel  per (class, position p, chunk of blocks):  partial[co][ci] = sum_tiles D_p[tile][co] V_p[tile][ci]
+//   c6_wino4_wgrad_finish_kernel   sums the chunks and applies G_v^T . G_h of each class: dW (OIHW)
+// A (6x4) = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1],  F(3): (5x3) = [1 0 0; 1 1 1; 1 -1 1; 1 2 4; 0 0 1]
+#define W4_A4_ROW(i, y0, y1, y2, y3)                                                                  \
+    ((i) == 0 ? (y0)                                                                                  \
+   : (i) == 1 ? ((y0) + (y2)) + ((y1) + (y3))                                                         \
+   : (i) == 2 ? ((y0) + (y2)) - ((y1) + (y3))                                                         \
+   : (i) == 3 ? w4_fma(4.f, y2, y0) + w4_fma(8.f, y3, (y1) + (y1))                                    \
+   : (i) == 4 ? w4_fma(4.f, y2, y0) - w4_fma(8.f, y3, (y1) + (y1))                                    \
+              : (y3))
+#define W4_A3_ROW(i, y0, y1, y2)                                                                      \
+    ((i) == 0 ? (y0) : (i) == 1 ? ((y0) + (y2)) + (y1) : (i) == 2 ? ((y0) + (y2)) - (y1) : (i) == 3 ? w4_fma(4.f, y2, y0) + ((y1) + (y1)) : (y2))
+template <int N>
+__global__ __launch_bounds__(256) void c6_wino4_dyt_kernel(const float *__restrict__ dy, float *__restrict__ D, long total_tiles) {
+    using G = W4Geom<N>;
+    constexpr int C = G::C, T = G::T, TW = G::TW;
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const W4Map<N> map(total_tiles / T);
+#pragma unroll 1
+    for (long t = wave0; t < total_tiles; t += nwaves) {
+        const long bd = t / T;
+        const int tt = (int)(t - bd * T), ty = tt / TW, tx = tt - ty * TW, cls = W4Map<N>::cls(ty, tx);
+        const long sl = map.slot(bd, ty, tx);
+        float *db = D + (size_t)(sl / W4_BT) * G::BLOCK_FLOATS + (size_t)(sl % W4_BT) * G::TILE_STRIDE + lane * 4;
+        f32x4 y[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int py = 4 * ty + a, px = 4 * tx + b;
+                const bool inb = py < N && px < N;
+                y[a][b] = inb ? *reinterpret_cast<const f32x4 *>(dy + ((size_t)bd * (N * N) + (size_t)(py * N + px)) * C + lane * 4) : zero4;
+            }
+        if (cls == W4_CLS_A) {
+            f32x4 r[6][4];      // vertical: r[i][b] = sum_a A[i][a] y[a][b]
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int i = 0; i < 6; i++) r[i][b] = W4_A4_ROW(i, y[0][b], y[1][b], y[2][b], y[3][b]);
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) *reinterpret_cast<f32x4 *>(db + (size_t)(i * 6 + j) * C) = W4_A4_ROW(j, r[i][0], r[i][1], r[i][2], r[i][3]);
+        } else if (cls == W4_CLS_BP) {      // 3 output rows: F(3) vertically, F(4) horizontally
+            f32x4 r[5][4];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int i = 0; i < 5; i++) r[i][b] = W4_A3_ROW(i, y[0][b], y[1][b], y[2][b]);
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) *reinterpret_cast<f32x4 *>(db + (size_t)(i * 6 + j) * C) = W4_A4_ROW(j, r[i][0], r[i][1], r[i][2], r[i][3]);
+        } else {                            // 3 output columns: F(4) vertically, F(3) horizontally, stored transposed
+            f32x4 r[6][3];
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int i = 0; i < 6; i++) r[i][b] = W4_A4_ROW(i, y[0][b], y[1][b], y[2][b], y[3][b]);
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 5; j++) *reinterpret_cast<f32x4 *>(db + (size_t)(j * 6 + i) * C) = W4_A3_ROW(j, r[i][0], r[i][1], r[i][2]);
+        }
+    }
+}
+
+// the work of the GEMM kernel: per class its blocks cut into chunks of `per`; item = (class, position, chunk)
+struct W4WgPlan {
+    int first_blk[3], nblk[3], chunks[3], item0[3], per, items;
+};
+template <int N>
+static W4WgPlan w4_wg_plan(int nboards, int num_cus) {
+    const W4Map<N> m(nboards);
+    W4WgPlan p;
+    p.first_blk[0] = 0; p.first_blk[1] = (int)m.blkB; p.first_blk[2] = (int)m.blkBP;
+    p.nblk[0] = (int)m.blkB; p.nblk[1] = (int)(m.blkBP - m.blkB); p.nblk[2] = (int)(m.nblocks - m.blkBP);
+    const long units = (long)W4_NP * p.nblk[0] + (long)W4_NP_EDGE * (p.nblk[1] + p.nblk[2]);
+    p.per = (int)((units + 2L * num_cus - 1) / (2L * num_cus));      // about two workgroups' worth of items per CU
+    if (p.per < 1) p.per = 1;
+    p.items = 0;
+    for (int s = 0; s < 3; s++) {
+        p.chunks[s] = (p.nblk[s] + p.per - 1) / p.per;
+        p.item0[s] = p.items;
+        p.items += (s == 0 ? W4_NP : W4_NP_EDGE) * p.chunks[s];
+    }
+    return p;
+}
+// Workgroup of 8 waves: wave w owns couts [32w, 32w + 32) x all 256 cins (8 accumulator tiles); K = the tiles of the item's blocks, 32
+// at a time: the 32 rows of D_p and of V_p (1 KiB each, stride one tile) land in LDS by LDS-DMA one stage ahead (rows padded to C + 32
+// floats: the two K rows of a 32x32x2 operand fall into different halves of the banks); per K step of 2 tiles one LDS read for the D
+// fragment and eight for the V fragments feed eight MFMAs.
+#define W4G_CP (W4_C + 32)
+#define W4G_ROWS 32
+template <int N>
+__global__ __launch_bounds__(512) void c6_wino4_wgrad_kernel(const float *__restrict__ D, const float *__restrict__ V, float *__restrict__ partial, W4WgPlan P) {
+    using G = W4Geom<N>;
+    constexpr int C = G::C, CP = W4G_CP, STG = W4G_ROWS * CP;      // floats of one operand's stage
+    extern __shared__ __attribute__((aligned(16))) float wsm[];      // [2 stages][D, V][32][CP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x;
+    const int set = item >= P.item0[2] ? 2 : item >= P.item0[1] ? 1 : 0;
+    const int local = item - P.item0[set], pos = local / P.chunks[set], chunk = local - pos * P.chunks[set];
+    const int b0 = P.first_blk[set] + chunk * P.per;
+    const int b1 = b0 + P.per < P.first_blk[set] + P.nblk[set] ? b0 + P.per : P.first_blk[set] + P.nblk[set];
+    const int nst = 2 * (b1 - b0);                                   // stages of 32 tiles
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // stage st -> buffer st & 1: wave w copies rows 4w .. 4w + 3 of D and of V
+    auto dma = [&](int st) {
+        const int blk = b0 + (st >> 1), half = st & 1, buf = st & 1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = wave * 4 + r;
+            const size_t src = (size_t)blk * G::BLOCK_FLOATS + (size_t)(half * W4G_ROWS + row) * G::TILE_STRIDE + (size_t)pos * C;
+            const float *gd = D + src, *gv = V + src;
+            const int ld = ((buf * 2 + 0) * STG + row * CP) * 4, lv = ((buf * 2 + 1) * STG + row * CP) * 4;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gd), "s"(ld) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gv), "s"(lv) : "memory");
+        }
+    };
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[j][v] = 0.f;
+    const int i = lane & 31, kk = lane >> 5;
+    dma(0);
+#pragma unroll 1
+    for (int st = 0; st < nst; st++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                             // stage st has landed; everyone is done with the other buffer
+        if (st + 1 < nst) dma(st + 1);
+        const float *dl = wsm + ((st & 1) * 2 + 0) * STG + kk * CP + wave * 32 + i;
+        const float *vl = wsm + ((st & 1) * 2 + 1) * STG + kk * CP + i;
+#pragma unroll 4
+        for (int s = 0; s < W4G_ROWS / 2; s++) {
+            const float a = dl[2 * s * CP];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, vl[2 * s * CP + 32 * j], acc[j], 0, 0, 0);
+        }
+    }
+    // partial[item][co][ci]: acc[j][v] = (co = 32 wave + 8 (v / 4) + 4 kk + v % 4, ci = 32 j + i)
+    float *pb = partial + (size_t)item * C * C;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) pb[(size_t)(32 * wave + 8 * (v / 4) + 4 * kk + (v % 4)) * C + 32 * j + i] = acc[j][v];
+}
+// dW[co][ci][a][b] (OIHW) = sum over classes and positions  G_v[.][a] dU_p G_h[.][b],  dU_p = the sum of the item's chunks in chunk order
+__global__ void c6_wino4_wgrad_finish_kernel(int C, const float *__restrict__ partial, float *__restrict__ dw, W4WgPlan P) {
+    const double G4[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const double G3[5][3] = {{1.0 / 2, 0.0, 0.0}, {-1.0 / 2, -1.0 / 2, -1.0 / 2}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
+    const size_t cc = (size_t)C * C;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cc; e += (size_t)gridDim.x * blockDim.x) {
+        double g[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) g[k] = 0.0;
+        for (int set = 0; set < 3; set++) {
+            const int npos = set == 0 ? W4_NP : W4_NP_EDGE;
+            for (int pos = 0; pos < npos; pos++) {
+                float du = 0.f;
+                for (int c = 0; c < P.chunks[set]; c++) du += partial[(size_t)(P.item0[set] + pos * P.chunks[set] + c) * cc + e];
+                const int p = pos / 6, q = pos % 6;
+                const double *gv = set == 0 ? G4[p] : set == 1 ? G4[q] : G3[p];
+                const double *gh = set == 0 ? G4[q] : set == 1 ? G3[p] : G4[q];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) g[a * 3 + b] += gv[a] * (double)du * gh[b];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) dw[e * 9 + k] = (float)g[k];
+    }
+}
+
+template <int N>
+static void launch_w4_wgrad(int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s) {
+    using G = W4Geom<N>;
+    const long tiles = (long)nboards * G::T;
+    float *Vb = vbuf, *Db = vbuf + w4_half_floats(N, nboards);
+    launch_w4<N>(nboards, x, nullptr, nullptr, nullptr, nullptr, vbuf, num_cus, 0, 1, s, nullptr, nullptr);      // V = B^T x B
+    const long want = (tiles + 3) / 4;
+    const int grid_t = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
+    hipLaunchKernelGGL((c6_wino4_dyt_kernel<N>), dim3(grid_t), dim3(256), 0, s, dy, Db, tiles);
+    if (w4_has_tail<N>(nboards)) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Db, nboards);
+    const W4WgPlan P = w4_wg_plan<N>(nboards, num_cus);
+    constexpr size_t smem = (size_t)4 * W4G_ROWS * W4G_CP * 4;
+    w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_wgrad_kernel<N>), (int)smem);
+    hipLaunchKernelGGL((c6_wino4_wgrad_kernel<N>), dim3(P.items), dim3(512), smem, s, Db, Vb, partial, P);
+    hipLaunchKernelGGL(c6_wino4_wgrad_finish_kernel, dim3(256), dim3(256), 0, s, W4_C, partial, dw, P);
+}
+size_t c6_conv_wino4_wgrad_partial_floats(int C, int N, int nboards, int num_cus) {
+    if (C != W4_C) return 0;
+    const W4WgPlan P = N == 19 ? w4_wg_plan<19>(nboards, num_cus) : N == 15 ? w4_wg_plan<15>(nboards, num_cus) : w4_wg_plan<9>(nboards, num_cus);
+    return (size_t)P.items * C * C;
+}
+// dW (OIHW, overwritten) of the 3x3 convolution y = conv(x, w) from dy; vbuf: c6_conv_wino4_vbuf_floats, partial: the size above
+bool c6_conv_wino4_wgrad(int C, int N, int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s) {
+    if (C != W4_C || nboards <= 0) return false;
+    if (N == 19) { launch_w4_wgrad<19>(nboards, dy, x, vbuf, partial, dw, num_cus, s); return true; }
+    if (N == 15) { launch_w4_wgrad<15>(nboards, dy, x, vbuf, partial, dw, num_cus, s); return true; }
+    if (N == 9) { launch_w4_wgrad<9>(nboards, dy, x, vbuf, partial, dw, num_cus, s); return true; }
+    return false;
+}

@@ -9,6 +9,7 @@
 #include "c6_train.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -58,6 +59,7 @@ struct c6_trainer {
     unsigned short *wpack = nullptr;
     float *wpack32 = nullptr;
     float *wpackw = nullptr, *vbuf = nullptr;      // FP32 at 256 channels: Winograd F(4x4) (conv_wino4.hip), transformed weights + its scratch
+    float *wgpart = nullptr;                        // ... and the partial sums of its weight gradient
 };
 
 extern "C" size_t c6_net_blob_floats(int board_size, int channels, int blocks);
@@ -139,6 +141,8 @@ extern "C" int c6_trainer_create(int board_size, int channels, int blocks, int b
     if (c6_conv_wino4_vbuf_floats((int)C, t->n, (int)B)) {
         TA(t->wpackw, c6_conv_packed_wino4_floats((int)C));
         TA(t->vbuf, c6_conv_wino4_vbuf_floats((int)C, t->n, (int)B));
+        static const bool wg_wino = [] { const char *e = getenv("C6_WGRAD_WINO"); return !e || atoi(e) != 0; }();      // 0: the direct FP32 kernel (A/B)
+        if (wg_wino) TA(t->wgpart, c6_conv_wino4_wgrad_partial_floats((int)C, t->n, (int)B, t->num_cus));
     }
 #undef TA
     if (rc == C6_OK && hipMemcpy(t->mask, mask.data(), t->nfloats, hipMemcpyHostToDevice) != hipSuccess) rc = tfail(C6_ERR_HIP, "mask upload");
@@ -195,6 +199,11 @@ extern "C" int c6_trainer_gradients(c6_trainer *t, float *blob, size_t nfloats) 
 }
 
 // ---- forward in train mode (model.hpp:52-95 with batch statistics) + loss (model.hpp:97-108) ------------------------
+// dW (OIHW) of a tower convolution from dy and the layer's input x: FP32 at 256 channels in the Winograd domain (conv_wino4.hip), else the direct kernels
+static bool wgrad(c6_trainer *t, const float *dy, const float *x, float *dw) {
+    if (t->precision == C6_PREC_FP32 && t->wgpart) return c6_conv_wino4_wgrad(t->C, t->n, t->B, dy, x, t->vbuf, t->wgpart, dw, t->num_cus, t->stream);
+    return c6t_wgrad(t->n, t->C, t->B, dy, x, t->partial, dw, t->stream, t->precision != C6_PREC_FP32);
+}
 static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const float *in, const float *bias, const float *res, float *out) {
     bool ok;
     if (t->precision == C6_PREC_FP32 && t->vbuf) {      // 256 channels: the evaluator's default FP32 form (2.2x fewer ms than the direct kernel here)
@@ -285,7 +294,7 @@ static int backward(c6_trainer *t) {
             c6t_colstats(1, R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, t->partial, G + u.be, G + u.g, s);
             c6t_bn_bwd_apply(R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, dz, s);
             c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, t->partial, G + u.b, nullptr, s);
-            if (!c6t_wgrad(t->n, C, B, dy, t->a[l1], t->partial, G + u.w, s, t->precision != C6_PREC_FP32)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
+            if (!wgrad(t, dy, t->a[l1], G + u.w)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
             int rc = conv3x3(t, P + u.w, 1, dy, nullptr, nullptr, dmid);
             if (rc) return rc;
         }
@@ -295,7 +304,7 @@ static int backward(c6_trainer *t) {
             c6t_colstats(1, R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, t->partial, G + u.be, G + u.g, s);
             c6t_bn_bwd_apply(R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, nullptr, s);
             c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, t->partial, G + u.b, nullptr, s);
-            if (!c6t_wgrad(t->n, C, B, dy, t->a[l0], t->partial, G + u.w, s, t->precision != C6_PREC_FP32)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
+            if (!wgrad(t, dy, t->a[l0], G + u.w)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
             int rc = conv3x3(t, P + u.w, 1, dy, nullptr, dz /* + the skip connection's gradient */, cur);
             if (rc) return rc;
         }
