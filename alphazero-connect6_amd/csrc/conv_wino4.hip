@@ -964,7 +964,7 @@ double c6_conv_wino4_exec_flops(int C, int N, int nboards) {
 // form (c6_wgrad_kernel, train_kernels.hip), in f32 like it.  Three kernels behind the input transform of x (c6_wino4_in_kernel):
 //   c6_wino4_dyt_kernel    dY (NHWC) -> D = A dY A^T in V's layout (regions, classes and the transposed class B as for V)
 //   c6_wino4_wgrad_kernel  per (class, position p, chunk of blocks):  partial[co][ci] = sum_tiles D_p[tile][co] V_p[tile][ci]
-//   c6_wino4_wgrad_finish_kernel   sums the chunks and applies G_v^T . G_h of each class: dW (OIHW)
+//   c6_wino4_wgrad_sum_kernel / _finish_kernel   sum the chunks; apply G_v^T . G_h of each class: dW (OIHW)
 // A (6x4) = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1],  F(3): (5x3) = [1 0 0; 1 1 1; 1 -1 1; 1 2 4; 0 0 1]
 #define W4_A4_ROW(i, y0, y1, y2, y3)                                                                  \
     ((i) == 0 ? (y0)                                                                                  \
@@ -1043,13 +1043,18 @@ static W4WgPlan w4_wg_plan(int nboards, int num_cus) {
     p.first_blk[0] = 0; p.first_blk[1] = (int)m.blkB; p.first_blk[2] = (int)m.blkBP;
     p.nblk[0] = (int)m.blkB; p.nblk[1] = (int)(m.blkBP - m.blkB); p.nblk[2] = (int)(m.nblocks - m.blkBP);
     const long units = (long)W4_NP * p.nblk[0] + (long)W4_NP_EDGE * (p.nblk[1] + p.nblk[2]);
-    p.per = (int)((units + 2L * num_cus - 1) / (2L * num_cus));      // about two workgroups' worth of items per CU
+    // two rounds of workgroups over the CUs, and not one item more: the smallest chunk size whose items fit into 2 x num_cus (a 513th item
+    // would run alone for a third round)
+    p.per = (int)((units + 2L * num_cus - 1) / (2L * num_cus));
     if (p.per < 1) p.per = 1;
-    p.items = 0;
-    for (int s = 0; s < 3; s++) {
-        p.chunks[s] = (p.nblk[s] + p.per - 1) / p.per;
-        p.item0[s] = p.items;
-        p.items += (s == 0 ? W4_NP : W4_NP_EDGE) * p.chunks[s];
+    for (;; p.per++) {
+        p.items = 0;
+        for (int s = 0; s < 3; s++) {
+            p.chunks[s] = (p.nblk[s] + p.per - 1) / p.per;
+            p.item0[s] = p.items;
+            p.items += (s == 0 ? W4_NP : W4_NP_EDGE) * p.chunks[s];
+        }
+        if (p.items <= 2 * num_cus || (p.chunks[0] <= 1 && p.chunks[1] <= 1 && p.chunks[2] <= 1)) break;
     }
     return p;
 }
@@ -1113,8 +1118,20 @@ __global__ __launch_bounds__(512) void c6_wino4_wgrad_kernel(const float *__rest
 #pragma unroll
         for (int v = 0; v < 16; v++) pb[(size_t)(32 * wave + 8 * (v / 4) + 4 * kk + (v % 4)) * C + 32 * j + i] = acc[j][v];
 }
-// dW[co][ci][a][b] (OIHW) = sum over classes and positions  G_v[.][a] dU_p G_h[.][b],  dU_p = the sum of the item's chunks in chunk order
-__global__ void c6_wino4_wgrad_finish_kernel(int C, const float *__restrict__ partial, float *__restrict__ dw, W4WgPlan P) {
+// dU[96 positions][co][ci] = the sum of an item's chunks in chunk order (positions of the three classes one behind the other)
+__global__ void c6_wino4_wgrad_sum_kernel(int C, const float *__restrict__ partial, float *__restrict__ du, W4WgPlan P) {
+    const size_t cc = (size_t)C * C, total = (size_t)(W4_NP + 2 * W4_NP_EDGE) * cc;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+        const int gp = (int)(k / cc);
+        const size_t e = k - (size_t)gp * cc;
+        const int set = gp < W4_NP ? 0 : gp < W4_NP + W4_NP_EDGE ? 1 : 2, pos = gp - (set == 0 ? 0 : set == 1 ? W4_NP : W4_NP + W4_NP_EDGE);
+        float v = 0.f;
+        for (int c = 0; c < P.chunks[set]; c++) v += partial[(size_t)(P.item0[set] + pos * P.chunks[set] + c) * cc + e];
+        du[k] = v;
+    }
+}
+// dW[co][ci][a][b] (OIHW) = sum over classes and positions  G_v[.][a] dU_p G_h[.][b]
+__global__ void c6_wino4_wgrad_finish_kernel(int C, const float *__restrict__ du, float *__restrict__ dw) {
     const double G4[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                              {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
     const double G3[5][3] = {{1.0 / 2, 0.0, 0.0}, {-1.0 / 2, -1.0 / 2, -1.0 / 2}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
@@ -1123,19 +1140,17 @@ __global__ void c6_wino4_wgrad_finish_kernel(int C, const float *__restrict__ pa
         double g[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) g[k] = 0.0;
-        for (int set = 0; set < 3; set++) {
-            const int npos = set == 0 ? W4_NP : W4_NP_EDGE;
-            for (int pos = 0; pos < npos; pos++) {
-                float du = 0.f;
-                for (int c = 0; c < P.chunks[set]; c++) du += partial[(size_t)(P.item0[set] + pos * P.chunks[set] + c) * cc + e];
-                const int p = pos / 6, q = pos % 6;
-                const double *gv = set == 0 ? G4[p] : set == 1 ? G4[q] : G3[p];
-                const double *gh = set == 0 ? G4[q] : set == 1 ? G3[p] : G4[q];
 #pragma unroll
-                for (int a = 0; a < 3; a++)
+        for (int gp = 0; gp < W4_NP + 2 * W4_NP_EDGE; gp++) {
+            const int set = gp < W4_NP ? 0 : gp < W4_NP + W4_NP_EDGE ? 1 : 2, pos = gp - (set == 0 ? 0 : set == 1 ? W4_NP : W4_NP + W4_NP_EDGE);
+            const double v = (double)du[(size_t)gp * cc + e];
+            const int p = pos / 6, q = pos % 6;
+            const double *gv = set == 0 ? G4[p] : set == 1 ? G4[q] : G3[p];
+            const double *gh = set == 0 ? G4[q] : set == 1 ? G3[p] : G4[q];
 #pragma unroll
-                    for (int b = 0; b < 3; b++) g[a * 3 + b] += gv[a] * (double)du * gh[b];
-            }
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) g[a * 3 + b] += gv[a] * v * gh[b];
         }
 #pragma unroll
         for (int k = 0; k < 9; k++) dw[e * 9 + k] = (float)g[k];
@@ -1156,12 +1171,14 @@ static void launch_w4_wgrad(int nboards, const float *dy, const float *x, float 
     constexpr size_t smem = (size_t)4 * W4G_ROWS * W4G_CP * 4;
     w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_wgrad_kernel<N>), (int)smem);
     hipLaunchKernelGGL((c6_wino4_wgrad_kernel<N>), dim3(P.items), dim3(512), smem, s, Db, Vb, partial, P);
-    hipLaunchKernelGGL(c6_wino4_wgrad_finish_kernel, dim3(256), dim3(256), 0, s, W4_C, partial, dw, P);
+    float *du = partial + (size_t)P.items * W4_C * W4_C;
+    hipLaunchKernelGGL(c6_wino4_wgrad_sum_kernel, dim3(2048), dim3(256), 0, s, W4_C, partial, du, P);
+    hipLaunchKernelGGL(c6_wino4_wgrad_finish_kernel, dim3(256), dim3(256), 0, s, W4_C, du, dw);
 }
 size_t c6_conv_wino4_wgrad_partial_floats(int C, int N, int nboards, int num_cus) {
     if (C != W4_C) return 0;
     const W4WgPlan P = N == 19 ? w4_wg_plan<19>(nboards, num_cus) : N == 15 ? w4_wg_plan<15>(nboards, num_cus) : w4_wg_plan<9>(nboards, num_cus);
-    return (size_t)P.items * C * C;
+    return (size_t)(P.items + W4_NP + 2 * W4_NP_EDGE) * C * C;      // the items' partial sums + dU
 }
 // dW (OIHW, overwritten) of the 3x3 convolution y = conv(x, w) from dy; vbuf: c6_conv_wino4_vbuf_floats, partial: the size above
 bool c6_conv_wino4_wgrad(int C, int N, int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s) {
