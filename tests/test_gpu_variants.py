@@ -7,7 +7,9 @@
   convolution leaves behind (net_kernels.hip): same outputs within float summation order (model.hpp:80-92);
 * C6_WINO_MID=0 -- the FP32 Winograd tower without the fused boundary kernel (conv_wino4.hip);
 * C6_WINO_STEM=0 -- the same tower with the stem as a kernel of its own (its activations written and read back) instead of being
-  computed inside the first input transform and the first block's boundary kernel.
+  computed inside the first input transform and the first block's boundary kernel;
+* C6_WGRAD_WINO=0 -- the FP32 trainer's weight gradient by the direct kernel (train_kernels.hip) instead of the Winograd-domain one
+  (conv_wino4.hip): two independent implementations of the same sums at a batch large enough for 64-tile blocks and several chunks.
 """
 import os
 import subprocess
@@ -30,7 +32,12 @@ from c6amd_loader import load_package
 pkg = load_package()
 d = np.load(sys.argv[1])
 out = {}
-if "boards" in d:
+if "train" in d:
+    t = pkg.Trainer(int(d["n"]), int(d["C"]), int(d["blocks"]), int(d["B"]), lr=1e-3, momentum=0.9, precision=pkg.PREC_FP32)
+    t.load_weights(d["blob"])
+    out["loss"] = np.float64(t.step(d["w"], d["p"], d["b"], d["q"]))
+    out["grads"] = t.gradients()
+elif "boards" in d:
     n = int(d["n"])
     out["winner"] = pkg.search_winner(n, d["boards"])
     b, t, r, w, e = pkg.board_step(n, d["boards"], d["turn"], d["remain"], d["pos"])
@@ -106,3 +113,22 @@ def test_winograd_separate_transform_kernels_match():
     for i in (0, 1, 35, 69):
         rpol, rval = net.forward(1.0, nb[i].astype(np.float32))
         assert np.abs(pol[i] - rpol).max() < 1e-5 and abs(val[i] - rval) < 1e-5
+
+
+def test_winograd_weight_gradient_matches_direct_kernel():
+    """FP32 training step at 256 channels: the weight gradient taken in the Winograd domain (dU = sum over tiles of A dY A^T x B^T x B,
+    dg = G^T dU G; c6_conv_wino4_wgrad) against the direct kernel (C6_WGRAD_WINO=0) on the same batch -- 15x15 (mixed tiling) and 19x19,
+    300 boards: every tile region holds whole and partial blocks and the reduction is cut into chunks.  Same sums, different order and
+    different intermediate values: the whole gradient within 1e-5 in L2 (the trainer's parity bar against PyTorch is 1e-4)."""
+    need_gpu()
+    import __graft_entry__ as ge
+    for n in (15, 19):
+        C, blocks, B = 256, 2, 300
+        rng = np.random.default_rng(7 + n)
+        blob = ge.make_random_blob(n, C, blocks, rng)
+        batch = dict(w=rng.integers(-1, 2, B).astype(np.float32), p=rng.choice([-1.0, 1.0], B).astype(np.float32),
+                     b=rng.integers(-1, 2, (B, n * n)).astype(np.float32), q=rng.integers(0, n * n, B).astype(np.float32))
+        a = run_child({"C6_WGRAD_WINO": "1"}, train=1, n=n, C=C, blocks=blocks, B=B, blob=blob, **batch)
+        b = run_child({"C6_WGRAD_WINO": "0"}, train=1, n=n, C=C, blocks=blocks, B=B, blob=blob, **batch)
+        assert abs(float(a["loss"]) - float(b["loss"])) <= 1e-6 * abs(float(b["loss"]))
+        assert np.linalg.norm(a["grads"] - b["grads"]) <= 1e-5 * np.linalg.norm(b["grads"]), (n, np.linalg.norm(a["grads"] - b["grads"]) / np.linalg.norm(b["grads"]))
