@@ -377,7 +377,7 @@ static bool w4_has_tail(int nboards) {
 //  * Y = A^T M A, and the positions of a patch row i arrive one after the other: Z_i[b] = sum_j M[i][j] A^T[b][j] (b = 0 .. 3) is
 //    accumulated in registers -- one row at a time, 4 x 32 registers -- and 24 instead of 36 values per (tile, cout) go to memory: a third
 //    less for this kernel to write and for the boundary kernel behind it to read.  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0;
-//    0 1 -1 8 -8 1]: position j = 0 accumulates straight into Z_0 and j = 5 straight into Z_3 (no vector instruction); j = 1 .. 4
+//    0 1 -1 8 -8 1]: position j = 0 accumulates straight into Z_0 and j = 5 straight into Z_3 (the MFMA's own accumulate); j = 1 .. 4
 //    accumulate aside and cost 40 packed vector instructions per position on average -- the one exception to the rule above: +1.5 % on
 //    this kernel, -19 % on the boundary kernels (same box, in the engine: 248.4 -> 236.8 ms per round).  Stores: Z_0, Z_1 during position
 //    j = 5 of their row, Z_2, Z_3 during j = 0 of the next.  Result: Zo[block][tile 64][row i 6][b 4][C].
@@ -586,8 +586,8 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// ---- output transform: A^T M A, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1], + bias (+ residual), ReLU ----
-// One wave per tile at a time, lane = 4 channels: the tile's 36 x 1 KiB of M are one contiguous run; the 4x4 pixels leave as
+// ---- output transform, the half the GEMM kernel left: A^T Z, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1], + bias (+ residual), ReLU ----
+// One wave per tile at a time, lane = 4 channels: the tile's 24 (edge tiles: 20) x 1 KiB of Z are one contiguous run; the 4x4 pixels leave as
 // 1-KiB NHWC runs (pixels beyond the board edge are dropped).  HEADS (the tower's last layer): the activations are consumed here --
 // the heads' three 1x1 filters (policy conv C -> 2 + folded BN + ReLU, value conv C -> 1 + BatchNorm1d over cells + ReLU;
 // model.hpp:80-92, c6_head_conv_kernel) are applied to every pixel (a wave sum per filter) and nothing else is written: 12 GB of
@@ -727,12 +727,12 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
 
 // ---- output transform of one layer + input transform of the next, in one pass ------------------------------------------
 // Between the two convolutions of a residual block the activations have one reader: written by the first layer's output transform
-// (12 GB per 32 768 boards) only to be read back by the second layer's input transform.  This kernel goes from M of layer l to V of
-// layer l + 1 with the activations passing through LDS: one workgroup per board at a time, wave = tile column, lane = 4 channels.
-// Step t: (a) the wave turns its tile (t, tx) of M into 4x4 pixels (A^T M A + bias, ReLU) and puts the FIRST of their rows, board
+// (12 GB per 32 768 boards) only to be read back by the second layer's input transform.  This kernel goes from Z of layer l (the GEMM
+// kernel's row sums) to V of layer l + 1 with the activations passing through LDS: one workgroup per board at a time, wave = tile column,
+// lane = 4 channels.  Step t: (a) the wave turns its tile (t, tx) of Z into 4x4 pixels (A^T Z + bias, ReLU) and puts the FIRST of their rows, board
 // row 4t, into the rolling 6-row window of c6_wino4_in_kernel; (b) the window now holds rows 4t - 5 .. 4t: the patch rows of tile
 // row t - 1, whose B^T d B goes out as the next layer's V; (c) pixel rows 4t + 1 .. 4t + 3, kept in registers meanwhile, take the
-// slots of the rows (b) read last.  HBM: M in, V out -- 60 GB instead of 84 for the pair of kernels it replaces.
+// slots of the rows (b) read last.  HBM: Z in, V out -- 47 GB instead of 72 for the pair of kernels it replaces.
 // RS: the residual is the STEM's output, computed here from the board (w4_stem_pixel; weights and board plane in LDS behind the window)
 template <int N, bool RS>
 __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const float *__restrict__ M, const float *__restrict__ bias,
