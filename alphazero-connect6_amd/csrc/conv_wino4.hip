@@ -245,28 +245,40 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_in_kernel(const float 
 
 // ---- the stem as an input ---------------------------------------------------------------------------------------------
 // conv 2 -> C (+ folded BN, ReLU) on the planes [player broadcast, board image] (model.hpp:56-59, c6_stem_kernel) at pixel (y, x)
-// for 4 channels: 18 multiply-adds per channel, in c6_stem_kernel's order.  bd = the board image as floats on the (N+2)-wide zero-haloed
-// grid, wt(t, plane) = the lane's 4 weights of tap t.  Cheap enough to be COMPUTED wherever the stem's activations are needed
+// for 4 channels: 9 multiply-adds per channel for the board plane + one for the player plane (below).  bd = the board image as floats on
+// the (N+2)-wide zero-haloed grid, w1(t) = the lane's 4 board-plane weights of tap t, pl_term = pv * S0[border class].  Cheap enough to be COMPUTED wherever the stem's activations are needed
 // (the first layer's input transform, the residual of the first block) instead of being written and read back: 36 GB per forward pass.
 template <int N, typename WT>
-__device__ __forceinline__ f32x4 w4_stem_pixel(const float *bd, float pv, int y, int x, f32x4 bias, WT wt) {
+__device__ __forceinline__ f32x4 w4_stem_pixel(const float *bd, f32x4 pl_term, int y, int x, f32x4 bias, WT w1) {
     constexpr int P = N + 2;
-    f32x4 acc = bias;
+    f32x4 acc = bias + pl_term;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        const float plv = (yy >= 0 && yy < N && xx >= 0 && xx < N) ? pv : 0.f;      // the player plane is zero padded like the board
-        const float bdv = bd[(yy + 1) * P + xx + 1];
-        const f32x4 w0 = wt(t, 0), w1 = wt(t, 1);
+        const float bdv = bd[(y + t / 3) * P + x + t % 3];      // the zero-haloed grid: tap (t / 3 - 1, t % 3 - 1)
+        const f32x4 w = w1(t);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            acc[r] = __builtin_fmaf(w0[r], plv, acc[r]);
-            acc[r] = __builtin_fmaf(w1[r], bdv, acc[r]);
-        }
+        for (int r = 0; r < 4; r++) acc[r] = __builtin_fmaf(w[r], bdv, acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
     return acc;
+}
+// The player plane is a constant inside the board and zero outside, so its nine taps collapse to  pv * (sum of the plane-0 weights of
+// the taps that lie on the board)  -- one of 9 sums per channel, by the pixel's border class 3 * (top, middle, bottom) + (left, middle,
+// right): this thread's 4 channels of the table S0[9][C]
+__device__ __forceinline__ int w4_border_class(int y, int x, int N) { return 3 * (y == 0 ? 0 : y == N - 1 ? 2 : 1) + (x == 0 ? 0 : x == N - 1 ? 2 : 1); }
+__device__ __forceinline__ void w4_stem_player_sums(const float *w /* [9][2][C] */, int C, int c4, float *s0 /* [9][C] */) {
+#pragma unroll
+    for (int cls = 0; cls < 9; cls++) {
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1, ry = cls / 3, rx = cls % 3;
+            const bool in = !(ry == 0 && dy < 0) && !(ry == 2 && dy > 0) && !(rx == 0 && dx < 0) && !(rx == 2 && dx > 0);
+            if (in) sum = sum + *reinterpret_cast<const f32x4 *>(w + (t * 2 + 0) * C + c4);
+        }
+        *reinterpret_cast<f32x4 *>(s0 + cls * C + c4) = sum;
+    }
 }
 // board image k of leaf b / images as floats on the zero-haloed grid (augment_way8, augment.rs:60-73: the stem's gather)
 template <int N>
@@ -286,19 +298,17 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemS
     constexpr int C = G::C, LPT = C / 4, TPI = W4_IN_THREADS / LPT, T = G::T, TW = G::TW, COLS = 4 * TW + 2, P = N + 2;
     constexpr int ROWF = COLS * C;
     static_assert(W4_IN_THREADS % LPT == 0, "a thread keeps its channel quad");
-    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] + the board plane [P][P]
-    float *bd = win + 6 * ROWF;
+    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] + the player-plane sums [9][C] + the board plane [P][P]
+    float *s0 = win + 6 * ROWF, *bd = s0 + 9 * C;
     const int tid = threadIdx.x, cq = tid % LPT, tsub = tid / LPT;
     const W4Map<N> map(nboards);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = tid; k < 6 * ROWF / 4; k += W4_IN_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
     for (int k = tid; k < P * P; k += W4_IN_THREADS) bd[k] = 0.f;
-    f32x4 sw[9][2];
+    f32x4 sw[9];
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-        sw[t][0] = *reinterpret_cast<const f32x4 *>(S.w + (t * 2 + 0) * C + cq * 4);
-        sw[t][1] = *reinterpret_cast<const f32x4 *>(S.w + (t * 2 + 1) * C + cq * 4);
-    }
+    for (int t = 0; t < 9; t++) sw[t] = *reinterpret_cast<const f32x4 *>(S.w + (t * 2 + 1) * C + cq * 4);
+    if (tid < LPT) w4_stem_player_sums(S.w, C, tid * 4, s0);
     const f32x4 sb = *reinterpret_cast<const f32x4 *>(S.bias + cq * 4);
     float pv = 0.f;
     float *ab = act;
@@ -307,7 +317,9 @@ __global__ __launch_bounds__(W4_IN_THREADS) void c6_wino4_stem_in_kernel(C6StemS
         for (int k = tid; k < nr * N * LPT; k += W4_IN_THREADS) {
             const int r = k / (N * LPT), px = (k / LPT) % N, y = y0 + r;
             const bool inb = y >= 0 && y < N;
-            const f32x4 v = inb ? w4_stem_pixel<N>(bd, pv, y, px, sb, [&](int t, int pl) { return sw[t][pl]; }) : zero4;
+            const f32x4 v = inb ? w4_stem_pixel<N>(bd, w4_fma(pv, *reinterpret_cast<const f32x4 *>(s0 + w4_border_class(y, px, N) * C + cq * 4), zero4), y, px, sb,
+                                                   [&](int t) { return sw[t]; })
+                                : zero4;
             *reinterpret_cast<f32x4 *>(win + ((y + 1) % 6) * ROWF + (px + 1) * C + cq * 4) = v;
             if (act && inb) *reinterpret_cast<f32x4 *>(ab + (size_t)(y * N + px) * C + cq * 4) = v;
         }
@@ -747,11 +759,12 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
     const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + lane * 4) : zero4;
     for (int k = tid; k < 6 * ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
     float *wpix = win + (4 * tx + 1) * C + lane * 4;       // window column of this wave's first pixel column (board column 4 tx)
-    float *swl = win + 6 * ROWF, *bdp = swl + 18 * C;     // RS: the stem's weights [9][2][C] and the board plane [(N+2)^2]
+    float *swl = win + 6 * ROWF, *s0 = swl + 9 * C, *bdp = s0 + 9 * C;     // RS: the stem's board-plane weights [9][C], its player-plane sums [9][C], the board plane [(N+2)^2]
     f32x4 sb = zero4;
     float pv = 0.f;
     if (RS) {
-        for (int k = tid; k < 18 * C / 4; k += NT) reinterpret_cast<f32x4 *>(swl)[k] = reinterpret_cast<const f32x4 *>(S.w)[k];
+        for (int k = tid; k < 9 * C / 4; k += NT) reinterpret_cast<f32x4 *>(swl)[k] = *reinterpret_cast<const f32x4 *>(S.w + ((k / (C / 4)) * 2 + 1) * C + (k % (C / 4)) * 4);
+        if (tid < C / 4) w4_stem_player_sums(S.w, C, tid * 4, s0);
         for (int k = tid; k < (N + 2) * (N + 2); k += NT) bdp[k] = 0.f;
         sb = *reinterpret_cast<const f32x4 *>(S.bias + lane * 4);
     }
@@ -779,7 +792,8 @@ __global__ __launch_bounds__(64 * W4Geom<N>::TW) void c6_wino4_mid_kernel(const 
                         const bool inb = py < N && 4 * tx + bb < N;
                         const size_t o = ((size_t)bd * (N * N) + (size_t)((inb ? py : 0) * N + (inb ? 4 * tx + bb : 0))) * C + lane * 4;
                         if (RS) {
-                            if (inb) v = v + w4_stem_pixel<N>(bdp, pv, py, 4 * tx + bb, sb, [&](int t, int pl) { return *reinterpret_cast<const f32x4 *>(swl + (t * 2 + pl) * C + lane * 4); });
+                            if (inb) v = v + w4_stem_pixel<N>(bdp, w4_fma(pv, *reinterpret_cast<const f32x4 *>(s0 + w4_border_class(py, 4 * tx + bb, N) * C + lane * 4), zero4), py, 4 * tx + bb, sb,
+                                                              [&](int t) { return *reinterpret_cast<const f32x4 *>(swl + t * C + lane * 4); });
                         } else if (res && inb) v = v + *reinterpret_cast<const f32x4 *>(res + o);
 #pragma unroll
                         for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : 0.f;
@@ -899,7 +913,7 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     const bool tail = w4_has_tail<N>(nboards);
     float *Vb = vbuf, *Mb = vbuf + w4_half_floats(N, nboards);
     if ((steps & 1) && stem) {      // the first layer: window rows computed from the boards
-        constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
+        constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4 + (size_t)9 * W4_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
         const int grid_in = nboards < num_cus ? nboards : num_cus;
         w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_stem_in_kernel<N>), (int)in_smem);
         hipLaunchKernelGGL((c6_wino4_stem_in_kernel<N>), dim3(grid_in), dim3(W4_IN_THREADS), in_smem, s, *stem, Vb, out, nboards);
