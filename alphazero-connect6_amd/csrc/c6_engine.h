@@ -251,11 +251,13 @@ void c6_pack_conv_weights_wino4_dev(int C, const float *w_oihw_dev, float *packe
 size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards);
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                             float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads = nullptr,
-                            const C6StemSrc *stem = nullptr);
+                            const C6StemSrc *stem = nullptr, float *zsep = nullptr);      // zsep: `vbuf` holds V only (c6_conv_wino4_v_floats), Z goes here
+size_t c6_conv_wino4_v_floats(int C, int N, int nboards);
 double c6_conv_wino4_exec_flops(int C, int N, int nboards);
 // weight gradient of the same convolution in the Winograd domain (trainer, FP32): dW (OIHW, overwritten) from dy and the layer's input x
 size_t c6_conv_wino4_wgrad_partial_floats(int C, int N, int nboards, int num_cus);
-bool c6_conv_wino4_wgrad(int C, int N, int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s);
+bool c6_conv_wino4_wgrad(int C, int N, int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s,
+                         const float *vkept = nullptr);      // vkept: B^T x B of this layer as the forward pass left it (then x is not transformed again)
 // FP32 direct (conv_f32n.hip)
 size_t c6_conv_packed_f32n_floats(int C);
 void c6_pack_conv_weights_f32n(int C, const float *w_oihw_folded, float *packed);

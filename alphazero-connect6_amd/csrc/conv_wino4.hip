@@ -905,13 +905,13 @@ static void w4_smem_once(const void *fn, int bytes) {
 }
 template <int N>
 static void launch_w4(int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out, float *vbuf, int num_cus,
-                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads, const C6StemSrc *stem) {
+                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep = nullptr) {
     using G = W4Geom<N>;
     const long tiles = (long)nboards * G::T;
     const W4Map<N> map(nboards);
     const int nblocks = (int)map.nblocks;
     const bool tail = w4_has_tail<N>(nboards);
-    float *Vb = vbuf, *Mb = vbuf + w4_half_floats(N, nboards);
+    float *Vb = vbuf, *Mb = zsep ? zsep : vbuf + w4_half_floats(N, nboards);      // zsep: V alone in `vbuf` (a caller that keeps V), Z elsewhere
     if ((steps & 1) && stem) {      // the first layer: window rows computed from the boards
         constexpr size_t in_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4 + (size_t)9 * W4_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
         const int grid_in = nboards < num_cus ? nboards : num_cus;
@@ -954,14 +954,15 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
 
 // steps: bit 0 input transform, bit 1 GEMMs, bit 2 output transform (7 = the layer); bit 4: output transform fused with the NEXT layer's input transform
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads, const C6StemSrc *stem) {
+                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep) {
     if (C != W4_C) return false;
     if (nboards <= 0) return true;
-    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem); return true; }
-    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem); return true; }
-    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem); return true; }
+    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep); return true; }
+    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep); return true; }
+    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep); return true; }
     return false;
 }
+size_t c6_conv_wino4_v_floats(int C, int N, int nboards) { return C == W4_C ? w4_half_floats(N, nboards) : 0; }
 // matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 or 30 positions x C x C MACs)
 template <int N>
 static double w4_exec_flops(int C, int nboards) {
@@ -1172,11 +1173,12 @@ __global__ void c6_wino4_wgrad_finish_kernel(int C, const float *__restrict__ du
 }
 
 template <int N>
-static void launch_w4_wgrad(int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s) {
+static void launch_w4_wgrad(int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s, const float *vkept) {
     using G = W4Geom<N>;
     const long tiles = (long)nboards * G::T;
-    float *Vb = vbuf, *Db = vbuf + w4_half_floats(N, nboards);
-    launch_w4<N>(nboards, x, nullptr, nullptr, nullptr, nullptr, vbuf, num_cus, 0, 1, s, nullptr, nullptr);      // V = B^T x B
+    const float *Vb = vkept ? vkept : vbuf;      // the forward pass's B^T x B of this layer, if the caller kept it
+    float *Db = vbuf + w4_half_floats(N, nboards);
+    if (!vkept) launch_w4<N>(nboards, x, nullptr, nullptr, nullptr, nullptr, vbuf, num_cus, 0, 1, s, nullptr, nullptr);      // V = B^T x B
     const long want = (tiles + 3) / 4;
     const int grid_t = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
     hipLaunchKernelGGL((c6_wino4_dyt_kernel<N>), dim3(grid_t), dim3(256), 0, s, dy, Db, tiles);
@@ -1195,10 +1197,11 @@ size_t c6_conv_wino4_wgrad_partial_floats(int C, int N, int nboards, int num_cus
     return (size_t)(P.items + W4_NP + 2 * W4_NP_EDGE) * C * C;      // the items' partial sums + dU
 }
 // dW (OIHW, overwritten) of the 3x3 convolution y = conv(x, w) from dy; vbuf: c6_conv_wino4_vbuf_floats, partial: the size above
-bool c6_conv_wino4_wgrad(int C, int N, int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s) {
+bool c6_conv_wino4_wgrad(int C, int N, int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s,
+                         const float *vkept) {
     if (C != W4_C || nboards <= 0) return false;
-    if (N == 19) { launch_w4_wgrad<19>(nboards, dy, x, vbuf, partial, dw, num_cus, s); return true; }
-    if (N == 15) { launch_w4_wgrad<15>(nboards, dy, x, vbuf, partial, dw, num_cus, s); return true; }
-    if (N == 9) { launch_w4_wgrad<9>(nboards, dy, x, vbuf, partial, dw, num_cus, s); return true; }
+    if (N == 19) { launch_w4_wgrad<19>(nboards, dy, x, vbuf, partial, dw, num_cus, s, vkept); return true; }
+    if (N == 15) { launch_w4_wgrad<15>(nboards, dy, x, vbuf, partial, dw, num_cus, s, vkept); return true; }
+    if (N == 9) { launch_w4_wgrad<9>(nboards, dy, x, vbuf, partial, dw, num_cus, s, vkept); return true; }
     return false;
 }

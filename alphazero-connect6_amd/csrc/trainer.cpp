@@ -60,6 +60,7 @@ struct c6_trainer {
     float *wpack32 = nullptr;
     float *wpackw = nullptr, *vbuf = nullptr;      // FP32 at 256 channels: Winograd F(4x4) (conv_wino4.hip), transformed weights + its scratch
     float *wgpart = nullptr;                        // ... and the partial sums of its weight gradient
+    std::vector<float *> vkeep;                     // ... and every layer's transformed input, kept from the forward pass for the weight gradient
 };
 
 extern "C" size_t c6_net_blob_floats(int board_size, int channels, int blocks);
@@ -143,6 +144,12 @@ extern "C" int c6_trainer_create(int board_size, int channels, int blocks, int b
         TA(t->vbuf, c6_conv_wino4_vbuf_floats((int)C, t->n, (int)B));
         static const bool wg_wino = [] { const char *e = getenv("C6_WGRAD_WINO"); return !e || atoi(e) != 0; }();      // 0: the direct FP32 kernel (A/B)
         if (wg_wino) TA(t->wgpart, c6_conv_wino4_wgrad_partial_floats((int)C, t->n, (int)B, t->num_cus));
+        static const bool keep_v = [] { const char *e = getenv("C6_TRAIN_KEEP_V"); return !e || atoi(e) != 0; }();      // 0: transform x again in the backward pass (A/B)
+        const size_t vf = c6_conv_wino4_v_floats((int)C, t->n, (int)B);
+        if (wg_wino && keep_v && vf * 4 * (size_t)t->L <= ((size_t)64 << 30)) {
+            t->vkeep.assign(t->L, nullptr);
+            for (int l = 0; l < t->L; l++) TA(t->vkeep[l], vf);
+        }
     }
 #undef TA
     if (rc == C6_OK && hipMemcpy(t->mask, mask.data(), t->nfloats, hipMemcpyHostToDevice) != hipSuccess) rc = tfail(C6_ERR_HIP, "mask upload");
@@ -200,15 +207,21 @@ extern "C" int c6_trainer_gradients(c6_trainer *t, float *blob, size_t nfloats) 
 
 // ---- forward in train mode (model.hpp:52-95 with batch statistics) + loss (model.hpp:97-108) ------------------------
 // dW (OIHW) of a tower convolution from dy and the layer's input x: FP32 at 256 channels in the Winograd domain (conv_wino4.hip), else the direct kernels
-static bool wgrad(c6_trainer *t, const float *dy, const float *x, float *dw) {
-    if (t->precision == C6_PREC_FP32 && t->wgpart) return c6_conv_wino4_wgrad(t->C, t->n, t->B, dy, x, t->vbuf, t->wgpart, dw, t->num_cus, t->stream);
+static bool wgrad(c6_trainer *t, const float *dy, const float *x, float *dw, int layer) {
+    if (t->precision == C6_PREC_FP32 && t->wgpart)
+        return c6_conv_wino4_wgrad(t->C, t->n, t->B, dy, x, t->vbuf, t->wgpart, dw, t->num_cus, t->stream, t->vkeep.empty() ? nullptr : t->vkeep[layer]);
     return c6t_wgrad(t->n, t->C, t->B, dy, x, t->partial, dw, t->stream, t->precision != C6_PREC_FP32);
 }
-static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const float *in, const float *bias, const float *res, float *out) {
+// keep_layer >= 0: a forward convolution whose transformed input is kept for the weight gradient
+static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const float *in, const float *bias, const float *res, float *out, int keep_layer = -1) {
     bool ok;
     if (t->precision == C6_PREC_FP32 && t->vbuf) {      // 256 channels: the evaluator's default FP32 form (2.2x fewer ms than the direct kernel here)
         c6_pack_conv_weights_wino4_dev(t->C, w_oihw, t->wpackw, transpose_flip, t->stream);
-        ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vbuf, t->num_cus, t->stream, /*relu=*/0, 7);
+        if (keep_layer >= 0 && !t->vkeep.empty())
+            ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vkeep[keep_layer], t->num_cus, t->stream, /*relu=*/0, 7, nullptr, nullptr,
+                                        t->vbuf + c6_conv_wino4_v_floats(t->C, t->n, t->B));
+        else
+            ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vbuf, t->num_cus, t->stream, /*relu=*/0, 7);
     } else if (t->precision == C6_PREC_FP32) {
         c6t_pack_f32n(t->C, w_oihw, t->wpack32, transpose_flip, t->stream);
         ok = c6_conv_f32n_dispatch(t->C, t->n, t->B, in, t->wpack32, bias, res, out, t->num_cus, t->stream, /*relu=*/0);
@@ -233,7 +246,7 @@ static int forward_loss(c6_trainer *t, bool want_grad_seed) {
     // tower
     for (int l = 0; l < L; l++) {
         const ConvBn &u = t->tower[l];
-        int rc = conv3x3(t, P + u.w, 0, t->a[l], P + u.b, nullptr, t->y[l + 1]);
+        int rc = conv3x3(t, P + u.w, 0, t->a[l], P + u.b, nullptr, t->y[l + 1], l);
         if (rc) return rc;
         float *m = t->mean + (size_t)(l + 1) * C, *v = t->var + (size_t)(l + 1) * C;
         c6t_colstats(0, R, C, t->y[l + 1], nullptr, nullptr, nullptr, nullptr, t->partial, m, v, s);
@@ -294,7 +307,7 @@ static int backward(c6_trainer *t) {
             c6t_colstats(1, R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, t->partial, G + u.be, G + u.g, s);
             c6t_bn_bwd_apply(R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, dz, s);
             c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, t->partial, G + u.b, nullptr, s);
-            if (!wgrad(t, dy, t->a[l1], G + u.w)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
+            if (!wgrad(t, dy, t->a[l1], G + u.w, l1)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
             int rc = conv3x3(t, P + u.w, 1, dy, nullptr, nullptr, dmid);
             if (rc) return rc;
         }
@@ -304,7 +317,7 @@ static int backward(c6_trainer *t) {
             c6t_colstats(1, R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, t->partial, G + u.be, G + u.g, s);
             c6t_bn_bwd_apply(R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, nullptr, s);
             c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, t->partial, G + u.b, nullptr, s);
-            if (!wgrad(t, dy, t->a[l0], G + u.w)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
+            if (!wgrad(t, dy, t->a[l0], G + u.w, l0)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
             int rc = conv3x3(t, P + u.w, 1, dy, nullptr, dz /* + the skip connection's gradient */, cur);
             if (rc) return rc;
         }
