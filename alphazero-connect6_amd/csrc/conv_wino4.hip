@@ -604,14 +604,16 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
 // the heads' three 1x1 filters (policy conv C -> 2 + folded BN + ReLU, value conv C -> 1 + BatchNorm1d over cells + ReLU;
 // model.hpp:80-92, c6_head_conv_kernel) are applied to every pixel (a wave sum per filter) and nothing else is written: 12 GB of
 // activations neither stored nor read back.
-__device__ __forceinline__ float w4_wave_sum(float v) {
+// sum over the wave, valid in lanes 48 .. 63: four butterfly steps inside the rows of 16 lanes, then row 0 -> 1 and 2 -> 3 (row_bcast:15) and
+// rows 0 + 1 -> 3 (row_bcast:31) -- six DPP additions
+__device__ __forceinline__ float w4_wave_sum_row3(float v) {
     v += c6_dpp_f32<C6_DPP_XOR1>(v);
     v += c6_dpp_f32<C6_DPP_XOR2>(v);
     v += c6_dpp_f32<C6_DPP_HALF_MIRROR>(v);
     v += c6_dpp_f32<C6_DPP_MIRROR>(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (r0 + r1) + (r2 + r3);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return v;
 }
 // the 4x4 outputs of a tile (before bias) for this lane's 4 channels from the GEMM kernel's row sums Z_i[b]: the other half of the
 // output transform; zb = the lane's corner of the tile in Z.  Class A: A^T Z with F(4)'s A^T over 6 rows.  Class B': F(3)'s
@@ -716,16 +718,16 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
 #pragma unroll
                 for (int bb = 0; bb < 4; bb++)
 #pragma unroll
-                    for (int f = 0; f < 3; f++) hs[a][bb][f] = w4_wave_sum(hs[a][bb][f]);
-            // every lane has all 48 sums: lane l < 16 writes pixel l of the tile (three 16-lane stores instead of 48 one-lane ones)
+                    for (int f = 0; f < 3; f++) hs[a][bb][f] = w4_wave_sum_row3(hs[a][bb][f]);
+            // lanes 48 .. 63 have all 48 sums: lane 48 + l writes pixel l of the tile (three 16-lane stores instead of 48 one-lane ones)
             float m0 = 0.f, m1 = 0.f, m2 = 0.f;
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int bb = 0; bb < 4; bb++)
-                    if (lane == a * 4 + bb) { m0 = hs[a][bb][0]; m1 = hs[a][bb][1]; m2 = hs[a][bb][2]; }
-            const int py = 4 * ty + (lane >> 2), px = 4 * tx + (lane & 3);
-            if (lane < 16 && py < N && px < N) {
+                    if ((lane & 15) == a * 4 + bb) { m0 = hs[a][bb][0]; m1 = hs[a][bb][1]; m2 = hs[a][bb][2]; }
+            const int py = 4 * ty + ((lane & 15) >> 2), px = 4 * tx + (lane & 3);
+            if (lane >= 48 && py < N && px < N) {
                 const int p = py * N + px;
                 const float y0 = m0 + hd.pc_b[0], y1 = m1 + hd.pc_b[1];
                 hd.ph[(size_t)bd * (2 * N * N) + p] = y0 > 0.f ? y0 : 0.f;             // flatten is channel-major (NCHW view)
