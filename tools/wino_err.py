@@ -55,7 +55,8 @@ def layer_err(AT, G, BT, m, C=128, tiles=64, seed=1):
     for c in range(C): M += U[c][None] * V[:, c]                                                    # f32 accumulate
     Y = np.einsum('ia,tab,jb->tij', AT32, M, AT32).astype(np.float32)
     return np.sqrt(np.mean((Y - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)), np.abs(Y - ref).max() / np.abs(ref).max()
-for name, pts, m in (("F(4,3) 0,1,-1,2,-2", [0, 1, -1, 2, -2], 4), ("F(6,3) 0,1,-1,2,-2,1/2,-1/2", [0, 1, -1, 2, -2, "1/2", "-1/2"], 6),
-                     ("F(6,3) 0,1,-1,1/2,-1/2,3/2?,-3/2?", [0, 1, -1, "1/2", "-1/2", "3/2", "-3/2"], 6), ("F(5,3) 0,1,-1,2,-2,1/2", [0, 1, -1, 2, -2, "1/2"], 5)):
-    AT, G, BT = cook_toom(pts, m)
-    print(name, "exactness", check(AT, G, BT, m), "rms rel err, max rel err (f32):", layer_err(AT, G, BT, m))
+if __name__ == "__main__":
+    for name, pts, m in (("F(4,3) 0,1,-1,2,-2", [0, 1, -1, 2, -2], 4), ("F(6,3) 0,1,-1,2,-2,1/2,-1/2", [0, 1, -1, 2, -2, "1/2", "-1/2"], 6),
+                         ("F(6,3) 0,1,-1,1/2,-1/2,3/2?,-3/2?", [0, 1, -1, "1/2", "-1/2", "3/2", "-3/2"], 6), ("F(5,3) 0,1,-1,2,-2,1/2", [0, 1, -1, 2, -2, "1/2"], 5)):
+        AT, G, BT = cook_toom(pts, m)
+        print(name, "exactness", check(AT, G, BT, m), "rms rel err, max rel err (f32):", layer_err(AT, G, BT, m))
