@@ -596,7 +596,9 @@ class Trainer:
     """The train-loop body of AlphaZero/cpp_weighted/main.cpp:148-160 on the GPU: `step` = zero_grad + model->loss +
     backward + SGD step (WeightedPolicy in train mode, model.hpp:52-108).  Weights are the engine's blob."""
 
-    def __init__(self, board_size, channels, blocks, batch, lr=1e-3, momentum=0.9, device=0, precision=PREC_BF16X3):
+    def __init__(self, board_size, channels, blocks, batch, lr=1e-3, momentum=0.9, device=0, precision=PREC_DEFAULT):
+        """precision: PREC_DEFAULT = PREC_FP32 (f32 like the reference trainer; Winograd-domain kernels at 256 channels), PREC_FP32_DIRECT
+        (the same arithmetic on the direct kernels), PREC_BF16X3 (split-bf16 products: the fast option, gradients within ~1e-3)"""
         self.n, self.cells, self.C, self.blocks, self.batch = board_size, board_size * board_size, channels, blocks, batch
         self.nfloats = lib().c6_net_blob_floats(board_size, channels, blocks)
         self.h = C.c_void_p()

@@ -165,6 +165,10 @@ extern "C" int c6_net_blob_check_header(const float *blob, size_t nfloats, int n
     if (f_bits(blob[0]) != C6_BLOB_MAGIC) return fail(C6_ERR_BAD_ARG, "weight blob: bad magic (not written by save_blob / c6_net_blob_write_header)");
     if (blob[1] != (float)C6_BLOB_VERSION) return fail(C6_ERR_BAD_ARG, "weight blob: unknown layout version");
     if (blob[2] != (float)n || blob[3] != (float)C || blob[4] != (float)nb) return fail(C6_ERR_BAD_ARG, "weight blob was written for another board size / channel count / block count");
+    // the size halves are converted only once they are known to be 24-bit integers (a float -> integer cast of a NaN / negative / huge
+    // value of a corrupted header is undefined behaviour)
+    for (int k = 5; k <= 7; k++)
+        if (!(blob[k] >= 0.f && blob[k] < 16777216.f) || blob[k] != std::floor(blob[k])) return fail(C6_ERR_BAD_ARG, "weight blob: corrupted header (size / checksum fields)");
     const size_t payload = ((size_t)blob[5] << 24) | (size_t)blob[6];
     if (payload != nfloats - C6_BLOB_HEADER_FLOATS || payload != c6_net_blob_floats(n, C, nb)) return fail(C6_ERR_BAD_ARG, "weight blob: payload size does not match its header");
     if (blob[7] != (float)blob_checksum(blob + C6_BLOB_HEADER_FLOATS, payload)) return fail(C6_ERR_BAD_ARG, "weight blob: checksum mismatch (corrupted or re-ordered payload)");
@@ -699,9 +703,11 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
         { Scoped t(&e->t_expand, e->stream, e->profiling); c6_launch_expand(d, e->stream); }
         e->rounds++;
         e->round_in_move++;
-        // K1 places the stones of the games whose policy() just ran: aligned games all move on the same round; staggered games
-        // (and games resumed after a pool growth) a few at a time, every round
-        if (e->cfg.stagger || e->desync || e->round_in_move >= d.S) {
+        // K1 places the stones of the games whose policy() just ran.  It runs EVERY round (35 us beside a net evaluation): a game's
+        // move round is a property of the game, not of the host's round counter -- staggered games, games resumed after waiting for
+        // pages and slots recycled after an error are all out of step with the aligned ones, and a move_pos published in a round
+        // without K1 would be finished by the next round's head with a stale winner / err.
+        {
             Scoped t(&e->t_move, e->stream, e->profiling);
             c6_launch_board_step(d.N, d.Gpad, d.board_soa, d.turn, d.remain, d.move_pos, d.winner, d.err, e->stream);
             moved = true;

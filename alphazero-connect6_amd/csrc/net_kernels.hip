@@ -16,6 +16,16 @@
 
 #include <vector>
 
+#ifndef C6_AB_HEAD_FUSE
+#define C6_AB_HEAD_FUSE 1
+#endif
+#ifndef C6_AB_WINO_MID
+#define C6_AB_WINO_MID 2
+#endif
+#ifndef C6_AB_WINO_STEM
+#define C6_AB_WINO_STEM 1
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -277,17 +287,20 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
     if (nb == 0) return;
     float *x = act0, *y = act1, *z = act2;
     const bool timed = timers && timers->enabled;
-    static const bool fuse_heads = [] { const char *e = getenv("C6_HEAD_FUSE"); return !(e && e[0] == '0'); }();   // A/B switch
-    static const bool fuse_mid = [] { const char *e = getenv("C6_WINO_MID"); return !(e && e[0] == '0'); }();       // A/B switch
-    static const int stem_mode = [] { const char *e = getenv("C6_WINO_STEM"); return e ? atoi(e) : 1; }();      // A/B switch: 0 the stem as a kernel of its own,
-    const bool fuse_stem = stem_mode != 0;                     // 1 never stored (computed twice), 2 computed by the first input transform and stored for the residual
+    // The forms that lost their A/B comparisons are compile-time options of A/B builds only (tools/ab_build.sh -DC6_AB_...=...):
+    // the product has one path per arithmetic.
+    constexpr bool fuse_heads = C6_AB_HEAD_FUSE != 0;          // 0: the heads' 1x1 convolutions as a kernel of their own
+    constexpr int mid_mode = C6_AB_WINO_MID;                   // boundary kernel: 0 off, 1 inside blocks, 2 also across blocks
+    constexpr bool fuse_mid = mid_mode != 0;
+    constexpr int stem_mode = C6_AB_WINO_STEM;                 // 0 the stem as a kernel of its own, 1 never stored (computed twice), 2 computed by the
+    constexpr bool fuse_stem = stem_mode != 0;                 // first input transform and stored for the residual
     bool head_fused = false, heads_done = false, v_ready = false;
     // FP32 Winograd F(4x4) with at least two residual blocks: the stem's activations are never stored -- the first layer's input transform
     // computes them from the boards, and so does the boundary kernel behind the first block, which needs them as its residual
     const C6StemSrc stem_src{boards, board_stride, player, player_stride, aug_map, images, net.stem_w, net.stem_b};
     bool stem_inline = false;
-    static const int mid_mode0 = [] { const char *e = getenv("C6_WINO_MID"); return e ? atoi(e) : 2; }();      // the boundary kernel across blocks must be on
-    if (net.variant == C6_CONV_WINO && fuse_stem && mid_mode0 >= 2 && net.blocks - 1 >= 2 && c6_conv_wino4_vbuf_floats(C, net.N, 1) > 0) stem_inline = true;
+    // (the boundary kernel across blocks must be on)
+    if (net.variant == C6_CONV_WINO && fuse_stem && mid_mode >= 2 && net.blocks - 1 >= 2 && c6_conv_wino4_vbuf_floats(C, net.N, 1) > 0) stem_inline = true;
     if (!stem_inline)
         hipLaunchKernelGGL(c6_stem_kernel, dim3(nb), dim3(256), 0, s, boards, board_stride, player, player_stride, aug_map, images, net.stem_w,
                            net.stem_b, act0, net.N, C);
@@ -316,7 +329,6 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
                 // are one kernel and the activations between them are never stored (F(4x4) form)
                 bool has_out = false;
                 const bool last_layer = l == 2 * (net.blocks - 1) - 1;
-                static const int mid_mode = [] { const char *e = getenv("C6_WINO_MID"); return e ? atoi(e) : 2; }();      // 0 off, 1 inside blocks, 2 also across blocks
                 if (fuse_mid && !last_layer && (half == 0 || mid_mode >= 2) &&
                     c6_conv_wino_mid(C, net.N, nb, vbuf, cb, half == 0 ? nullptr : cres, half == 0 ? nullptr : cout, net.num_cus, s,
                                      stem_inline && stem_mode != 2 && l == 1 ? &stem_src : nullptr)) {

@@ -25,6 +25,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BN_EPS 1e-5f
+#ifndef C6_AB_WGRAD_WS
+#define C6_AB_WGRAD_WS 1          // A/B builds only: 0 = c6_wgrad_b3_kernel (two workgroups per CU) instead of the wave-specialised kernel
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // weights OIHW [C][C][3][3] -> the b3s layout [stage = ks*9 + tap][wave][ct][plane][lane][8] (conv_bf16x3.hip), on the
@@ -1174,7 +1177,7 @@ size_t c6t_wgrad_partial_floats(int C, int B) { return (size_t)c6t_wgrad_splits(
 template <int N>
 static void launch_wgrad(int C, int B, const float *dy, const float *x, float *partial, float *dw, int split_bf16, hipStream_t s) {
     const int splits = c6t_wgrad_splits(C, B), per = (B + splits - 1) / splits;
-    static const int ws = [] { const char *e = getenv("C6_WGRAD_WS"); return e ? atoi(e) : 1; }();   // 0: the two-workgroup kernel (A/B)
+    constexpr int ws = C6_AB_WGRAD_WS;      // 0 (A/B builds only, tools/ab_build.sh -DC6_AB_WGRAD_WS=0): the two-workgroup kernel
     if (split_bf16 && ws) {
         using G = WGradWSGeom<N>;
         hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_wgrad_b3w_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);

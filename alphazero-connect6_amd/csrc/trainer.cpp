@@ -8,6 +8,10 @@
 #include "c6_engine.h"
 #include "c6_train.h"
 
+#ifndef C6_AB_TRAIN_KEEP_V
+#define C6_AB_TRAIN_KEEP_V 1      // A/B builds only (tools/ab_build.sh): 0 = the backward pass transforms x again
+#endif
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,7 +38,8 @@ struct Bn { size_t g, be, rm, rv; };
 struct c6_trainer {
     int n = 0, cells = 0, C = 0, nb = 0, L = 0, B = 0, device = 0, num_cus = 256;
     float lr = 1e-3f, momentum = 0.9f;
-    int precision = C6_PREC_BF16X3;     // of the 3x3 convolutions: forward, input gradient and weight gradient
+    int precision = C6_PREC_FP32;       // of the 3x3 convolutions (forward, input gradient, weight gradient): f32 like the reference trainer
+                                        // (main.cpp:107-157), the same meaning C6_PREC_DEFAULT has in the engine
     long steps = 0;
     size_t nfloats = 0, act = 0;
     hipStream_t stream = nullptr;
@@ -142,11 +147,10 @@ extern "C" int c6_trainer_create(int board_size, int channels, int blocks, int b
     if (c6_conv_wino4_vbuf_floats((int)C, t->n, (int)B)) {
         TA(t->wpackw, c6_conv_packed_wino4_floats((int)C));
         TA(t->vbuf, c6_conv_wino4_vbuf_floats((int)C, t->n, (int)B));
-        static const bool wg_wino = [] { const char *e = getenv("C6_WGRAD_WINO"); return !e || atoi(e) != 0; }();      // 0: the direct FP32 kernel (A/B)
-        if (wg_wino) TA(t->wgpart, c6_conv_wino4_wgrad_partial_floats((int)C, t->n, (int)B, t->num_cus));
-        static const bool keep_v = [] { const char *e = getenv("C6_TRAIN_KEEP_V"); return !e || atoi(e) != 0; }();      // 0: transform x again in the backward pass (A/B)
+        TA(t->wgpart, c6_conv_wino4_wgrad_partial_floats((int)C, t->n, (int)B, t->num_cus));
+        // the forward pass keeps every layer's B^T x B for the weight gradient (C6_AB_TRAIN_KEEP_V=0 in an A/B build: transform x again)
         const size_t vf = c6_conv_wino4_v_floats((int)C, t->n, (int)B);
-        if (wg_wino && keep_v && vf * 4 * (size_t)t->L <= ((size_t)64 << 30)) {
+        if (C6_AB_TRAIN_KEEP_V && vf * 4 * (size_t)t->L <= ((size_t)64 << 30)) {
             t->vkeep.assign(t->L, nullptr);
             for (int l = 0; l < t->L; l++) TA(t->vkeep[l], vf);
         }
@@ -207,10 +211,11 @@ extern "C" int c6_trainer_gradients(c6_trainer *t, float *blob, size_t nfloats) 
 
 // ---- forward in train mode (model.hpp:52-95 with batch statistics) + loss (model.hpp:97-108) ------------------------
 // dW (OIHW) of a tower convolution from dy and the layer's input x: FP32 at 256 channels in the Winograd domain (conv_wino4.hip), else the direct kernels
+static bool is_f32(const c6_trainer *t) { return t->precision == C6_PREC_FP32 || t->precision == C6_PREC_FP32_DIRECT; }
 static bool wgrad(c6_trainer *t, const float *dy, const float *x, float *dw, int layer) {
     if (t->precision == C6_PREC_FP32 && t->wgpart)
         return c6_conv_wino4_wgrad(t->C, t->n, t->B, dy, x, t->vbuf, t->wgpart, dw, t->num_cus, t->stream, t->vkeep.empty() ? nullptr : t->vkeep[layer]);
-    return c6t_wgrad(t->n, t->C, t->B, dy, x, t->partial, dw, t->stream, t->precision != C6_PREC_FP32);
+    return c6t_wgrad(t->n, t->C, t->B, dy, x, t->partial, dw, t->stream, !is_f32(t));
 }
 // keep_layer >= 0: a forward convolution whose transformed input is kept for the weight gradient
 static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const float *in, const float *bias, const float *res, float *out, int keep_layer = -1) {
@@ -222,7 +227,7 @@ static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const
                                         t->vbuf + c6_conv_wino4_v_floats(t->C, t->n, t->B));
         else
             ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vbuf, t->num_cus, t->stream, /*relu=*/0, 7);
-    } else if (t->precision == C6_PREC_FP32) {
+    } else if (is_f32(t)) {
         c6t_pack_f32n(t->C, w_oihw, t->wpack32, transpose_flip, t->stream);
         ok = c6_conv_f32n_dispatch(t->C, t->n, t->B, in, t->wpack32, bias, res, out, t->num_cus, t->stream, /*relu=*/0);
     } else {
@@ -404,9 +409,13 @@ extern "C" int c6_trainer_set_lr(c6_trainer *t, float lr, float momentum) {
 
 extern "C" int c6_trainer_set_precision(c6_trainer *t, int precision) {
     if (!t) return tfail(C6_ERR_BAD_ARG, "c6_trainer_set_precision: NULL trainer");
-    if (precision != C6_PREC_FP32 && precision != C6_PREC_BF16X3 && precision != C6_PREC_DEFAULT)
-        return tfail(C6_ERR_BAD_ARG, "c6_trainer_set_precision: C6_PREC_FP32 or C6_PREC_BF16X3");
-    t->precision = precision == C6_PREC_FP32 ? C6_PREC_FP32 : C6_PREC_BF16X3;
+    // C6_PREC_DEFAULT = C6_PREC_FP32, as in the engine: the reference trainer is f32 (main.cpp:107-157).  C6_PREC_FP32_DIRECT: the same
+    // arithmetic on the direct kernels (forward / input gradient: c6_conv3x3_f32n_kernel, weight gradient: c6_wgrad_kernel) -- the yardstick
+    // the Winograd-domain path is tested against.  C6_PREC_BF16X3: split-bf16 products (gradients within ~1e-3), the fast option.
+    if (precision == C6_PREC_DEFAULT) precision = C6_PREC_FP32;
+    if (precision != C6_PREC_FP32 && precision != C6_PREC_FP32_DIRECT && precision != C6_PREC_BF16X3)
+        return tfail(C6_ERR_BAD_ARG, "c6_trainer_set_precision: C6_PREC_DEFAULT (= C6_PREC_FP32), C6_PREC_FP32, C6_PREC_FP32_DIRECT or C6_PREC_BF16X3");
+    t->precision = precision;
     return C6_OK;
 }
 

@@ -10,7 +10,10 @@ stream while the engine's own stream keeps playing:
     side stream   :                    wait(ev) all-gather(counts) -> host ; all-gather(max(count) records) ; zero count
 
 Only `max(counts)` records travel (rounded up to 64), nothing at all when no game finished on any rank, and the host only
-ever waits for work that is BEHIND rounds already enqueued -- the device is never idle for the exchange.
+ever waits for work that is BEHIND rounds already enqueued.  (The engine's stream waits for the pooling of the buffer it is
+about to write again -- two intervals back -- so it idles only if an all-gather takes longer than an interval of rounds.)
+A rank that finishes more records in one interval than a buffer holds loses the excess (the engine stops writing at `cap`):
+that is counted in `dropped` and raised by `check()`, never silent -- size `cap` for games x stones per interval.
 """
 import numpy as np
 import torch
@@ -76,6 +79,7 @@ class TuplePool:
         self.total = torch.zeros(1, dtype=torch.int64, device=self.dev)   # records pooled so far (all ranks), device side
         self.exchanges = 0
         self.payload_gathers = 0
+        self.dropped = 0                      # records beyond `cap` in some interval (all ranks): lost by the engine, counted here
         self.side = torch.cuda.Stream(device=self.dev)
         self.eng_stream = torch.cuda.ExternalStream(eng.stream_ptr(), device=self.dev)
         self.free_ev = [None, None]           # side-stream event after which buffer i may be written again
@@ -135,13 +139,15 @@ class TuplePool:
         buf, cnt = self.bufs[old], self.counts[old]
         if self.backend != "nccl":
             ev.synchronize()
-            n_mine = min(int(cnt.item()), self.cap)
+            n_raw = int(cnt.item())
             if self.world > 1:
                 counts = torch.empty(self.world, dtype=torch.int32)
-                dist.all_gather_into_tensor(counts, torch.tensor([n_mine], dtype=torch.int32), group=self.group)
+                dist.all_gather_into_tensor(counts, torch.tensor([n_raw], dtype=torch.int32), group=self.group)
                 counts = counts.tolist()
             else:
-                counts = [n_mine]
+                counts = [n_raw]
+            self.dropped += sum(max(0, c - self.cap) for c in counts)
+            counts = [min(c, self.cap) for c in counts]
             m = self._padded(max(counts))
             if m:
                 mine = buf[:m].cpu()
@@ -163,7 +169,9 @@ class TuplePool:
             else:
                 dcounts = cnt.clone()
             self.total += dcounts.clamp(max=self.cap).sum()
-            counts = dcounts.clamp(max=self.cap).cpu().tolist()      # the only host wait: work behind already enqueued rounds
+            raw = dcounts.cpu().tolist()                             # the only host wait: work behind already enqueued rounds
+            self.dropped += sum(max(0, c - self.cap) for c in raw)
+            counts = [min(c, self.cap) for c in raw]
             m = self._padded(max(counts))
             if m:                                                    # every rank takes the same branch: counts are pooled
                 if self.world > 1:
@@ -207,6 +215,11 @@ class TuplePool:
         self.exchange()
         torch.cuda.synchronize()
         return self.collect()
+
+    def check(self):
+        """raise if any rank has lost records to a full buffer"""
+        if self.dropped:
+            raise RuntimeError(f"TuplePool: {self.dropped} training tuples were dropped (buffer of {self.cap} records too small for an interval)")
 
     def pooled_total(self):
         torch.cuda.synchronize()

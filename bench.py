@@ -96,16 +96,22 @@ def pmc_record(kernel_substr):
     return {}
 
 
-def committed_stones_probe(workload, sims=None):
+def committed_stones_probe(workload, sims=None, ignored=None):
     """profiles/r*_stones_probe*.json (tools/stones_probe.py): complete games of the benchmark's net.  The probe taken at the workload's
-    own simulation budget wins; otherwise the one with the most games."""
+    own simulation budget wins; otherwise the one with the most games.  Only probes of THESE kernel sources in the reference's f32
+    arithmetic count (`src_hash`, `precision`): the others are listed in `ignored`."""
     best = None
+    h = kernel_source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stones_probe*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         if d.get("workload") != workload:
+            continue
+        if d.get("src_hash") != h or d.get("precision") != "fp32":
+            if ignored is not None:
+                ignored.append(f"{os.path.basename(f)}: " + ("taken on other kernel sources" if d.get("src_hash") != h else f"precision {d.get('precision')}"))
             continue
         d = dict(d, file=os.path.basename(f))
         key = (d.get("num_simulation") == sims, d.get("games", 0))
@@ -277,11 +283,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision, steps, warmup, evaluator=ev, settle_rounds=0):
-        """one engine, `warmup` untimed + `steps` timed rounds; returns a dict"""
+    def measure(precision, steps, warmup, evaluator=ev, settle_rounds=0, geom=None):
+        """one engine, `warmup` untimed + `steps` timed rounds; returns a dict.  geom = (n, G, S): another geometry than the workload's
+        (the tree-kernel side report)"""
+        n, G, S = geom or (wl["n"], wl["games"], wl["sims"])
         eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=2024, evaluator=evaluator, net_channels=max(wl["channels"], 64),
-                         net_blocks=max(wl["blocks"], 1), recycle=True, stagger=True, device=local_rank, game_uid_base=uid_base,
-                         game_uid_stride=uid_stride, net_precision=precision)
+                         net_blocks=max(wl["blocks"], 1), recycle=True, stagger=True, device=local_rank, game_uid_base=uid_base if not geom else 0,
+                         game_uid_stride=uid_stride if not geom else 0, net_precision=precision)
         if evaluator == pkg.EVAL_NET:
             import __graft_entry__ as ge
             eng.load_weights(ge.make_random_blob(n, wl["channels"], wl["blocks"], np.random.default_rng(0)))
@@ -365,10 +373,11 @@ def main():
         relaxed = measure(pkg.PREC_BF16, args.steps, args.warmup)      # side report only, never `value`
 
     # ---- stones per game: measured --------------------------------------------------------------------------------------
-    probe_file = committed_stones_probe(args.workload if args.workload != "config4" else "config2", S)
+    probes_ignored = []
+    probe_file = committed_stones_probe(args.workload if args.workload != "config4" else "config2", S, probes_ignored)
     live = None
     if world == 1 and is_net and not args.no_probe:
-        live = stones_probe(pkg, wl, args.probe_games, 8, pkg.PREC_BF16X3, device=local_rank)
+        live = stones_probe(pkg, wl, args.probe_games, 8, prec, device=local_rank)
     if is_net:
         if probe_file:
             stones, stones_src = probe_file["stones_per_game"], (f"measured: {probe_file['games']} complete games of this net at {probe_file['num_simulation']} "
@@ -399,6 +408,30 @@ def main():
                        "steady_select_steps_per_sim": ss["st"]["select_steps"] / max(ss["st"]["simulations"], 1),
                        "abandoned_games": ss["st"]["abandoned_games"]}
 
+    # ---- K1 (board kernel) and K2 (tree kernel) against the HBM roofline, in every default run (N = 1) ----------------------------
+    board_side, tree_side = None, None
+    if world == 1 and not args.no_probe:
+        board_side = {"kernel": "c6_board_kernel<N, true> (Game::set + winner scan, one stone per game) / <N, false> (winner scan only)",
+                      "algorithmic_bytes_per_board_step": n * n + 2, "peak_gbs": PEAK_HBM_GBS, "cases": []}
+        for games in sorted({G, 1 << 20, 1 << 22}):
+            for scan in (False, True):
+                ms = pkg.bench_board(n, games, 30, scan_only=scan)
+                b = (n * n + (1 if scan else 2)) * games
+                board_side["cases"].append({"games": games, "launch": "search-only" if scan else "board-step", "us_per_launch": 1e3 * ms,
+                                            "algorithmic_gbs": b / ms / 1e6, "frac": b / ms / 1e6 / PEAK_HBM_GBS})
+        c5 = WORKLOADS["config5"]
+        k = 200
+        tm = measure(0, k, 20, evaluator=pkg.EVAL_UNIFORM, settle_rounds=int(c5["sims"] * c5["stones_prior"]), geom=(c5["n"], c5["games"], c5["sims"]))
+        d_ = tm["st"]["select_steps"] / max(tm["st"]["simulations"], 1)
+        bsim = (12.0 * d_ + 13.0) * c5["n"] ** 2
+        tree_ms = tm["prof"]["select_ms"] + tm["prof"]["expand_ms"]
+        tree_side = {"kernel": "c6_search_kernel<2, 2> at config 5's geometry (32 768 9x9 games, S = 100, uniform evaluator), steady state",
+                     "ms_per_round": 1000.0 * tm["dt"] / k, "kernel_ms_per_round": tree_ms / k, "select_steps_per_sim": d_, "algorithmic_bytes_per_sim": bsim,
+                     "algorithmic_gbs": bsim * c5["games"] * k / max(tree_ms * 1e-3, 1e-9) / 1e9, "peak_gbs": PEAK_HBM_GBS,
+                     "frac": bsim * c5["games"] * k / max(tree_ms * 1e-3, 1e-9) / 1e9 / PEAK_HBM_GBS,
+                     "sims_per_s": c5["games"] * k / tm["dt"], "abandoned_games": tm["st"]["abandoned_games"],
+                     "note": "bound by the vector ALU (noise sampler) and small HBM transactions, not by streaming bandwidth (DESIGN 5.3)"}
+
     if rank == 0:
         def line(m):
             sims = m["sims_in_window"] * world / m["dt"] if world == 1 else args.steps * G * world / m["dt"]
@@ -410,18 +443,27 @@ def main():
             gemm_ms = prof["conv_ms"] - prof["conv_pre_ms"] - prof.get("conv_post_ms", 0.0)
             peak = PEAK_FP32_MFMA_TFLOPS if name.startswith("fp32") else PEAK_BF16_MFMA_TFLOPS
             L = max(prof["conv_launches"], 1)
-            ach = prof["conv_flops"] / (gemm_ms * 1e-3) / 1e12      # algorithmic (direct-convolution) FLOPs over the dominant kernel's time
+            alg = prof["conv_flops"] / (gemm_ms * 1e-3) / 1e12      # algorithmic (direct-convolution) FLOPs over the dominant kernel's time
+            exe = prof["conv_exec_flops"] / (gemm_ms * 1e-3) / 1e12 # matrix FLOPs the kernel executes over the same time
             std = args.workload == "config2" and not args.games
             rec = pmc_record(kern) if std else {}
+            # `achieved` / `frac`: what the named kernel DOES against the roof that bounds it (executed matrix FLOP/s over the dense peak --
+            # a fraction of a roof, <= 1).  The algorithmic count of SURVEY 8d (2*9*C^2*N^2 per board and layer) is reported beside it:
+            # Winograd executes 3.8x fewer products than that, so algorithmic / peak is a ratio, not a roofline fraction.
+            ach = exe if name.startswith("fp32") else alg
             r = {"bound": "mfma", "kernel": f"{kern} ({desc})", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                  "traffic": rec.get("hbm_bytes_per_launch"), "avg_launch_ms": gemm_ms / L, "launches": prof["conv_launches"],
-                 "algorithmic_flops_per_launch": prof["conv_flops"] / L,
-                 "executed_mfma_tflops": prof["conv_exec_flops"] / (gemm_ms * 1e-3) / 1e12, "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt_)}
-            r["frac_executed"] = r["executed_mfma_tflops"] / peak
+                 "algorithmic_flops_per_launch": prof["conv_flops"] / L, "executed_flops_per_launch": prof["conv_exec_flops"] / L,
+                 "algorithmic_tflops": alg, "algorithmic_ratio": alg / peak,
+                 "executed_mfma_tflops": exe, "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt_)}
+            r["frac_executed"] = exe / peak
+            # the layer as a whole: the same executed FLOPs over GEMM + boundary-kernel time (an MFMA-bound phase and an HBM-bound phase that
+            # alternate: their times add)
+            r["layer_frac"] = prof["conv_exec_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 / peak
             if name == "fp32":
-                r["note"] = ("frac = ALGORITHMIC FLOP/s (2*9*C^2*N^2 per board and layer, SURVEY 8d) / dense FP32-MFMA peak; Winograd F(4x4,3x3) with F(3,3) edge tiles executes 3.8x "
-                             "fewer matrix FLOPs than that count (846 products per channel pair and board instead of 3249), so frac exceeds 1 -- "
-                             "frac_executed is the matrix-pipe utilisation; the two transforms are HBM-bound kernels of their own, reported beside it")
+                r["note"] = ("achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + "
+                             "boundary-kernel time; algorithmic_tflops / algorithmic_ratio count 2*9*C^2*N^2 per board and layer (SURVEY 8d), of which Winograd "
+                             "F(4x4,3x3) with F(3,3) edge tiles executes 1 / 3.84 (846 products per channel pair and board instead of 3249)")
                 nbd, Cc, tiles = min(G * 8, 32768), wl["channels"], ((n + 3) // 4) ** 2
                 # between the GEMM kernels: one input transform in front of the tower, then ONE kernel per layer boundary (output transform of
                 # layer l + input transform of layer l + 1; the activations between the two convolutions of a block are never stored), and
@@ -443,9 +485,9 @@ def main():
                                    "traffic_mid_kernel": pmc_record("c6_wino4_mid_kernel<19, false>").get("hbm_bytes_per_launch") if std else None}
                 r["conv_layer_tflops_algorithmic"] = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
             if name == "bf16x3":
-                r.update(mfma_flops_per_algorithmic_flop=3, executed_mfma_tflops=3 * ach, frac_executed=3 * ach / peak)
+                r.update(mfma_flops_per_algorithmic_flop=3, executed_mfma_tflops=3 * alg, frac_executed=3 * alg / peak)
             if name == "f16f8":
-                r.update(scheme_ceiling_tflops=peak / (1.0 + 10.0 / 9.0), frac_of_scheme_ceiling=ach * (1.0 + 10.0 / 9.0) / peak)
+                r.update(scheme_ceiling_tflops=peak / (1.0 + 10.0 / 9.0), frac_of_scheme_ceiling=alg * (1.0 + 10.0 / 9.0) / peak)
             if "mfma_util" in rec:
                 r["pmc_mfma_busy_frac"] = rec["mfma_util"]
                 r["pmc_effective_clock_ghz"] = rec.get("effective_clock_ghz")
@@ -484,6 +526,10 @@ def main():
             out["stones_per_finished_game_in_window"] = head["stones_in_window"] / head["games_in_window"]
         if live:
             out["config"]["stones_per_game_live_probe"] = live
+            if is_net:
+                out["value_with_live_probe"] = sims_s / (S * live["stones_per_game"])
+        if probes_ignored:
+            out["config"]["stones_probes_ignored"] = probes_ignored
         if is_net and head["prof"]["conv_launches"]:
             out["roofline"] = conv_roofline(head, args.precision)
             out["net_tflops_end_to_end"] = net_flops_per_board(n, wl["channels"], wl["blocks"]) * 8 * sims_s / 1e12
@@ -518,6 +564,10 @@ def main():
                                "note": "algorithmic bytes (SURVEY 8d: (12 d + 13) N^2 per simulation) over the kernel's time; the kernel is bound by the vector "
                                        "ALU (the Gamma sampler of the Dirichlet noise is half of it) and by small HBM transactions, not by streaming bandwidth: "
                                        "profiles/r02_tree_ablation.txt"}
+        if board_side:
+            out["board_kernel"] = board_side
+        if tree_side:
+            out["tree_kernel"] = tree_side
         out["phase_ms"] = {k: head["prof"][k] for k in ("conv_ms", "conv_pre_ms", "conv_post_ms", "select_ms", "expand_ms", "eval_other_ms", "move_ms")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, stones, args.cpu_seconds)

@@ -381,9 +381,10 @@ typedef struct c6_trainer c6_trainer;
 int c6_trainer_create(int board_size, int channels, int blocks, int batch, float lr, float momentum, int device, c6_trainer **out);
 void c6_trainer_destroy(c6_trainer *t);
 int c6_trainer_set_lr(c6_trainer *t, float lr, float momentum);
-/* precision of the 3x3 convolutions of the forward pass and of the input gradient: C6_PREC_BF16X3 (the trainer's default, the evaluator's
- * split-bf16 kernels, weight gradient included) or C6_PREC_FP32 (exact-FP32 MFMA everywhere, 2.4x slower; gradient parity with
- * an FP32 framework to ~1e-6). */
+/* precision of the 3x3 convolutions (forward pass, input gradient, weight gradient).  C6_PREC_DEFAULT = C6_PREC_FP32 -- the same meaning
+ * it has in the engine, and the trainer's initial setting: f32 like the reference trainer (main.cpp:107-157), at 256 channels in the
+ * Winograd domain; gradient parity with an FP32 framework to ~1e-6.  C6_PREC_FP32_DIRECT: the same arithmetic on the direct kernels
+ * (the yardstick).  C6_PREC_BF16X3: the evaluator's split-bf16 kernels, weight gradient included -- 1.3x faster, gradients to ~1e-3. */
 int c6_trainer_set_precision(c6_trainer *t, int precision);
 /* torch::load / torch::save (main.cpp:100,163) in blob form; load resets the momentum buffers */
 int c6_trainer_load_weights(c6_trainer *t, const float *blob, size_t nfloats);

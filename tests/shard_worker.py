@@ -3,7 +3,11 @@ tools/shard_rehearsal.py): games sharded by uid (shard.uid_plan), played to the 
 pooled over all ranks by shard.TuplePool (all-gather).  The reference's counterpart is the per-task policy + mpsc collection
 of AsyncAgent::run (agent/async_agent/mod.rs:100-137): results are a concatenation in any order.
 
-    python tests/shard_worker.py RANK WORLD PORT N GAMES_PER_RANK S SEED OUT.npz [device] [backend]
+    python tests/shard_worker.py RANK WORLD PORT N GAMES_PER_RANK S SEED OUT.npz [device] [backend] [mode]
+
+mode "play" (default): every game to its end.  mode "props": config 4's shape -- many games per rank for a few rounds, root
+invariants on samples, then ONE game per rank finished from outside (c6_engine_apply_moves, the scripted 11-stone game of
+agent_impl/tests.rs:65-130) so that the tuple exchange carries a payload.
 """
 import os
 import sys
@@ -19,6 +23,7 @@ def main():
     out = sys.argv[8]
     device = int(sys.argv[9]) if len(sys.argv) > 9 else 0
     backend = sys.argv[10] if len(sys.argv) > 10 else "gloo"
+    mode = sys.argv[11] if len(sys.argv) > 11 else "play"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
@@ -35,9 +40,11 @@ def main():
     base, stride_uid = shard.uid_plan(G, world, rank)
     eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_RANDOM, device=device,
                      game_uid_base=base, game_uid_stride=stride_uid)
-    cap = G * n * n
+    cap = G * n * n if mode == "play" else 4096
     pool = shard.TuplePool(eng, cap, world, backend=backend)
     records = []
+    if mode == "props":
+        return props(eng, pool, rank, world, n, G, out, dist)
     # a few rounds at a time, pooling in between: the collective runs while the next rounds are already enqueued
     for _ in range(100000):
         eng.step(S)
@@ -59,6 +66,33 @@ def main():
     allrec = np.concatenate(records, axis=0) if records else np.zeros((0, pool.stride), np.uint8)
     np.savez(out, records=allrec, finished=st["games_finished"], overflow=st["overflow_games"],
              uids=np.array(sorted(g["uid"] for g in games), np.int64))
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def props(eng, pool, rank, world, n, G, out, dist):
+    R = 6
+    eng.step(R)
+    pool.exchange()
+    st = eng.stats()
+    ok = st["simulations"] == G * R and st["overflow_games"] == 0 and st["live_games"] == G
+    for g in list(range(0, G, max(1, G // 16))) + [G - 1]:
+        r = eng.root(g)
+        ok = ok and r["root_visit"] == R and int(r["visits"].sum()) == R - 1 and r["stones"] == 0
+    gathers_before = pool.payload_gathers
+    # game `rank` of this rank's engine: Black (0,0) | White (5,0),(5,1) | Black (0,1),(0,2) | White (5,2),(5,3) | Black (0,3),(0,4) |
+    # White (5,4),(5,5): White's six -- 11 stones, 11 tuples
+    script = [(0, 0), (5, 0), (5, 1), (0, 1), (0, 2), (5, 2), (5, 3), (0, 3), (0, 4), (5, 4), (5, 5)]
+    for (r_, c_) in script:
+        pos = np.full(G, -2, np.int32)
+        pos[rank] = r_ * n + c_
+        eng.apply_moves(pos)
+    got = pool.flush()
+    games = eng.fetch_games()
+    np.savez(out, ok=int(ok), gathers=pool.payload_gathers - gathers_before, pooled=0 if got is None else got.shape[0],
+             total=pool.pooled_total(), dropped=pool.dropped, finished=len(games), winner=games[0]["winner"] if games else 0,
+             records=got if got is not None else np.zeros((0, pool.stride), np.uint8))
     eng.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -57,6 +57,11 @@ def test_header_rejects_permutation_geometry_and_corruption(tmp_path):
         pkg.check_blob(headed, n, C * 2, blocks)
     with pytest.raises(pkg.C6Error, match="magic"):
         pkg.check_blob(np.concatenate([np.zeros(8, np.float32), want]), n, C, blocks)
+    for k, v in ((5, np.nan), (6, -1.0), (5, 3.0e38), (6, 0.5), (7, np.inf)):      # size / checksum fields that are not 24-bit integers
+        junk = headed.copy()
+        junk[k] = v
+        with pytest.raises(pkg.C6Error, match="corrupted header"):
+            pkg.check_blob(junk, n, C, blocks)
     path = str(tmp_path / "net.c6w")
     pkg.save_blob(path, dict(m.state_dict()), n, C, blocks)
     assert (pkg.load_blob(path, n, C, blocks)[8:] == want).all()

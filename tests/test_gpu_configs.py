@@ -16,10 +16,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+CONFIG3_SAMPLES = (0, 1, 511, 2047, 4095, 4096, 5000, 8191, 8192, 12287, 12288, 16383)
+
+
 def test_config3_full_size():
-    """16 384 games x 19x19 x S = 800 x 8-block resident net (131 072 dihedral images per round, ~80 GB of node records):
-    after R rounds every root has visit R and its children R - 1 (alphazero_policy/tests.rs:90-136 generalised), nothing
-    overflowed; three sampled games equal the seeded oracle driven by its own FP32 net (visits exactly, priors / q to 1e-5)."""
+    """16 384 games x 19x19 x S = 800 x 8-block resident net (131 072 dihedral images per round in 4 chunks of 32 768, ~80 GB of
+    node records): after R rounds every root has visit R and its children R - 1 (alphazero_policy/tests.rs:90-136 generalised),
+    nothing overflowed; twelve sampled games equal the seeded oracle driven by its own FP32 net (visits exactly, priors / q to
+    1e-5).  The samples are the first, last and middle leaves of the net's chunks: their eight images sit in the first and the
+    last (partial) block of each of the Winograd scratch's tile regions and on the chunk boundaries."""
     need_gpu()
     import __graft_entry__ as ge
     n, G, S, C, blocks, R, seed = 19, 16384, 800, 256, 8, 3, 31
@@ -36,7 +41,7 @@ def test_config3_full_size():
     net = o.Net(n, C, blocks, blob)
     fn, ctx = net.eval_fn()
     empty = np.zeros((n, n), np.int8)
-    for g in (0, 5000, G - 1):
+    for g in CONFIG3_SAMPLES:
         az = o.AlphaZero(n, num_simulation=S, eval_kind=o.EVAL_CUSTOM, eval_fn=fn, ctx=ctx, seed=seed, game_uid=g)
         s = o.sim_from_game(o.new_game(n))
         az.init(s)
@@ -50,6 +55,96 @@ def test_config3_full_size():
         az.close()
     net.close()
     eng.close()
+
+
+def test_config3_geometry_mid_game():
+    """The same geometry (16 384 games, 19x19, S = 800) with the uniform evaluator through two whole moves and all but the last
+    search of the third, so that mid-game trees, next()'s prune, tree reuse and the hand-over of record pages between games run
+    at that size: every game has placed 2 stones, simulations == G * rounds, nothing overflowed, and sampled games' roots equal
+    the seeded oracle's at the same point (child visits, q and priors bit for bit)."""
+    need_gpu()
+    n, G, S, seed, moves = 19, 16384, 800, 32, 2
+    rounds = moves * S + S - 1
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_UNIFORM)
+    eng.step(rounds)
+    st = eng.stats()
+    assert st["simulations"] == G * rounds and st["overflow_games"] == 0 and st["abandoned_games"] == 0 and st["live_games"] == G
+    assert st["stones"] == G * moves
+    for g in (0, 4097, G - 1):
+        az = o.AlphaZero(n, num_simulation=S, eval_kind=o.EVAL_UNIFORM, seed=seed, game_uid=g)
+        game = o.new_game(n)
+        for _ in range(moves):
+            cell = az.next(game)
+            o.game_set(game, cell // n, cell % n)
+        s = o.sim_from_game(game)
+        az.init(s)
+        for _ in range(S - 1):
+            az.search(s)
+        r = eng.root(g)
+        board = game.np_board()
+        assert (r["board"] == board).all(), g
+        vis, q, p = az.children(board)
+        empty = board.reshape(-1) == 0
+        assert (r["visits"][empty] == vis[empty]).all() and (r["q"][empty] == q[empty]).all() and (r["prior"][empty] == p[empty]).all(), g
+        az.close()
+    eng.close()
+
+
+def test_config5_engine_full_size():
+    """BASELINE config 5 as an ENGINE at full size: 32 768 concurrent 9x9 games, S = 100, uniform evaluator, recycling slots,
+    for about two game lengths of rounds through c6_search_kernel<2, 2> (the kernel the config-5 bench times).  Nothing
+    overflowed or was abandoned, simulations == G * rounds, every finished game replays legally on K1 with K1's winner and
+    length (a game ends exactly at its first six / on the full board), and sampled games -- first-generation and recycled
+    uids -- equal the seeded oracle stone for stone."""
+    need_gpu()
+    n, G, S, seed, rounds = 9, 32768, 100, 77, 13200
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_UNIFORM, recycle=True)
+    eng.step(rounds)
+    st = eng.stats()
+    games = eng.fetch_games()
+    eng.close()
+    assert st["simulations"] == G * rounds and st["overflow_games"] == 0 and st["abandoned_games"] == 0 and st["live_games"] == G
+    assert len(games) == st["games_finished"] and len(games) > G
+    uids = np.array([g["uid"] for g in games])
+    assert len(set(uids.tolist())) == len(games) and (uids % G).size       # every uid finishes once
+    # legality + winner: all finished games replayed in lock step through K1
+    F = len(games)
+    Fp = (F + 3) & ~3
+    lens = np.array([len(g["moves"]) for g in games] + [0] * (Fp - F))
+    mv = np.full((Fp, n * n), -2, np.int32)
+    for i, g in enumerate(games):
+        mv[i, :len(g["moves"])] = g["moves"]
+    soa = np.zeros((n * n, Fp), np.int8)
+    turn = np.full(Fp, -1, np.int8)
+    remain = np.ones(Fp, np.int8)
+    won_at = np.full(Fp, -1, np.int32)
+    winner = np.zeros(Fp, np.int8)
+    for k in range(n * n):
+        pos = np.ascontiguousarray(mv[:, k])
+        if (pos < 0).all():
+            break
+        soa, turn, remain, win, err = pkg.board_step(n, soa, turn, remain, pos)
+        live = pos >= 0
+        assert (err[live] == 0).all(), k
+        first = live & (win != 0) & (won_at < 0)
+        won_at[first] = k
+        winner[first] = win[first]
+    want_w = np.array([g["winner"] for g in games] + [0] * (Fp - F))
+    assert (winner == want_w).all()
+    decided = want_w != 0
+    assert (won_at[decided] == lens[decided] - 1).all()                      # the game stopped at its first six
+    assert (lens[~decided][:F - decided.sum()] <= n * n).all()
+    draws = (~decided)[:F]
+    assert (lens[:F][draws] == n * n).all()                                  # no winner: the board is full (policy() had no move)
+    # stone for stone against the oracle: slots' first games and recycled ones
+    by_uid = {g["uid"]: g for g in games}
+    first_gen = [u for u in (0, 1, 12345, G - 1) if u in by_uid]
+    recycled = sorted(u for u in by_uid if u >= G)[:4]
+    assert len(first_gen) >= 3 and len(recycled) == 4
+    for u in first_gen + recycled:
+        ref = o.self_play(n, num=1, threads=1, num_simulation=S, seed=seed, eval_kind=o.EVAL_UNIFORM, uid_base=u)[0]
+        want = [r * n + c for _, _, (r, c) in ref["path"]]
+        assert list(by_uid[u]["moves"]) == want and by_uid[u]["winner"] == ref["winner"], u
 
 
 def _free_port():
@@ -97,3 +192,64 @@ def test_two_process_engine_shard_on_one_gpu(tmp_path):
     # the pooled set replays to the oracle's games too (engine == oracle is tested elsewhere; this ties the shard to it)
     ref = o.self_play(n, num=G, threads=min(G, os.cpu_count() or 1), num_simulation=S, seed=seed)
     assert sorted(len(g_["path"]) for g_ in ref) == sorted(len(g["moves"]) for g in games)
+
+
+def _spawn_ranks(tmp_path, world, n, per_rank, S, seed, backend, mode, devices):
+    port = _free_port()
+    outs = [str(tmp_path / f"{mode}_rank{r}.npz") for r in range(world)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), str(r), str(world), str(port), str(n),
+                               str(per_rank), str(S), str(seed), outs[r], str(devices[r]), backend, mode], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    return [np.load(f) for f in outs]
+
+
+def _config4_checks(tmp_path, backend, devices, per_rank_props):
+    world = 2
+    # (a) whole games: every rank ends with the same pooled set = the single-process run of all the uids
+    n, per_rank, S, seed = 9, 6, 12, 78
+    got = _spawn_ranks(tmp_path, world, n, per_rank, S, seed, backend, "play", devices)
+    G = per_rank * world
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_RANDOM)
+    eng.enable_tuples(G * n * n)
+    eng.run()
+    games = eng.fetch_games()
+    stride = pkg.lib().c6_tuple_stride(n)
+    buf = np.zeros((G * n * n, stride), np.uint8)
+    import ctypes as C
+    cnt = C.c_size_t()
+    assert pkg.lib().c6_engine_fetch_tuples(eng.h, G * n * n, C.byref(cnt), buf.ctypes.data_as(C.c_void_p)) == 0
+    eng.close()
+    want = sorted(bytes(r) for r in buf[: cnt.value])
+    assert len(want) == sum(len(g["moves"]) for g in games)
+    for r in range(world):
+        assert int(got[r]["overflow"]) == 0 and int(got[r]["finished"]) == per_rank
+        assert list(got[r]["uids"]) == list(range(r * per_rank, (r + 1) * per_rank))
+        assert sorted(bytes(x) for x in got[r]["records"]) == want
+    # (b) config 4's shape: many 19x19 games per rank for a few rounds, then one game per rank finished from outside
+    got = _spawn_ranks(tmp_path, world, 19, per_rank_props, 400, seed, backend, "props", devices)
+    for r in range(world):
+        assert int(got[r]["ok"]) == 1, r                      # root visit == R, sum(child visits) == R - 1, nothing overflowed
+        assert int(got[r]["gathers"]) >= 1 and int(got[r]["dropped"]) == 0
+        assert int(got[r]["finished"]) == 1 and int(got[r]["winner"]) == 1        # the scripted game: White's six
+        assert int(got[r]["pooled"]) == 11 * world and int(got[r]["total"]) == 11 * world
+    assert sorted(bytes(x) for x in got[0]["records"]) == sorted(bytes(x) for x in got[1]["records"])
+
+
+def test_config4_two_gpu_rccl(tmp_path):
+    """BASELINE config 4's mechanism on real RCCL: 2 fresh child processes, ONE GPU EACH, backend nccl -- the device-tensor branch
+    of shard.TuplePool (all-gather of the counts, then of max(count) records, on a side stream).  Runs whenever the box has
+    at least two GPUs; the one-GPU box of this pool skips it (and runs the same protocol over gloo, below)."""
+    need_gpu()
+    if pkg.device_count() < 2:
+        pytest.skip("needs 2 GPUs: RCCL wants one device per rank")
+    _config4_checks(tmp_path, "nccl", (0, 1), 8192)
+
+
+def test_config4_two_ranks_one_gpu_gloo(tmp_path):
+    """the same checks with both ranks on GPU 0 (gloo carries the all-gathers; RCCL refuses two ranks on one device), at
+    2 x 2048 games of config 4's shape so that both engines fit beside the other tests"""
+    need_gpu()
+    _config4_checks(tmp_path, "gloo", (0, 0), 2048)
