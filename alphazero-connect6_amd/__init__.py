@@ -45,7 +45,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
-                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_engine_apply_moves", "c6_engine_last_moves",
+                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_conv_wgrad_op", "c6_engine_apply_moves", "c6_engine_last_moves",
                   "c6_rollout_create", "c6_rollout_destroy", "c6_rollout_reset", "c6_rollout_next", "c6_rollout_slot_info",
                   "c6_rollout_node", "c6_rollout_bench_playouts"]
 
@@ -193,6 +193,7 @@ def lib():
     L.c6_trainer_destroy.argtypes = [C.c_void_p]
     L.c6_trainer_set_lr.argtypes = [C.c_void_p, C.c_float, C.c_float]
     L.c6_trainer_set_precision.argtypes = [C.c_void_p, C.c_int]
+    L.c6_conv_wgrad_op.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
     L.c6_trainer_load_weights.argtypes = [C.c_void_p, f32p, C.c_size_t]
     L.c6_trainer_export_weights.argtypes = [C.c_void_p, f32p, C.c_size_t]
     L.c6_trainer_gradients.argtypes = [C.c_void_p, f32p, C.c_size_t]
@@ -918,6 +919,16 @@ def conv_pack_m8(channels, w_oihw):
     out = np.zeros(nbytes, np.uint8)
     _chk(lib().c6_conv_pack_m8(channels, _p(w, C.c_float), _p(out, C.c_uint8), nbytes))
     return out
+
+
+def conv_wgrad(n, channels, dy, x, method):
+    """dW [C, C, 3, 3] of a 3x3 convolution from dy and x (NHWC [B, N*N, C], f32): method 0 direct kernel, 1 Winograd domain (C = 256)"""
+    dy = np.ascontiguousarray(dy, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B = dy.shape[0]
+    dw = np.zeros((channels, channels, 3, 3), np.float32)
+    _chk(lib().c6_conv_wgrad_op(n, channels, B, _p(dy, C.c_float), _p(x, C.c_float), method, _p(dw, C.c_float)))
+    return dw
 
 
 def bench_board(n, num_games, iters=20, scan_only=False):

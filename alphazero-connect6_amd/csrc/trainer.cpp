@@ -420,3 +420,37 @@ extern "C" int c6_trainer_set_precision(c6_trainer *t, int precision) {
 }
 
 extern "C" const char *c6_trainer_last_error(void) { return t_err.c_str(); }
+
+// Stand-alone operator for the parity tests: dW (OIHW [C][C][3][3]) of y = conv3x3(x, w) from dy and x (both NHWC [B][N*N][C], host
+// buffers), in f32 -- method 0: the direct kernel (c6_wgrad_kernel, train_kernels.hip), 1: in the Winograd domain (c6_conv_wino4_wgrad,
+// conv_wino4.hip; C = 256).  The two are independent implementations of the same sums.
+extern "C" int c6_conv_wgrad_op(int n, int C, int B, const float *dy, const float *x, int method, float *dw) {
+    if (!dy || !x || !dw) return tfail(C6_ERR_BAD_ARG, "c6_conv_wgrad_op: NULL argument");
+    if ((n != 9 && n != 15 && n != 19) || C % 64 || B < 1 || (method != 0 && method != 1)) return tfail(C6_ERR_BAD_ARG, "c6_conv_wgrad_op: bad geometry / method");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return tfail(C6_ERR_NO_GPU, "c6_conv_wgrad_op: no HIP device (this library has no CPU fallback)");
+    hipDeviceProp_t prop;
+    const int cus = hipGetDeviceProperties(&prop, 0) == hipSuccess ? prop.multiProcessorCount : 256;
+    const size_t act = (size_t)B * n * n * C;
+    float *d_dy = nullptr, *d_x = nullptr, *d_dw = nullptr, *d_part = nullptr, *d_vbuf = nullptr;
+    int rc = C6_OK;
+    auto done = [&](int r) { hipFree(d_dy); hipFree(d_x); hipFree(d_dw); hipFree(d_part); hipFree(d_vbuf); return r; };
+    if (hipMalloc(&d_dy, act * 4) != hipSuccess || hipMalloc(&d_x, act * 4) != hipSuccess || hipMalloc(&d_dw, (size_t)9 * C * C * 4) != hipSuccess)
+        return done(tfail(C6_ERR_HIP, "c6_conv_wgrad_op: hipMalloc"));
+    hipMemcpy(d_dy, dy, act * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_x, x, act * 4, hipMemcpyHostToDevice);
+    bool ok;
+    if (method == 1) {
+        const size_t vb = c6_conv_wino4_vbuf_floats(C, n, B), pf = c6_conv_wino4_wgrad_partial_floats(C, n, B, cus);
+        if (!vb) return done(tfail(C6_ERR_BAD_ARG, "c6_conv_wgrad_op: the Winograd-domain weight gradient needs C = 256"));
+        if (hipMalloc(&d_vbuf, vb * 4) != hipSuccess || hipMalloc(&d_part, pf * 4) != hipSuccess) return done(tfail(C6_ERR_HIP, "c6_conv_wgrad_op: hipMalloc"));
+        ok = c6_conv_wino4_wgrad(C, n, B, d_dy, d_x, d_vbuf, d_part, d_dw, cus, nullptr, nullptr);
+    } else {
+        if (hipMalloc(&d_part, c6t_wgrad_partial_floats(C, B) * 4) != hipSuccess) return done(tfail(C6_ERR_HIP, "c6_conv_wgrad_op: hipMalloc"));
+        ok = c6t_wgrad(n, C, B, d_dy, d_x, d_part, d_dw, nullptr, 0);
+    }
+    if (!ok) rc = tfail(C6_ERR_BAD_ARG, "c6_conv_wgrad_op: no kernel for this geometry");
+    if (hipDeviceSynchronize() != hipSuccess) rc = tfail(C6_ERR_HIP, "c6_conv_wgrad_op: kernel failed");
+    if (rc == C6_OK) hipMemcpy(dw, d_dw, (size_t)9 * C * C * 4, hipMemcpyDeviceToHost);
+    return done(rc);
+}

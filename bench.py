@@ -283,7 +283,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision, steps, warmup, evaluator=ev, settle_rounds=0, geom=None):
+    def measure(precision, steps, warmup, evaluator=ev, settle_rounds=0, geom=None, chunk=0):
         """one engine, `warmup` untimed + `steps` timed rounds; returns a dict.  geom = (n, G, S): another geometry than the workload's
         (the tree-kernel side report)"""
         n, G, S = geom or (wl["n"], wl["games"], wl["sims"])
@@ -303,7 +303,7 @@ def main():
             # for its counts, which sit behind work already enqueued) -- no per-round synchronisation of the engine's stream
             done = 0
             while done < k:
-                c = min(gather_every, k - done)
+                c = min(chunk or gather_every, k - done)
                 ta = time.perf_counter()
                 eng.step(c)
                 tb = time.perf_counter()
@@ -420,8 +420,8 @@ def main():
                 board_side["cases"].append({"games": games, "launch": "search-only" if scan else "board-step", "us_per_launch": 1e3 * ms,
                                             "algorithmic_gbs": b / ms / 1e6, "frac": b / ms / 1e6 / PEAK_HBM_GBS})
         c5 = WORKLOADS["config5"]
-        k = 200
-        tm = measure(0, k, 20, evaluator=pkg.EVAL_UNIFORM, settle_rounds=int(c5["sims"] * c5["stones_prior"]), geom=(c5["n"], c5["games"], c5["sims"]))
+        k = 256
+        tm = measure(0, k, 32, evaluator=pkg.EVAL_UNIFORM, settle_rounds=int(c5["sims"] * c5["stones_prior"]), geom=(c5["n"], c5["games"], c5["sims"]), chunk=64)
         d_ = tm["st"]["select_steps"] / max(tm["st"]["simulations"], 1)
         bsim = (12.0 * d_ + 13.0) * c5["n"] ** 2
         tree_ms = tm["prof"]["select_ms"] + tm["prof"]["expand_ms"]

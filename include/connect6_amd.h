@@ -386,6 +386,9 @@ int c6_trainer_set_lr(c6_trainer *t, float lr, float momentum);
  * Winograd domain; gradient parity with an FP32 framework to ~1e-6.  C6_PREC_FP32_DIRECT: the same arithmetic on the direct kernels
  * (the yardstick).  C6_PREC_BF16X3: the evaluator's split-bf16 kernels, weight gradient included -- 1.3x faster, gradients to ~1e-3. */
 int c6_trainer_set_precision(c6_trainer *t, int precision);
+/* parity-test operator: dW (OIHW [C][C][3][3], f32) of y = conv3x3(x, w) from dy and x (host buffers, NHWC [B][N*N][C]).
+ * method 0: the direct kernel, 1: in the Winograd domain (C = 256) -- the two implementations the FP32 trainer chooses between */
+int c6_conv_wgrad_op(int n, int C, int B, const float *dy, const float *x, int method, float *dw);
 /* torch::load / torch::save (main.cpp:100,163) in blob form; load resets the momentum buffers */
 int c6_trainer_load_weights(c6_trainer *t, const float *blob, size_t nfloats);
 int c6_trainer_export_weights(c6_trainer *t, float *blob, size_t nfloats);

@@ -67,28 +67,49 @@ def test_board_global_load_kernel_matches(n):
 
 
 def test_winograd_weight_gradient_matches_direct_kernel():
-    """FP32 training step at 256 channels: forward, input gradient and weight gradient in the Winograd domain (dU = sum over tiles of
-    A dY A^T x B^T x B, dg = G^T dU G; c6_conv_wino4_wgrad) against the direct kernels (C6_PREC_FP32_DIRECT) on the same batch -- 15x15
-    (mixed tiling) and 19x19, 300 boards: every tile region holds whole and partial blocks and the reduction is cut into chunks.  Same
-    sums, different order and different intermediate values: the whole gradient within 1e-5 in L2 (the trainer's parity bar against
-    PyTorch is 1e-4)."""
+    """The FP32 trainer's two weight-gradient implementations on the SAME dy and x (c6_conv_wgrad_op): in the Winograd domain (dU = sum
+    over tiles of A dY A^T x B^T x B, dg = G^T dU G; c6_conv_wino4_wgrad) against the direct kernel (c6_wgrad_kernel) -- 15x15 (mixed
+    tiling) and 19x19, 300 boards: every tile region holds whole and partial blocks and the reduction is cut into chunks.  Same sums,
+    different order and different intermediate values: within 1e-5 in L2 of each other, and both within 1e-5 of float64 on a slice."""
+    need_gpu()
+    for n in (15, 19):
+        C, B = 256, 300
+        rng = np.random.default_rng(7 + n)
+        x = np.maximum(rng.standard_normal((B, n * n, C)), 0).astype(np.float32)          # post-ReLU activations
+        dy = (rng.standard_normal((B, n * n, C)) * 0.1).astype(np.float32)
+        direct = pkg.conv_wgrad(n, C, dy, x, 0)
+        wino = pkg.conv_wgrad(n, C, dy, x, 1)
+        assert np.linalg.norm(wino - direct) <= 1e-5 * np.linalg.norm(direct), (n, np.linalg.norm(wino - direct) / np.linalg.norm(direct))
+        # float64 reference of dW[co, ci, a, b] = sum_{board, y, x} dy[., y, x, co] * x[., y + a - 1, x + b - 1, ci] for 8 x 8 channel pairs
+        xs = np.zeros((B, n + 2, n + 2, 8), np.float64)
+        xs[:, 1:-1, 1:-1] = x.reshape(B, n, n, C)[..., 5:13]
+        dys = dy.reshape(B, n, n, C)[..., 100:108].astype(np.float64)
+        want = np.stack([np.stack([np.einsum("byxo,byxi->oi", dys, xs[:, a:a + n, b:b + n]) for b in range(3)], -1) for a in range(3)], -2)
+        for got in (direct, wino):
+            g = got[100:108, 5:13].astype(np.float64)
+            assert np.linalg.norm(g - want) <= 1e-5 * np.linalg.norm(want), n
+
+
+def test_trainer_fp32_paths_agree_on_a_step():
+    """a whole FP32 training step on the Winograd-domain kernels (C6_PREC_FP32) and on the direct kernels (C6_PREC_FP32_DIRECT): the same
+    loss to 1e-6; the gradients agree as far as ReLU allows -- the two forward passes round differently (~1e-6), a few ReLU inputs next
+    to zero fall on the other side, and the gradient is discontinuous there (tests/test_gpu_train.py explains the protocol): L2 5e-3."""
     need_gpu()
     import __graft_entry__ as ge
-    for n in (15, 19):
-        C, blocks, B = 256, 2, 300
-        rng = np.random.default_rng(7 + n)
-        blob = ge.make_random_blob(n, C, blocks, rng)
-        batch = (rng.integers(-1, 2, B).astype(np.float32), rng.choice([-1.0, 1.0], B).astype(np.float32),
-                 rng.integers(-1, 2, (B, n * n)).astype(np.float32), rng.integers(0, n * n, B).astype(np.float32))
-        res = {}
-        for name, prec in (("wino", pkg.PREC_FP32), ("direct", pkg.PREC_FP32_DIRECT)):
-            t = pkg.Trainer(n, C, blocks, B, lr=1e-3, momentum=0.9, precision=prec)
-            t.load_weights(blob)
-            res[name] = (float(t.step(*batch)), t.gradients())
-            t.close()
-        (la, ga), (lb, gb) = res["wino"], res["direct"]
-        assert abs(la - lb) <= 1e-6 * abs(lb)
-        assert np.linalg.norm(ga - gb) <= 1e-5 * np.linalg.norm(gb), (n, np.linalg.norm(ga - gb) / np.linalg.norm(gb))
+    n, C, blocks, B = 15, 256, 2, 300
+    rng = np.random.default_rng(22)
+    blob = ge.make_random_blob(n, C, blocks, rng)
+    batch = (rng.integers(-1, 2, B).astype(np.float32), rng.choice([-1.0, 1.0], B).astype(np.float32),
+             rng.integers(-1, 2, (B, n * n)).astype(np.float32), rng.integers(0, n * n, B).astype(np.float32))
+    res = []
+    for prec in (pkg.PREC_FP32, pkg.PREC_FP32_DIRECT):
+        t = pkg.Trainer(n, C, blocks, B, lr=1e-3, momentum=0.9, precision=prec)
+        t.load_weights(blob)
+        res.append((float(t.step(*batch)), t.gradients()))
+        t.close()
+    (la, ga), (lb, gb) = res
+    assert abs(la - lb) <= 1e-6 * abs(lb)
+    assert np.linalg.norm(ga - gb) <= 5e-3 * np.linalg.norm(gb), np.linalg.norm(ga - gb) / np.linalg.norm(gb)
 
 
 def test_trainer_default_precision_is_the_engines():
