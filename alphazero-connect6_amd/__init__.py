@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C6_LIB_PATH") or os.path.join(_HERE, "libconnect6_amd.so")   # override: A/B builds (tools/)
 
 BLACK, NONE, WHITE = -1, 0, 1
-EVAL_RANDOM, EVAL_UNIFORM, EVAL_NET, EVAL_CALLBACK = 1, 2, 3, 4
+EVAL_RANDOM, EVAL_UNIFORM, EVAL_NET, EVAL_CALLBACK, EVAL_STRESS = 1, 2, 3, 4, 5
 OK, ERR_NO_GPU, ERR_BAD_ARG, ERR_OVERFLOW, ERR_HIP, ERR_INVALID_POSITION, ERR_ALREADY_SET = range(7)
 # arithmetic of the 3x3 convolutions (include/connect6_amd.h C6_PREC_*).  DEFAULT = FP32: f32 like the reference net, evaluated as
 # Winograd F(4x4,3x3) (256 channels) / F(2x2,3x3) (64, 128) on the FP32 matrix cores; FP32_DIRECT: the same arithmetic as a direct implicit GEMM
@@ -45,7 +45,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
-                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_conv_wgrad_op", "c6_engine_apply_moves", "c6_engine_last_moves",
+                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_conv_wgrad_op", "c6_engine_boards", "c6_engine_apply_moves", "c6_engine_last_moves",
                   "c6_rollout_create", "c6_rollout_destroy", "c6_rollout_reset", "c6_rollout_next", "c6_rollout_slot_info",
                   "c6_rollout_node", "c6_rollout_bench_playouts"]
 
@@ -60,14 +60,16 @@ class Config(C.Structure):
                 ("game_uid_base", C.c_uint32), ("game_uid_stride", C.c_uint32), ("evaluator", C.c_int),
                 ("net_channels", C.c_int), ("net_blocks", C.c_int), ("records_per_game", C.c_int), ("recycle", C.c_int),
                 ("stagger", C.c_int), ("device", C.c_int), ("net_chunk_boards", C.c_int), ("net_precision", C.c_int),
-                ("max_records_per_game", C.c_int)]
+                ("max_records_per_game", C.c_int), ("stress_every", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rounds", C.c_uint64), ("simulations", C.c_uint64), ("select_steps", C.c_uint64), ("stones", C.c_uint64),
                 ("games_finished", C.c_uint64), ("tuples", C.c_uint64), ("live_games", C.c_uint32),
                 ("overflow_games", C.c_uint32), ("max_records_used", C.c_uint32), ("max_depth", C.c_uint32),
-                ("abandoned_games", C.c_uint64), ("records_per_game", C.c_uint32), ("pool_grows", C.c_uint32)]
+                ("abandoned_games", C.c_uint64), ("records_per_game", C.c_uint32), ("pool_grows", C.c_uint32),
+                ("pool_pages", C.c_uint32), ("pool_pages_free", C.c_uint32), ("pool_pages_low", C.c_uint32), ("cap_raises", C.c_uint32),
+                ("parked_games", C.c_uint32), ("max_pages_held", C.c_uint32), ("pool_bytes", C.c_uint64)]
 
 
 class RootInfo(C.Structure):
@@ -147,6 +149,7 @@ def lib():
     L.c6_engine_apply_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_last_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.c6_engine_boards.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
     L.c6_rollout_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
     L.c6_rollout_destroy.argtypes = [C.c_void_p]
     L.c6_rollout_reset.argtypes = [C.c_void_p, u8p]
@@ -378,7 +381,7 @@ class Engine:
     def __init__(self, board_size=15, num_games=1, num_simulation=800, epsilon=0.25, dirichlet_alpha=0.03, c_puct=1.0,
                  seed=0, evaluator=EVAL_RANDOM, net_channels=256, net_blocks=10, records_per_game=0, recycle=False,
                  stagger=False, device=0, game_uid_base=0, game_uid_stride=0, net_chunk_boards=0, net_precision=PREC_DEFAULT,
-                 max_records_per_game=0):
+                 max_records_per_game=0, stress_every=0):
         L = lib()
         cfg = Config()
         L.c6_default_config(C.byref(cfg))
@@ -389,6 +392,7 @@ class Engine:
         cfg.game_uid_base, cfg.game_uid_stride, cfg.net_chunk_boards = game_uid_base, game_uid_stride, net_chunk_boards
         cfg.net_precision = net_precision
         cfg.max_records_per_game = max_records_per_game
+        cfg.stress_every = stress_every
         self.cfg = cfg
         self.n, self.cells, self.G = board_size, board_size * board_size, num_games
         self.h = C.c_void_p()
@@ -431,8 +435,8 @@ class Engine:
         _chk(lib().c6_engine_sync(self.h))
 
     def maintain(self):
-        """synchronise and double the per-game record pools if a game is waiting for space or they pass 3/4 (c6_engine_run does
-        this by itself; callers of step() call it now and then)"""
+        """synchronise; raise the per-game caps / map more memory into the shared record pool if games are waiting for it or it is
+        running low (c6_engine_run does this by itself; callers of step() call it now and then)"""
         _chk(lib().c6_engine_maintain(self.h))
 
     def last_moves(self):
@@ -447,6 +451,14 @@ class Engine:
         if p.size != self.G:
             raise C6Error("apply_moves needs one entry per game")
         _chk(lib().c6_engine_apply_moves(self.h, _p(p, C.c_int32)))
+
+    def boards(self):
+        """K1's canonical state: (boards int8 [G, N*N], turn [G], remain [G])"""
+        b = np.zeros((self.G, self.cells), np.int8)
+        t = np.zeros(self.G, np.int8)
+        r = np.zeros(self.G, np.int8)
+        _chk(lib().c6_engine_boards(self.h, _p(b, C.c_int8), _p(t, C.c_int8), _p(r, C.c_int8)))
+        return b, t, r
 
     def stats(self):
         s = Stats()
@@ -919,6 +931,20 @@ def conv_pack_m8(channels, w_oihw):
     out = np.zeros(nbytes, np.uint8)
     _chk(lib().c6_conv_pack_m8(channels, _p(w, C.c_float), _p(out, C.c_uint8), nbytes))
     return out
+
+
+def stress_eval(n, player, boards):
+    """C6_EVAL_STRESS's peaked evaluator on the host, bit for bit (include/connect6_amd.h): boards [len, N*N] -> (values, priors)"""
+    b = np.asarray(boards).reshape(-1, n * n)
+    rr, cc = np.divmod(np.arange(n * n), n)
+    d2 = (rr - n // 2) ** 2 + (cc - n // 2) ** 2
+    pol = np.zeros(b.shape, np.float32)
+    for i in range(b.shape[0]):
+        empty = b[i] == 0
+        if empty.any():
+            k = np.minimum(d2 - d2[empty].min(), 6)
+            pol[i] = np.where(empty, np.ldexp(np.float32(1.0), (-20 * k).astype(np.int32)), np.float32(0.0))
+    return np.full(b.shape[0], -0.875 * player, np.float32), pol
 
 
 def conv_wgrad(n, channels, dy, x, method):

@@ -5,10 +5,11 @@
 // game/player/mod.rs:8-12) that the board kernel K1 reads with lane == game.  The tree
 // kernels run one wave per game and keep, per game:
 //   * an AoS copy of the root position (root_board, root_key, root_sig),
-//   * a pool of R "expanded node" records (edge-major: prior[N*N] per record) and an
-//     open-addressed table  board key -> record  (64-bit Zobrist), which together
-//     reproduce the reference's HashMap<u64, Node> (alphazero_policy/mod.rs:186-190)
-//     without materialising the N*N children of every expansion,
+//   * "expanded node" records (edge-major: prior[N*N] per record) in PAGES of 64 taken from one pool shared by all games
+//     (page table per game; pages are acquired and handed back at move boundaries) and an open-addressed table
+//     board key -> record  (64-bit Zobrist) in CHUNKS of 1024 slots from a second pool, which together reproduce the
+//     reference's HashMap<u64, Node> (alphazero_policy/mod.rs:186-190): it grows per game, without a bound other than
+//     memory, and a game's share is proportional to its tree,
 //   * one tag byte per table slot (the wave holds the whole row in LDS: an absent child costs no memory access) and the
 //     root's children as one contiguous row (rootc).
 #pragma once
@@ -34,10 +35,27 @@ struct C6RootChild {
     float q;
 };
 
-#define C6_MAXD0 64       // initial capacity of the select path kept per search (C6Dev::maxd; grown with the record pool)
+// ---- paged storage of the trees ---------------------------------------------------------------------------------------------
+// Records live in pages of C6_PAGE_RECS: record r of a game is slot r & 63 of pool page page_table[game][r >> 6]; a game's logical
+// page slots are stable (a record's index never changes), slots whose page was handed back hold C6_NOPAGE.  The table of a game has
+// hslots = C6_CHUNK_SLOTS * 2^k slots: slot s is entry s & 1023 of pool chunk chunk_table[game][s >> 10].  Both pools keep their
+// free ids in a ring (tickets head / tail); ids pushed during a kernel become poppable when the NEXT kernel starts (limit = tail is
+// taken by c6_pool_snapshot_kernel between launches): a page changes hands across a kernel boundary only, where the caches of all
+// XCDs are written back and invalidated -- never between two waves of one launch.
+#define C6_PAGE_SHIFT 6
+#define C6_PAGE_RECS 64
+#define C6_CHUNK_SHIFT 10
+#define C6_CHUNK_SLOTS 1024
+#define C6_NOPAGE 0xFFFFFFFFu
+#define C6_MAX_RECORDS 65000      // per game: record indices travel as 16 bits (idx + 1)
+enum { C6_POOL_PAGE_HEAD = 0, C6_POOL_PAGE_TAIL, C6_POOL_PAGE_LIMIT, C6_POOL_CHUNK_HEAD, C6_POOL_CHUNK_TAIL, C6_POOL_CHUNK_LIMIT,
+       C6_POOL_PAGE_LOW, C6_POOL_N };      // PAGE_LOW: fewest free pages seen by a popper (statistics)
+enum { C6_PARK_NONE = 0, C6_PARK_POOL = 1, C6_PARK_CAPS = 2 };
 
-// C6_ST_OVERFLOW: the game ran out of records (or of select-path slots) BEFORE anything of the current search was written:
-// once the host has grown the pool (engine.cpp: grow_pool) the game continues exactly where it stopped.
+// C6_ST_OVERFLOW: the game is PARKED at a move boundary -- after a move / a reset it could not be given the records (>= S free ones)
+// or the table (>= 2 x (live records + S) slots) its next move may need: the pool had no free page (hdr.park = C6_PARK_POOL; other
+// games hand pages back all the time, and the host can map more memory) or the game is at the per-game caps (C6_PARK_CAPS; the host
+// raises them).  Nothing of a search is ever interrupted: the head of every round retries, and the game plays on as if nothing had been.
 // C6_ST_ERROR: NaN scores (the reference panics, mod.rs:287) or an illegal stone from outside (Game::set Err).
 enum { C6_ST_PLAYING = 0, C6_ST_FINISHED = 1, C6_ST_ERROR = 2, C6_ST_OVERFLOW = 3 };
 enum { C6_LEAF_NONE = 0, C6_LEAF_EVAL = 1, C6_LEAF_TERMINAL = 2 };
@@ -53,11 +71,14 @@ struct C6GameHdr {
     int32_t root_rec;                 //   8  record of the root, -1 = not expanded
     uint32_t game_uid;                //  12  C6RNG key of the game
     uint32_t rootc_ok;                //  16  the rootc row holds the current root's children
-    uint32_t pad2[3];
+    uint16_t npages;                  //  20  logical page slots in use (high-water mark; slots handed back hold C6_NOPAGE)
+    uint16_t alloc_page;              //  22  logical page the next record comes from: has a free record whenever free_top > 0
+    uint32_t hslots;                  //  24  slots of the game's table: C6_CHUNK_SLOTS * a power of two
+    uint32_t park;                    //  28  C6_PARK_*: why the game is in C6_ST_OVERFLOW
     uint32_t nsearch;                 //  32  searches since the game's start
     int32_t sim_in_move;              //  36
-    int32_t free_top;                 //  40  free records left
-    int32_t rec_hi;                   //  44  1 + highest record index handed out since the game's reset
+    int32_t free_top;                 //  40  free records in the game's pages
+    int32_t live_pages;               //  44  pages the game holds (statistics)
     int16_t nstones;                  //  48
     int8_t status;                    //  50  C6_ST_*
     int8_t leaf_kind;                 //  51  C6_LEAF_*
@@ -86,7 +107,13 @@ static_assert(sizeof(C6RecStat) == 32, "one sector per record");
 
 struct C6Dev {
     // geometry / hyper-parameters (policy/alphazero_policy/mod.rs:91-96)
-    int N, cells, cellsP, G, Gpad, S, R, H, maxd;
+    int N, cells, cellsP, G, Gpad, S, maxd;
+    // paged storage: absolute per-game limits (array widths), the caps games may grow to without the host (they size the LDS copies
+    // of a game's page table / chunk list / tag row and are raised by c6_engine_maintain), and the pools' sizes
+    int maxpages, maxchunks, pages_cap, hcap;
+    unsigned int pages_total, chunks_total, page_ring_mask, chunk_ring_mask;
+    int stress_every;        // C6_EVAL_STRESS: games with uid % stress_every == 0 get the peaked evaluator
+    int abandon_parked;      // steady-state mode: a parked game whose request cannot be met is abandoned (counted) -- set once growth has failed
     float eps, cpuct;
     double alpha, gam_d, gam_c;
     uint32_t seed_lo, seed_hi, uid_base, uid_stride;
@@ -101,15 +128,19 @@ struct C6Dev {
     uint16_t *moves;       // [G][cells] cell of stone k
     uint16_t *hist_pi;     // [G][cells][cells] root child visits at move k
     // expanded-node records
-    C6RecStat *rec_stat;   // [G][R]
-    float *rec_prior;      // [G][R][cells]  n_prob of the child at each empty cell
-    C6HtEntry *ht;         // [G][H]
-    uint8_t *ht_tag;       // [G][H] c6_ht_tag_of(key) of the slot's entry, 0 = empty
+    C6RecStat *rec_stat;   // [pages][64]
+    float *rec_prior;      // [pages][64][cells]  n_prob of the child at each empty cell
+    unsigned long long *page_free;   // [pages] bit i: record i of the page is free
+    uint32_t *page_table;  // [G][maxpages] logical page -> pool page (C6_NOPAGE: none)
+    C6HtEntry *ht;         // [chunks][1024]
+    uint8_t *ht_tag;       // [chunks][1024] c6_ht_tag_of(key) of the slot's entry, 0 = empty
+    uint32_t *chunk_table; // [G][maxchunks] logical chunk -> pool chunk
+    uint32_t *page_ring, *chunk_ring;      // free ids
+    unsigned long long *pool_ctr;          // [C6_POOL_N]
     C6RootChild *rootc;    // [G][cellsP] the root's children (valid while hdr.rootc_ok)
-    uint16_t *free_stack;  // [G][R]
     // per-round leaf exchange
     int8_t *leaf_board;    // [G][cellsP]
-    uint32_t *path_rec;    // [G][maxd] step i of the select path: record | chosen cell << 16
+    uint32_t *path_rec;    // [G][maxd] step i of the select path: record | chosen cell << 16 (maxd = cellsP: a path adds a stone per step)
     float *eval_prior;     // [G][cells]
     float *img_val;        // [G][8]
     float *img_pol;        // [G][8][cells]
@@ -142,9 +173,11 @@ void c6_launch_recover(const C6Dev &d, hipStream_t s);
 void c6_launch_augment(const C6Dev &d, float *img_boards, hipStream_t s);
 void c6_launch_post_move(const C6Dev &d, hipStream_t s);
 void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s);
-// record-pool growth (engine.cpp grow_pool): `nw` has the new R / H and freshly allocated, zeroed arrays whose [G][R] prefix was
-// copied from `old`; this fills the tails, rebuilds free stacks and tables and re-opens the games that stopped for space
-void c6_launch_grow_fix(const C6Dev &old, const C6Dev &nw, hipStream_t s);
+// limit = tail of both pools' rings: launched in front of every kernel that may acquire pages (ids handed back by earlier launches
+// become available)
+void c6_launch_pool_snapshot(const C6Dev &d, hipStream_t s);
+// dynamic LDS of the kernels that keep a game's tag row / chunk list / page table per wave
+size_t c6_tree_lds_bytes(const C6Dev &d);
 // games in an error state -> the finished queue as they stand (winner 0, the stones played so far), agent_impl/mod.rs:163
 void c6_launch_flush_errors(const C6Dev &d, hipStream_t s);
 void c6_launch_noise_op(int N, int num, double alpha, double gd, double gc, const uint32_t *k0, const uint32_t *k1,

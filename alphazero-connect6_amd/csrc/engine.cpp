@@ -139,6 +139,79 @@ struct DevPool {
         if (rc_ != C6_OK) return rc_;                   \
     } while (0)
 
+// A device array whose physical memory is mapped piece by piece behind one address (HIP virtual memory management): the record and
+// table pools grow without a copy and without a second allocation living beside the first.  Without VMM support the array is one
+// hipMalloc of its initial size and cannot grow.
+struct VmRange {
+    char *base = nullptr;
+    size_t reserved = 0, mapped = 0, gran = 0;
+    bool vmm = false;
+    int device = 0;
+    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> parts;      // handle, bytes
+    static bool supported(int device) {
+        int v = 0;
+        return hipDeviceGetAttribute(&v, hipDeviceAttributeVirtualMemoryManagementSupported, device) == hipSuccess && v != 0;
+    }
+    hipMemAllocationProp prop() const {
+        hipMemAllocationProp p = {};
+        p.type = hipMemAllocationTypePinned;
+        p.location.type = hipMemLocationTypeDevice;
+        p.location.id = device;
+        return p;
+    }
+    int reserve(size_t max_bytes, int dev, bool use_vmm) {
+        device = dev;
+        vmm = use_vmm;
+        if (!vmm) { reserved = max_bytes; return C6_OK; }
+        const hipMemAllocationProp p = prop();
+        if (hipMemGetAllocationGranularity(&gran, &p, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) gran = (size_t)2 << 20;
+        reserved = (max_bytes + gran - 1) / gran * gran;
+        void *b = nullptr;
+        hipError_t e = hipMemAddressReserve(&b, reserved, 0, nullptr, 0);
+        if (e != hipSuccess) return fail(C6_ERR_HIP, std::string("hipMemAddressReserve: ") + hipGetErrorString(e));
+        base = reinterpret_cast<char *>(b);
+        return C6_OK;
+    }
+    // physical memory behind [0, bytes): bytes must be a multiple of gran (VMM) -- or the one and only allocation (no VMM)
+    int map_to(size_t bytes) {
+        if (bytes <= mapped) return C6_OK;
+        if (!vmm) {
+            if (base) return fail(C6_ERR_OVERFLOW, "this device has no virtual memory management: the pools cannot grow");
+            void *b = nullptr;
+            hipError_t e = hipMalloc(&b, bytes);
+            if (e != hipSuccess) return fail(C6_ERR_HIP, std::string("hipMalloc (pool): ") + hipGetErrorString(e));
+            base = reinterpret_cast<char *>(b);
+            mapped = bytes;
+            return C6_OK;
+        }
+        if (bytes > reserved) return fail(C6_ERR_OVERFLOW, "pool beyond its reserved address range");
+        const size_t add = bytes - mapped;
+        const hipMemAllocationProp p = prop();
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, add, &p, 0);
+        if (e != hipSuccess) return fail(C6_ERR_OVERFLOW, std::string("hipMemCreate: ") + hipGetErrorString(e));
+        e = hipMemMap(base + mapped, add, 0, h, 0);
+        if (e != hipSuccess) { hipMemRelease(h); return fail(C6_ERR_HIP, std::string("hipMemMap: ") + hipGetErrorString(e)); }
+        hipMemAccessDesc acc = {};
+        acc.location = p.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(base + mapped, add, &acc, 1);
+        if (e != hipSuccess) { hipMemUnmap(base + mapped, add); hipMemRelease(h); return fail(C6_ERR_HIP, std::string("hipMemSetAccess: ") + hipGetErrorString(e)); }
+        parts.emplace_back(h, add);
+        mapped = bytes;
+        return C6_OK;
+    }
+    void release() {
+        if (!base) return;
+        if (!vmm) { hipFree(base); base = nullptr; return; }
+        size_t off = 0;
+        for (auto &pr : parts) { hipMemUnmap(base + off, pr.second); hipMemRelease(pr.first); off += pr.second; }
+        parts.clear();
+        hipMemAddressFree(base, reserved);
+        base = nullptr;
+    }
+};
+
 // ---- self-describing weight blobs -------------------------------------------------------------------
 // header = 8 floats in front of the payload: magic "C6WB" (bit pattern), layout version, N, C, num_block, payload floats (as two
 // 24-bit halves) and a checksum of the payload (FNV-1a of the u32 bit patterns folded to 24 bits, exactly representable)
@@ -439,9 +512,14 @@ struct c6_engine {
     uint64_t rounds = 0;
     int round_in_move = 0;
     unsigned long long fetched = 0;   // finished games already handed to the caller
-    bool desync = false;              // a game resumed after a pool growth: it is out of step with the aligned move rounds,
-                                      // so the move phase runs every round from then on (it only acts on games at S simulations)
-    uint32_t pool_grows = 0;
+    // the pools of record pages and table chunks (c6_engine.h): four arrays that grow by mapping more memory behind them
+    VmRange vm_prior, vm_stat, vm_ht, vm_tag;
+    size_t pages_max = 0, chunks_max = 0;      // what the rings / page_free / the address ranges are sized for
+    size_t page_quantum = 1, chunk_quantum = 1; // growth steps keep every array's mapped size a multiple of the mapping granularity
+    int hmax = 0;                              // absolute per-game table size
+    int pages_per_game0 = 0;
+    uint32_t pool_grows = 0;                   // times memory was added to the pools
+    uint32_t cap_raises = 0;                   // times the per-game caps were raised
     bool grow_failed = false;
 };
 
@@ -463,6 +541,52 @@ extern "C" size_t c6_tuple_stride(int n) {
     return (cells + (cells & 1) + 2 * cells + 2 + 2 + 3) & ~(size_t)3;   // state | pad | pi u16 | pos u16 | turn | z
 }
 
+static size_t gcd_sz(size_t a, size_t b) { while (b) { const size_t t = a % b; a = b; b = t; } return a; }
+static size_t lcm_sz(size_t a, size_t b) { return a / gcd_sz(a, b) * b; }
+static int pow2_at_least(long v, int lo) { int h = lo; while (h < v) h <<= 1; return h; }
+
+// pools up to `pages` record pages and `chunks` table chunks mapped (both multiples of their quanta or the final size); new pages'
+// records are marked free (level -1 = 0xffff: a byte fill), new ids go onto the rings.  Stream idle.
+static int pools_map(c6_engine *e, size_t pages, size_t chunks) {
+    C6Dev &d = e->d;
+    const size_t cells = d.cells, old_p = d.pages_total, old_c = d.chunks_total;
+    int rc;
+    if (pages > old_p) {
+        if ((rc = e->vm_prior.map_to(pages * C6_PAGE_RECS * cells * 4)) || (rc = e->vm_stat.map_to(pages * C6_PAGE_RECS * sizeof(C6RecStat)))) return rc;
+        d.rec_prior = reinterpret_cast<float *>(e->vm_prior.base);
+        d.rec_stat = reinterpret_cast<C6RecStat *>(e->vm_stat.base);
+        HIPCHK(hipMemset(d.rec_stat + old_p * C6_PAGE_RECS, 0xff, (pages - old_p) * C6_PAGE_RECS * sizeof(C6RecStat)));
+    }
+    if (chunks > old_c) {
+        if ((rc = e->vm_ht.map_to(chunks * C6_CHUNK_SLOTS * sizeof(C6HtEntry))) || (rc = e->vm_tag.map_to(chunks * C6_CHUNK_SLOTS))) return rc;
+        d.ht = reinterpret_cast<C6HtEntry *>(e->vm_ht.base);
+        d.ht_tag = reinterpret_cast<uint8_t *>(e->vm_tag.base);
+    }
+    unsigned long long ctr[C6_POOL_N];
+    HIPCHK(hipMemcpy(ctr, d.pool_ctr, sizeof ctr, hipMemcpyDeviceToHost));
+    auto push = [&](uint32_t *ring, uint32_t mask, unsigned long long &tail, size_t from, size_t to) -> int {
+        std::vector<uint32_t> ids(to - from);
+        for (size_t i = 0; i < ids.size(); i++) ids[i] = (uint32_t)(from + i);
+        size_t done = 0;
+        while (done < ids.size()) {      // the ring wraps
+            const size_t at = (size_t)(tail & mask), n = std::min(ids.size() - done, (size_t)mask + 1 - at);
+            HIPCHK(hipMemcpy(ring + at, ids.data() + done, n * 4, hipMemcpyHostToDevice));
+            done += n;
+            tail += n;
+        }
+        return C6_OK;
+    };
+    if (pages > old_p && (rc = push(d.page_ring, d.page_ring_mask, ctr[C6_POOL_PAGE_TAIL], old_p, pages))) return rc;
+    if (chunks > old_c && (rc = push(d.chunk_ring, d.chunk_ring_mask, ctr[C6_POOL_CHUNK_TAIL], old_c, chunks))) return rc;
+    ctr[C6_POOL_PAGE_LIMIT] = ctr[C6_POOL_PAGE_TAIL];
+    ctr[C6_POOL_CHUNK_LIMIT] = ctr[C6_POOL_CHUNK_TAIL];
+    if (old_p == 0) ctr[C6_POOL_PAGE_LOW] = pages;
+    HIPCHK(hipMemcpy(d.pool_ctr, ctr, sizeof ctr, hipMemcpyHostToDevice));
+    d.pages_total = (unsigned)pages;
+    d.chunks_total = (unsigned)chunks;
+    return C6_OK;
+}
+
 static int engine_alloc(c6_engine *e) {
     const c6_config &c = e->cfg;
     C6Dev &d = e->d;
@@ -470,12 +594,7 @@ static int engine_alloc(c6_engine *e) {
     const int N = c.board_size, cells = N * N, G = c.num_games;
     d.N = N; d.cells = cells; d.cellsP = (cells + 15) & ~15; d.G = G; d.Gpad = (G + 3) & ~3;
     d.S = c.num_simulation;
-    d.R = c.records_per_game > 0 ? c.records_per_game : 4 * c.num_simulation + 64;
-    if (d.R > 65000) return fail(C6_ERR_BAD_ARG, "records_per_game too large (max 65000)");
-    d.maxd = C6_MAXD0;
-    int H = 64;
-    while (H < 2 * d.R) H <<= 1;
-    d.H = H;
+    d.maxd = d.cellsP;      // a select path adds a stone per step
     d.eps = c.epsilon; d.cpuct = c.c_puct; d.alpha = c.dirichlet_alpha;
     d.gam_d = (c.dirichlet_alpha + 1.0) - 1.0 / 3.0;       // Marsaglia-Tsang constants at shape alpha + 1
     d.gam_c = 1.0 / std::sqrt(9.0 * d.gam_d);
@@ -483,15 +602,64 @@ static int engine_alloc(c6_engine *e) {
     d.uid_base = c.game_uid_base;
     d.uid_stride = c.game_uid_stride ? c.game_uid_stride : (uint32_t)G;
     d.recycle = c.recycle;
+    d.stress_every = c.stress_every > 0 ? c.stress_every : 1;
+
+    // ---- the pools (c6_engine.h).  records_per_game is the AVERAGE the pool is sized for at creation (whole pages, and never less
+    // than one move's searches + a page); a single game may hold up to max_records_per_game; the pool grows by mapping more memory.
+    const int R0 = c.records_per_game > 0 ? c.records_per_game : 4 * c.num_simulation + 64;
+    if (R0 > C6_MAX_RECORDS) return fail(C6_ERR_BAD_ARG, "records_per_game too large (max 65000)");
+    const int move_pages = (d.S + C6_PAGE_RECS - 1) / C6_PAGE_RECS + 1;
+    if (move_pages * C6_PAGE_RECS > C6_MAX_RECORDS) return fail(C6_ERR_BAD_ARG, "num_simulation too large for 16-bit record indices");
+    e->pages_per_game0 = std::max((R0 + C6_PAGE_RECS - 1) / C6_PAGE_RECS, move_pages);
+    int maxR = c.max_records_per_game > 0 ? std::min(C6_MAX_RECORDS, c.max_records_per_game) : C6_MAX_RECORDS;
+    d.maxpages = std::max((maxR + C6_PAGE_RECS - 1) / C6_PAGE_RECS, move_pages);
+    e->hmax = pow2_at_least(2L * ((long)d.maxpages * C6_PAGE_RECS + d.S), C6_CHUNK_SLOTS);
+    d.maxchunks = e->hmax >> C6_CHUNK_SHIFT;
+    d.pages_cap = std::min(d.maxpages, 2 * e->pages_per_game0);
+    d.hcap = std::min(e->hmax, pow2_at_least(2L * ((long)d.pages_cap * C6_PAGE_RECS + d.S), C6_CHUNK_SLOTS));
+    d.abandon_parked = 0;
+    const size_t page_bytes = (size_t)C6_PAGE_RECS * ((size_t)cells * 4 + sizeof(C6RecStat)), chunk_bytes = (size_t)C6_CHUNK_SLOTS * (sizeof(C6HtEntry) + 1);
+    const size_t pages0 = (size_t)G * e->pages_per_game0;
+    const size_t chunks0 = (size_t)G * std::max<size_t>(pow2_at_least(2L * R0, C6_CHUNK_SLOTS) >> C6_CHUNK_SHIFT, pow2_at_least(2L * d.S, C6_CHUNK_SLOTS) >> C6_CHUNK_SHIFT);
+    size_t fr = 0, tot = 0;
+    hipMemGetInfo(&fr, &tot);
+    const bool vmm = VmRange::supported(c.device);
+    e->pages_max = vmm ? std::max(pages0, std::min((size_t)G * d.maxpages, (size_t)(0.9 * (double)tot / (double)page_bytes))) : pages0;
+    e->chunks_max = vmm ? std::max(chunks0, std::min((size_t)G * d.maxchunks, e->pages_max / 4 + chunks0)) : chunks0;      // a table slot costs 17 B, a record >= 356
+    if (e->pages_max > 0xfffffff0ull || e->chunks_max > 0xfffffff0ull) return fail(C6_ERR_BAD_ARG, "pool too large");
+    int rc;
+    if ((rc = e->vm_prior.reserve(e->pages_max * C6_PAGE_RECS * cells * 4, c.device, vmm)) || (rc = e->vm_stat.reserve(e->pages_max * C6_PAGE_RECS * sizeof(C6RecStat), c.device, vmm)) ||
+        (rc = e->vm_ht.reserve(e->chunks_max * C6_CHUNK_SLOTS * sizeof(C6HtEntry), c.device, vmm)) || (rc = e->vm_tag.reserve(e->chunks_max * C6_CHUNK_SLOTS, c.device, vmm)))
+        return rc;
+    if (vmm) {      // quanta: every array's mapped size stays a multiple of the granularity
+        const size_t g1 = e->vm_prior.gran;
+        e->page_quantum = lcm_sz(g1 / gcd_sz(g1, (size_t)C6_PAGE_RECS * cells * 4), g1 / gcd_sz(g1, (size_t)C6_PAGE_RECS * sizeof(C6RecStat)));
+        e->chunk_quantum = lcm_sz(g1 / gcd_sz(g1, (size_t)C6_CHUNK_SLOTS * sizeof(C6HtEntry)), g1 / gcd_sz(g1, (size_t)C6_CHUNK_SLOTS));
+        e->pages_max = e->pages_max / e->page_quantum * e->page_quantum;
+        e->chunks_max = e->chunks_max / e->chunk_quantum * e->chunk_quantum;
+    }
+    auto round_up = [](size_t v, size_t q) { return (v + q - 1) / q * q; };
+    const size_t pages_init = std::max(round_up(pages0, e->page_quantum), e->page_quantum), chunks_init = std::max(round_up(chunks0, e->chunk_quantum), e->chunk_quantum);
+    e->pages_max = std::max(e->pages_max, pages_init);
+    e->chunks_max = std::max(e->chunks_max, chunks_init);
+    if (vmm && (e->pages_max * C6_PAGE_RECS * cells * 4 > e->vm_prior.reserved || e->chunks_max * C6_CHUNK_SLOTS * sizeof(C6HtEntry) > e->vm_ht.reserved))
+        return fail(C6_ERR_BAD_ARG, "pool sizing error");
+    d.page_ring_mask = (unsigned)pow2_at_least((long)e->pages_max, 64) - 1u;
+    d.chunk_ring_mask = (unsigned)pow2_at_least((long)e->chunks_max, 64) - 1u;
+    ALLOC(d.page_free, e->pages_max);
+    ALLOC(d.page_ring, (size_t)d.page_ring_mask + 1); ALLOC(d.chunk_ring, (size_t)d.chunk_ring_mask + 1);
+    ALLOC(d.pool_ctr, C6_POOL_N);
+    ALLOC(d.page_table, (size_t)G * d.maxpages); ALLOC(d.chunk_table, (size_t)G * d.maxchunks);
+    HIPCHK(hipMemset(d.page_table, 0xff, (size_t)G * d.maxpages * 4));      // C6_NOPAGE
+    d.pages_total = d.chunks_total = 0;
+    if ((rc = pools_map(e, pages_init, chunks_init))) return rc;
 
     ALLOC(d.board_soa, (size_t)cells * d.Gpad);
     ALLOC(d.turn, d.Gpad); ALLOC(d.remain, d.Gpad); ALLOC(d.winner, d.Gpad); ALLOC(d.err, d.Gpad);
     ALLOC(d.hdr, G);
     ALLOC(d.root_board, (size_t)G * d.cellsP);
     ALLOC(d.moves, (size_t)G * cells); ALLOC(d.hist_pi, (size_t)G * cells * cells);
-    const size_t GR = (size_t)G * d.R;
-    ALLOC(d.rec_stat, GR); ALLOC(d.rec_prior, GR * cells);
-    ALLOC(d.ht, (size_t)G * d.H); ALLOC(d.ht_tag, (size_t)G * d.H); ALLOC(d.rootc, (size_t)G * d.cellsP); ALLOC(d.free_stack, GR);
+    ALLOC(d.rootc, (size_t)G * d.cellsP);
     ALLOC(d.leaf_board, (size_t)G * d.cellsP); ALLOC(d.path_rec, (size_t)G * d.maxd);
     ALLOC(d.eval_prior, (size_t)G * cells);
     ALLOC(d.move_pos, d.Gpad); ALLOC(d.last_move, d.Gpad); ALLOC(d.move_turn, G);
@@ -505,7 +673,6 @@ static int engine_alloc(c6_engine *e) {
     build_zobrist(zob);
     std::vector<int16_t> aug, rec;
     build_maps(N, aug, rec);
-    int rc;
     if ((rc = upload(pool, zob, &d.zob)) || (rc = upload(pool, aug, &d.aug_map)) || (rc = upload(pool, rec, &d.rec_map))) return rc;
 
     if (c.evaluator == C6_EVAL_NET || c.evaluator == C6_EVAL_CALLBACK) {
@@ -535,7 +702,7 @@ extern "C" int c6_engine_create(const c6_config *cfg, c6_engine **out) {
     const int N = cfg->board_size;
     if (N != 9 && N != 15 && N != 19) return fail(C6_ERR_BAD_ARG, "board_size must be 9, 15 or 19");
     if (cfg->num_games < 1 || cfg->num_simulation < 1) return fail(C6_ERR_BAD_ARG, "num_games and num_simulation must be >= 1");
-    if (cfg->evaluator < C6_EVAL_RANDOM || cfg->evaluator > C6_EVAL_CALLBACK) return fail(C6_ERR_BAD_ARG, "bad evaluator kind");
+    if (cfg->evaluator < C6_EVAL_RANDOM || cfg->evaluator > C6_EVAL_STRESS) return fail(C6_ERR_BAD_ARG, "bad evaluator kind");
     if (!(cfg->dirichlet_alpha > 0.0)) return fail(C6_ERR_BAD_ARG, "dirichlet_alpha must be > 0 (Dirichlet::new_with_param asserts it)");
     int rc = require_gpu(cfg->device);
     if (rc != C6_OK) return rc;
@@ -556,6 +723,7 @@ extern "C" void c6_engine_destroy(c6_engine *e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     e->t_select.destroy(); e->t_expand.destroy(); e->t_eval.destroy(); e->t_move.destroy();
     c6_timers_free(e->timers);
+    e->vm_prior.release(); e->vm_stat.release(); e->vm_ht.release(); e->vm_tag.release();
     e->pool.release();
     e->net.pool.release();
     if (e->stream) hipStreamDestroy(e->stream);
@@ -680,13 +848,13 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
     if (ev == C6_EVAL_NET && !e->net.loaded) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_NET but no weights are loaded");
     bool moved = false;
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d.last_move, (int)0xFFFFFFFE, (size_t)d.Gpad, e->stream));      // -2: "did not move in this call"
-    if (ev == C6_EVAL_RANDOM || ev == C6_EVAL_UNIFORM) {
+    if (ev == C6_EVAL_RANDOM || ev == C6_EVAL_UNIFORM || ev == C6_EVAL_STRESS) {
         // built-in evaluators: whole rounds -- search() and, when its budget is spent, the move itself -- inside one kernel, several
         // rounds of every game per launch (tree_kernels.hip: c6_search_kernel)
         for (int r = 0; r < rounds;) {
             const int k = std::min(rounds - r, C6_SEARCH_ROUNDS_PER_LAUNCH);
             Scoped t(&e->t_select, e->stream, e->profiling);
-            c6_launch_search(d, ev == C6_EVAL_RANDOM ? 1 : 2, k, e->stream);
+            c6_launch_search(d, ev == C6_EVAL_RANDOM ? 1 : ev == C6_EVAL_UNIFORM ? 2 : 3, k, e->stream);
             r += k;
             e->rounds += k;
         }
@@ -783,91 +951,69 @@ static int live_games(c6_engine *e, int *live, int *errors, int *overflow = null
     return range_status(e->net);      // every host-synchronising entry point passes through here
 }
 
-// ---- record-pool growth -------------------------------------------------------------------------------------------
-// The reference's HashMap<u64, Node> grows without limit (alphazero_policy/mod.rs:186-190, 360-377); the engine's per-game
-// pool of R expanded-node records is a device allocation.  When a game runs out (status C6_ST_OVERFLOW: it stopped BEFORE
-// writing anything of the search it could not finish) or the high-water mark passes 3/4 of R, the host doubles R (and the
-// select-path capacity): new arrays, every game's prefix copied with one strided copy per array, free stacks / tables
-// rebuilt on the device, stopped games re-opened.  Results are unchanged -- a record's index is never observable.
-template <typename T> static int grow_array(DevPool &pool, T **arr, int G, size_t old_row, size_t new_row, std::vector<void *> &fresh,
-                                            std::vector<void *> &stale) {
-    T *n = nullptr;
-    int rc = pool.alloc(&n, (size_t)G * new_row);
+// ---- the pools grow ------------------------------------------------------------------------------------------------------
+// The reference's HashMap<u64, Node> grows without limit (alphazero_policy/mod.rs:186-190, 360-377).  Here a game takes pages of
+// records and chunks of table slots from two pools at every move boundary, as many as its tree needs, and hands back what it no
+// longer uses (tree_kernels.hip: reprovision_wave) -- all on the device.  The host's part (c6_engine_maintain, and c6_engine_run
+// between its chunks of rounds):
+//   * a game at the per-game caps (which size the LDS copies of its page table / tag row) is parked with hdr.park = C6_PARK_CAPS:
+//     the caps are doubled, up to max_records_per_game;
+//   * a pool that runs low (or a game parked with C6_PARK_POOL) gets more memory MAPPED behind the same addresses (VmRange):
+//     nothing is copied, nothing is allocated twice, games in progress are not touched.
+// A parked game has lost nothing -- it waits at a move boundary and asks again at the head of every round.
+static int grow_pools(c6_engine *e, size_t need_pages) {
+    C6Dev &d = e->d;
+    if (d.pages_total >= e->pages_max || !e->vm_prior.vmm) return fail(C6_ERR_OVERFLOW, "record pool is at its maximum");
+    size_t add = std::max<size_t>(need_pages, d.pages_total / 4);
+    add = std::max(add, std::min<size_t>(e->pages_max, ((size_t)1 << 30) / ((size_t)C6_PAGE_RECS * d.cells * 4)));      // >= 1 GiB of priors a step
+    add = (add + e->page_quantum - 1) / e->page_quantum * e->page_quantum;
+    size_t pages = std::min(e->pages_max, d.pages_total + add);
+    size_t fr = 0, tot = 0;
+    hipMemGetInfo(&fr, &tot);
+    const size_t page_bytes = (size_t)C6_PAGE_RECS * ((size_t)d.cells * 4 + sizeof(C6RecStat)), chunk_bytes = (size_t)C6_CHUNK_SLOTS * (sizeof(C6HtEntry) + 1);
+    const size_t reserve = (size_t)1 << 30;      // left to the rest of the process
+    // chunks follow the pages in proportion
+    size_t chunks = std::min(e->chunks_max, (size_t)((double)pages / (double)d.pages_total * (double)d.chunks_total));
+    chunks = std::min(e->chunks_max, (chunks + e->chunk_quantum - 1) / e->chunk_quantum * e->chunk_quantum);
+    while (pages > d.pages_total && (pages - d.pages_total) * page_bytes + (chunks - d.chunks_total) * chunk_bytes + reserve > fr) {
+        pages = pages - d.pages_total > e->page_quantum ? d.pages_total + (pages - d.pages_total) / 2 / e->page_quantum * e->page_quantum : d.pages_total;
+        chunks = d.chunks_total;
+    }
+    if (pages <= d.pages_total) return fail(C6_ERR_OVERFLOW, "not enough device memory to grow the record pool");
+    int rc = pools_map(e, pages, chunks);
     if (rc != C6_OK) return rc;
-    fresh.push_back(n);
-    hipError_t he = hipMemcpy2D(n, new_row * sizeof(T), *arr, old_row * sizeof(T), old_row * sizeof(T), (size_t)G, hipMemcpyDeviceToDevice);
-    if (he != hipSuccess) return fail(C6_ERR_HIP, std::string("grow copy: ") + hipGetErrorString(he));
-    stale.push_back(*arr);
-    *arr = n;
-    return C6_OK;
-}
-
-static int grow_pool(c6_engine *e) {
-    C6Dev &d = e->d;
-    HIPCHK(hipStreamSynchronize(e->stream));
-    const int maxR = e->cfg.max_records_per_game > 0 ? std::min(65000, e->cfg.max_records_per_game) : 65000;
-    if (d.R >= maxR) { e->grow_failed = true; return fail(C6_ERR_OVERFLOW, "record pool is at its maximum (max_records_per_game / 65000 records per game)"); }
-    const C6Dev old = d;
-    C6Dev nw = d;
-    nw.R = std::min(maxR, 2 * d.R);
-    nw.maxd = std::min(8192, 2 * d.maxd);
-    int H = 64;
-    while (H < 2 * nw.R) H <<= 1;
-    nw.H = H;
-    const int G = d.G, cells = d.cells;
-    DevPool &pool = e->pool;
-    {   // old and new pools live side by side during the copy
-        size_t fr = 0, tot = 0;
-        hipMemGetInfo(&fr, &tot);
-        const size_t need = (size_t)G * nw.R * ((size_t)cells * 4 + 64) + (size_t)G * nw.H * sizeof(C6HtEntry);
-        if (need + ((size_t)256 << 20) > fr) { e->grow_failed = true; return fail(C6_ERR_OVERFLOW, "not enough device memory to grow the record pool"); }
-    }
-    std::vector<void *> fresh, stale;
-    uint16_t *nfs = nullptr;
-    C6HtEntry *nht = nullptr;
-    uint8_t *ntag = nullptr;
-    int rc;
-    if ((rc = grow_array(pool, &nw.rec_prior, G, (size_t)old.R * cells, (size_t)nw.R * cells, fresh, stale)) ||
-        (rc = grow_array(pool, &nw.rec_stat, G, old.R, nw.R, fresh, stale)) ||
-        (rc = grow_array(pool, &nw.path_rec, G, old.maxd, nw.maxd, fresh, stale)) ||
-        (rc = pool.alloc(&nfs, (size_t)G * nw.R)) || (rc = pool.alloc(&nht, (size_t)G * nw.H)) || (rc = pool.alloc(&ntag, (size_t)G * nw.H))) {
-        for (void *p : fresh) pool.free_one(p);      // the engine keeps running on the old, untouched pool
-        if (nfs) pool.free_one(nfs);
-        if (nht) pool.free_one(nht);
-        if (ntag) pool.free_one(ntag);
-        e->grow_failed = true;
-        return rc;
-    }
-    // free stack and table are rebuilt from the old ones by the device (c6_grow_fix_kernel)
-    nw.free_stack = nfs;
-    nw.ht = nht;
-    nw.ht_tag = ntag;
-    c6_launch_grow_fix(old, nw, e->stream);
-    HIPCHK(hipStreamSynchronize(e->stream));
-    for (void *p : stale) pool.free_one(p);
-    pool.free_one(old.free_stack);
-    pool.free_one(old.ht);
-    pool.free_one(old.ht_tag);
-    d = nw;
     e->pool_grows++;
-    if (!e->cfg.stagger) e->desync = true;
     return C6_OK;
 }
 
-// grow when a game has stopped for space or the pools are filling up; C6_OK also when there was nothing to do
-static int maintain(c6_engine *e, int overflowed) {
+// raise the caps / map more memory if games are waiting for it or the pool is running low; C6_OK also when there was nothing to do.
+// (live_games has just refreshed e->h_hdr; the stream is idle.)
+static int maintain(c6_engine *e) {
     C6Dev &d = e->d;
-    if (e->grow_failed) return C6_OK;
-    bool want = overflowed > 0;
-    if (!want) {
-        // (live_games has just refreshed e->h_hdr) the fullest pool NOW -- g_maxrec is only a high-water mark since the game's reset
-        int lo = d.R;
-        for (const C6GameHdr &h : e->h_hdr) if (h.status == C6_ST_PLAYING) lo = std::min(lo, (int)h.free_top);
-        want = (size_t)(d.R - lo) * 4 > (size_t)d.R * 3;
+    int parked_caps = 0, parked_pool = 0, near_cap = 0;
+    for (const C6GameHdr &h : e->h_hdr) {
+        if (h.status == C6_ST_OVERFLOW) { parked_caps += h.park == C6_PARK_CAPS; parked_pool += h.park != C6_PARK_CAPS; }
+        else if (h.status == C6_ST_PLAYING && ((size_t)h.live_pages * 4 > (size_t)d.pages_cap * 3 || (size_t)h.hslots * 2 > (size_t)d.hcap)) near_cap++;
     }
-    if (!want) return C6_OK;
-    int rc = grow_pool(e);
-    if (rc != C6_OK && !e->grow_failed) return rc;
+    if (parked_caps > 0 || near_cap > 0) {
+        const int pc = std::min(d.maxpages, 2 * d.pages_cap);
+        const int hc = std::min(e->hmax, pow2_at_least(2L * ((long)pc * C6_PAGE_RECS + d.S), C6_CHUNK_SLOTS));
+        if (pc != d.pages_cap || hc != d.hcap) { d.pages_cap = pc; d.hcap = hc; e->cap_raises++; }
+        else if (parked_caps > 0) e->grow_failed = true;      // a game at max_records_per_game: it stays parked (steady state: abandoned)
+    }
+    unsigned long long ctr[C6_POOL_N];
+    HIPCHK(hipMemcpy(ctr, d.pool_ctr, sizeof ctr, hipMemcpyDeviceToHost));
+    const size_t free_pages = (size_t)(ctr[C6_POOL_PAGE_TAIL] - ctr[C6_POOL_PAGE_HEAD]);
+    const size_t move_pages = (size_t)(d.S + C6_PAGE_RECS - 1) / C6_PAGE_RECS + 1;
+    const size_t low_water = std::max<size_t>(64, (size_t)d.G * move_pages / 8);      // an eighth of the games could start a move
+    if (parked_pool > 0 || free_pages < low_water) {
+        int rc = grow_pools(e, (size_t)parked_pool * move_pages + low_water);
+        if (rc != C6_OK) {
+            if (parked_pool > 0) e->grow_failed = true;
+            g_err.clear();      // not an error of this call: the games wait, or leave as partial results (c6_engine_run)
+        }
+    }
+    if (e->grow_failed && d.recycle) d.abandon_parked = 1;
     return C6_OK;
 }
 
@@ -877,23 +1023,26 @@ extern "C" int c6_engine_maintain(c6_engine *e) {
     int live = 0, errs = 0, ov = 0;
     int rc = live_games(e, &live, &errs, &ov);
     if (rc != C6_OK) return rc;
-    return maintain(e, ov);
+    return maintain(e);
 }
 
 extern "C" int c6_engine_run(c6_engine *e, long max_rounds) {
     if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
     long done = 0;
-    int errs = 0;
+    int errs = 0, stuck = 0;
     for (;;) {
         int live = 0, ov = 0;
         int rc = live_games(e, &live, &errs, &ov);
         if (rc != C6_OK) return rc;
-        rc = maintain(e, ov);
+        rc = maintain(e);
         if (rc != C6_OK) return rc;
-        if (ov > 0 && !e->grow_failed) continue;      // re-opened games: count them as live
-        if (live == 0) break;
+        // parked games wait for pages: while others play, pages keep coming back; when nobody plays any more, only the host's growth
+        // (just attempted) can help -- they get two more rounds to pick the new pages up
+        if (live == 0 && (ov == 0 || e->grow_failed || stuck >= 2)) break;
+        stuck = live == 0 ? stuck + 1 : 0;
         if (max_rounds > 0 && done >= max_rounds) break;
-        int chunk = (e->cfg.stagger || e->desync) ? std::min(e->d.S, 64) : e->d.S - e->round_in_move;
+        int chunk = e->cfg.stagger ? std::min(e->d.S, 64) : e->d.S - e->round_in_move;
+        if (live == 0) chunk = 1;
         if (max_rounds > 0) chunk = (int)std::min<long>(chunk, max_rounds - done);
         rc = c6_engine_step(e, chunk);
         if (rc != C6_OK) return rc;
@@ -904,8 +1053,8 @@ extern "C" int c6_engine_run(c6_engine *e, long max_rounds) {
         // never silently: the stopped games leave as partial results (winner 0, stones so far) and the call says so
         c6_launch_flush_errors(e->d, e->stream);
         HIPCHK(hipStreamSynchronize(e->stream));
-        char msg[160];
-        snprintf(msg, sizeof msg, "%d game(s) stopped in an error state (record pool exhausted or NaN scores); they are returned as "
+        char msg[200];
+        snprintf(msg, sizeof msg, "%d game(s) stopped (record pool exhausted at max_records_per_game / device memory, or NaN scores); they are returned as "
                  "partial games with winner 0", errs);
         return fail(C6_ERR_OVERFLOW, msg);
     }
@@ -934,8 +1083,21 @@ extern "C" int c6_engine_stats(c6_engine *e, c6_stats *out) {
     out->live_games = (uint32_t)live;
     out->overflow_games = (uint32_t)errs + (uint32_t)c[C6_CNT_OVERFLOW];   // stopped now + abandoned / flushed so far: 0 means none was lost
     out->abandoned_games = c[C6_CNT_OVERFLOW];
-    out->records_per_game = (uint32_t)e->d.R;
+    out->records_per_game = (uint32_t)(e->d.pages_cap * C6_PAGE_RECS);
     out->pool_grows = e->pool_grows;
+    {
+        unsigned long long pc[C6_POOL_N];
+        HIPCHK(hipMemcpy(pc, e->d.pool_ctr, sizeof pc, hipMemcpyDeviceToHost));
+        out->pool_pages = e->d.pages_total;
+        out->pool_pages_free = (uint32_t)(pc[C6_POOL_PAGE_TAIL] - pc[C6_POOL_PAGE_HEAD]);
+        out->pool_pages_low = (uint32_t)std::min<unsigned long long>(pc[C6_POOL_PAGE_LOW], 0xffffffffull);
+        out->pool_bytes = (uint64_t)e->vm_prior.mapped + e->vm_stat.mapped + e->vm_ht.mapped + e->vm_tag.mapped;
+        out->cap_raises = e->cap_raises;
+        uint32_t parked = 0, mp = 0;
+        for (const C6GameHdr &h : e->h_hdr) { parked += h.status == C6_ST_OVERFLOW; mp = std::max<uint32_t>(mp, (uint32_t)h.live_pages); }
+        out->parked_games = parked;
+        out->max_pages_held = mp;
+    }
     out->max_records_used = (uint32_t)c[C6_CNT_MAXREC];
     out->max_depth = (uint32_t)c[C6_CNT_MAXDEPTH];
     return C6_OK;
@@ -1000,33 +1162,33 @@ extern "C" int c6_engine_enable_tuples(c6_engine *e, size_t capacity_records) {
 __global__ void c6_root_probe_kernel(C6Dev E, int g, int32_t *visits, float *q, float *prior, int *root_stats, float *root_f) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int cells = E.cells;
-    const int p = E.hdr[g].root_rec;
-    const size_t rbase = (size_t)g * E.R;
+    const int p = E.hdr[g].root_rec, H = (int)E.hdr[g].hslots;
+    const uint32_t *pt = E.page_table + (size_t)g * E.maxpages, *ck = E.chunk_table + (size_t)g * E.maxchunks;
+    auto rec = [&](int r) { return ((size_t)pt[r >> C6_PAGE_SHIFT] << C6_PAGE_SHIFT) | (size_t)(r & (C6_PAGE_RECS - 1)); };
     if (c == 0) {
-        root_stats[0] = p >= 0 ? E.rec_stat[rbase + p].visit : 0;
-        root_stats[1] = E.R - E.hdr[g].free_top;
-        root_f[0] = p >= 0 ? E.rec_stat[rbase + p].value : 0.f;
-        root_f[1] = p >= 0 ? E.rec_stat[rbase + p].qsum : 0.f;
-        root_f[2] = p >= 0 ? E.rec_stat[rbase + p].q : 0.f;
+        root_stats[0] = p >= 0 ? E.rec_stat[rec(p)].visit : 0;
+        root_stats[1] = E.hdr[g].live_pages * C6_PAGE_RECS - E.hdr[g].free_top;
+        root_f[0] = p >= 0 ? E.rec_stat[rec(p)].value : 0.f;
+        root_f[1] = p >= 0 ? E.rec_stat[rec(p)].qsum : 0.f;
+        root_f[2] = p >= 0 ? E.rec_stat[rec(p)].q : 0.f;
     }
     if (c >= cells) return;
     const int8_t v = E.root_board[(size_t)g * E.cellsP + c];
     visits[c] = -1; q[c] = 0.f; prior[c] = 0.f;
-    if (v != 0 || p < 0) { if (v == 0) visits[c] = 0; return; }
+    if (v != 0 || p < 0 || H <= 0) { if (v == 0) visits[c] = 0; return; }
     const int turn = E.turn[g];
     const unsigned long long key = E.hdr[g].root_key ^ E.zob[(turn == C6_WHITE ? C6_MAXCELLS : 0) + c];
-    const C6HtEntry *ht = E.ht + (size_t)g * E.H;
-    uint32_t slot = (uint32_t)(key ^ (key >> 32)) & (uint32_t)(E.H - 1);
+    uint32_t slot = (uint32_t)(key ^ (key >> 32)) & (uint32_t)(H - 1);
     int idx = -1;
-    for (int it = 0; it < E.H; it++) {
-        const C6HtEntry en = ht[slot];
+    for (int it = 0; it < H; it++) {
+        const C6HtEntry en = E.ht[((size_t)ck[slot >> C6_CHUNK_SHIFT] << C6_CHUNK_SHIFT) | (size_t)(slot & (C6_CHUNK_SLOTS - 1))];
         if (en.key == key) { idx = (int)en.idx1 - 1; break; }
         if (en.key == 0ull) break;
-        slot = (slot + 1) & (uint32_t)(E.H - 1);
+        slot = (slot + 1) & (uint32_t)(H - 1);
     }
-    visits[c] = idx >= 0 ? E.rec_stat[rbase + idx].visit : 0;
-    q[c] = idx >= 0 ? E.rec_stat[rbase + idx].q : 0.f;
-    prior[c] = E.rec_prior[(rbase + p) * (size_t)cells + c];
+    visits[c] = idx >= 0 ? E.rec_stat[rec(idx)].visit : 0;
+    q[c] = idx >= 0 ? E.rec_stat[rec(idx)].q : 0.f;
+    prior[c] = E.rec_prior[rec(p) * (size_t)cells + c];
 }
 
 extern "C" int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *board, int32_t *visits, float *q, float *prior) {
@@ -1065,6 +1227,23 @@ extern "C" int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *b
         info->root_value = rf[0]; info->root_q_sum = rf[1]; info->root_q_value = rf[2];
         info->nsearch = nsr;
     }
+    return C6_OK;
+}
+
+// the canonical game state K1 works on (structure-of-arrays on the device): boards[g][N*N] (-1 black, 0 empty, +1 white), the side to move
+// and the stones it still has to place (Game{turn, num_remain}, game_impl/mod.rs:117-121).  Synchronises.
+extern "C" int c6_engine_boards(c6_engine *e, int8_t *boards, int8_t *turn, int8_t *remain) {
+    if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
+    const C6Dev &d = e->d;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (boards) {
+        std::vector<int8_t> soa((size_t)d.cells * d.Gpad);
+        HIPCHK(hipMemcpy(soa.data(), d.board_soa, soa.size(), hipMemcpyDeviceToHost));
+        for (int g = 0; g < d.G; g++)
+            for (int c = 0; c < d.cells; c++) boards[(size_t)g * d.cells + c] = soa[(size_t)c * d.Gpad + g];
+    }
+    if (turn) HIPCHK(hipMemcpy(turn, d.turn, (size_t)d.G, hipMemcpyDeviceToHost));
+    if (remain) HIPCHK(hipMemcpy(remain, d.remain, (size_t)d.G, hipMemcpyDeviceToHost));
     return C6_OK;
 }
 

@@ -19,6 +19,11 @@
 // (path stones of the mover's colour) x (empty cells of Q), each looked up by key.  Round 1 scanned
 // all records of the game for every expansion (26 bytes per record and two 64-bit divisions).
 //
+// Storage is paged (c6_engine.h): a game's records sit in pages of 64 from a pool shared by all games, its table in chunks of 1024
+// slots from a second pool.  The wave copies its game's page table and chunk list (a few dozen words) into LDS with the tag row, so a
+// record / table-slot address costs one LDS read.  Pages and chunks change hands at MOVE boundaries only (post_move / reset:
+// reprovision_wave): a game enters a move with >= S free records and a table of >= 2 x (live + S) slots, so no search ever waits.
+//
 // Memory accesses are what a search costs (profiles/r02_tree_traffic.txt), so:
 //  * every table slot has a TAG byte (c6_ht_tag_of); the wave loads the game's whole tag row into LDS
 //    once per search (H bytes, contiguous): looking up an absent child -- most children of most
@@ -52,8 +57,8 @@
 __device__ __forceinline__ uint32_t ht_home(unsigned long long key, int H) { return (uint32_t)(key ^ (key >> 32)) & (uint32_t)(H - 1); }
 
 // one 16-byte load of an entry
-__device__ __forceinline__ C6HtEntry ht_load(const C6HtEntry *ht, uint32_t slot) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(ht + slot);
+__device__ __forceinline__ C6HtEntry ht_load(const C6HtEntry *ep) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(ep);
     C6HtEntry e;
     e.key = ((unsigned long long)v.y << 32) | v.x;
     e.idx1 = (uint16_t)(v.z & 0xffffu);
@@ -61,44 +66,69 @@ __device__ __forceinline__ C6HtEntry ht_load(const C6HtEntry *ht, uint32_t slot)
     e.q = __uint_as_float(v.w);
     return e;
 }
-__device__ __forceinline__ void ht_store(C6HtEntry *ht, uint32_t slot, unsigned long long key, int idx, int visit, float q) {
+__device__ __forceinline__ void ht_store(C6HtEntry *ep, unsigned long long key, int idx, int visit, float q) {
     const uint32_t v = (uint32_t)(visit > 65535 ? 65535 : visit);
-    *reinterpret_cast<uint4 *>(ht + slot) = uint4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(idx + 1) | (v << 16), __float_as_uint(q)};
+    *reinterpret_cast<uint4 *>(ep) = uint4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(idx + 1) | (v << 16), __float_as_uint(q)};
 }
 
 __device__ __forceinline__ uint16_t sat16(int v) { return (uint16_t)(v > 65535 ? 65535 : v); }
 
-// The tag row of the wave's game: in LDS when the table has at most C6_TAG_LDS_MAX slots (l != nullptr), else read in memory.
-// Tags mirror the table exactly: tag 0 <=> empty slot.
+// The wave's view of its game's paged storage: chunk list and page table in LDS, and the tag row too when the game's table has at
+// most C6_TAG_LDS_MAX slots (else the tags are read in memory, through the chunk list).  Tags mirror the table exactly: tag 0 <=>
+// empty slot.
 typedef __attribute__((address_space(3))) uint8_t c6_lds_u8;
+typedef __attribute__((address_space(3))) uint32_t c6_lds_u32;
 struct C6Tags {
-    uint8_t *g;
-    c6_lds_u8 *l;
+    c6_lds_u8 *l;          // tag row (lds)
+    c6_lds_u32 *ck, *pt;   // logical chunk -> pool chunk, logical page -> pool page
+    uint8_t *tagp;         // E.ht_tag
+    C6HtEntry *htp;        // E.ht
     bool lds;
-    uint32_t mask;
+    uint32_t mask;         // hslots - 1
+    __device__ __forceinline__ size_t slot_at(uint32_t s) const { return ((size_t)ck[s >> C6_CHUNK_SHIFT] << C6_CHUNK_SHIFT) | (size_t)(s & (C6_CHUNK_SLOTS - 1)); }
+    __device__ __forceinline__ C6HtEntry *entry(uint32_t s) const { return htp + slot_at(s); }
+    __device__ __forceinline__ size_t rec(int r) const { return ((size_t)pt[r >> C6_PAGE_SHIFT] << C6_PAGE_SHIFT) | (size_t)(r & (C6_PAGE_RECS - 1)); }
     __device__ __forceinline__ uint8_t at(uint32_t s) const {
         if (lds) return l[s];
-        return g[s];
+        return tagp[slot_at(s)];
     }
     __device__ __forceinline__ void set(uint32_t s, uint8_t t) const {
         if (lds) l[s] = t;
-        g[s] = t;
+        tagp[slot_at(s)] = t;
     }
 };
-__host__ __device__ __forceinline__ int tag_row_bytes(int H) { return H <= C6_TAG_LDS_MAX ? H : 0; }
-__device__ __forceinline__ void tags_load(const C6Dev &E, int g, int lane, uint8_t *lds, C6Tags &T) {
-    T.g = E.ht_tag + (size_t)g * E.H;
-    T.mask = (uint32_t)(E.H - 1);
-    T.lds = E.H <= C6_TAG_LDS_MAX;
+// LDS of one wave: [tag row: min(hcap, C6_TAG_LDS_MAX) bytes][chunk list: hcap / 1024 words][page table: pages_cap words]
+__host__ __device__ __forceinline__ int c6_tagrow_bytes(int hcap) { return hcap < C6_TAG_LDS_MAX ? hcap : C6_TAG_LDS_MAX; }
+__host__ __device__ __forceinline__ int c6_cklist_bytes(int hcap) { return (((hcap >> C6_CHUNK_SHIFT) * 4) + 15) & ~15; }
+__host__ __device__ __forceinline__ int c6_wave_lds(int hcap, int pages_cap) { return c6_tagrow_bytes(hcap) + c6_cklist_bytes(hcap) + ((pages_cap * 4 + 15) & ~15); }
+// bind T to the wave's LDS area without loading anything (the rare paths work on the global tables)
+__device__ __forceinline__ void tags_bind(const C6Dev &E, uint8_t *lds, C6Tags &T) {
     T.l = (c6_lds_u8 *)lds;
+    T.ck = (c6_lds_u32 *)(lds + c6_tagrow_bytes(E.hcap));
+    T.pt = (c6_lds_u32 *)(lds + c6_tagrow_bytes(E.hcap) + c6_cklist_bytes(E.hcap));
+    T.tagp = E.ht_tag;
+    T.htp = E.ht;
+}
+// the game's chunk list, page table and (small tables) tag row into the wave's LDS
+__device__ __forceinline__ void tags_load(const C6Dev &E, int g, int lane, uint8_t *lds, C6Tags &T) {
+    tags_bind(E, lds, T);
+    const int H = (int)E.hdr[g].hslots, np = (int)E.hdr[g].npages;
+    T.mask = (uint32_t)(H - 1);
+    T.lds = H <= C6_TAG_LDS_MAX;
+    const int nck = H >> C6_CHUNK_SHIFT;
+    const uint32_t *ckg = E.chunk_table + (size_t)g * E.maxchunks, *ptg = E.page_table + (size_t)g * E.maxpages;
+    for (int i = lane; i < nck; i += 64) T.ck[i] = ckg[i];
+    for (int i = lane; i < np; i += 64) T.pt[i] = ptg[i];
     if (T.lds) {
         typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
         typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(T.g);
         lds_u32x4 *dst = (lds_u32x4 *)lds;
-        for (int i = lane; i < E.H / 16; i += 64) dst[i] = src[i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int c = 0; c < nck; c++) {      // a chunk's 1024 tags: one 16-byte load per lane
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(E.ht_tag + ((size_t)ckg[c] << C6_CHUNK_SHIFT));
+            dst[c * (C6_CHUNK_SLOTS / 16) + lane] = src[lane];
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 // from `slot` on: the first slot whose tag is t (true) or that is empty (false); `budget` bounds the walk by the table size
 __device__ __forceinline__ bool tag_seek(const C6Tags &T, uint8_t t, uint32_t &slot, int &budget) {
@@ -111,28 +141,28 @@ __device__ __forceinline__ bool tag_seek(const C6Tags &T, uint8_t t, uint32_t &s
     return false;
 }
 // continue a lookup whose first tag match `slot` has been loaded into `e`: true and the entry when `key` is in the table
-__device__ __forceinline__ bool ht_verify(const C6HtEntry *ht, const C6Tags &T, unsigned long long key, uint8_t t, uint32_t &slot, int &budget, C6HtEntry &e) {
+__device__ __forceinline__ bool ht_verify(const C6Tags &T, unsigned long long key, uint8_t t, uint32_t &slot, int &budget, C6HtEntry &e) {
     while (e.key != key) {      // a different key with the same tag (1 in 255): walk on
         slot = (slot + 1) & T.mask;
         if (!tag_seek(T, t, slot, budget)) return false;
-        e = ht_load(ht, slot);
+        e = ht_load(T.entry(slot));
     }
     return true;
 }
-__device__ __forceinline__ bool ht_find(const C6HtEntry *ht, const C6Tags &T, unsigned long long key, C6HtEntry &e) {
+__device__ __forceinline__ bool ht_find(const C6Tags &T, unsigned long long key, C6HtEntry &e) {
     const uint8_t t = c6_ht_tag_of(key);
     uint32_t slot = ht_home(key, (int)T.mask + 1);
     int budget = (int)T.mask + 1;
     if (!tag_seek(T, t, slot, budget)) return false;
-    e = ht_load(ht, slot);
-    return ht_verify(ht, T, key, t, slot, budget, e);
+    e = ht_load(T.entry(slot));
+    return ht_verify(T, key, t, slot, budget, e);
 }
 // insert by the game's one writer (the tags say where the first empty slot is: no probe); returns the slot, -1 = table full
-__device__ __forceinline__ int ht_insert(C6HtEntry *ht, const C6Tags &T, unsigned long long key, int idx, int visit, float q) {
+__device__ __forceinline__ int ht_insert(const C6Tags &T, unsigned long long key, int idx, int visit, float q) {
     uint32_t slot = ht_home(key, (int)T.mask + 1);
     for (int it = 0; it <= (int)T.mask; it++) {
         if (T.at(slot) == 0) {
-            ht_store(ht, slot, key, idx, visit, q);
+            ht_store(T.entry(slot), key, idx, visit, q);
             T.set(slot, c6_ht_tag_of(key));
             return (int)slot;
         }
@@ -140,16 +170,17 @@ __device__ __forceinline__ int ht_insert(C6HtEntry *ht, const C6Tags &T, unsigne
     }
     return -1;
 }
-// concurrent insert by the lanes of the game's wave (distinct keys) into a table being rebuilt: memory only, no LDS copy
-__device__ __forceinline__ int ht_insert_atomic(C6HtEntry *ht, uint8_t *tag, int H, unsigned long long key, int idx, int visit, float q) {
+// concurrent insert by the lanes of the game's wave (distinct keys) into a table being rebuilt: memory only (global chunk list `ckg`)
+__device__ __forceinline__ int ht_insert_atomic(C6HtEntry *htp, uint8_t *tagp, const uint32_t *ckg, int H, unsigned long long key, int idx, int visit, float q) {
     uint32_t slot = ht_home(key, H);
     for (int it = 0; it < H; it++) {
-        unsigned long long prev = atomicCAS(&ht[slot].key, 0ull, key);
+        const size_t at = ((size_t)ckg[slot >> C6_CHUNK_SHIFT] << C6_CHUNK_SHIFT) | (size_t)(slot & (C6_CHUNK_SLOTS - 1));
+        unsigned long long prev = atomicCAS(&htp[at].key, 0ull, key);
         if (prev == 0ull || prev == key) {
-            ht[slot].idx1 = (uint16_t)(idx + 1);
-            ht[slot].visit = sat16(visit);
-            ht[slot].q = q;
-            tag[slot] = c6_ht_tag_of(key);
+            htp[at].idx1 = (uint16_t)(idx + 1);
+            htp[at].visit = sat16(visit);
+            htp[at].q = q;
+            tagp[at] = c6_ht_tag_of(key);
             return (int)slot;
         }
         slot = (slot + 1) & (uint32_t)(H - 1);
@@ -178,7 +209,8 @@ struct C6GameRegs {
     unsigned long long key;
     int root_rec, turn, remain, level, top, sim_in_move, rootc_ok;
     uint32_t uid, nsearch;
-    int free_idx;           // the record the next expansion takes (free_stack[top - 1]), fetched behind `top`
+    int alloc_page;         // logical page the next expansion takes its record from
+    unsigned long long alloc_mask;      // that page's free mask (page_free), fetched behind the page table: free_record_prefetch
     int8_t st[J];           // the root position, lane's cells
 };
 template <int J>
@@ -199,9 +231,16 @@ __device__ __forceinline__ void load_game_regs(const C6Dev &E, int g, int lane, 
     R.key = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(R.key >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)R.key);
     C6_SGPR(R.root_rec); C6_SGPR(R.turn); C6_SGPR(R.remain); C6_SGPR(R.level); C6_SGPR(R.top); C6_SGPR(R.sim_in_move); C6_SGPR(R.rootc_ok);
     R.uid = __builtin_amdgcn_readfirstlane(R.uid); R.nsearch = __builtin_amdgcn_readfirstlane(R.nsearch);
-    R.free_idx = R.top > 0 ? (int)E.free_stack[(size_t)g * E.R + R.top - 1] : -1;      // second trip, overlapped with the first select level
-    C6_SGPR(R.free_idx);
+    R.alloc_page = (int)E.hdr[g].alloc_page;
+    C6_SGPR(R.alloc_page);
+    R.alloc_mask = 0ull;
 #undef C6_SGPR
+}
+// the free mask of the page the next expansion allocates from (second trip, overlapped with the first select level); T.pt is loaded
+template <int J>
+__device__ __forceinline__ void free_record_prefetch(const C6Dev &E, const C6Tags &T, C6GameRegs<J> &R) {
+    unsigned long long m = R.top > 0 ? E.page_free[T.pt[R.alloc_page]] : 0ull;
+    R.alloc_mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
 }
 
 // colour of the stone the select path places at step m, from the root's (turn, remain): simulate/mod.rs:268-273 unrolled
@@ -216,8 +255,7 @@ __device__ __forceinline__ int path_colour(int root_turn, int root_remain, int m
 template <int J>
 __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, double *gscratch, const C6Tags &T, const C6GameRegs<J> &R, C6Leaf<J> &L) {
     const int cells = E.cells;
-    const C6HtEntry *ht = E.ht + (size_t)g * E.H;
-    const size_t rbase = (size_t)g * E.R;
+    const int H = (int)T.mask + 1;
 
     unsigned long long key = R.key;
     int p = R.root_rec;
@@ -233,9 +271,9 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
     while (p >= 0) {
         const int nchild = cells - level;
         if (nchild == 0) break;                 // cannot happen: full boards are never records
-        if (d >= E.maxd) { kind = -2; break; }  // path overflow: nothing written yet, the host grows the path buffer
+        if (d >= E.maxd) { kind = -1; break; }  // cannot happen: a path adds a stone per step and maxd >= cells
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
-        const float *prior = E.rec_prior + (rbase + p) * (size_t)cells;
+        const float *prior = E.rec_prior + T.rec(p) * (size_t)cells;
 
         int cidx[J], cvis[J];
         float cq[J], cpr[J];
@@ -256,7 +294,7 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
                 cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f;
                 if (L.st[j] == 0 && (v[j].x & 0xffffu) != 0u) {
                     cidx[j] = (int)(v[j].x & 0xffffu) - 1;
-                    cvis[j] = (v[j].x >> 16) == 65535u ? E.rec_stat[rbase + cidx[j]].visit : (int)(v[j].x >> 16);
+                    cvis[j] = (v[j].x >> 16) == 65535u ? E.rec_stat[T.rec(cidx[j])].visit : (int)(v[j].x >> 16);
                     cq[j] = __uint_as_float(v[j].y);
                     vs += cvis[j];
                 }
@@ -273,22 +311,22 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
                 const int c = lane + 64 * j;
                 const bool mine = L.st[j] == 0;
                 ck[j] = key ^ zk[mine ? c : 0];
-                cslot[j] = ht_home(ck[j], E.H);
-                budget[j] = E.H;
+                cslot[j] = ht_home(ck[j], H);
+                budget[j] = H;
                 hit[j] = mine && tag_seek(T, c6_ht_tag_of(ck[j]), cslot[j], budget[j]);
             }
 #pragma unroll
             for (int j = 0; j < J; j++) {
                 const int c = lane + 64 * j;
-                if (hit[j]) ce[j] = ht_load(ht, cslot[j]);
+                if (hit[j]) ce[j] = ht_load(T.entry(cslot[j]));
                 cpr[j] = L.st[j] == 0 ? prior[c] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < J; j++) {
                 cidx[j] = -1; cvis[j] = 0; cq[j] = 0.f;
-                if (hit[j] && ht_verify(ht, T, ck[j], c6_ht_tag_of(ck[j]), cslot[j], budget[j], ce[j])) {
+                if (hit[j] && ht_verify(T, ck[j], c6_ht_tag_of(ck[j]), cslot[j], budget[j], ce[j])) {
                     cidx[j] = (int)ce[j].idx1 - 1;
-                    cvis[j] = ce[j].visit == 65535 ? E.rec_stat[rbase + cidx[j]].visit : (int)ce[j].visit;
+                    cvis[j] = ce[j].visit == 65535 ? E.rec_stat[T.rec(cidx[j])].visit : (int)ce[j].visit;
                     cq[j] = ce[j].q;
                     vs += cvis[j];
                 }
@@ -384,10 +422,10 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
     L.kind = kind; L.turn = turn; L.level = level; L.len = d; L.key = key;
 }
 
-// the game stops (pool / path exhausted: resumable; NaN scores: an error) -- reported through status, never silently
+// the game stops (NaN scores: the reference panics) -- reported through status, never silently
 __device__ __forceinline__ void select_failed(const C6Dev &E, int g, int lane, int kind) {
     if (lane == 0) {
-        E.hdr[g].status = kind == -2 ? C6_ST_OVERFLOW : C6_ST_ERROR;
+        E.hdr[g].status = C6_ST_ERROR;
         E.hdr[g].leaf_kind = C6_LEAF_NONE;
     }
 }
@@ -421,10 +459,42 @@ __device__ __forceinline__ void recover_wave(int cells, int lane, const int16_t 
 // RandomEvaluator (mod.rs:137-169) / uniform evaluator, evaluated on device: get_from's tail (recover_way8 + mask) of the lane's
 // own cells, in registers.  Same arithmetic as recover_wave (the summation order of augment.rs:79-88).
 template <int J>
-__device__ __forceinline__ void eval_builtin_regs(const C6Dev &E, int g, int lane, int kind, uint32_t t, const int8_t (&st)[J], float (&pr)[J],
+__device__ __forceinline__ void eval_builtin_regs(const C6Dev &E, int g, int lane, int kind, uint32_t t, int leaf_turn, const int8_t (&st)[J], float (&pr)[J],
                                                   float &value) {
     const int cells = E.cells;
     const uint32_t k0 = E.seed_lo, k1 = E.seed_hi + E.hdr[g].game_uid;
+    if (kind == 3 && E.hdr[g].game_uid % (uint32_t)E.stress_every == 0u) {
+        // C6_EVAL_STRESS (connect6_amd.h): prior 2^(-20 min(d2 - d2min, 6)) on the empty cells, d2 = squared distance to the board centre,
+        // value -0.875 * side to move.  The function is invariant under the 8 dihedral images and its values are powers of two, so the
+        // average of recover_way8 (augment.rs:79-88) returns them exactly.
+        const int N = E.N, ctr = N / 2;
+        int d2[J], d2min = 1 << 20;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c = lane + 64 * j, r = c / N, q = c - r * N;
+            d2[j] = (r - ctr) * (r - ctr) + (q - ctr) * (q - ctr);
+            if (c < cells && st[j] == 0 && d2[j] < d2min) d2min = d2[j];
+        }
+        d2min = c6_wave_min_i32(d2min);
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c = lane + 64 * j;
+            int k = d2[j] - d2min;
+            k = k > 6 ? 6 : k;
+            const float p = __uint_as_float((uint32_t)(127 - 20 * k) << 23);      // 2^(-20 k), a normal float
+            float total = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) total = total + (p + p);
+            total = total / 8.f;
+            pr[j] = c < cells && st[j] == 0 ? total : 0.f;
+        }
+        const float v = -0.875f * (float)leaf_turn;
+        float sv = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sv = sv + v;
+        value = sv / 8.f;
+        return;
+    }
     if (kind == 1) {
         auto pf = [&](int k, int cell) -> float {
             const c6_u4 w = c6_philox((uint32_t)(cell >> 2), (uint32_t)k, t, C6_TAG_EVAL_P, k0, k1);
@@ -531,25 +601,25 @@ template <int J>
 __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, const C6Tags &T, const C6GameRegs<J> &R, const C6Leaf<J> &L, float evalue,
                                             const float *prob, const int8_t *board) {
     const int cells = E.cells;
-    const size_t rbase = (size_t)g * E.R;
     const int kind = L.kind, len = L.len, level = L.level, turn = L.turn;
     const unsigned long long key = L.key;
     const int top = R.top, sim_in_move = R.sim_in_move;
     const uint32_t nsearch = R.nsearch;
-    C6HtEntry *ht = E.ht + (size_t)g * E.H;
     float value;
     // these leave together: the rest of the game's words, and the backup's loads (lane i: the path's i-th record)
-    const int hi0 = E.hdr[g].rec_hi;
     const unsigned long long gsims = E.hdr[g].g_sims;
     const uint32_t maxrec = E.hdr[g].g_maxrec;
+    const int npages = (int)E.hdr[g].npages, held = E.hdr[g].live_pages;
     const int my_rec = L.my_path & 0xffff, my_cell = (int)((uint32_t)L.my_path >> 16);
     uint32_t bk_slot = 0;
     int bk_visit = 0;
     float bk_qsum = 0.f;
+    size_t my_at = 0;
     if (lane < len) {
-        bk_slot = E.rec_stat[rbase + my_rec].slot;
-        bk_visit = E.rec_stat[rbase + my_rec].visit;
-        bk_qsum = E.rec_stat[rbase + my_rec].qsum;
+        my_at = T.rec(my_rec);
+        bk_slot = E.rec_stat[my_at].slot;
+        bk_visit = E.rec_stat[my_at].visit;
+        bk_qsum = E.rec_stat[my_at].qsum;
     }
     const int cell0 = __shfl(my_cell, 0, 64);      // the root's move of this path (len >= 1): its rootc entry follows the child
     C6RootChild *rootc = E.rootc + (size_t)g * E.cellsP;
@@ -559,20 +629,23 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         const float cost = (float)turn;
         value = w == turn ? cost : (w != 0 ? -cost : 0.f);
     } else {
-        // allocate the record of the newly expanded node (every lane reads the same stack slot)
-        if (top <= 0) {      // pool exhausted; nothing of this search has been written: resumable after grow_pool
-            if (lane == 0) E.hdr[g].status = C6_ST_OVERFLOW;
+        // the record of the newly expanded node: the lowest free one of the allocation page.  A move starts with >= S free records
+        // (reprovision_wave), so this cannot run dry; if it ever did, the game stops with an error instead of writing anywhere.
+        if (top <= 0 || R.alloc_mask == 0ull) {
+            if (lane == 0) E.hdr[g].status = C6_ST_ERROR;
             return false;
         }
-        const int idx = R.free_idx;
-        const int hi = idx + 1 > hi0 ? idx + 1 : hi0;
+        const int bit = __ffsll((long long)R.alloc_mask) - 1;
+        const int idx = (R.alloc_page << C6_PAGE_SHIFT) | bit;
+        const unsigned long long left = R.alloc_mask & (R.alloc_mask - 1ull);
+        const size_t at = T.rec(idx);
         value = evalue;
-        float *prior = E.rec_prior + (rbase + idx) * (size_t)cells;
+        float *prior = E.rec_prior + at * (size_t)cells;
         for (int c = lane; c < cells; c += 64) prior[c] = prob[c];      // child.n_prob = prob[r][c], mod.rs:370
         if (lane == 0) {
             E.hdr[g].free_top = top - 1;
-            if (hi != hi0) E.hdr[g].rec_hi = hi;
-            const int slot = ht_insert(ht, T, key, idx, 1, 0.f);
+            E.page_free[T.pt[R.alloc_page]] = left;
+            const int slot = ht_insert(T, key, idx, 1, 0.f);
             if (slot < 0) E.hdr[g].status = C6_ST_ERROR;
             C6RecStat rs;
             rs.visit = 1;             // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
@@ -580,13 +653,25 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
             rs.slot = (uint32_t)(slot < 0 ? 0 : slot);
             rs.level = (int16_t)level; rs.pad = 0;
             rs.key = key;
-            uint4 *dst = reinterpret_cast<uint4 *>(E.rec_stat + rbase + idx);
+            uint4 *dst = reinterpret_cast<uint4 *>(E.rec_stat + at);
             const uint4 *src = reinterpret_cast<const uint4 *>(&rs);
             dst[0] = src[0]; dst[1] = src[1];
             if (len == 0) E.hdr[g].root_rec = idx;
             if (len == 1) *reinterpret_cast<uint2 *>(rootc + cell0) = uint2{(uint32_t)(idx + 1) | (1u << 16), 0u};
-            const uint32_t used = (uint32_t)(E.R - (top - 1));
+            const uint32_t used = (uint32_t)(held * C6_PAGE_RECS - (top - 1));
             if (used > maxrec) E.hdr[g].g_maxrec = used;
+        }
+        if (left == 0ull && top - 1 > 0) {
+            // the allocation page is used up: the next page (in logical order, wrapping) that has a free record.  Once in 64 expansions.
+            int next = -1;
+            for (int base = 0; base < npages && next < 0; base += 64) {
+                const int lp = base + lane;
+                const uint32_t ph = lp < npages ? T.pt[lp] : C6_NOPAGE;
+                const bool has = ph != C6_NOPAGE && lp != R.alloc_page && E.page_free[ph] != 0ull;
+                const unsigned long long m = __ballot(has);
+                if (m) next = base + __ffsll((long long)m) - 1;
+            }
+            if (lane == 0) E.hdr[g].alloc_page = (uint16_t)(next < 0 ? 0 : next);
         }
         // last-writer rule for transposed children (entry().or_insert + n_prob overwrite, mod.rs:366-370): every expanded P with
         // P + i == Q + s sees its child i's prior become prob_Q[s].  i: a stone of the mover's colour the path added to the root
@@ -601,7 +686,7 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
                     const int c = lane + 64 * j;
                     if (L.st[j] != 0) continue;
                     const uint32_t pi1 = rc[c].x & 0xffffu;
-                    if (pi1 != 0u) E.rec_prior[(rbase + (size_t)pi1 - 1) * (size_t)cells + cell0] = prob[c];
+                    if (pi1 != 0u) E.rec_prior[T.rec((int)pi1 - 1) * (size_t)cells + cell0] = prob[c];
                 }
             }
         } else
@@ -620,7 +705,7 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
                     const int c = lane + 64 * j;
                     if (L.st[j] != 0) continue;
                     C6HtEntry e;
-                    if (ht_find(ht, T, kq ^ zk[c], e)) E.rec_prior[(rbase + (size_t)e.idx1 - 1) * (size_t)cells + i] = prob[c];
+                    if (ht_find(T, kq ^ zk[c], e)) E.rec_prior[T.rec((int)e.idx1 - 1) * (size_t)cells + i] = prob[c];
                 }
             }
         }
@@ -632,18 +717,20 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         const int i = base + lane;
         if (i < len) {
             const int r = base == 0 ? my_rec : (int)(E.path_rec[(size_t)g * E.maxd + i] & 0xffffu);
-            const uint32_t slot = base == 0 ? bk_slot : E.rec_stat[rbase + r].slot;
-            const int v = (base == 0 ? bk_visit : E.rec_stat[rbase + r].visit) + 1;
-            float qs = base == 0 ? bk_qsum : E.rec_stat[rbase + r].qsum;
+            const size_t at = base == 0 ? my_at : T.rec(r);
+            const uint32_t slot = base == 0 ? bk_slot : E.rec_stat[at].slot;
+            const int v = (base == 0 ? bk_visit : E.rec_stat[at].visit) + 1;
+            float qs = base == 0 ? bk_qsum : E.rec_stat[at].qsum;
             if (i == len - 1) {      // the leaf's parent receives the value
                 qs = qs + value;
-                E.rec_stat[rbase + r].qsum = qs;
+                E.rec_stat[at].qsum = qs;
             }
             const float qv = qs / (float)v;   // recalc_q :77-79
-            E.rec_stat[rbase + r].visit = v;
-            E.rec_stat[rbase + r].q = qv;
-            ht[slot].visit = sat16(v);
-            ht[slot].q = qv;
+            E.rec_stat[at].visit = v;
+            E.rec_stat[at].q = qv;
+            C6HtEntry *ep = T.entry(slot);
+            ep->visit = sat16(v);
+            ep->q = qv;
             if (i == 1) {
                 rootc[cell0].visit = sat16(v);
                 rootc[cell0].q = qv;
@@ -669,8 +756,6 @@ __device__ __forceinline__ int move_select_wave(const C6Dev &E, int g, int lane,
     const int turn = E.turn[g];
     int pos = -1;
     if (p >= 0 && level < cells) {
-        const C6HtEntry *ht = E.ht + (size_t)g * E.H;
-        const size_t rbase = (size_t)g * E.R;
         const unsigned long long key = E.hdr[g].root_key;
         const unsigned long long *zk = E.zob + (turn == C6_WHITE ? C6_MAXCELLS : 0);
         const int8_t *board = E.root_board + (size_t)g * E.cellsP;
@@ -683,7 +768,7 @@ __device__ __forceinline__ int move_select_wave(const C6Dev &E, int g, int lane,
             if (c < cells && board[c] == 0) {
                 C6HtEntry e;
                 cv[j] = 0;
-                if (ht_find(ht, T, key ^ zk[c], e)) cv[j] = e.visit == 65535 ? E.rec_stat[rbase + (int)e.idx1 - 1].visit : (int)e.visit;
+                if (ht_find(T, key ^ zk[c], e)) cv[j] = e.visit == 65535 ? E.rec_stat[T.rec((int)e.idx1 - 1)].visit : (int)e.visit;
                 vs += cv[j];
             }
         }
@@ -719,21 +804,233 @@ __device__ __forceinline__ int move_select_wave(const C6Dev &E, int g, int lane,
     return pos;
 }
 
+// ---- pages and chunks: the pools' rings ---------------------------------------------------------------------------------
+// pop n ids (n <= 64): lane k < n gets id k; false (nothing taken) if fewer than n are available to this launch.  Tickets beyond
+// `limit` belong to ids pushed during this launch (by waves on other XCDs, possibly still in their caches): not ours yet.
+__device__ __forceinline__ bool ring_pop(const uint32_t *ring, uint32_t mask, unsigned long long *ctr, int head_i, int limit_i, int n, int lane, uint32_t &id) {
+    unsigned long long h = 0ull;
+    int ok = 0;
+    if (lane == 0) {
+        h = atomicAdd(&ctr[head_i], (unsigned long long)n);
+        const unsigned long long lim = ctr[limit_i];
+        ok = h + (unsigned long long)n <= lim;
+        if (!ok) atomicAdd(&ctr[head_i], 0ull - (unsigned long long)n);      // undo: tickets behind a failed one fail too, so nothing is lost
+        else if (head_i == C6_POOL_PAGE_HEAD) atomicMin(&ctr[C6_POOL_PAGE_LOW], lim - (h + (unsigned long long)n));
+    }
+    ok = __shfl(ok, 0, 64);
+    if (!ok) return false;
+    h = (unsigned long long)__shfl((long long)h, 0, 64);
+    id = lane < n ? ring[(uint32_t)(h + (unsigned long long)lane) & mask] : C6_NOPAGE;
+    return true;
+}
+// push the ids of the lanes in `m` (a ballot)
+__device__ __forceinline__ void ring_push(uint32_t *ring, uint32_t mask, unsigned long long *ctr, int tail_i, unsigned long long m, int lane, uint32_t id) {
+    if (m == 0ull) return;
+    unsigned long long t = 0ull;
+    if (lane == 0) t = atomicAdd(&ctr[tail_i], (unsigned long long)__popcll(m));
+    t = (unsigned long long)__shfl((long long)t, 0, 64);
+    if ((m >> lane) & 1ull) ring[(uint32_t)(t + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))) & mask] = id;
+}
+
+// Move boundary (after next()'s prune, at a reset, and for a parked game at every round's head): give game g what its next move may
+// need -- at least `want_free` (= E.S) free records and a table of >= 2 x (live + S) slots (a power of two of chunks) -- hand back what
+// it does not, and rebuild the table from the live records (its slots hold the records' current statistics).  kill_level: records
+// whose level is <= kill_level are dropped first (next(), mod.rs:473-484: the old root's level; 32767: all of them; -1: none).
+// want_free = 0 (a finished game that is not recycled): everything goes back.  Returns the record whose key is `find` (-1: none).
+// If the pool cannot serve the request, or the game is at the per-game caps, the game is PARKED (status C6_ST_OVERFLOW, hdr.park says
+// why) with everything it holds intact and its table rebuilt at the old size, and the call is repeated at the head of the following
+// rounds.
+template <int J>
+__device__ __forceinline__ int reprovision_wave(const C6Dev &E, int g, int lane, int kill_level, unsigned long long find, int want_free) {
+    uint32_t *ptg = E.page_table + (size_t)g * E.maxpages, *ckg = E.chunk_table + (size_t)g * E.maxchunks;
+    int npages = (int)E.hdr[g].npages;
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
+    // pass 1: drop the records of the pruned levels; per page its free mask; empty pages are candidates for handing back
+    int free_ne = 0, nlive = 0, nempty = 0, nheld = 0;      // wave-uniform; free_ne: free records of the non-empty pages
+    for (int base = 0; base < npages; base += 64) {
+        const int lp = base + lane;
+        const uint32_t ph = lp < npages ? ptg[lp] : C6_NOPAGE;
+        unsigned long long my_fm = 0ull;
+        const int cnt = npages - base < 64 ? npages - base : 64;
+        for (int i = 0; i < cnt; i++) {
+            const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)ph, i);
+            if (phi == C6_NOPAGE) continue;
+            C6RecStat *rs = E.rec_stat + (((size_t)phi << C6_PAGE_SHIFT) | (size_t)lane);
+            const int lv = rs->level;
+            const bool kill = lv >= 0 && lv <= kill_level;
+            if (kill) rs->level = -1;
+            const unsigned long long lm = __ballot(lv >= 0 && !kill);
+            if (lane == i) my_fm = ~lm;
+        }
+        const bool valid = ph != C6_NOPAGE;
+        if (valid) E.page_free[ph] = my_fm;
+        const unsigned long long vm = __ballot(valid), em = __ballot(valid && my_fm == ~0ull);
+        nheld += __popcll(vm);
+        nempty += __popcll(em);
+        const int f = c6_wave_sum_i32(valid && my_fm != ~0ull ? __popcll(my_fm) : 0);
+        free_ne += f;
+        nlive += C6_PAGE_RECS * __popcll(vm & ~em) - f;
+    }
+    __threadfence_block();
+    // what the next move needs
+    const int need_pages = free_ne >= want_free ? 0 : (want_free - free_ne + C6_PAGE_RECS - 1) >> C6_PAGE_SHIFT;      // empty pages to keep / acquire
+    const int keep_empty = need_pages < nempty ? need_pages : nempty;
+    int acquire = need_pages - keep_empty;
+    int Hn = 0;
+    if (want_free > 0 || nlive > 0) {
+        Hn = C6_CHUNK_SLOTS;
+        while (Hn < 2 * (nlive + E.S)) Hn <<= 1;
+    }
+    int park = C6_PARK_NONE;
+    if (nheld - (nempty - keep_empty) + acquire > E.pages_cap || Hn > E.hcap) park = C6_PARK_CAPS;
+    // pass 2: hand back the empty pages beyond keep_empty (their logical slots become vacant)
+    if (nempty > keep_empty) {
+        int seen = 0;
+        for (int base = 0; base < npages; base += 64) {
+            const int lp = base + lane;
+            const uint32_t ph = lp < npages ? ptg[lp] : C6_NOPAGE;
+            const bool empty = ph != C6_NOPAGE && E.page_free[ph] == ~0ull;
+            const unsigned long long em = __ballot(empty);
+            const bool give = empty && seen + __popcll(em & ltmask) >= keep_empty;
+            const unsigned long long gm = __ballot(give);
+            ring_push(E.page_ring, E.page_ring_mask, E.pool_ctr, C6_POOL_PAGE_TAIL, gm, lane, ph);
+            if (give) ptg[lp] = C6_NOPAGE;
+            seen += __popcll(em);
+        }
+        nheld -= nempty - keep_empty;
+        __threadfence_block();
+    }
+    int nfree = free_ne + keep_empty * C6_PAGE_RECS;
+    // acquire, in batches of <= 64: pop, then place into the vacant logical slots from the bottom (the caps check above guarantees
+    // that enough of them lie below pages_cap)
+    if (park == C6_PARK_NONE) {
+        int lp0 = 0;
+        while (acquire > 0) {
+            const int n = acquire < 64 ? acquire : 64;
+            uint32_t nid = C6_NOPAGE;
+            if (!ring_pop(E.page_ring, E.page_ring_mask, E.pool_ctr, C6_POOL_PAGE_HEAD, C6_POOL_PAGE_LIMIT, n, lane, nid)) { park = C6_PARK_POOL; break; }
+            if (lane < n) E.page_free[nid] = ~0ull;      // (its records are level -1: a page is handed back only when it is empty)
+            int placed = 0;
+            while (placed < n && lp0 < E.pages_cap) {
+                const int lp = lp0 + lane;
+                const bool vac = lp < E.pages_cap && (lp >= npages || ptg[lp] == C6_NOPAGE);
+                const unsigned long long vm = __ballot(vac);
+                const int rank = placed + __popcll(vm & ltmask);
+                const uint32_t src = (uint32_t)__shfl((int)nid, rank < n ? rank : 0, 64);
+                const bool take = vac && rank < n;
+                if (take) ptg[lp] = src;
+                const int last = c6_wave_max_i32(take ? lp : -1);
+                if (last + 1 > npages) npages = last + 1;
+                const int avail = __popcll(vm);
+                if (avail <= n - placed) { placed += avail; lp0 += 64; }      // group used up
+                else placed = n;                                                // the next batch starts in this group again
+            }
+            __threadfence_block();
+            nheld += n;
+            nfree += n * C6_PAGE_RECS;
+            acquire -= n;
+        }
+    }
+    // trailing vacant slots shrink npages
+    {
+        int hi = 0;
+        for (int base = 0; base < npages; base += 64) {
+            const int lp = base + lane;
+            const bool valid = lp < npages && ptg[lp] != C6_NOPAGE;
+            const int top = c6_wave_max_i32(valid ? lp + 1 : 0);
+            if (top > hi) hi = top;
+        }
+        npages = hi;
+    }
+    // the table: Hn slots if the game is not parked, else the size it has (a parked game does not search)
+    const int Hold = (int)E.hdr[g].hslots;
+    if (park != C6_PARK_NONE) Hn = Hold;
+    if (Hn != Hold) {
+        const int nold = Hold >> C6_CHUNK_SHIFT, nnew = Hn >> C6_CHUNK_SHIFT;
+        if (nnew < nold) {
+            for (int base = nnew; base < nold; base += 64) {
+                const int k = base + lane;
+                ring_push(E.chunk_ring, E.chunk_ring_mask, E.pool_ctr, C6_POOL_CHUNK_TAIL, __ballot(k < nold), lane, k < nold ? ckg[k] : 0u);
+            }
+        } else {
+            int have = nold;
+            while (have < nnew) {
+                const int n = nnew - have < 64 ? nnew - have : 64;
+                uint32_t nid = 0u;
+                if (!ring_pop(E.chunk_ring, E.chunk_ring_mask, E.pool_ctr, C6_POOL_CHUNK_HEAD, C6_POOL_CHUNK_LIMIT, n, lane, nid)) break;
+                if (lane < n) ckg[have + lane] = nid;
+                have += n;
+            }
+            if (have < nnew) {      // not enough chunks: what was taken goes back, the table keeps its old size, the game is parked
+                for (int base = nold; base < have; base += 64) {
+                    const int k = base + lane;
+                    ring_push(E.chunk_ring, E.chunk_ring_mask, E.pool_ctr, C6_POOL_CHUNK_TAIL, __ballot(k < have), lane, k < have ? ckg[k] : 0u);
+                }
+                park = C6_PARK_POOL;
+                Hn = Hold;
+            }
+        }
+    }
+    __threadfence_block();
+    // rebuild: clear the chunks, insert the live records
+    int rr = -1;
+    if (Hn > 0) {
+        const int nck = Hn >> C6_CHUNK_SHIFT;
+        for (int c = 0; c < nck; c++) {
+            const size_t cb = (size_t)ckg[c] << C6_CHUNK_SHIFT;
+            uint4 *h4 = reinterpret_cast<uint4 *>(E.ht + cb), *t4 = reinterpret_cast<uint4 *>(E.ht_tag + cb);
+            for (int i = lane; i < C6_CHUNK_SLOTS; i += 64) h4[i] = uint4{0u, 0u, 0u, 0u};
+            t4[lane] = uint4{0u, 0u, 0u, 0u};
+        }
+        __threadfence_block();
+        for (int base = 0; base < npages; base += 64) {
+            const int lp = base + lane;
+            const uint32_t ph = lp < npages ? ptg[lp] : C6_NOPAGE;
+            const int cnt = npages - base < 64 ? npages - base : 64;
+            for (int i = 0; i < cnt; i++) {
+                const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)ph, i);
+                if (phi == C6_NOPAGE) continue;
+                const size_t at = ((size_t)phi << C6_PAGE_SHIFT) | (size_t)lane;
+                const C6RecStat rs = E.rec_stat[at];
+                if (rs.level >= 0) {
+                    const int r = ((base + i) << C6_PAGE_SHIFT) | lane;
+                    const int slot = ht_insert_atomic(E.ht, E.ht_tag, ckg, Hn, rs.key, r, rs.visit, rs.q);
+                    if (slot >= 0) E.rec_stat[at].slot = (uint32_t)slot;
+                    if (rs.key == find) rr = r;
+                }
+            }
+        }
+    }
+    rr = c6_wave_max_i32(rr);
+    // the allocation page: the first one with a free record
+    int ap = -1;
+    for (int base = 0; base < npages && ap < 0; base += 64) {
+        const int lp = base + lane;
+        const uint32_t ph = lp < npages ? ptg[lp] : C6_NOPAGE;
+        const unsigned long long m = __ballot(ph != C6_NOPAGE && E.page_free[ph] != 0ull);
+        if (m) ap = base + __ffsll((long long)m) - 1;
+    }
+    if (lane == 0) {
+        C6GameHdr &h = E.hdr[g];
+        h.npages = (uint16_t)npages;
+        h.alloc_page = (uint16_t)(ap < 0 ? 0 : ap);
+        h.hslots = (uint32_t)Hn;
+        h.free_top = nfree;
+        h.live_pages = nheld;
+        h.park = (uint32_t)park;
+        if (park != C6_PARK_NONE) { if (h.status == C6_ST_PLAYING) h.status = C6_ST_OVERFLOW; }
+        else if (h.status == C6_ST_OVERFLOW) h.status = C6_ST_PLAYING;
+    }
+    return rr;
+}
+
+template <int J>
 __device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane, uint32_t uid, int presims) {
     const int cells = E.cells;
     for (int c = lane; c < cells; c += 64) {
         E.board_soa[(size_t)c * E.Gpad + g] = 0;
         E.root_board[(size_t)g * E.cellsP + c] = 0;
     }
-    const size_t rbase = (size_t)g * E.R;
-    for (int r = lane; r < E.R; r += 64) {
-        E.rec_stat[rbase + r].level = -1;
-        E.free_stack[rbase + r] = (uint16_t)(E.R - 1 - r);   // pop order 0,1,2,...
-    }
-    uint4 *ht = reinterpret_cast<uint4 *>(E.ht + (size_t)g * E.H);
-    for (int i = lane; i < E.H; i += 64) ht[i] = uint4{0u, 0u, 0u, 0u};
-    uint4 *tg = reinterpret_cast<uint4 *>(E.ht_tag + (size_t)g * E.H);
-    for (int i = lane; i < E.H / 16; i += 64) tg[i] = uint4{0u, 0u, 0u, 0u};
     if (lane == 0) {
         E.turn[g] = C6_BLACK;       // Game::new, game_impl/mod.rs:125-131
         E.remain[g] = 1;
@@ -747,40 +1044,20 @@ __device__ __forceinline__ void reset_game_wave(const C6Dev &E, int g, int lane,
         E.hdr[g].root_key = C6_EMPTY_BOARD_KEY;
         E.hdr[g].rootc_ok = 0u;
         E.hdr[g].root_rec = -1;
-        E.hdr[g].free_top = E.R;
-        E.hdr[g].rec_hi = 0;
         E.hdr[g].leaf_kind = C6_LEAF_NONE;
         E.move_pos[g] = -2;
     }
+    __threadfence_block();
+    reprovision_wave<J>(E, g, lane, 32767, 0ull, E.S);      // every record dropped; pages beyond one move's worth go back to the pool
 }
 
+// engine creation: the games own nothing yet (npages = 0, no chunks)
+template <int J>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_reset_kernel(C6Dev E) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= E.G) return;
-    reset_game_wave(E, g, lane, E.uid_base + (uint32_t)g, 0);
-}
-
-// table of a game rebuilt from its live records (after a prune / a growth): entries carry the records' current statistics;
-// returns (wave-uniform) the record whose key is `find`, or -1
-__device__ __forceinline__ int rebuild_table_wave(const C6Dev &E, int g, int lane, int hi, unsigned long long find) {
-    const size_t rbase = (size_t)g * E.R;
-    C6HtEntry *ht = E.ht + (size_t)g * E.H;
-    uint8_t *tag = E.ht_tag + (size_t)g * E.H;
-    uint4 *ht4 = reinterpret_cast<uint4 *>(ht), *tg4 = reinterpret_cast<uint4 *>(tag);
-    for (int i = lane; i < E.H; i += 64) ht4[i] = uint4{0u, 0u, 0u, 0u};
-    for (int i = lane; i < E.H / 16; i += 64) tg4[i] = uint4{0u, 0u, 0u, 0u};
-    __threadfence_block();
-    int rr = -1;
-    for (int r = lane; r < hi; r += 64) {
-        const C6RecStat rs = E.rec_stat[rbase + r];
-        if (rs.level >= 0) {
-            const int slot = ht_insert_atomic(ht, tag, E.H, rs.key, r, rs.visit, rs.q);
-            if (slot >= 0) E.rec_stat[rbase + r].slot = (uint32_t)slot;
-            if (rs.key == find) rr = r;
-        }
-    }
-    return c6_wave_max_i32(rr);
+    reset_game_wave<J>(E, g, lane, E.uid_base + (uint32_t)g, 0);
 }
 
 // after the stone of game g was placed (by K1, or by the search kernel itself): advance the root, prune (next(), mod.rs:473-487),
@@ -789,7 +1066,6 @@ __device__ __forceinline__ int rebuild_table_wave(const C6Dev &E, int g, int lan
 template <int J>
 __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, int pos, int mover, int win_in, int err) {
     const int cells = E.cells;
-    const size_t rbase = (size_t)g * E.R;
     const int old_level = E.hdr[g].nstones;
     const unsigned long long old_key = E.hdr[g].root_key;
     unsigned long long new_key = old_key;
@@ -821,31 +1097,11 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
     __builtin_amdgcn_wave_barrier();
 
     if (!finished) {
-        // prune: nodes of the old root's level are dropped (mod.rs:473-484).  The re-inserted old root
-        // (:486) and older levels can never be reached again, so they are dropped too.
-        int top = E.hdr[g].free_top;
-        const int hi = E.hdr[g].rec_hi;
-        for (int r0 = 0; r0 < hi; r0 += 64) {
-            const int r = r0 + lane;
-            bool kill = false;
-            if (r < hi) {
-                const int lv = E.rec_stat[rbase + r].level;
-                kill = lv >= 0 && lv <= old_level;
-            }
-            const unsigned long long m = __ballot(kill);
-            if (kill) {
-                const int off = __popcll(m & ((1ull << lane) - 1ull));
-                E.free_stack[rbase + top + off] = (uint16_t)r;
-                E.rec_stat[rbase + r].level = -1;
-            }
-            top += __popcll(m);
-        }
-        __threadfence_block();
-        const int rr = rebuild_table_wave(E, g, lane, hi, new_key);   // rr: record of the new root, if that child was expanded (tree reuse)
-        if (lane == 0) {
-            E.hdr[g].free_top = top;
-            E.hdr[g].root_rec = rr;
-        }
+        // prune: nodes of the old root's level are dropped (mod.rs:473-484).  The re-inserted old root (:486) and older levels can
+        // never be reached again, so they are dropped too.  Then the pages / table for the next move, and the table rebuilt from the
+        // surviving records; rr: record of the new root, if that child was expanded (tree reuse)
+        const int rr = reprovision_wave<J>(E, g, lane, old_level, new_key, E.S);
+        if (lane == 0) E.hdr[g].root_rec = rr;
         return;
     }
 
@@ -898,15 +1154,22 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
         if (lane == 0) atomicAdd(&E.counters[C6_CNT_TUPLES], (unsigned long long)nst);
     }
     if (E.recycle) {
-        reset_game_wave(E, g, lane, uid + E.uid_stride, 0);
-    } else if (lane == 0) {
-        E.hdr[g].status = C6_ST_FINISHED;
-        E.winner[g] = (int8_t)win;
+        reset_game_wave<J>(E, g, lane, uid + E.uid_stride, 0);
+    } else {
+        if (lane == 0) {
+            E.hdr[g].status = C6_ST_FINISHED;
+            E.hdr[g].root_rec = -1;
+            E.winner[g] = (int8_t)win;
+        }
+        __threadfence_block();
+        reprovision_wave<J>(E, g, lane, 32767, 0ull, 0);      // a finished game holds nothing
     }
 }
 
-// head of every round for game g: the move K1 applied last round, if any.  Steady-state mode also abandons -- counted, never
-// silently -- a slot whose game stopped in an error state (pool exhausted with no host to grow it, NaN scores).
+// head of every round for game g: the move K1 applied last round, if any; a parked game asks the pools again (pages come back from
+// other games all the time, and the host may have mapped more memory or raised the caps).  Steady-state mode also abandons -- counted,
+// never silently -- a slot whose game stopped with NaN scores, and a parked one once the host has said that nothing more can be done
+// (E.abandon_parked: growth failed).
 template <int J>
 __device__ __forceinline__ void round_head_wave(const C6Dev &E, int g, int lane) {
     const int pos = E.move_pos[g];
@@ -918,11 +1181,19 @@ __device__ __forceinline__ void round_head_wave(const C6Dev &E, int g, int lane)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return;
     }
-    const int stt = E.hdr[g].status;
+    int stt = E.hdr[g].status;
+    if (stt == C6_ST_OVERFLOW) {
+        const int rr = reprovision_wave<J>(E, g, lane, -1, E.hdr[g].root_key, E.S);
+        if (lane == 0 && rr >= 0) E.hdr[g].root_rec = rr;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        stt = E.hdr[g].status;
+        if (!(stt == C6_ST_OVERFLOW && E.recycle && E.abandon_parked)) return;
+    }
     if (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW)) {
         const uint32_t uid_ = E.hdr[g].game_uid;
         if (lane == 0) atomicAdd(&E.counters[C6_CNT_OVERFLOW], 1ull);
-        reset_game_wave(E, g, lane, uid_ + E.uid_stride, 0);
+        reset_game_wave<J>(E, g, lane, uid_ + E.uid_stride, 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
@@ -937,8 +1208,10 @@ __device__ __noinline__ void round_head_call(const C6Dev *Es, int g, int lane) {
 template <int J>
 __device__ __noinline__ void move_call(const C6Dev *Es, int g, int lane, uint8_t *tag_row, int8_t *lboard) {
     const C6Dev &E = *Es;
-    C6Tags T;
-    T.g = E.ht_tag + (size_t)g * E.H; T.mask = (uint32_t)(E.H - 1); T.lds = E.H <= C6_TAG_LDS_MAX; T.l = (c6_lds_u8 *)tag_row;
+    C6Tags T;      // the wave's LDS copies (tags_load) are still current: nothing of the game's storage has moved since
+    tags_bind(E, tag_row, T);
+    T.mask = E.hdr[g].hslots - 1u;
+    T.lds = E.hdr[g].hslots <= (uint32_t)C6_TAG_LDS_MAX;
     const int pos = move_select_wave<J>(E, g, lane, T, false);
     const int mover = E.turn[g];
     int win = 0;
@@ -990,7 +1263,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
     int stt = E.hdr[g].status;
     C6GameRegs<J> R;
     load_game_regs<J>(E, g, lane, R);
-    if (pos0 != -2 || (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW))) {
+    if (pos0 != -2 || stt == C6_ST_OVERFLOW || (E.recycle && stt == C6_ST_ERROR)) {
         round_head_call<J>(&Es, g, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -999,8 +1272,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
     }
     if (stt != C6_ST_PLAYING) return;
     C6Tags T;
-    uint8_t *tag_row = c6_tag_lds + (size_t)wv * tag_row_bytes(E.H);
+    uint8_t *tag_row = c6_tag_lds + (size_t)wv * c6_wave_lds(E.hcap, E.pages_cap);
     tags_load(E, g, lane, tag_row, T);
+    free_record_prefetch<J>(E, T, R);
     float *probs = reinterpret_cast<float *>(gscratch[wv]);
     int8_t *lboard = reinterpret_cast<int8_t *>(probs + 64 * J);
     for (int it = 0;;) {
@@ -1013,7 +1287,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
         }
         float pr[J], value = 0.f;
         if (L.kind == C6_LEAF_EVAL) {
-            eval_builtin_regs<J>(E, g, lane, KIND, R.nsearch, L.st, pr, value);
+            eval_builtin_regs<J>(E, g, lane, KIND, R.nsearch, L.turn, L.st, pr, value);
 #pragma unroll
             for (int j = 0; j < J; j++) probs[lane + 64 * j] = pr[j];
         } else {
@@ -1034,7 +1308,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
         // the next round of the same game: its state as this wave left it
         if (E.hdr[g].status != C6_ST_PLAYING) break;
         load_game_regs<J>(E, g, lane, R);
-        if (spent) tags_load(E, g, lane, tag_row, T);      // the table was rebuilt
+        if (spent) tags_load(E, g, lane, tag_row, T);      // the table was rebuilt, pages may have changed hands
+        free_record_prefetch<J>(E, T, R);
     }
 }
 
@@ -1054,7 +1329,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)
     C6GameRegs<J> R;
     load_game_regs<J>(E, g, lane, R);
     C6Tags T;
-    tags_load(E, g, lane, c6_tag_lds + (size_t)wv * tag_row_bytes(E.H), T);
+    tags_load(E, g, lane, c6_tag_lds + (size_t)wv * c6_wave_lds(E.hcap, E.pages_cap), T);
     C6Leaf<J> L;
     select_wave<J>(E, g, lane, gscratch[wv], T, R, L);
     if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
@@ -1098,7 +1373,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
     }
     if (L.kind == C6_LEAF_NONE) return;
     C6Tags T;
-    tags_load(E, g, lane, c6_tag_lds + (size_t)wv * tag_row_bytes(E.H), T);
+    tags_load(E, g, lane, c6_tag_lds + (size_t)wv * c6_wave_lds(E.hcap, E.pages_cap), T);
+    free_record_prefetch<J>(E, T, R);
     if (expand_wave<J>(E, g, lane, T, R, L, evalue, E.eval_prior + (size_t)g * E.cells, E.leaf_board + (size_t)g * E.cellsP)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1122,30 +1398,14 @@ __global__ void c6_stagger_kernel(C6Dev E) {
     if (g < E.G) E.hdr[g].sim_in_move = g % E.S;
 }
 
-// ---- record-pool growth ---------------------------------------------------------------------
-// Host side (engine.cpp grow_pool) allocated arrays for N.R > O.R records per game and copied every game's [0, O.R) prefix.
-// Here: the new records are free (level -1) and go UNDER the old free stack (old free indices are handed out first), the
-// table is rebuilt at its new size from the live records, and a game that had stopped for space plays on -- its interrupted
-// search had written nothing (select: before the path store; expand: before the pop), so it is repeated identically.
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_grow_fix_kernel(C6Dev O, C6Dev Nw) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (g >= Nw.G) return;
-    const size_t ob = (size_t)g * O.R, nb = (size_t)g * Nw.R;
-    const int add = Nw.R - O.R, top = O.hdr[g].free_top;
-    for (int r = O.R + lane; r < Nw.R; r += 64) Nw.rec_stat[nb + r].level = -1;
-    for (int i = lane; i < add; i += 64) Nw.free_stack[nb + i] = (uint16_t)(Nw.R - 1 - i);       // bottom of the stack: pops O.R, O.R+1, ... last
-    for (int i = lane; i < top; i += 64) Nw.free_stack[nb + add + i] = O.free_stack[ob + i];
-    __threadfence_block();
-    rebuild_table_wave(Nw, g, lane, O.hdr[g].rec_hi, 0ull);      // the table at its new size, entries with the records' current statistics
-    if (lane == 0) {
-        Nw.hdr[g].free_top = top + add;
-        if (Nw.hdr[g].status == C6_ST_OVERFLOW) Nw.hdr[g].status = C6_ST_PLAYING;
+// limit = tail of both rings: what earlier launches handed back becomes available to this one (c6_engine.h)
+__global__ void c6_pool_snapshot_kernel(C6Dev E) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        E.pool_ctr[C6_POOL_PAGE_LIMIT] = E.pool_ctr[C6_POOL_PAGE_TAIL];
+        E.pool_ctr[C6_POOL_CHUNK_LIMIT] = E.pool_ctr[C6_POOL_CHUNK_TAIL];
     }
 }
-void c6_launch_grow_fix(const C6Dev &old, const C6Dev &nw, hipStream_t s) {
-    hipLaunchKernelGGL(c6_grow_fix_kernel, dim3((nw.G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(64 * WAVES_PER_BLOCK), 0, s, old, nw);
-}
+void c6_launch_pool_snapshot(const C6Dev &d, hipStream_t s) { hipLaunchKernelGGL(c6_pool_snapshot_kernel, dim3(1), dim3(64), 0, s, d); }
 
 // Games that stopped in an error state leave as they stand: PlayResult{winner None, the path so far} -- what a caller of the
 // reference would hold had Agent::play returned its Err (agent_impl/mod.rs:163) instead of the bindings' unwrap().
@@ -1173,7 +1433,8 @@ void c6_launch_flush_errors(const C6Dev &d, hipStream_t s) {
 }
 
 static inline int wave_grid(int G) { return (G + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }
-static inline size_t tag_lds(const C6Dev &d) { return (size_t)WAVES_PER_BLOCK * tag_row_bytes(d.H); }      // dynamic LDS of the kernels that hold tag rows
+static inline size_t tag_lds(const C6Dev &d) { return (size_t)WAVES_PER_BLOCK * c6_wave_lds(d.hcap, d.pages_cap); }      // dynamic LDS of the kernels that hold a game's tag row / lists
+size_t c6_tree_lds_bytes(const C6Dev &d) { return tag_lds(d); }
 
 // J = cells owned by one lane: 2 (9x9), 4 (15x15), 6 (19x19)
 #define C6_LAUNCH_J(KERNEL, d, s)                                                                                     \
@@ -1191,11 +1452,16 @@ static inline size_t tag_lds(const C6Dev &d) { return (size_t)WAVES_PER_BLOCK * 
         else hipLaunchKernelGGL((KERNEL<6, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d, n);             \
     } while (0)
 
-void c6_launch_search(const C6Dev &d, int kind, int nsims, hipStream_t s) {      // kind 1: RandomEvaluator, 2: uniform
+void c6_launch_search(const C6Dev &d, int kind, int nsims, hipStream_t s) {      // kind 1: RandomEvaluator, 2: uniform, 3: stress (peaked / uniform by uid)
+    c6_launch_pool_snapshot(d, s);
     if (kind == 1) C6_LAUNCH_JK(c6_search_kernel, 1, d, nsims, s);
-    else C6_LAUNCH_JK(c6_search_kernel, 2, d, nsims, s);
+    else if (kind == 2) C6_LAUNCH_JK(c6_search_kernel, 2, d, nsims, s);
+    else C6_LAUNCH_JK(c6_search_kernel, 3, d, nsims, s);
 }
-void c6_launch_select(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_select_kernel, d, s); }
+void c6_launch_select(const C6Dev &d, hipStream_t s) {
+    c6_launch_pool_snapshot(d, s);
+    C6_LAUNCH_J(c6_select_kernel, d, s);
+}
 void c6_launch_expand(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_expand_kernel, d, s); }
 void c6_launch_recover(const C6Dev &d, hipStream_t s) {
     hipLaunchKernelGGL(c6_recover_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
@@ -1203,9 +1469,13 @@ void c6_launch_recover(const C6Dev &d, hipStream_t s) {
 void c6_launch_augment(const C6Dev &d, float *img, hipStream_t s) {
     hipLaunchKernelGGL(c6_augment_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d, img);
 }
-void c6_launch_post_move(const C6Dev &d, hipStream_t s) { C6_LAUNCH_J(c6_post_move_kernel, d, s); }
+void c6_launch_post_move(const C6Dev &d, hipStream_t s) {
+    c6_launch_pool_snapshot(d, s);
+    C6_LAUNCH_J(c6_post_move_kernel, d, s);
+}
 void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s) {
-    hipLaunchKernelGGL(c6_reset_kernel, dim3(wave_grid(d.G)), dim3(64 * WAVES_PER_BLOCK), 0, s, d);
+    c6_launch_pool_snapshot(d, s);
+    C6_LAUNCH_J(c6_reset_kernel, d, s);
     if (stagger) hipLaunchKernelGGL(c6_stagger_kernel, dim3((d.G + 255) / 256), dim3(256), 0, s, d);
 }
 

@@ -129,7 +129,13 @@ enum {
     C6_EVAL_RANDOM = 1,   /* RandomEvaluator (mod.rs:137-169) on the seeded C6RNG stream, on device */
     C6_EVAL_UNIFORM = 2,  /* value 0, policy 1/N^2 on device ("zero-cost evaluator", BASELINE config 5) */
     C6_EVAL_NET = 3,      /* resident policy/value ResNet (AlphaZero/cpp_weighted/model.hpp:9-95) */
-    C6_EVAL_CALLBACK = 4  /* host callback with the reference's signature */
+    C6_EVAL_CALLBACK = 4, /* host callback with the reference's signature */
+    C6_EVAL_STRESS = 5    /* soak test of the record pools, on device: games whose uid is a multiple of `stress_every` get a prior peaked on
+                             the innermost ring of empty cells around the board centre -- prior(c) = 2^(-20 min(d2(c) - d2min, 6)), d2 = squared
+                             distance to the centre, d2min its minimum over the empty cells -- and value -0.875 * side to move (with a small
+                             epsilon nearly every search follows the peak level after level: the tree grows DEEP and keeps several times
+                             num_simulation records alive); the other games get the uniform evaluator.  All values are powers of two /
+                             multiples of 1/8: the dihedral average is exact and a CPU evaluator reproduces it bit for bit */
 };
 
 /* Arithmetic of the net's 3x3 convolutions (everything else is FP32).  The reference net is f32 (AlphaZero/cpp_weighted/model.hpp:52-95),
@@ -167,14 +173,17 @@ typedef struct c6_config {
     int evaluator;           /* C6_EVAL_* */
     int net_channels;        /* C (reference: 256) */
     int net_blocks;          /* reference `num_block`: stem + (num_block-1) residual blocks */
-    int records_per_game;    /* 0: 4 * num_simulation + 64 */
+    int records_per_game;    /* AVERAGE expanded-node records per game the shared pool is sized for at creation (0: 4 * num_simulation + 64;
+                                whole pages of 64, never less than one move's searches + a page).  The pool is shared: a game holds what
+                                its tree needs, and more memory is mapped when the pool runs low (c6_engine_run / c6_engine_maintain) */
     int recycle;             /* 1: a finished game slot restarts at once (steady-state mode) */
     int stagger;             /* 1: game i starts its first move with (i mod num_simulation) simulations
                                 already counted, so every round advances num_games/num_simulation games */
     int device;              /* HIP device ordinal */
     int net_chunk_boards;    /* 0: automatic; boards (dihedral images) per net pass */
     int net_precision;       /* C6_PREC_*: arithmetic of the 3x3 convolutions (everything else is FP32) */
-    int max_records_per_game;/* 0: 65000.  Ceiling for the automatic growth of records_per_game (c6_engine_run / c6_engine_maintain) */
+    int max_records_per_game;/* 0: 65000 (record indices travel as 16 bits).  The most records ONE game may hold */
+    int stress_every;        /* C6_EVAL_STRESS: games with uid % stress_every == 0 get the peaked evaluator (0: every game) */
 } c6_config;
 
 typedef struct c6_engine c6_engine;
@@ -224,6 +233,10 @@ int c6_engine_run(c6_engine *e, long max_rounds);
 int c6_engine_maintain(c6_engine *e);
 int c6_engine_sync(c6_engine *e);
 
+/* the canonical game state (what K1 reads and writes): boards[g][N*N] in {-1, 0, +1}, the side to move and the stones it still has
+ * to place (Game{turn, num_remain}, game_impl/mod.rs:117-121); any of the pointers may be NULL.  Synchronises. */
+int c6_engine_boards(c6_engine *e, int8_t *boards, int8_t *turn, int8_t *remain);
+
 typedef struct c6_stats {
     uint64_t rounds;          /* rounds stepped */
     uint64_t simulations;     /* searches performed (all games) */
@@ -236,8 +249,16 @@ typedef struct c6_stats {
     uint32_t max_records_used;
     uint32_t max_depth;
     uint64_t abandoned_games;  /* games given up in an error state (recycled slots, or flushed as partial results by c6_engine_run) */
-    uint32_t records_per_game; /* current capacity R of a game's record pool (grows, see c6_engine_maintain) */
-    uint32_t pool_grows;       /* times the pool was doubled */
+    uint32_t records_per_game; /* records ONE game may hold right now without the host (64 x the per-game page cap; raised by
+                                  c6_engine_maintain up to max_records_per_game) */
+    uint32_t pool_grows;       /* times memory was mapped into the pools after creation */
+    uint32_t pool_pages;       /* record pages (64 records each) in the pool shared by all games */
+    uint32_t pool_pages_free;  /* ... of which no game holds now */
+    uint32_t pool_pages_low;   /* fewest free pages any acquisition has seen */
+    uint32_t cap_raises;       /* times the per-game caps were raised */
+    uint32_t parked_games;     /* games waiting at a move boundary for pages / chunks / caps (they are part of overflow_games) */
+    uint32_t max_pages_held;   /* most pages one game holds now */
+    uint64_t pool_bytes;       /* device memory mapped for the two pools */
 } c6_stats;
 int c6_engine_stats(c6_engine *e, c6_stats *out); /* synchronises */
 

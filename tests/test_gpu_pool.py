@@ -40,36 +40,59 @@ def oracle_games(G, S, seed, eps):
     return [([r * N + c for _, _, (r, c) in g["path"]], g["winner"]) for g in ref]
 
 
-def test_pool_grows_under_a_peaked_prior_and_games_stay_exact():
-    """8 records per game to start with, a prior that drives the select depth far beyond 8: c6_engine_run doubles the pools (and
-    the select-path buffer) as often as needed and every game still equals the oracle's unbounded map stone for stone."""
+def stress_eval_fn(n):
+    """the oracle's side of C6_EVAL_STRESS (every game peaked): pkg.stress_eval as an EVAL_CUSTOM callback"""
+    def fn(ctx, turn, nn, ln, boards, values, policies):
+        b = np.ctypeslib.as_array(boards, shape=(ln, nn * nn))
+        v, p = pkg.stress_eval(nn, turn, b)
+        np.ctypeslib.as_array(values, shape=(ln,))[:] = v
+        np.ctypeslib.as_array(policies, shape=(ln, nn * nn))[:] = p
+        return 0
+    return fn
+
+
+def test_trees_grow_past_the_per_game_caps_and_games_stay_exact():
+    """A pool sized for 8 records per game (rounded up to one move's worth: 2 pages) and a prior that keeps several times
+    num_simulation records alive: the games take page after page from the shared pool at their move boundaries, c6_engine_run
+    raises the per-game caps when they reach them, and every game still equals the oracle's unbounded map stone for stone."""
     need_gpu()
     G, S, seed, eps = 4, 60, 5, 0.001
     eng = pkg.Engine(board_size=N, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_CALLBACK, records_per_game=8)
     eng.set_callback(peaked)
+    st0 = eng.stats()
+    assert st0["records_per_game"] == 4 * 64 and st0["pool_pages_free"] == st0["pool_pages"] - G * 1      # every game holds one move's worth (60 records: a page)
     eng.run()
     st = eng.stats()
     games = {g["uid"]: g for g in eng.fetch_games()}
     eng.close()
     assert st["overflow_games"] == 0 and st["abandoned_games"] == 0 and len(games) == G
-    assert st["pool_grows"] >= 3 and st["records_per_game"] >= 64 and st["max_depth"] > 8, st
+    assert st["cap_raises"] >= 1 and st["records_per_game"] >= 8 * 64 and st["max_depth"] > 8 and st["max_records_used"] > 4 * 64, st
+    assert st["pool_pages_free"] == st["pool_pages"]                                            # finished games hold nothing
     for uid, (mv, w) in enumerate(oracle_games(G, S, seed, eps)):
         assert list(games[uid]["moves"]) == mv and games[uid]["winner"] == w
 
 
 def test_step_without_maintain_parks_the_game_and_maintain_resumes_it_exactly():
-    """c6_engine_step never synchronises, so it cannot grow: the game waits in status overflow (visible in the stats), loses
-    nothing, and continues after c6_engine_maintain -- same final game as the oracle."""
+    """c6_engine_step never synchronises, so it cannot raise the caps: a game that needs more pages than the cap allows waits at its
+    move boundary (visible in the stats: parked_games), loses nothing, and continues after c6_engine_maintain -- same final game as
+    the oracle."""
     need_gpu()
-    G, S, seed, eps = 2, 30, 9, 0.001
+    G, S, seed, eps = 2, 60, 9, 0.001
     eng = pkg.Engine(board_size=N, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_CALLBACK, records_per_game=8)
     eng.set_callback(peaked)
-    eng.step(20)
-    st = eng.stats()
-    assert st["overflow_games"] == G and st["live_games"] == 0 and st["simulations"] == 8 * G      # stopped when the 8 records were used
+    sims = -1
+    for _ in range(400):
+        eng.step(S)
+        st = eng.stats()
+        if st["parked_games"] == G and st["simulations"] == sims:
+            break
+        sims = st["simulations"]
+    assert st["parked_games"] == G and st["live_games"] == 0 and st["overflow_games"] == G, st
+    assert st["simulations"] % S == 0                         # parked at move boundaries: no search was cut short
     eng.maintain()
+    eng.step(1)
     st = eng.stats()
-    assert st["overflow_games"] == 0 and st["live_games"] == G and st["records_per_game"] == 16
+    assert st["parked_games"] == 0 and st["live_games"] == G and st["cap_raises"] == 1, st
     eng.run()
     games = {g["uid"]: g for g in eng.fetch_games()}
     eng.close()
@@ -84,7 +107,7 @@ def test_exhausted_pool_returns_partial_games_and_says_so():
     need_gpu()
     G, S, seed, eps = 3, 40, 5, 0.001
     eng = pkg.Engine(board_size=N, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_CALLBACK, records_per_game=8,
-                     max_records_per_game=32)
+                     max_records_per_game=128)
     eng.set_callback(peaked)
     with pytest.raises(pkg.C6Error) as ei:
         eng.run()
@@ -105,12 +128,70 @@ def test_exhausted_pool_returns_partial_games_and_says_so():
     assert partial == st["abandoned_games"]
 
 
+def test_shared_pool_grows_by_mapping_and_pages_change_hands():
+    """4096 games on the device-side stress evaluator (C6_EVAL_STRESS: every fourth game's tree keeps ~6 x num_simulation records
+    alive, the others stay small), a pool created for one move's worth per game: the deep games take what the shallow ones never
+    need, the pool maps more memory when it runs low (pool_grows), pages return when games end.  Sampled games of both kinds equal
+    the oracle stone for stone; at the end every page is back in the pool."""
+    need_gpu()
+    n, G, S, seed, eps, every = 9, 4096, 60, 13, 0.001, 4
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_STRESS, stress_every=every,
+                     records_per_game=8)
+    st0 = eng.stats()
+    eng.run()
+    st = eng.stats()
+    games = {g["uid"]: g for g in eng.fetch_games()}
+    eng.close()
+    assert len(games) == G and st["overflow_games"] == 0 and st["abandoned_games"] == 0
+    assert st["pool_pages_free"] == st["pool_pages"] and st["pool_pages_low"] < st0["pool_pages_free"]
+    assert st["pool_grows"] >= 1 and st["pool_pages"] > st0["pool_pages"] and st["pool_bytes"] > st0["pool_bytes"], (st0, st)
+    assert st["max_records_used"] > 4 * S and st["cap_raises"] >= 1
+    fn = stress_eval_fn(n)
+    for uid in (0, 4, 1024, 4092):                              # peaked
+        ref = o.self_play(n, num=1, threads=1, num_simulation=S, seed=seed, epsilon=eps, eval_kind=o.EVAL_CUSTOM, eval_fn=fn, uid_base=uid)[0]
+        assert list(games[uid]["moves"]) == [r * n + c for _, _, (r, c) in ref["path"]] and games[uid]["winner"] == ref["winner"], uid
+    for uid in (1, 2, 1023, 4095):                              # uniform
+        ref = o.self_play(n, num=1, threads=1, num_simulation=S, seed=seed, epsilon=eps, eval_kind=o.EVAL_UNIFORM, uid_base=uid)[0]
+        assert list(games[uid]["moves"]) == [r * n + c for _, _, (r, c) in ref["path"]] and games[uid]["winner"] == ref["winner"], uid
+
+
+def test_recycled_error_slots_stay_consistent_without_stagger():
+    """recycle = 1, stagger = 0 and a host evaluator.  Games that cannot be served (max_records_per_game = 128) are abandoned
+    and their slots restart OUT OF PHASE with the aligned move rounds; K1 runs every round, so every move of a restarted game is applied
+    with its own winner / err: the canonical boards (K1's state) and the tree kernels' root positions stay identical for every slot, and
+    every game that finishes is the oracle's game."""
+    need_gpu()
+    G, S, seed, eps = 4, 20, 17, 0.001
+    eng = pkg.Engine(board_size=N, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_CALLBACK, records_per_game=8,
+                     max_records_per_game=128, recycle=True)
+    eng.set_callback(peaked)
+    done = []
+    for it in range(60):
+        eng.step(37)                                            # not a multiple of S: calls end in the middle of moves
+        eng.maintain()
+        boards, turn, remain = eng.boards()
+        for g in range(G):
+            r = eng.root(g)
+            if r["status"] == 0:
+                assert (r["board"].reshape(-1) == boards[g]).all() and r["turn"] == turn[g] and r["remain"] == remain[g], (it, g)
+        done += eng.fetch_games()
+    st = eng.stats()
+    eng.close()
+    assert st["abandoned_games"] >= 1, st
+    uids = [g["uid"] for g in done]
+    assert len(uids) == len(set(uids))
+    fn = None
+    for g in done[:6]:
+        ref = o.self_play(N, num=1, threads=1, num_simulation=S, seed=seed, epsilon=eps, eval_kind=o.EVAL_CUSTOM, eval_fn=oracle_eval, uid_base=g["uid"])[0]
+        assert list(g["moves"]) == [r * N + c for _, _, (r, c) in ref["path"]] and g["winner"] == ref["winner"], g["uid"]
+
+
 def test_dropin_self_play_survives_an_exhausted_pool(monkeypatch, capfd):
     """cpp_self_play with the pool capped by the environment knobs: no abort; every game comes back, the stopped ones as
     {winner 0, stones so far} with the reason on stderr (SURVEY 8b "Errors")."""
     need_gpu()
-    monkeypatch.setenv("C6_RECORDS", "48")          # the first move's 40 searches fit, the second move's do not
-    monkeypatch.setenv("C6_MAX_RECORDS", "48")
+    monkeypatch.setenv("C6_RECORDS", "48")
+    monkeypatch.setenv("C6_MAX_RECORDS", "128")      # two pages per game: the first moves fit, the trees the peaked prior grows do not
     monkeypatch.setenv("C6_SEED", "3")
     n = pkg.REF_N
 
