@@ -942,7 +942,7 @@ def stress_eval(n, player, boards):
     for i in range(b.shape[0]):
         empty = b[i] == 0
         if empty.any():
-            k = np.minimum(d2 - d2[empty].min(), 6)
+            k = np.clip(d2 - d2[empty].min(), 0, 6)
             pol[i] = np.where(empty, np.ldexp(np.float32(1.0), (-20 * k).astype(np.int32)), np.float32(0.0))
     return np.full(b.shape[0], -0.875 * player, np.float32), pol
 

@@ -142,9 +142,12 @@ struct DevPool {
 // A device array whose physical memory is mapped piece by piece behind one address (HIP virtual memory management): the record and
 // table pools grow without a copy and without a second allocation living beside the first.  Without VMM support the array is one
 // hipMalloc of its initial size and cannot grow.
+// Every piece of an array has the SAME size (`unit`, a multiple of the mapping granularity) and sits at a multiple of it: on this runtime
+// (ROCm 7.2) hipMemSetAccess refuses a piece whose size differs from its neighbours' at most offsets, and setting the access of a whole
+// mapped prefix at once is accepted but leaves part of it unmapped (profiles/r03_vmm_probe.txt: "81 then 567", "mode 1").
 struct VmRange {
     char *base = nullptr;
-    size_t reserved = 0, mapped = 0, gran = 0;
+    size_t reserved = 0, mapped = 0, gran = 0, unit = 0;
     bool vmm = false;
     int device = 0;
     std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> parts;      // handle, bytes
@@ -159,13 +162,26 @@ struct VmRange {
         p.location.id = device;
         return p;
     }
-    int reserve(size_t max_bytes, int dev, bool use_vmm) {
+    // mapped in 2 MiB multiples (large pages behind the pools) unless the device asks for more
+    static size_t granularity(int dev) {
+        hipMemAllocationProp p = {};
+        p.type = hipMemAllocationTypePinned;
+        p.location.type = hipMemLocationTypeDevice;
+        p.location.id = dev;
+        size_t g = 0, gmin = 0;
+        if (hipMemGetAllocationGranularity(&g, &p, hipMemAllocationGranularityRecommended) != hipSuccess) g = 0;
+        if (hipMemGetAllocationGranularity(&gmin, &p, hipMemAllocationGranularityMinimum) != hipSuccess) gmin = 0;
+        (void)hipGetLastError();      // a query this runtime does not answer is not an error of the engine
+        return std::max<size_t>((size_t)2 << 20, std::max(g, gmin));
+    }
+    int reserve(size_t max_bytes, size_t unit_bytes, int dev, bool use_vmm) {
         device = dev;
         vmm = use_vmm;
+        unit = unit_bytes;
         if (!vmm) { reserved = max_bytes; return C6_OK; }
-        const hipMemAllocationProp p = prop();
-        if (hipMemGetAllocationGranularity(&gran, &p, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) gran = (size_t)2 << 20;
-        reserved = (max_bytes + gran - 1) / gran * gran;
+        gran = granularity(dev);
+        if (unit == 0 || unit % gran) return fail(C6_ERR_BAD_ARG, "pool unit is not a multiple of the mapping granularity");
+        reserved = (max_bytes + unit - 1) / unit * unit;
         void *b = nullptr;
         hipError_t e = hipMemAddressReserve(&b, reserved, 0, nullptr, 0);
         if (e != hipSuccess) return fail(C6_ERR_HIP, std::string("hipMemAddressReserve: ") + hipGetErrorString(e));
@@ -184,21 +200,22 @@ struct VmRange {
             mapped = bytes;
             return C6_OK;
         }
-        if (bytes > reserved) return fail(C6_ERR_OVERFLOW, "pool beyond its reserved address range");
-        const size_t add = bytes - mapped;
+        if (bytes > reserved || bytes % unit) return fail(C6_ERR_OVERFLOW, "pool beyond its reserved address range (or not in whole units)");
         const hipMemAllocationProp p = prop();
-        hipMemGenericAllocationHandle_t h;
-        hipError_t e = hipMemCreate(&h, add, &p, 0);
-        if (e != hipSuccess) return fail(C6_ERR_OVERFLOW, std::string("hipMemCreate: ") + hipGetErrorString(e));
-        e = hipMemMap(base + mapped, add, 0, h, 0);
-        if (e != hipSuccess) { hipMemRelease(h); return fail(C6_ERR_HIP, std::string("hipMemMap: ") + hipGetErrorString(e)); }
-        hipMemAccessDesc acc = {};
-        acc.location = p.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        e = hipMemSetAccess(base + mapped, add, &acc, 1);
-        if (e != hipSuccess) { hipMemUnmap(base + mapped, add); hipMemRelease(h); return fail(C6_ERR_HIP, std::string("hipMemSetAccess: ") + hipGetErrorString(e)); }
-        parts.emplace_back(h, add);
-        mapped = bytes;
+        while (mapped < bytes) {
+            hipMemGenericAllocationHandle_t h;
+            hipError_t e = hipMemCreate(&h, unit, &p, 0);
+            if (e != hipSuccess) { (void)hipGetLastError(); return fail(C6_ERR_OVERFLOW, std::string("hipMemCreate: ") + hipGetErrorString(e)); }
+            e = hipMemMap(base + mapped, unit, 0, h, 0);
+            if (e != hipSuccess) { hipMemRelease(h); (void)hipGetLastError(); return fail(C6_ERR_HIP, std::string("hipMemMap: ") + hipGetErrorString(e)); }
+            hipMemAccessDesc acc = {};
+            acc.location = p.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(base + mapped, unit, &acc, 1);
+            if (e != hipSuccess) { hipMemUnmap(base + mapped, unit); hipMemRelease(h); (void)hipGetLastError(); return fail(C6_ERR_HIP, std::string("hipMemSetAccess: ") + hipGetErrorString(e)); }
+            parts.emplace_back(h, unit);
+            mapped += unit;
+        }
         return C6_OK;
     }
     void release() {
@@ -626,24 +643,23 @@ static int engine_alloc(c6_engine *e) {
     const bool vmm = VmRange::supported(c.device);
     e->pages_max = vmm ? std::max(pages0, std::min((size_t)G * d.maxpages, (size_t)(0.9 * (double)tot / (double)page_bytes))) : pages0;
     e->chunks_max = vmm ? std::max(chunks0, std::min((size_t)G * d.maxchunks, e->pages_max / 4 + chunks0)) : chunks0;      // a table slot costs 17 B, a record >= 356
-    if (e->pages_max > 0xfffffff0ull || e->chunks_max > 0xfffffff0ull) return fail(C6_ERR_BAD_ARG, "pool too large");
-    int rc;
-    if ((rc = e->vm_prior.reserve(e->pages_max * C6_PAGE_RECS * cells * 4, c.device, vmm)) || (rc = e->vm_stat.reserve(e->pages_max * C6_PAGE_RECS * sizeof(C6RecStat), c.device, vmm)) ||
-        (rc = e->vm_ht.reserve(e->chunks_max * C6_CHUNK_SLOTS * sizeof(C6HtEntry), c.device, vmm)) || (rc = e->vm_tag.reserve(e->chunks_max * C6_CHUNK_SLOTS, c.device, vmm)))
-        return rc;
-    if (vmm) {      // quanta: every array's mapped size stays a multiple of the granularity
-        const size_t g1 = e->vm_prior.gran;
+    auto round_up = [](size_t v, size_t q) { return (v + q - 1) / q * q; };
+    if (vmm) {      // quanta: every array's mapped size stays a multiple of the mapping granularity
+        const size_t g1 = VmRange::granularity(c.device);
         e->page_quantum = lcm_sz(g1 / gcd_sz(g1, (size_t)C6_PAGE_RECS * cells * 4), g1 / gcd_sz(g1, (size_t)C6_PAGE_RECS * sizeof(C6RecStat)));
         e->chunk_quantum = lcm_sz(g1 / gcd_sz(g1, (size_t)C6_CHUNK_SLOTS * sizeof(C6HtEntry)), g1 / gcd_sz(g1, (size_t)C6_CHUNK_SLOTS));
-        e->pages_max = e->pages_max / e->page_quantum * e->page_quantum;
-        e->chunks_max = e->chunks_max / e->chunk_quantum * e->chunk_quantum;
     }
-    auto round_up = [](size_t v, size_t q) { return (v + q - 1) / q * q; };
-    const size_t pages_init = std::max(round_up(pages0, e->page_quantum), e->page_quantum), chunks_init = std::max(round_up(chunks0, e->chunk_quantum), e->chunk_quantum);
-    e->pages_max = std::max(e->pages_max, pages_init);
-    e->chunks_max = std::max(e->chunks_max, chunks_init);
-    if (vmm && (e->pages_max * C6_PAGE_RECS * cells * 4 > e->vm_prior.reserved || e->chunks_max * C6_CHUNK_SLOTS * sizeof(C6HtEntry) > e->vm_ht.reserved))
-        return fail(C6_ERR_BAD_ARG, "pool sizing error");
+    const size_t pages_init = round_up(pages0, e->page_quantum), chunks_init = round_up(chunks0, e->chunk_quantum);
+    e->pages_max = round_up(std::max(e->pages_max, pages_init), e->page_quantum);
+    e->chunks_max = round_up(std::max(e->chunks_max, chunks_init), e->chunk_quantum);
+    if (e->pages_max > 0xfffffff0ull || e->chunks_max > 0xfffffff0ull) return fail(C6_ERR_BAD_ARG, "pool too large");
+    int rc;
+    // the pools grow in whole quanta; one quantum of an array = one mapped piece (VmRange)
+    if ((rc = e->vm_prior.reserve(e->pages_max * C6_PAGE_RECS * cells * 4, e->page_quantum * C6_PAGE_RECS * cells * 4, c.device, vmm)) ||
+        (rc = e->vm_stat.reserve(e->pages_max * C6_PAGE_RECS * sizeof(C6RecStat), e->page_quantum * C6_PAGE_RECS * sizeof(C6RecStat), c.device, vmm)) ||
+        (rc = e->vm_ht.reserve(e->chunks_max * C6_CHUNK_SLOTS * sizeof(C6HtEntry), e->chunk_quantum * C6_CHUNK_SLOTS * sizeof(C6HtEntry), c.device, vmm)) ||
+        (rc = e->vm_tag.reserve(e->chunks_max * C6_CHUNK_SLOTS, e->chunk_quantum * C6_CHUNK_SLOTS, c.device, vmm)))
+        return rc;
     d.page_ring_mask = (unsigned)pow2_at_least((long)e->pages_max, 64) - 1u;
     d.chunk_ring_mask = (unsigned)pow2_at_least((long)e->chunks_max, 64) - 1u;
     ALLOC(d.page_free, e->pages_max);
@@ -1009,8 +1025,13 @@ static int maintain(c6_engine *e) {
     if (parked_pool > 0 || free_pages < low_water) {
         int rc = grow_pools(e, (size_t)parked_pool * move_pages + low_water);
         if (rc != C6_OK) {
-            if (parked_pool > 0) e->grow_failed = true;
-            g_err.clear();      // not an error of this call: the games wait, or leave as partial results (c6_engine_run)
+            // not an error of this call: the games wait, or leave as partial results (c6_engine_run).  Said once, on stderr.
+            if (parked_pool > 0) {
+                if (!e->grow_failed) fprintf(stderr, "[connect6_amd] the record pool cannot grow any further: %s\n", g_err.c_str());
+                e->grow_failed = true;
+            }
+            g_err.clear();
+            (void)hipGetLastError();
         }
     }
     if (e->grow_failed && d.recycle) d.abandon_parked = 1;

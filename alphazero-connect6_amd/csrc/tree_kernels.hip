@@ -1436,20 +1436,38 @@ static inline int wave_grid(int G) { return (G + WAVES_PER_BLOCK - 1) / WAVES_PE
 static inline size_t tag_lds(const C6Dev &d) { return (size_t)WAVES_PER_BLOCK * c6_wave_lds(d.hcap, d.pages_cap); }      // dynamic LDS of the kernels that hold a game's tag row / lists
 size_t c6_tree_lds_bytes(const C6Dev &d) { return tag_lds(d); }
 
+// the dynamic-LDS limit of a kernel is raised (once per kernel and device) when the per-game caps have grown the LDS copies past the default
+#include <mutex>
+#include <set>
+#include <utility>
+static void tree_smem(const void *fn, size_t dyn) {
+    if (dyn <= 32768) return;
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({fn, dev}).second) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
 // J = cells owned by one lane: 2 (9x9), 4 (15x15), 6 (19x19)
+#define C6_LAUNCH_ONE(KERNEL, d, s, ...)                                                                              \
+    do {                                                                                                              \
+        tree_smem(reinterpret_cast<const void *>(&KERNEL), tag_lds(d));                                               \
+        hipLaunchKernelGGL((KERNEL), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, __VA_ARGS__);  \
+    } while (0)
 #define C6_LAUNCH_J(KERNEL, d, s)                                                                                     \
     do {                                                                                                              \
         const int j_ = ((d).cells + 63) / 64;                                                                         \
-        if (j_ <= 2) hipLaunchKernelGGL((KERNEL<2>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d);      \
-        else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d); \
-        else hipLaunchKernelGGL((KERNEL<6>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d);             \
+        if (j_ <= 2) C6_LAUNCH_ONE(KERNEL<2>, d, s, d);                                                               \
+        else if (j_ <= 4) C6_LAUNCH_ONE(KERNEL<4>, d, s, d);                                                          \
+        else C6_LAUNCH_ONE(KERNEL<6>, d, s, d);                                                                       \
     } while (0)
-#define C6_LAUNCH_JK(KERNEL, K, d, n, s)                                                                                       \
-    do {                                                                                                                        \
-        const int j_ = ((d).cells + 63) / 64;                                                                                   \
-        if (j_ <= 2) hipLaunchKernelGGL((KERNEL<2, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d, n);      \
-        else if (j_ <= 4) hipLaunchKernelGGL((KERNEL<4, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d, n); \
-        else hipLaunchKernelGGL((KERNEL<6, K>), dim3(wave_grid((d).G)), dim3(64 * WAVES_PER_BLOCK), tag_lds(d), s, d, n);             \
+#define C6_LAUNCH_JK(KERNEL, K, d, n, s)                                                                              \
+    do {                                                                                                              \
+        const int j_ = ((d).cells + 63) / 64;                                                                         \
+        if (j_ <= 2) C6_LAUNCH_ONE((KERNEL<2, K>), d, s, d, n);                                                       \
+        else if (j_ <= 4) C6_LAUNCH_ONE((KERNEL<4, K>), d, s, d, n);                                                  \
+        else C6_LAUNCH_ONE((KERNEL<6, K>), d, s, d, n);                                                               \
     } while (0)
 
 void c6_launch_search(const C6Dev &d, int kind, int nsims, hipStream_t s) {      // kind 1: RandomEvaluator, 2: uniform, 3: stress (peaked / uniform by uid)

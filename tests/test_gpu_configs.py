@@ -90,6 +90,56 @@ def test_config3_geometry_mid_game():
     eng.close()
 
 
+def test_config3_geometry_deep_trees_share_the_pool():
+    """config 3's geometry (16 384 games, 19x19, S = 800) on the stress evaluator with every 100th game peaked:
+    those games' trees grow deep and keep more than 4 x S records alive while the others stay small -- they take their pages from
+    the shared pool at move boundaries (nothing is copied, no other game is touched).  Memory stays under 200 GB, no game is
+    abandoned or left parked, and the deep games -- and a shallow one -- equal the oracle's unbounded map (root children bit for bit)."""
+    need_gpu()
+    n, G, S, seed, eps, every, moves = 19, 16384, 800, 41, 0.001, 100, 6
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_STRESS, stress_every=every)
+    for _ in range(moves):
+        eng.step(S)
+        eng.maintain()
+    eng.step(S - 1)
+    st = eng.stats()
+    rounds = moves * S + S - 1
+    assert st["simulations"] == G * rounds and st["stones"] == G * moves, st
+    assert st["abandoned_games"] == 0 and st["parked_games"] == 0 and st["overflow_games"] == 0 and st["live_games"] == G
+    assert st["max_records_used"] > 4 * S and st["max_pages_held"] * 64 > 4 * S, st
+    assert st["pool_bytes"] < 200e9, st
+
+    def oracle_stress(ctx, turn, nn, ln, boards, values, policies):
+        b = np.ctypeslib.as_array(boards, shape=(ln, nn * nn))
+        v, p = pkg.stress_eval(nn, turn, b)
+        np.ctypeslib.as_array(values, shape=(ln,))[:] = v
+        np.ctypeslib.as_array(policies, shape=(ln, nn * nn))[:] = p
+        return 0
+
+    for g in (0, 100, 16300, 7):                                 # three peaked games, one uniform
+        peaked = g % every == 0
+        az = o.AlphaZero(n, num_simulation=S, epsilon=eps, eval_kind=o.EVAL_CUSTOM if peaked else o.EVAL_UNIFORM,
+                         eval_fn=oracle_stress if peaked else None, seed=seed, game_uid=g)
+        game = o.new_game(n)
+        for _ in range(moves):
+            cell = az.next(game)
+            o.game_set(game, cell // n, cell % n)
+        s = o.sim_from_game(game)
+        az.init(s)
+        for _ in range(S - 1):
+            az.search(s)
+        r = eng.root(g)
+        board = game.np_board()
+        assert (r["board"] == board).all(), g
+        vis, q, p = az.children(board)
+        empty = board.reshape(-1) == 0
+        assert (r["visits"][empty] == vis[empty]).all() and (r["q"][empty] == q[empty]).all() and (r["prior"][empty] == p[empty]).all(), g
+        if peaked:
+            assert r["records_used"] > 4 * S, (g, r["records_used"])
+        az.close()
+    eng.close()
+
+
 def test_config5_engine_full_size():
     """BASELINE config 5 as an ENGINE at full size: 32 768 concurrent 9x9 games, S = 100, uniform evaluator, recycling slots,
     for about two game lengths of rounds through c6_search_kernel<2, 2> (the kernel the config-5 bench times).  Nothing

@@ -150,34 +150,28 @@ def test_recycle_and_stagger_keep_games_exact():
 
 
 def test_tables_beyond_the_lds_tag_row_stay_exact():
-    """records_per_game = 5000 -> a table of 16384 slots: its tag row (one byte per slot) no longer fits the 8192 bytes a wave
-    keeps in LDS and is read in memory instead (tree_kernels.hip: C6Tags, C6_TAG_LDS_MAX).  Fused search kernel (built-in
-    evaluator) and the split select / expand kernels (callback evaluator) against the oracle's unbounded map."""
+    """Trees that keep more than 4096 records alive -> tables of 16384+ slots: the tag row (one byte per slot) no longer fits the 8192
+    bytes a wave keeps in LDS and is read in memory through the chunk list instead (tree_kernels.hip: C6Tags, C6_TAG_LDS_MAX).  The
+    stress evaluator (a deep tree: ~6 x num_simulation records) at 1200 simulations per move, in the fused search kernel (device
+    evaluator) and in the split select / expand kernels (the same evaluator as a host callback), against the oracle's unbounded map."""
     need_gpu()
-    n, G, S = 9, 6, 30
-    st, games, tup, ref = run_pair(n, G, S, seed=21, evaluator=pkg.EVAL_RANDOM, oracle_kind=o.EVAL_RANDOM, records_per_game=5000)
-    assert st["overflow_games"] == 0 and st["records_per_game"] == 5000
-    check_games(n, G, games, ref)
+    n, G, S, eps = 9, 3, 1200, 0.001
 
-    def uniform(player, boards):      # the uniform evaluator as a host callback: value 0, prior 1 / #empty on the empty cells
-        b = np.asarray(boards).reshape(-1, n * n)
-        e = (b == 0).astype(np.float32)
-        return np.zeros(b.shape[0], np.float32), e / np.maximum(e.sum(axis=1, keepdims=True), 1.0)
-
-    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=22, evaluator=pkg.EVAL_CALLBACK, records_per_game=5000)
-    eng.set_callback(uniform)
-    eng.run()
-    st = eng.stats()
-    games = {g["uid"]: g for g in eng.fetch_games()}
-    eng.close()
-
-    def oracle_uniform(ctx, turn, nn, ln, boards, values, policies):
+    def oracle_stress(ctx, turn, nn, ln, boards, values, policies):
         b = np.ctypeslib.as_array(boards, shape=(ln, nn * nn))
-        v, p = uniform(turn, b)
+        v, p = pkg.stress_eval(nn, turn, b)
         np.ctypeslib.as_array(values, shape=(ln,))[:] = v
         np.ctypeslib.as_array(policies, shape=(ln, nn * nn))[:] = p
         return 0
 
-    ref = o.self_play(n, num=G, threads=1, num_simulation=S, seed=22, eval_kind=o.EVAL_CUSTOM, eval_fn=oracle_uniform)
-    assert st["overflow_games"] == 0
-    check_games(n, G, games, ref)
+    for seed, evaluator in ((21, pkg.EVAL_STRESS), (22, pkg.EVAL_CALLBACK)):
+        eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=evaluator)
+        if evaluator == pkg.EVAL_CALLBACK:
+            eng.set_callback(lambda player, boards: pkg.stress_eval(n, player, boards))
+        eng.run()
+        st = eng.stats()
+        games = {g["uid"]: g for g in eng.fetch_games()}
+        eng.close()
+        assert st["overflow_games"] == 0 and st["max_records_used"] > 4096 + S, st      # 2 x (live + S) > 8192 slots: tags in memory
+        ref = o.self_play(n, num=G, threads=1, num_simulation=S, seed=seed, epsilon=eps, eval_kind=o.EVAL_CUSTOM, eval_fn=oracle_stress)
+        check_games(n, G, games, ref)
