@@ -640,7 +640,9 @@ static int engine_alloc(c6_engine *e) {
     const size_t chunks0 = (size_t)G * std::max<size_t>(pow2_at_least(2L * R0, C6_CHUNK_SLOTS) >> C6_CHUNK_SHIFT, pow2_at_least(2L * d.S, C6_CHUNK_SLOTS) >> C6_CHUNK_SHIFT);
     size_t fr = 0, tot = 0;
     hipMemGetInfo(&fr, &tot);
-    const bool vmm = VmRange::supported(c.device);
+    // C6_NO_VMM=1: the pools as plain allocations of their initial size (what a device without virtual memory management gets): test hook
+    static const bool no_vmm = [] { const char *v = getenv("C6_NO_VMM"); return v && v[0] == '1'; }();
+    const bool vmm = !no_vmm && VmRange::supported(c.device);
     e->pages_max = vmm ? std::max(pages0, std::min((size_t)G * d.maxpages, (size_t)(0.9 * (double)tot / (double)page_bytes))) : pages0;
     e->chunks_max = vmm ? std::max(chunks0, std::min((size_t)G * d.maxchunks, e->pages_max / 4 + chunks0)) : chunks0;      // a table slot costs 17 B, a record >= 356
     auto round_up = [](size_t v, size_t q) { return (v + q - 1) / q * q; };

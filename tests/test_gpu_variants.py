@@ -7,6 +7,9 @@
   weight gradient, conv_wino4.hip) against C6_PREC_FP32_DIRECT (the direct kernels of conv_f32n.hip / train_kernels.hip) -- two
   independent implementations of the same sums at a batch large enough for 64-tile blocks and several chunks.
 
+* C6_NO_VMM=1 (child process) -- the record pools as plain allocations of their initial size, what a device without HIP virtual memory
+  management gets (engine.cpp: VmRange): the pool cannot grow, so deep trees end as partial games with the reason said -- never silently.
+
 (The forms that lost their A/B comparisons -- separate transform kernels, a stem kernel of its own, unfused heads, the two-workgroup
 weight-gradient kernel -- are no longer in the product: compile-time options of A/B builds only, tools/ab_build.sh.)
 """
@@ -37,6 +40,38 @@ b, t, r, w, e = pkg.board_step(n, d["boards"], d["turn"], d["remain"], d["pos"])
 out.update(b=b, t=t, r=r, w=w, e=e, mask=pkg.legal_mask(n, d["boards"]))
 np.savez(sys.argv[2], **out)
 """ % (ROOT, os.path.join(ROOT, "tests"))
+
+
+POOL_CHILD = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from c6amd_loader import load_package
+pkg = load_package()
+n, G, S = 9, 64, 60
+eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=3, epsilon=0.001, evaluator=pkg.EVAL_STRESS, records_per_game=8)
+st0 = eng.stats()
+err = ""
+try:
+    eng.run()
+except pkg.C6Error as e:
+    err = str(e)
+st = eng.stats()
+games = eng.fetch_games()
+json.dump(dict(err=err, st0=st0, st=st, lens=[len(g["moves"]) for g in games], winners=[g["winner"] for g in games]), open(sys.argv[1], "w"))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_pools_without_vmm_cannot_grow_and_say_so():
+    need_gpu()
+    import json
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "out.json")
+        subprocess.run([sys.executable, "-c", POOL_CHILD, out], check=True, env=dict(os.environ, C6_NO_VMM="1"), timeout=300)
+        d = json.load(open(out))
+    assert d["st0"]["pool_pages"] == 64 * 2 and d["st"]["pool_pages"] == 64 * 2 and d["st"]["pool_grows"] == 0      # 2 pages per game, for good
+    assert "partial" in d["err"] and d["st"]["abandoned_games"] >= 1
+    assert len(d["lens"]) == 64                                          # every game comes back: finished ones and partial ones
+    assert sum(1 for w, l in zip(d["winners"], d["lens"]) if w == 0 and l < 81) == d["st"]["abandoned_games"]
 
 
 def run_child(env_extra, **arrays):
