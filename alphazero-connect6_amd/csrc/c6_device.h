@@ -5,8 +5,9 @@
 //    Gamma(alpha < 1) sampler that replaces rand 0.6's `Dirichlet::sample`
 //    (reference call sites: policy/alphazero_policy/mod.rs:262,283,294,145,163).
 //    Only IEEE +,-,*,/ and sqrt are used (no fma contraction: this translation unit
-//    is compiled with -ffp-contract=off), so the stream is bit-reproducible.  The Gamma
-//    variates are single precision (C6RNG v2), their normaliser double.
+//    is compiled with -ffp-contract=off) plus explicitly written fused multiply-adds (v4: correctly rounded on both
+//    sides), so the stream is bit-reproducible.  C6RNG v4: Gamma variates are (float mantissa, integer exponent) pairs,
+//    their normaliser is single precision on exponents relative to the largest of the vector -- no double anywhere.
 //  * wave64 reductions used by the tree kernels.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -30,8 +31,10 @@ struct c6_u4 { uint32_t x, y, z, w; };
 __device__ __forceinline__ c6_u4 c6_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32) instead of a high and a low multiplication
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;
@@ -49,92 +52,126 @@ __device__ __forceinline__ double c6_open01(uint32_t hi, uint32_t lo) {
 // U[-1,1) with 24 bits, RandomEvaluator (policy/alphazero_policy/mod.rs:141-168)
 __device__ __forceinline__ float c6_u11(uint32_t w) { return 2.0f * ((float)(w >> 8) * (1.0f / 16777216.0f)) - 1.0f; }
 
-// single-precision log / exp of the Gamma sampler: explicit polynomials on IEEE + - * / (no contraction) -> the same
-// bits on the CPU oracle (c6o_det_logf / c6o_det_expf_parts).  logf: x > 0 normal.
-__device__ __forceinline__ float c6_det_logf(float x) {
-    uint32_t b = __float_as_uint(x);
-    int e = (int)((b >> 23) & 0xff) - 127;
-    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
-    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-    float f = (m - 1.0f) / (m + 1.0f), f2 = f * f;
-    float p = 1.0f / 11.0f;
-    p = p * f2 + 1.0f / 9.0f;
-    p = p * f2 + 1.0f / 7.0f;
-    p = p * f2 + 1.0f / 5.0f;
-    p = p * f2 + 1.0f / 3.0f;
-    p = p * f2 + 1.0f;
-    float lm = 2.0f * f * p;
-    float de = (float)e;
-    return de * 0.693145751953125f + (lm + de * 1.42860677e-6f);
-}
-
-// exp(x) = p * 2^k with p in about [0.7, 1.42]: the polynomial part in float, the exponent returned separately -- the
-// sampler's U^(1/alpha) reaches 1e-250 at alpha = 0.03 and must not underflow (an all-zero noise vector would be NaN
-// after normalisation), so the scaling is applied in double
-__device__ __forceinline__ float c6_det_expf_parts(float x, int &k) {
-    float t = x * 1.44269504f;
-    k = (int)(t + (t >= 0.0f ? 0.5f : -0.5f));
-    float dk = (float)k;
-    float r = (x - dk * 0.693145751953125f) - dk * 1.42860677e-6f;
-    float p = 1.0f / 40320.0f;
-    p = p * r + 1.0f / 5040.0f;
-    p = p * r + 1.0f / 720.0f;
-    p = p * r + 1.0f / 120.0f;
-    p = p * r + 1.0f / 24.0f;
-    p = p * r + 1.0f / 6.0f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
-    return p;
-}
-
 // 24-bit uniform strictly inside (0,1)
 __device__ __forceinline__ float c6_open01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // m * 2^k for a normal float m and -126 <= k <= 127 with a normal result: exact
 __device__ __forceinline__ float c6_scale2f(float m, int k) { return m * __uint_as_float((uint32_t)(k + 127) << 23); }
 
-// Gamma(alpha, 1).  C6RNG v3, one ATTEMPT of the spec (counter word c1 = att of this cell): true and the variate if it is
-// accepted.  A cell's variate is that of its first accepted attempt; attempts are independent of one another, so who
-// evaluates them, and in which order, is free (c6_wave_gamma below spreads them over the wave).  Single precision (the
-// reference casts the noise to f32 before it is used, alphazero_policy/mod.rs:283; f64 vector arithmetic runs at half the
-// f32 rate on gfx950), one Philox block per attempt.
-//  * alpha < 1 (the reference's 0.03): Ahrens-Dieter GS -- p = (1 + alpha/e) u1; p <= 1: x = p^(1/alpha), accepted with
-//    probability exp(-x); else x = -log((1 + alpha/e - p) / alpha), accepted with probability x^(alpha-1).  Two attempts per
-//    Philox block (c6_gamma_try2).
-//    One log and one exp per attempt, 97 % accepted at alpha = 0.03 (v2 drew Marsaglia-Tsang at alpha+1 times
-//    U^(1/alpha) with polar normals as rand 0.6 does for small shapes: three logs, an exp, a sqrt and two divisions per
-//    attempt, 75 % accepted; the distribution is the same, the select kernel spends its time here).
-//  * alpha >= 1: Marsaglia-Tsang at shape alpha+1 times U^(1/alpha) with polar normals (words: v1, v2, squeeze u, power
-//    u); d and c are its constants (double, rounded to float here).
-// one GS attempt on the uniforms (u1, u2)
-__device__ __forceinline__ bool c6_gamma_gs(float a, float inv_alpha, float b, float u1, float u2, double &out) {
-    const float p = b * u1;
-    if (p <= 1.0f) {
-        int k;
-        const float m = c6_det_expf_parts(c6_det_logf(p) * inv_alpha, k);      // x = m 2^k, m in about [0.7, 1.42]
-        if (k >= -30) {      // below 2^-30, exp(-x) exceeds every u2 (<= 1 - 2^-25)
-            int k2;
-            const float e2 = c6_det_expf_parts(-c6_scale2f(m, k), k2);
-            if (!(u2 <= c6_scale2f(e2, k2))) return false;
-        }
-        // 2^k exactly, in double (k >= -1000: far inside the normal range; smaller variates are 0)
-        out = k < -1000 ? 0.0 : (double)m * __longlong_as_double((long long)(k + 1023) << 52);
-        return true;
+// ---- C6RNG v4: the Gamma sampler -------------------------------------------------------------------------------------------
+// log and exp of the sampler: polynomial forms (Cephes' logf / expf coefficients) on explicitly fused multiply-adds -- no division, no
+// table; a value pair at a time (the two attempts of a Philox block) on the packed f32 instructions.  |error| ~ 1e-7: what the
+// sampler owes the reference is a DISTRIBUTION (below); the routines are part of the spec, the oracle evaluates the same operations.
+typedef float c6_f2 __attribute__((ext_vector_type(2)));
+typedef int c6_i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c6_f2 c6_fma2(c6_f2 a, c6_f2 b, c6_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ c6_f2 c6_fma2(c6_f2 a, c6_f2 b, float c) { return __builtin_elementwise_fma(a, b, c6_f2{c, c}); }
+__device__ __forceinline__ c6_f2 c6_fma2(c6_f2 a, float b, c6_f2 c) { return __builtin_elementwise_fma(a, c6_f2{b, b}, c); }
+// log(x), x > 0 normal
+__device__ __forceinline__ c6_f2 c6_log4(c6_f2 x) {
+    c6_f2 m, fe;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t b = __float_as_uint(x[i]);
+        int e = (int)((b >> 23) & 0xff) - 127;
+        float mm = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+        if (mm > 1.41421356f) { mm = mm * 0.5f; e += 1; }
+        m[i] = mm;
+        fe[i] = (float)e;
     }
-    const float y = (b - p) * inv_alpha;      // in (0, 1/e]
-    if (!(y > 0.0f)) return false;            // p rounded up to b
-    const float x = 0.0f - c6_det_logf(y);
-    int k2;
-    const float e2 = c6_det_expf_parts((a - 1.0f) * c6_det_logf(x), k2);
-    if (!(u2 <= c6_scale2f(e2, k2))) return false;
-    out = (double)x;
+    const c6_f2 y = m - 1.0f, z = y * y;
+    c6_f2 p = c6_f2{7.0376836292e-2f, 7.0376836292e-2f};
+    p = c6_fma2(p, y, -1.1514610310e-1f);
+    p = c6_fma2(p, y, 1.1676998740e-1f);
+    p = c6_fma2(p, y, -1.2420140846e-1f);
+    p = c6_fma2(p, y, 1.4249322787e-1f);
+    p = c6_fma2(p, y, -1.6668057665e-1f);
+    p = c6_fma2(p, y, 2.0000714765e-1f);
+    p = c6_fma2(p, y, -2.4999993993e-1f);
+    p = c6_fma2(p, y, 3.3333331174e-1f);
+    p = (p * y) * z;
+    c6_f2 r = c6_fma2(fe, -2.12194440e-4f, p);
+    r = c6_fma2(z, -0.5f, r);
+    r = y + r;
+    return c6_fma2(fe, 0.693359375f, r);
+}
+// exp(t) = p 2^k with p in about [0.7, 1.42]: the sampler's U^(1/alpha) reaches 2^-830 at alpha = 0.03, so the exponent stays an integer
+__device__ __forceinline__ c6_f2 c6_exp4(c6_f2 t, c6_i2 &k) {
+    const c6_f2 tt = t * 1.44269504f;
+    c6_f2 fk;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        k[i] = (int)(tt[i] + (tt[i] >= 0.0f ? 0.5f : -0.5f));
+        fk[i] = (float)k[i];
+    }
+    c6_f2 r = c6_fma2(fk, -0.693359375f, t);
+    r = c6_fma2(fk, 2.12194440e-4f, r);
+    const c6_f2 z = r * r;
+    c6_f2 p = c6_f2{1.9875691500e-4f, 1.9875691500e-4f};
+    p = c6_fma2(p, r, 1.3981999507e-3f);
+    p = c6_fma2(p, r, 8.3334519073e-3f);
+    p = c6_fma2(p, r, 4.1665795894e-2f);
+    p = c6_fma2(p, r, 1.6666665459e-1f);
+    p = c6_fma2(p, r, 5.0000001201e-1f);
+    p = c6_fma2(p, z, r);
+    return p + 1.0f;
+}
+// the routines on one value (tests, the Marsaglia-Tsang branch)
+__device__ __forceinline__ float c6_log4(float x) { return c6_log4(c6_f2{x, x})[0]; }
+__device__ __forceinline__ float c6_exp4(float t, int &k) { c6_i2 kk; const c6_f2 p = c6_exp4(c6_f2{t, t}, kk); k = kk[0]; return p[0]; }
+
+// a Gamma variate: m * 2^k (m a normal float or 0, k <= 0 for the small ones): no double, no underflow
+struct c6_gam { float m; int k; };
+#define C6_GAM_NONE (-(1 << 30))      // exponent of "no variate" (a cell that needs none): never the largest, scales to 0
+
+// Gamma(alpha, 1).  C6RNG v4.  Attempts 2 i and 2 i + 1 of a cell come out of ONE Philox block (counter word c1 = i; words x, y serve
+// the even attempt, z, w the odd one) and are evaluated TOGETHER, a pair of values per packed instruction; a cell's variate is that of
+// its first accepted attempt.  Attempts are independent of one another, so who evaluates them, and in which order, is free
+// (c6_wave_gamma below spreads them over the wave).  Single precision (the reference casts the noise to f32 before it is used,
+// alphazero_policy/mod.rs:283).
+//  * alpha < 1 (the reference's 0.03): Ahrens-Dieter GS.  b = 1 + alpha/e, p = b u1, E = -log(u2) (an Exp(1) variate).
+//      p <= 1:  x = p^(1/alpha) = exp(log(p) / alpha), accepted iff x <= E           (<=> u2 <= exp(-x))
+//      p >  1:  x = -log((b - p) / alpha),            accepted iff E >= (1 - alpha) log(x)   (<=> u2 <= x^(alpha - 1))
+//    One log of the branch's argument, one log of u2 and one exp per attempt; 97 % of the attempts are accepted, a pair fails once
+//    in ~1000.  (v3 evaluated the attempts one after the other with a division in its log, unfused polynomials, a second exp for the
+//    acceptance test and variates in double; v2 drew Marsaglia-Tsang at alpha + 1 times U^(1/alpha) as rand 0.6 does for small shapes.
+//    The distribution is the same -- tests/test_oracle_rng.py: Kolmogorov-Smirnov and moments on both branches; the select kernel
+//    spends its arithmetic here.)
+//  * alpha >= 1: Marsaglia-Tsang at shape alpha + 1 times U^(1/alpha) with polar normals (words: v1, v2, squeeze u, power u), one
+//    attempt per Philox block (counter word c1 = attempt).
+__device__ __forceinline__ bool c6_gamma_gs2(float a, float ia, float b, c6_u4 w, c6_gam &out) {
+    const c6_f2 u1 = {c6_open01f(w.x), c6_open01f(w.z)}, u2 = {c6_open01f(w.y), c6_open01f(w.w)};
+    const c6_f2 p = u1 * b;
+    const c6_f2 y = (b - p) * ia;
+    const bool b1[2] = {p[0] <= 1.0f, p[1] <= 1.0f};
+    c6_f2 arg = {b1[0] ? p[0] : y[0], b1[1] ? p[1] : y[1]};
+    const bool bad[2] = {!(arg[0] > 0.0f), !(arg[1] > 0.0f)};      // p rounded up to b: the attempt is rejected
+    if (bad[0]) arg[0] = 1.0f;
+    if (bad[1]) arg[1] = 1.0f;
+    const c6_f2 L = c6_log4(arg), E = 0.0f - c6_log4(u2);
+    c6_i2 k;
+    const c6_f2 m = c6_exp4(L * ia, k);
+    bool acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) acc[i] = k[i] < -30 || c6_scale2f(m[i], k[i] < -30 ? -30 : k[i]) <= E[i];      // below 2^-30 every E (>= 2^-25) accepts
+    c6_f2 x2 = {1.0f, 1.0f};
+    if (!(b1[0] && b1[1])) {      // 1 % of the attempts
+        x2 = 0.0f - L;
+        const c6_f2 lx = c6_log4(c6_f2{b1[0] ? 1.0f : x2[0], b1[1] ? 1.0f : x2[1]});
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            if (!b1[i]) acc[i] = !bad[i] && E[i] >= (1.0f - a) * lx[i];
+    }
+    const int i = acc[0] ? 0 : 1;
+    if (!acc[i]) return false;
+    out.m = b1[i] ? m[i] : x2[i];
+    out.k = b1[i] ? k[i] : 0;
     return true;
 }
 
 // one Marsaglia-Tsang attempt (alpha >= 1), Philox counter word c1 = att
 __device__ __forceinline__ bool c6_gamma_mt(double alpha, double d_, double c_, uint32_t k0, uint32_t k1, uint32_t cell,
-                                            uint32_t search, uint32_t depth, uint32_t att, double &out) {
+                                            uint32_t search, uint32_t depth, uint32_t att, c6_gam &out) {
     const uint32_t tag = C6_TAG_NOISE | (depth << 8);
     const float inv_alpha = 1.0f / (float)alpha;
     const c6_u4 w = c6_philox(cell, att, search, tag, k0, k1);
@@ -142,40 +179,35 @@ __device__ __forceinline__ bool c6_gamma_mt(double alpha, double d_, double c_, 
     const float v1 = 2.0f * c6_open01f(w.x) - 1.0f, v2 = 2.0f * c6_open01f(w.y) - 1.0f;
     const float s = v1 * v1 + v2 * v2;
     if (s >= 1.0f || s == 0.0f) return false;
-    const float x = v1 * sqrtf(-2.0f * c6_det_logf(s) / s);
+    const float x = v1 * sqrtf(-2.0f * c6_log4(s) / s);
     const float vc = 1.0f + c * x;
     if (vc <= 0.0f) return false;
     const float v = vc * vc * vc;
     const float u = c6_open01f(w.z), u2 = c6_open01f(w.w);
     const float x2 = x * x;
-    if (u < 1.0f - 0.0331f * x2 * x2 || c6_det_logf(u) < 0.5f * x2 + d * (1.0f - v + c6_det_logf(v))) {
+    if (u < 1.0f - 0.0331f * x2 * x2 || c6_log4(u) < 0.5f * x2 + d * (1.0f - v + c6_log4(v))) {
         int k;
-        const float g = (d * v) * c6_det_expf_parts(c6_det_logf(u2) * inv_alpha, k);      // in [~1e-30, ~50]: a normal float
-        out = k < -1000 ? 0.0 : (double)g * __longlong_as_double((long long)(k + 1023) << 52);
+        out.m = (d * v) * c6_exp4(c6_log4(u2) * inv_alpha, k);      // in [~1e-30, ~50] x 2^k: a normal float
+        out.k = k;
         return true;
     }
     return false;
 }
 
-// attempts 2 * pair and 2 * pair + 1 of a cell: true and the variate of the first accepted one.  alpha < 1: both GS
-// attempts come out of ONE Philox block (counter word c1 = pair; words x, y serve the even attempt, z, w the odd one) and
-// the odd one is only evaluated where the even one was rejected (3 %): a pair fails once in ~1000, so a second packing
-// round of c6_wave_gamma is rare.
+// attempts 2 * pair and 2 * pair + 1 of a cell: true and the variate of the first accepted one
 __device__ __forceinline__ bool c6_gamma_try2(double alpha, double d_, double c_, uint32_t k0, uint32_t k1, uint32_t cell,
-                                              uint32_t search, uint32_t depth, uint32_t pair, double &out) {
+                                              uint32_t search, uint32_t depth, uint32_t pair, c6_gam &out) {
     if (alpha < 1.0) {
-        const float a = (float)alpha, inv_alpha = 1.0f / a, b = 1.0f + a * 0.36787944f;
-        const c6_u4 w = c6_philox(cell, pair, search, C6_TAG_NOISE | (depth << 8), k0, k1);
-        if (c6_gamma_gs(a, inv_alpha, b, c6_open01f(w.x), c6_open01f(w.y), out)) return true;
-        return c6_gamma_gs(a, inv_alpha, b, c6_open01f(w.z), c6_open01f(w.w), out);
+        const float a = (float)alpha, ia = 1.0f / a, b = __builtin_fmaf(a, 0.36787944f, 1.0f);
+        return c6_gamma_gs2(a, ia, b, c6_philox(cell, pair, search, C6_TAG_NOISE | (depth << 8), k0, k1), out);
     }
     if (c6_gamma_mt(alpha, d_, c_, k0, k1, cell, search, depth, 2u * pair, out)) return true;
     return c6_gamma_mt(alpha, d_, c_, k0, k1, cell, search, depth, 2u * pair + 1u, out);
 }
 
-__device__ __forceinline__ double c6_gamma_draw(double alpha, double d, double c, uint32_t k0, uint32_t k1, uint32_t cell,
+__device__ __forceinline__ c6_gam c6_gamma_draw(double alpha, double d, double c, uint32_t k0, uint32_t k1, uint32_t cell,
                                                 uint32_t search, uint32_t depth) {
-    double g;
+    c6_gam g;
     for (uint32_t pair = 0;; pair++)
         if (c6_gamma_try2(alpha, d, c, k0, k1, cell, search, depth, pair, g)) return g;
 }
@@ -209,6 +241,17 @@ __device__ __forceinline__ double c6_butterfly_sum(double v) {
     v = v + c6_dpp_f64<C6_DPP_HALF_MIRROR>(v);
     v = v + c6_dpp_f64<C6_DPP_MIRROR>(v);
     const double r0 = c6_readlane_f64(v, 0), r1 = c6_readlane_f64(v, 16), r2 = c6_readlane_f64(v, 32), r3 = c6_readlane_f64(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+
+// the same summation tree in single precision (C6RNG v4: the Dirichlet normaliser)
+__device__ __forceinline__ float c6_butterfly_sum_f32(float v) {
+    v = v + c6_dpp_f32<C6_DPP_XOR1>(v);
+    v = v + c6_dpp_f32<C6_DPP_XOR2>(v);
+    v = v + c6_dpp_f32<C6_DPP_HALF_MIRROR>(v);
+    v = v + c6_dpp_f32<C6_DPP_MIRROR>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return (r0 + r1) + (r2 + r3);
 }
 
@@ -277,23 +320,24 @@ __device__ __forceinline__ int c6_select_bit(unsigned long long m, int n) {
 
 // Gamma variates for the cells a wave owns (lane owns cells lane + 64 j where need[j]).  Same values as calling
 // c6_gamma_draw per cell -- the attempt that is accepted for a cell does not depend on who evaluates it -- but the
-// rejection loops are not run in lockstep: with one loop per lane the wave pays max-over-64-lanes attempts per j
-// (~4.3 for the 21 % polar rejection, 26 evaluations at N = 19), here the cells still without a variate are packed
-// onto lanes 0..k-1 in every round (~11 evaluations on an empty 19x19 board, ~4 instead of ~9 in a 9x9 middle game).
-// `scratch` = cells doubles of wave-private LDS: workers hand the variates (or -1 = rejected) back to the owners.
+// rejection loops are not run in lockstep: the cells still without a variate are packed onto lanes 0..k-1 in every round
+// (occupied cells cost nothing: in the middle of a 9x9 game the 2 x 64 owned slots hold ~47 empty cells -- one pass instead of two).
+// `scratch` = cells 8-byte words of wave-private LDS: workers hand the variates (mantissa | exponent, or "rejected") back to the
+// owners.  Cells that need none come back as {0, C6_GAM_NONE}.
+#define C6_GAM_REJ 0x7fffffff
 template <int J>
-__device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], double (&gam)[J], double *scratch, int lane, double alpha,
+__device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], c6_gam (&gam)[J], double *scratch_, int lane, double alpha,
                                               double d, double c, uint32_t k0, uint32_t k1, uint32_t search, uint32_t depth) {
+    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(scratch_);
     unsigned long long pend[J];
     bool any = false;
 #pragma unroll
     for (int j = 0; j < J; j++) {
-        gam[j] = 0.0;
+        gam[j].m = 0.f;
+        gam[j].k = C6_GAM_NONE;
         pend[j] = __ballot(need[j]);
         any |= pend[j] != 0ull;
     }
-    // every round -- the first included -- packs the pending cells onto the lanes: occupied cells cost nothing (in the
-    // middle of a 9x9 game the 2 x 64 owned slots hold ~47 empty cells: one pass instead of two)
     for (uint32_t att = 0; any;) {
         int tot = 0;
 #pragma unroll
@@ -314,13 +358,13 @@ __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], double (&ga
                     else rem -= pc;
                 }
             }
-            double v = 0.0;
+            c6_gam v = {0.f, 0};
             const bool ok = active && c6_gamma_try2(alpha, d, c, k0, k1, (uint32_t)cell, search, depth, att + (uint32_t)sub, v);
             // lanes of one cell are consecutive (sub = 0..k-1, one batch whenever k > 1): the first accepted one writes
             const unsigned long long okm = __ballot(ok);
             const unsigned long long mine = (okm >> (lane - sub)) & (k >= 64 ? ~0ull : ((1ull << k) - 1ull));
-            if (active && sub == 0 && mine == 0ull) scratch[cell] = -1.0;
-            if (ok && (mine & ((1ull << sub) - 1ull)) == 0ull) scratch[cell] = v;
+            if (active && sub == 0 && mine == 0ull) scratch[cell] = (unsigned long long)(uint32_t)C6_GAM_REJ << 32;
+            if (ok && (mine & ((1ull << sub) - 1ull)) == 0ull) scratch[cell] = (unsigned long long)__float_as_uint(v.m) | ((unsigned long long)(uint32_t)v.k << 32);
         }
         att += (uint32_t)k;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS is in order within a wave; this binds the compiler
@@ -329,12 +373,34 @@ __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], double (&ga
         for (int j = 0; j < J; j++) {
             bool still = false;
             if ((pend[j] >> lane) & 1ull) {
-                const double v = scratch[lane + 64 * j];
-                if (v < 0.0) still = true; else gam[j] = v;
+                const unsigned long long v = scratch[lane + 64 * j];
+                if ((int)(v >> 32) == C6_GAM_REJ) still = true;
+                else { gam[j].m = __uint_as_float((uint32_t)v); gam[j].k = (int)(v >> 32); }
             }
             pend[j] = __ballot(still);
             any |= pend[j] != 0ull;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+}
+
+// Dirichlet noise from the Gamma variates of a wave's cells (C6RNG v4): exponents relative to the LARGEST of the vector (its scaled
+// value lies in [0.7, 18): the sum cannot vanish, whatever the range of the others), values more than 2^100 below it are 0; lane
+// partial sums in ascending j, the wave sum by the butterfly (ascending offsets), noise = scaled * (1 / sum).
+template <int J>
+__device__ __forceinline__ void c6_wave_dirichlet(const c6_gam (&gam)[J], float (&noise)[J]) {
+    int kmax = C6_GAM_NONE;
+#pragma unroll
+    for (int j = 0; j < J; j++) kmax = gam[j].k > kmax ? gam[j].k : kmax;
+    kmax = c6_wave_max_i32(kmax);
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int dk = gam[j].k - kmax;
+        noise[j] = dk >= -100 ? c6_scale2f(gam[j].m, dk) : 0.f;
+        part = part + noise[j];
+    }
+    const float rs = 1.0f / c6_butterfly_sum_f32(part);
+#pragma unroll
+    for (int j = 0; j < J; j++) noise[j] = noise[j] * rs;
 }

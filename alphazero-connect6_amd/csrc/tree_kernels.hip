@@ -351,21 +351,26 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
             chosen = c6_wave_max_i32(mine);
         } else {
             const float visit_sum = (float)c6_wave_sum_i32(vs);
-            // Dirichlet noise: Gamma draws normalised by their sum (C6RNG), mod.rs:260-262,283
-            double gam[J], part = 0.0;
+            // Dirichlet noise: Gamma draws normalised by their sum (C6RNG v4), mod.rs:260-262,283
+            c6_gam gam[J];
+            float noise_[J];
             bool need[J];
 #pragma unroll
             for (int j = 0; j < J; j++) need[j] = L.st[j] == 0;
-            c6_wave_gamma<J>(need, gam, gscratch, lane, E.alpha, E.gam_d, E.gam_c, k0, k1, t, (uint32_t)d);
+#ifdef C6_AB_NOISE_TWICE   // ablation builds only: the noise of another counter first, kept alive -- the difference to the tree is one noise evaluation
+            c6_wave_gamma<J>(need, gam, gscratch, lane, E.alpha, E.gam_d, E.gam_c, k0, k1, t, (uint32_t)d + 128u);
+            c6_wave_dirichlet<J>(gam, noise_);
 #pragma unroll
-            for (int j = 0; j < J; j++) part = part + gam[j];     // cells that need none hold 0.0 (+ 0.0 is exact)
-            const double gsum = c6_butterfly_sum(part);
+            for (int j = 0; j < J; j++) asm volatile("" ::"v"(noise_[j]));
+#endif
+            c6_wave_gamma<J>(need, gam, gscratch, lane, E.alpha, E.gam_d, E.gam_c, k0, k1, t, (uint32_t)d);
+            c6_wave_dirichlet<J>(gam, noise_);
             float sc[J], best = -INFINITY;
 #pragma unroll
             for (int j = 0; j < J; j++) {
                 sc[j] = -INFINITY;
                 if (L.st[j] == 0) {                // mod.rs:265-280
-                    const float noise = (float)(gam[j] / gsum);
+                    const float noise = noise_[j];
                     const float visit = (float)cvis[j];
                     const float prob = E.eps * noise + (1.f - E.eps) * cpr[j];
                     const float puct = prob * sqrtf(visit_sum - visit) / (1.f + visit);
@@ -1509,7 +1514,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_noise_op_kernel(int N
     const int cells = N * N;
     const int8_t *board = boards + (size_t)b * cells;
     __shared__ double gscratch[WAVES_PER_BLOCK][64 * C6_MAXJ];
-    double gam[C6_MAXJ], part = 0.0;
+    c6_gam gam[C6_MAXJ];
+    float nz[C6_MAXJ];
     bool need[C6_MAXJ];
 #pragma unroll
     for (int j = 0; j < C6_MAXJ; j++) {
@@ -1518,13 +1524,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_noise_op_kernel(int N
     }
     // the same wave-cooperative sampler as c6_select_kernel (the oracle draws cell by cell with its own loop)
     c6_wave_gamma<C6_MAXJ>(need, gam, gscratch[threadIdx.x >> 6], lane, alpha, gd, gc, k0[b], k1[b], search[b], depth[b]);
-#pragma unroll
-    for (int j = 0; j < C6_MAXJ; j++) part = part + gam[j];
-    const double gsum = c6_butterfly_sum(part);
+    c6_wave_dirichlet<C6_MAXJ>(gam, nz);
 #pragma unroll
     for (int j = 0; j < C6_MAXJ; j++) {
         const int c = lane + 64 * j;
-        if (c < cells) noise[(size_t)b * cells + c] = board[c] == 0 ? (float)(gam[j] / gsum) : 0.f;
+        if (c < cells) noise[(size_t)b * cells + c] = board[c] == 0 ? nz[j] : 0.f;
     }
 }
 

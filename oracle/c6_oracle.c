@@ -268,43 +268,48 @@ static inline double open01(uint32_t hi, uint32_t lo) {
 static inline float bits2f(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline uint32_t f2bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 
-/* single-precision log / exp of the Gamma sampler (C6RNG v2/v3): explicit polynomials on IEEE + - * / -- this file is
- * compiled with -ffp-contract=off and x86-64 evaluates float expressions in float, so the bits equal the GPU's */
-float c6o_det_logf(float x) {
+/* C6RNG v4: log and exp of the Gamma sampler -- polynomial forms (Cephes' logf / expf coefficients) on explicitly FUSED multiply-adds
+ * (fmaf: one rounding; this file is compiled with -mfma and -ffp-contract=off, so exactly the fmaf written here are fused) and IEEE
+ * + - *: the same operations, in the same order, as c6_log4 / c6_exp4 of the kernels (c6_device.h), hence the same bits. */
+float c6o_log4(float x) {
     uint32_t b = f2bits(x);
     int e = (int)((b >> 23) & 0xff) - 127;
     float m = bits2f((b & 0x007fffffu) | 0x3f800000u);
     if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-    float f = (m - 1.0f) / (m + 1.0f), f2 = f * f;
-    float p = 1.0f / 11.0f;
-    p = p * f2 + 1.0f / 9.0f;
-    p = p * f2 + 1.0f / 7.0f;
-    p = p * f2 + 1.0f / 5.0f;
-    p = p * f2 + 1.0f / 3.0f;
-    p = p * f2 + 1.0f;
-    float lm = 2.0f * f * p;
-    float de = (float)e;
-    return de * 0.693145751953125f + (lm + de * 1.42860677e-6f);
+    const float fe = (float)e, y = m - 1.0f, z = y * y;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, y, -1.1514610310e-1f);
+    p = fmaf(p, y, 1.1676998740e-1f);
+    p = fmaf(p, y, -1.2420140846e-1f);
+    p = fmaf(p, y, 1.4249322787e-1f);
+    p = fmaf(p, y, -1.6668057665e-1f);
+    p = fmaf(p, y, 2.0000714765e-1f);
+    p = fmaf(p, y, -2.4999993993e-1f);
+    p = fmaf(p, y, 3.3333331174e-1f);
+    p = (p * y) * z;
+    float r = fmaf(fe, -2.12194440e-4f, p);
+    r = fmaf(z, -0.5f, r);
+    r = y + r;
+    return fmaf(fe, 0.693359375f, r);
 }
 
-/* exp(x) = p * 2^k, p in about [0.7, 1.42]: polynomial part in float, exponent returned separately (the sampler applies it
- * in double: U^(1/alpha) reaches 1e-250 at alpha = 0.03 and must not underflow) */
-float c6o_det_expf_parts(float x, int *kout) {
-    float t = x * 1.44269504f;
-    int k = (int)(t + (t >= 0.0f ? 0.5f : -0.5f));
-    float dk = (float)k;
-    float r = (x - dk * 0.693145751953125f) - dk * 1.42860677e-6f;
-    float p = 1.0f / 40320.0f;
-    p = p * r + 1.0f / 5040.0f;
-    p = p * r + 1.0f / 720.0f;
-    p = p * r + 1.0f / 120.0f;
-    p = p * r + 1.0f / 24.0f;
-    p = p * r + 1.0f / 6.0f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+/* exp(t) = p * 2^k, p in about [0.7, 1.42]; the exponent stays an integer (U^(1/alpha) reaches 2^-830 at alpha = 0.03) */
+float c6o_exp4(float t, int *kout) {
+    const float tt = t * 1.44269504f;
+    const int k = (int)(tt + (tt >= 0.0f ? 0.5f : -0.5f));
+    const float fk = (float)k;
+    float r = fmaf(fk, -0.693359375f, t);
+    r = fmaf(fk, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    p = fmaf(p, z, r);
     *kout = k;
-    return p;
+    return p + 1.0f;
 }
 
 /* 24-bit uniform strictly inside (0,1) */
@@ -313,90 +318,113 @@ static inline float open01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0
 /* m * 2^k, exact for a normal m and a normal result */
 static inline float scale2f(float m, int k) { return m * bits2f((uint32_t)(k + 127) << 23); }
 
+/* one Ahrens-Dieter GS attempt on the uniforms (u1, u2); 1 and the variate m 2^k if it is accepted (spec: c6_device.h, C6RNG v4) */
+static int gs_attempt(float a, float ia, float b, float u1, float u2, float *m_out, int *k_out) {
+    const float p = b * u1;
+    const float E = 0.0f - c6o_log4(u2);
+    if (p <= 1.0f) {
+        int k;
+        const float m = c6o_exp4(c6o_log4(p) * ia, &k);
+        if (!(k < -30 || scale2f(m, k) <= E)) return 0;
+        *m_out = m;
+        *k_out = k;
+        return 1;
+    }
+    const float y = (b - p) * ia;
+    if (!(y > 0.0f)) return 0;
+    const float x = 0.0f - c6o_log4(y);
+    if (!(E >= (1.0f - a) * c6o_log4(x))) return 0;
+    *m_out = x;
+    *k_out = 0;
+    return 1;
+}
+
 /*
  * Gamma(alpha, 1): what `Dirichlet::new_with_param(alpha, n).sample` draws per component
  * (rand 0.6, called from alphazero_policy/mod.rs:262,283).  The reference's generator is unseeded and rand's own
- * stream cannot be reproduced, so only the DISTRIBUTION is the reference's; the algorithm is C6RNG's (v3), in single
- * precision (the reference casts the noise to f32 before use, mod.rs:283), one Philox block per attempt:
- *   alpha < 1:  Ahrens-Dieter GS (1974).  b = 1 + alpha/e, p = b u1.  p <= 1: x = p^(1/alpha), accept iff
- *               u2 <= exp(-x); else x = -log((b - p)/alpha), accept iff u2 <= x^(alpha-1).  Attempts 2i and 2i + 1
+ * stream cannot be reproduced, so only the DISTRIBUTION is the reference's; the algorithm is C6RNG's (v4), in single
+ * precision (the reference casts the noise to f32 before use, mod.rs:283); a variate is m * 2^k:
+ *   alpha < 1:  Ahrens-Dieter GS (1974).  b = 1 + alpha/e, p = b u1, E = -log(u2).  p <= 1: x = p^(1/alpha), accept iff
+ *               x <= E; else x = -log((b - p)/alpha), accept iff E >= (1 - alpha) log(x).  Attempts 2i and 2i + 1
  *               share the Philox block with counter word c1 = i (words 0, 1 and 2, 3).
  *   alpha >= 1: Marsaglia-Tsang for shape alpha+1 times U^(1/alpha) (rand's GammaSmallShape form) with polar-method
  *               normals.  Words: polar v1, polar v2, squeeze u, power u.
- * x = p^(1/alpha) reaches 1e-250 at alpha = 0.03: exp returns mantissa and exponent, the power of two is applied in
- * double.
  */
-double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth) {
+void c6o_gamma_draw4(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth, float *m_out, int *k_out) {
     const double shape = alpha + 1.0;
     const double dd = shape - 1.0 / 3.0;
     const double cd = 1.0 / sqrt(9.0 * dd);
     const float d = (float)dd, c = (float)cd, inv_alpha = 1.0f / (float)alpha;
-    const float a = (float)alpha, b = 1.0f + a * 0.36787944f;
+    const float a = (float)alpha, b = fmaf(a, 0.36787944f, 1.0f);
     uint32_t key[2] = {k0, k1};
     for (uint32_t att = 0;; att++) {
         /* alpha < 1: one Philox block serves the attempts 2i (words 0, 1) and 2i + 1 (words 2, 3) */
         uint32_t ctr[4] = {cell, alpha < 1.0 ? att >> 1 : att, search, (uint32_t)C6O_TAG_NOISE | (depth << 8)}, w[4];
         c6o_philox4x32_10(ctr, key, w);
         if (alpha < 1.0) {
-            const float u1 = open01f(w[2 * (att & 1)]), u2 = open01f(w[2 * (att & 1) + 1]);
-            const float p = b * u1;
-            int k, k2;
-            if (p <= 1.0f) {
-                const float m = c6o_det_expf_parts(c6o_det_logf(p) * inv_alpha, &k);
-                if (k >= -30) { /* below 2^-30 exp(-x) exceeds every u2 */
-                    const float e2 = c6o_det_expf_parts(-scale2f(m, k), &k2);
-                    if (!(u2 <= scale2f(e2, k2))) continue;
-                }
-                return k < -1000 ? 0.0 : (double)m * bits2d((uint64_t)(k + 1023) << 52); /* 2^k exactly, in double */
-            }
-            const float y = (b - p) * inv_alpha;
-            if (!(y > 0.0f)) continue;
-            const float x = 0.0f - c6o_det_logf(y);
-            const float e2 = c6o_det_expf_parts((a - 1.0f) * c6o_det_logf(x), &k2);
-            if (!(u2 <= scale2f(e2, k2))) continue;
-            return (double)x;
+            if (gs_attempt(a, inv_alpha, b, open01f(w[2 * (att & 1)]), open01f(w[2 * (att & 1) + 1]), m_out, k_out)) return;
+            continue;
         }
         const float v1 = 2.0f * open01f(w[0]) - 1.0f, v2 = 2.0f * open01f(w[1]) - 1.0f;
         const float s = v1 * v1 + v2 * v2;
         if (s >= 1.0f || s == 0.0f) continue;
-        const float x = v1 * sqrtf(-2.0f * c6o_det_logf(s) / s);
+        const float x = v1 * sqrtf(-2.0f * c6o_log4(s) / s);
         const float vc = 1.0f + c * x;
         if (vc <= 0.0f) continue;
         const float v = vc * vc * vc;
         const float u = open01f(w[2]), u2 = open01f(w[3]);
         const float x2 = x * x;
-        if (u < 1.0f - 0.0331f * x2 * x2 || c6o_det_logf(u) < 0.5f * x2 + d * (1.0f - v + c6o_det_logf(v))) {
+        if (u < 1.0f - 0.0331f * x2 * x2 || c6o_log4(u) < 0.5f * x2 + d * (1.0f - v + c6o_log4(v))) {
             int k;
-            const float g = (d * v) * c6o_det_expf_parts(c6o_det_logf(u2) * inv_alpha, &k);
-            return k < -1000 ? 0.0 : (double)g * bits2d((uint64_t)(k + 1023) << 52);
+            *m_out = (d * v) * c6o_exp4(c6o_log4(u2) * inv_alpha, &k);
+            *k_out = k;
+            return;
         }
     }
 }
 
-double c6o_butterfly_sum64(const double part[64]) {
-    double v[64], t[64];
+/* the variate as a double (distribution tests) */
+double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth) {
+    float m;
+    int k;
+    c6o_gamma_draw4(alpha, k0, k1, cell, search, depth, &m, &k);
+    return ldexp((double)m, k);
+}
+
+/* the wave's summation tree: xor-butterfly with ascending offsets 1 .. 32 over the 64 lane partial sums (part of the C6RNG spec) */
+float c6o_butterfly_sum64f(const float part[64]) {
+    float v[64], t[64];
     memcpy(v, part, sizeof v);
-    for (int off = 1; off <= 32; off <<= 1) { /* C6RNG v3: ascending offsets */
+    for (int off = 1; off <= 32; off <<= 1) {
         for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
         memcpy(v, t, sizeof v);
     }
     return v[0];
 }
 
+/* Dirichlet noise of the empty cells (C6RNG v4): Gamma variates m 2^k scaled by 2^-kmax (kmax: the largest exponent of the vector; values
+ * more than 2^100 below it are 0), lane partial sums (cell c belongs to lane c & 63, ascending c), the butterfly, noise = scaled * (1 / sum) */
 void c6o_dirichlet_noise(double alpha, uint32_t k0, uint32_t k1, uint32_t search, uint32_t depth,
                          const int8_t *board, int n, float *noise) {
-    double g[C6O_MAXCELLS], part[64];
+    float m[C6O_MAXCELLS], part[64];
+    int k[C6O_MAXCELLS], kmax = -(1 << 30);
     int cells = n * n;
-    for (int l = 0; l < 64; l++) part[l] = 0.0;
     for (int c = 0; c < cells; c++) {
-        g[c] = 0.0;
+        m[c] = 0.f;
+        k[c] = -(1 << 30);
         if (board[c] == C6O_NONE) {
-            g[c] = c6o_gamma_draw(alpha, k0, k1, (uint32_t)c, search, depth);
-            part[c & 63] = part[c & 63] + g[c]; /* ascending within a lane: c, c+64, ... */
+            c6o_gamma_draw4(alpha, k0, k1, (uint32_t)c, search, depth, &m[c], &k[c]);
+            if (k[c] > kmax) kmax = k[c];
         }
     }
-    double sum = c6o_butterfly_sum64(part);
-    for (int c = 0; c < cells; c++) noise[c] = board[c] == C6O_NONE ? (float)(g[c] / sum) : 0.f;
+    for (int l = 0; l < 64; l++) part[l] = 0.f;
+    for (int c = 0; c < cells; c++) {
+        const int dk = k[c] - kmax;
+        noise[c] = board[c] == C6O_NONE && dk >= -100 ? scale2f(m[c], dk) : 0.f;
+        part[c & 63] = part[c & 63] + noise[c]; /* ascending within a lane: c, c+64, ... (cells that need none add 0) */
+    }
+    const float rs = 1.0f / c6o_butterfly_sum64f(part);
+    for (int c = 0; c < cells; c++) noise[c] = noise[c] * rs;
 }
 
 /* ===================================================================== */

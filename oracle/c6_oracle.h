@@ -109,12 +109,13 @@ enum {
     C6O_TAG_ROLL_POLICY = 7 /* DefaultPolicy::policy fallback,  ctr = (0, 0, searches so far, tag) word 0 */
 };
 void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-float c6o_det_logf(float x);   /* single-precision pair used by the Gamma sampler (C6RNG v2/v3) */
-float c6o_det_expf_parts(float x, int *k);   /* exp(x) = return value * 2^k */
+float c6o_log4(float x);            /* log / exp of the Gamma sampler (C6RNG v4): fused polynomial forms, no division */
+float c6o_exp4(float t, int *k);    /* exp(t) = return value * 2^k */
+void c6o_gamma_draw4(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth, float *m, int *k); /* variate m 2^k */
 /* Gamma(alpha<1,1) draw number `cell` of select step (search, depth) of a game */
 double c6o_gamma_draw(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth);
 /* sum of 64 lane-partials with the xor-butterfly order of the spec */
-double c6o_butterfly_sum64(const double part[64]);
+float c6o_butterfly_sum64f(const float part[64]);
 /* Dirichlet noise for the empty cells of `board` (noise[cell], 0 elsewhere) */
 void c6o_dirichlet_noise(double alpha, uint32_t k0, uint32_t k1, uint32_t search, uint32_t depth,
                          const int8_t *board, int n, float *noise);

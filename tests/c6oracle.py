@@ -99,14 +99,15 @@ def lib():
     L.c6o_augment_way8.argtypes = [i8p, C.c_int, i8p]
     L.c6o_recover_way8.argtypes = [f32p, C.c_int, f32p]
     L.c6o_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    L.c6o_det_logf.restype = C.c_float
-    L.c6o_det_logf.argtypes = [C.c_float]
-    L.c6o_det_expf_parts.restype = C.c_float
-    L.c6o_det_expf_parts.argtypes = [C.c_float, C.POINTER(C.c_int)]
+    L.c6o_log4.restype = C.c_float
+    L.c6o_log4.argtypes = [C.c_float]
+    L.c6o_exp4.restype = C.c_float
+    L.c6o_exp4.argtypes = [C.c_float, C.POINTER(C.c_int)]
+    L.c6o_gamma_draw4.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.c6o_gamma_draw.restype = C.c_double
     L.c6o_gamma_draw.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
-    L.c6o_butterfly_sum64.restype = C.c_double
-    L.c6o_butterfly_sum64.argtypes = [f64p]
+    L.c6o_butterfly_sum64f.restype = C.c_float
+    L.c6o_butterfly_sum64f.argtypes = [C.POINTER(C.c_float)]
     L.c6o_dirichlet_noise.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, i8p, C.c_int, f32p]
     L.c6o_az_new.restype = C.c_void_p
     L.c6o_az_new.argtypes = [C.c_int, C.POINTER(Hyper), C.c_int, EVAL_FN, C.c_void_p, C.c_uint64, C.c_uint32]

@@ -17,17 +17,19 @@ def test_philox_known_answers():
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def test_det_logf_expf_accuracy():
-    """the single-precision pair of the Gamma sampler (C6RNG v2/v3): a few ulp of float over the ranges the sampler uses"""
+def test_log4_exp4_accuracy():
+    """the single-precision pair of the Gamma sampler (C6RNG v4: division-free fused polynomials): a few ulp of float over the ranges
+    the sampler uses -- far more than the sampler needs (its distribution is tested below)"""
     L = o.lib()
     rng = np.random.default_rng(0)
     xs = np.concatenate([rng.uniform(2.0 ** -25, 1, 3000), rng.uniform(1, 64, 500), 10.0 ** rng.uniform(-7, 0, 500)]).astype(np.float32)
     for x in xs:
-        assert abs(L.c6o_det_logf(float(x)) - math.log(float(x))) <= 6e-7 * max(1.0, abs(math.log(float(x))))
+        assert abs(L.c6o_log4(float(x)) - math.log(float(x))) <= 6e-7 * max(1.0, abs(math.log(float(x))))
+    assert L.c6o_log4(1.0) == 0.0
     import ctypes as C
     k = C.c_int()
     for x in rng.uniform(-600, 10, 3000).astype(np.float32):
-        p = L.c6o_det_expf_parts(float(x), C.byref(k))
+        p = L.c6o_exp4(float(x), C.byref(k))
         assert 0.70 < p < 1.42
         # the argument is a float: at |x| ~ 600 its own resolution (2^-24 |x|) bounds the accuracy of exp
         assert abs(math.ldexp(p, k.value) - math.exp(float(x))) <= (1e-6 + 1.5e-7 * abs(float(x))) * math.exp(float(x))
@@ -70,10 +72,28 @@ def test_dirichlet_noise_shape():
 
 def test_butterfly_sum_order():
     rng = np.random.default_rng(1)
-    part = rng.uniform(0, 1, 64) * 10.0 ** rng.integers(-12, 3, 64)
+    part = (rng.uniform(0, 1, 64) * 10.0 ** rng.integers(-12, 3, 64)).astype(np.float32)
     v = part.copy()
-    for off in (1, 2, 4, 8, 16, 32):      # C6RNG v3: ascending offsets (DPP stages, then the four row sums)
+    for off in (1, 2, 4, 8, 16, 32):      # ascending offsets (DPP stages, then the four row sums), in single precision (C6RNG v4)
         v = v + v[np.arange(64) ^ off]
     import ctypes as C
-    got = o.lib().c6o_butterfly_sum64(part.ctypes.data_as(C.POINTER(C.c_double)))
-    assert got == v[0] and (v == v[0]).all()
+    got = o.lib().c6o_butterfly_sum64f(part.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.float32(got) == v[0] and (v == v[0]).all()
+
+
+def test_noise_survives_tiny_variates():
+    """two empty cells: at alpha = 0.03 both Gamma variates are often below 1e-40 (U^(1/alpha)); the normaliser works on exponents
+    relative to the larger one, so the noise is still a probability vector -- never NaN, never all zero"""
+    b = np.ones((9, 9), np.int8)
+    b[0, 0] = 0
+    b[8, 8] = 0
+    worst = 0.0
+    for s in range(400):
+        nz = o.dirichlet_noise(0.03, 5, 6, s, 0, b).astype(np.float64)
+        assert np.isfinite(nz).all() and abs(nz.sum() - 1.0) < 1e-6 and nz[0, 0] >= 0 and nz[8, 8] >= 0
+        m = np.zeros(2, np.float32)
+        import ctypes as C
+        mm, kk = C.c_float(), C.c_int()
+        o.lib().c6o_gamma_draw4(0.03, 5, 6, 0, s, 0, C.byref(mm), C.byref(kk))
+        worst = min(worst, kk.value)
+    assert worst < -126          # the range a float alone could not hold
