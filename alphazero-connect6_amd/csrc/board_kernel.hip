@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void c6_board_kernel(int Gpad, int8_t *__restr
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (placed[k]) {
+#ifndef C6_AB_BOARD_NO_STONE      // ablation builds only (tools/ab_build.sh): the board-step without its one scattered store
             boards[(size_t)cellidx[k] * Gpad + g0 + k] = (int8_t)mover[k];   // game_impl/mod.rs:158
+#endif
             int rem = (int)(int8_t)(r4 >> (8 * k)) - 1;                      // game_impl/mod.rs:160
             if (rem <= 0) {                                                  // :164-167
                 rem = 2;
@@ -312,9 +314,13 @@ __global__ __launch_bounds__(256) void c6_board_kernel(int Gpad, int8_t *__restr
             nr4 = (nr4 & ~(0xffu << (8 * k))) | ((uint32_t)(uint8_t)rem << (8 * k));
         }
     }
+#ifdef C6_AB_BOARD_NO_STATUS      // ablation builds only: one status dword instead of three
+    *reinterpret_cast<uint32_t *>(winner + g0) = ((ow4 & keep) | (w4 & ~keep)) ^ nr4 ^ nt4;
+#else
     *reinterpret_cast<uint32_t *>(winner + g0) = (ow4 & keep) | (w4 & ~keep);
     *reinterpret_cast<uint32_t *>(remain + g0) = nr4;
     if (nt4 != t4) *reinterpret_cast<uint32_t *>(turn + g0) = nt4;
+#endif
 }
 
 template <int N>
