@@ -45,7 +45,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
-                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_conv_wgrad_op", "c6_engine_boards", "c6_engine_apply_moves", "c6_engine_last_moves",
+                  "c6_trainer_last_error", "c6_trainer_set_precision", "c6_conv_wgrad_op", "c6_engine_boards", "c6_engine_play_match", "c6_engine_apply_moves", "c6_engine_last_moves",
                   "c6_rollout_create", "c6_rollout_destroy", "c6_rollout_reset", "c6_rollout_next", "c6_rollout_slot_info",
                   "c6_rollout_node", "c6_rollout_bench_playouts"]
 
@@ -149,6 +149,7 @@ def lib():
     L.c6_engine_apply_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_last_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.c6_engine_play_match.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_long]
     L.c6_engine_boards.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
     L.c6_rollout_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
     L.c6_rollout_destroy.argtypes = [C.c_void_p]
@@ -451,6 +452,12 @@ class Engine:
         if p.size != self.G:
             raise C6Error("apply_moves needs one entry per game")
         _chk(lib().c6_engine_apply_moves(self.h, _p(p, C.c_int32)))
+
+    def play_match(self, engine_colour, opponent="random", rollout=None, opp_seed=0, max_stones=0):
+        """evaluation games of this engine's search (as `engine_colour`: -1 Black, +1 White) against RandomPolicy ("random") or a
+        DefaultPolicy object ("rollout", rollout=DefaultPolicy(...)) on the device; results: fetch_games()"""
+        kind = {"random": 1, "rollout": 2}[opponent]
+        _chk(lib().c6_engine_play_match(self.h, engine_colour, kind, rollout.h if rollout is not None else None, opp_seed, max_stones))
 
     def boards(self):
         """K1's canonical state: (boards int8 [G, N*N], turn [G], remain [G])"""

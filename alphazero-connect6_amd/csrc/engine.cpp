@@ -133,6 +133,20 @@ struct DevPool {
         if (it != ptrs.end()) { ptrs.erase(it); hipFree(p); }
     }
 };
+// device scratch of one call, freed when it returns
+struct TmpDev {
+    std::vector<void *> p;
+    ~TmpDev() { for (void *q : p) hipFree(q); }
+    template <typename T> T *get(size_t n, const T *src = nullptr) {
+        void *q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(n * sizeof(T), 16)) != hipSuccess) return nullptr;
+        p.push_back(q);
+        if (src) hipMemcpy(q, src, n * sizeof(T), hipMemcpyHostToDevice);
+        else hipMemset(q, 0, std::max<size_t>(n * sizeof(T), 16));
+        return reinterpret_cast<T *>(q);
+    }
+};
+
 #define ALLOC(p, n)                                     \
     do {                                                \
         int rc_ = pool.alloc(&(p), (size_t)(n));        \
@@ -913,17 +927,109 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
 // + is_game_end on the GPU, then the same re-rooting as after the engine's own move -- the AlphaZero tree of the other
 // colour keeps every node below the new position (the reference's policy is simply not consulted for this stone and
 // finds its old nodes again at its next turn).
+// pos_dev: int32 [Gpad] on the device (entries beyond G: -2)
+static int apply_moves_dev(c6_engine *e, const int32_t *pos_dev) {
+    C6Dev &d = e->d;
+    HIPCHK(hipMemcpyAsync(d.move_pos, pos_dev, (size_t)d.Gpad * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.move_turn, d.turn, (size_t)d.G, hipMemcpyDeviceToDevice, e->stream));   // the mover = the side to move now
+    c6_launch_board_step(d.N, d.Gpad, d.board_soa, d.turn, d.remain, d.move_pos, d.winner, d.err, e->stream);
+    c6_launch_post_move(d, e->stream);
+    HIPCHK(hipGetLastError());
+    return C6_OK;
+}
 extern "C" int c6_engine_apply_moves(c6_engine *e, const int32_t *pos) {
     if (!e || !pos) return fail(C6_ERR_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
     C6Dev &d = e->d;
     std::vector<int32_t> h((size_t)d.Gpad, -2);
     for (int g = 0; g < d.G; g++) h[g] = pos[g];
-    HIPCHK(hipMemcpyAsync(d.move_pos, h.data(), (size_t)d.Gpad * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(d.move_turn, d.turn, (size_t)d.G, hipMemcpyDeviceToDevice, e->stream));   // the mover = the side to move now
-    HIPCHK(hipStreamSynchronize(e->stream));       // h goes out of scope
-    c6_launch_board_step(d.N, d.Gpad, d.board_soa, d.turn, d.remain, d.move_pos, d.winner, d.err, e->stream);
-    c6_launch_post_move(d, e->stream);
+    int32_t *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, (size_t)d.Gpad * sizeof(int32_t)));
+    hipError_t he = hipMemcpy(tmp, h.data(), (size_t)d.Gpad * sizeof(int32_t), hipMemcpyHostToDevice);
+    int rc = he == hipSuccess ? apply_moves_dev(e, tmp) : fail(C6_ERR_HIP, "apply_moves: copy failed");
+    hipStreamSynchronize(e->stream);
+    hipFree(tmp);
+    return rc;
+}
+
+// ---- evaluation matches on the device: MultiPolicy(AlphaZero of this engine, opponent) ----------------------------------------------
+// policy/multi_policy/mod.rs:61-71 gives each colour its own policy; here the engine's search plays `engine_colour` and the opponent --
+// RandomPolicy (policy/random_policy/mod.rs:39-47) or DefaultPolicy (pure MCTS with random playouts, c6_rollout) -- the other one, for
+// all games at once, and no board, move or result crosses the host between the first stone and the last: the opponent reads the engine's
+// root positions in place, its stones reach K1 device to device (apply_moves_dev), and the host only reads one word per stone (the
+// number of games still playing).
+__global__ void c6_match_prepare_kernel(C6Dev E, int opp_colour, int8_t *boards, uint8_t *active, int *live) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.G) return;
+    const bool playing = E.hdr[g].status == C6_ST_PLAYING;
+    active[g] = playing && E.turn[g] == opp_colour;
+    if (playing) atomicAdd(live, 1);
+    for (int c = 0; c < E.cells; c++) boards[(size_t)g * E.cells + c] = E.root_board[(size_t)g * E.cellsP + c];
+}
+// RandomPolicy::next: a uniformly random empty cell (`possible.choose(rng)`); the unseeded thread_rng becomes C6RNG tag 8:
+// word 0 of Philox(key = (seed_lo, seed_hi + game uid); ctr = (stones on the board, 0, 0, 8)), the k-th empty cell in row-major order with
+// k = (w * len) >> 32 (as the DefaultPolicy picks of part 5)
+#define C6_TAG_RANDOM_POLICY 8u
+__global__ void c6_random_policy_kernel(C6Dev E, uint32_t seed_lo, uint32_t seed_hi, const int8_t *boards, const uint8_t *active, int32_t *pos) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.G) return;
+    pos[g] = -1;
+    if (!active[g]) return;
+    const int8_t *b = boards + (size_t)g * E.cells;
+    int len = 0;
+    for (int c = 0; c < E.cells; c++) len += b[c] == 0;
+    if (len == 0) return;
+    const c6_u4 w = c6_philox((uint32_t)E.hdr[g].nstones, 0u, 0u, C6_TAG_RANDOM_POLICY, seed_lo, seed_hi + E.hdr[g].game_uid);
+    int k = (int)(((unsigned long long)w.x * (unsigned long long)len) >> 32);
+    for (int c = 0; c < E.cells; c++)
+        if (b[c] == 0 && k-- == 0) { pos[g] = c; break; }
+}
+// the opponent's answers as K1 takes them: the cell, -1 (an active game without an empty cell: a draw) or -2 (not this game's turn)
+__global__ void c6_match_moves_kernel(int G, int Gpad, const uint8_t *active, const int32_t *pos, int32_t *move) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < Gpad) move[g] = g < G && active[g] ? pos[g] : -2;
+}
+
+extern "C" int c6_engine_play_match(c6_engine *e, int engine_colour, int opponent, c6_rollout *r, uint64_t opp_seed, long max_stones) {
+    if (!e || (engine_colour != -1 && engine_colour != 1)) return fail(C6_ERR_BAD_ARG, "c6_engine_play_match: engine_colour is -1 (Black) or +1 (White)");
+    if (opponent != C6_OPP_RANDOM && opponent != C6_OPP_ROLLOUT) return fail(C6_ERR_BAD_ARG, "c6_engine_play_match: opponent is C6_OPP_RANDOM or C6_OPP_ROLLOUT");
+    if (opponent == C6_OPP_ROLLOUT && !r) return fail(C6_ERR_BAD_ARG, "c6_engine_play_match: C6_OPP_ROLLOUT needs a c6_rollout with as many slots as the engine has games");
+    if (e->cfg.recycle || e->cfg.stagger) return fail(C6_ERR_BAD_ARG, "c6_engine_play_match: evaluation games are played once, in step (recycle = stagger = 0)");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    C6Dev &d = e->d;
+    TmpDev t;
+    int8_t *boards = t.get<int8_t>((size_t)d.G * d.cells);
+    uint8_t *active = t.get<uint8_t>(d.G);
+    int32_t *pos = t.get<int32_t>(d.Gpad), *move = t.get<int32_t>(d.Gpad);
+    int *live = t.get<int>(1);
+    if (!boards || !active || !pos || !move || !live) return fail(C6_ERR_HIP, "hipMalloc failed");
+    const unsigned gb = (unsigned)((d.Gpad + 255) / 256);
+    // every game is at the same stone of the same turn: Black 1, then 2 each (game_impl/mod.rs:125-169)
+    int turn = C6_BLACK, remain = 1;
+    for (long stone = 0; max_stones <= 0 || stone < max_stones; stone++) {
+        HIPCHK(hipMemsetAsync(live, 0, sizeof(int), e->stream));
+        hipLaunchKernelGGL(c6_match_prepare_kernel, dim3(gb), dim3(256), 0, e->stream, d, -engine_colour, boards, active, live);
+        int h_live = 0;
+        HIPCHK(hipMemcpyAsync(&h_live, live, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (h_live == 0) break;
+        if (turn == engine_colour) {
+            int rc = c6_engine_step(e, d.S);      // S searches and the stone of every live game
+            if (rc != C6_OK) return rc;
+        } else {
+            if (opponent == C6_OPP_RANDOM)
+                hipLaunchKernelGGL(c6_random_policy_kernel, dim3(gb), dim3(256), 0, e->stream, d, (uint32_t)opp_seed, (uint32_t)(opp_seed >> 32), boards, active, pos);
+            else {
+                HIPCHK(hipStreamSynchronize(e->stream));
+                int rc = c6_rollout_next(r, boards, active, pos, 1);      // device pointers; synchronises its own stream
+                if (rc != C6_OK) return fail(rc, "c6_engine_play_match: c6_rollout_next failed (tree full?)");
+            }
+            hipLaunchKernelGGL(c6_match_moves_kernel, dim3(gb), dim3(256), 0, e->stream, d.G, d.Gpad, active, pos, move);
+            int rc = apply_moves_dev(e, move);
+            if (rc != C6_OK) return rc;
+        }
+        if (--remain <= 0) { remain = 2; turn = -turn; }
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
     return C6_OK;
@@ -1297,18 +1403,6 @@ extern "C" int c6_engine_profile_read(c6_engine *e, c6_profile *out, int reset) 
 
 // ---- stand-alone operators ------------------------------------------------------------------
 
-struct TmpDev {
-    std::vector<void *> p;
-    ~TmpDev() { for (void *q : p) hipFree(q); }
-    template <typename T> T *get(size_t n, const T *src = nullptr) {
-        void *q = nullptr;
-        if (hipMalloc(&q, std::max<size_t>(n * sizeof(T), 16)) != hipSuccess) return nullptr;
-        p.push_back(q);
-        if (src) hipMemcpy(q, src, n * sizeof(T), hipMemcpyHostToDevice);
-        else hipMemset(q, 0, std::max<size_t>(n * sizeof(T), 16));
-        return reinterpret_cast<T *>(q);
-    }
-};
 
 static int check_n(int n) {
     if (n != 9 && n != 15 && n != 19) return fail(C6_ERR_BAD_ARG, "board_size must be 9, 15 or 19");

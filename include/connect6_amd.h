@@ -233,6 +233,17 @@ int c6_engine_run(c6_engine *e, long max_rounds);
 int c6_engine_maintain(c6_engine *e);
 int c6_engine_sync(c6_engine *e);
 
+/* Evaluation games MultiPolicy(this engine's AlphaZero search, opponent) for all games at once, on the device from the first stone to
+ * the last (policy/multi_policy/mod.rs:61-71: one policy per colour).  engine_colour: -1 the engine plays Black, +1 White.  opponent:
+ * C6_OPP_RANDOM = RandomPolicy (policy/random_policy/mod.rs:39-47; its unseeded pick becomes C6RNG tag 8: word 0 of Philox(key =
+ * (seed_lo, seed_hi + game uid); ctr = (stones on the board, 0, 0, 8)), the k-th empty cell in row-major order, k = (w * len) >> 32);
+ * C6_OPP_ROLLOUT = DefaultPolicy, pure MCTS with random playouts: `r` from c6_rollout_create with num_games slots (part 5).
+ * The engine must have been created with recycle = stagger = 0 and be at the start of its games; results: c6_engine_fetch_games.
+ * max_stones <= 0: to the end.  No board, move or result crosses the host while the games are played. */
+enum { C6_OPP_RANDOM = 1, C6_OPP_ROLLOUT = 2 };
+struct c6_rollout;
+int c6_engine_play_match(c6_engine *e, int engine_colour, int opponent, struct c6_rollout *r, uint64_t opp_seed, long max_stones);
+
 /* the canonical game state (what K1 reads and writes): boards[g][N*N] in {-1, 0, +1}, the side to move and the stones it still has
  * to place (Game{turn, num_remain}, game_impl/mod.rs:117-121); any of the pointers may be NULL.  Synchronises. */
 int c6_engine_boards(c6_engine *e, int8_t *boards, int8_t *turn, int8_t *remain);
