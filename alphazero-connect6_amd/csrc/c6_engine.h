@@ -207,6 +207,7 @@ struct C6NetDev {
     const float *stem_w;  // [9][2][C]
     const float *stem_b;  // [C]
     int variant;          // C6_CONV_*
+    int wino6;            // C6_CONV_WINO at 19x19, C = 256, >= 2 residual blocks: conv_ww holds conv_wino6.hip's weight sets
     int num_cus;
     // per layer [(blocks-1)*2], only the image of the selected kernel is resident:
     const float *conv_ww;          // Winograd-transformed weights G g G^T packed per wave (conv_wino.hip), 16 C^2 floats
@@ -291,6 +292,16 @@ double c6_conv_wino4_exec_flops(int C, int N, int nboards);
 size_t c6_conv_wino4_wgrad_partial_floats(int C, int N, int nboards, int num_cus);
 bool c6_conv_wino4_wgrad(int C, int N, int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s,
                          const float *vkept = nullptr);      // vkept: B^T x B of this layer as the forward pass left it (then x is not transformed again)
+// the evaluator's tower at 19x19, C = 256, >= 2 residual blocks (conv_wino6.hip): the same F(4x4) Winograd pipeline on tiles six pixels wide
+bool c6_w6_available(int C, int N, int blocks);
+size_t c6_w6_packed_floats(void);
+void c6_w6_pack_weights(const float *w_oihw_folded, float *packed);
+size_t c6_w6_vbuf_floats(int nboards);
+// steps: 1 the first layer's input transform from the boards (`stem`), 2 the GEMMs, 16 the boundary kernel (bias, residual `res` or the
+// recomputed stem, activations to `act` if given), 4 the last output transform with the heads' filters
+bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float *res, float *act, float *vbuf, int num_cus, hipStream_t s, int steps,
+                    const C6HeadFuse *heads = nullptr, const C6StemSrc *stem = nullptr);
+double c6_w6_exec_flops(int nboards);
 // FP32 direct (conv_f32n.hip)
 size_t c6_conv_packed_f32n_floats(int C);
 void c6_pack_conv_weights_f32n(int C, const float *w_oihw_folded, float *packed);

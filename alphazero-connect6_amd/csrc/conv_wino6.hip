@@ -1,0 +1,797 @@
+// conv_wino6.hip -- the evaluator's FP32 Winograd tower at 19x19, C = 256: the tiling of conv_wino4.hip with tiles SIX pixels wide.
+//
+// Same layer and the same f32 arithmetic as conv_wino4.hip (conv3x3 C -> C, pad 1, + folded-BN bias (+ residual) + ReLU;
+// AlphaZero/cpp_weighted/model.hpp:61-78; f32 operands, exact f32 products, f32 accumulate).  What changes is how a board is cut:
+//     columns 19 = 6 + 6 + 4 + 3     F(6,3) (8 patch columns: points 0, +-1, +-2, +-1/2, inf), F(6,3), F(4,3), F(3,3)
+//     rows    19 = 4 + 4 + 4 + 4 + 3 as before (the boundary kernels' rolling window holds 6 pixel rows of LDS: an 8-row window for tiles six
+//                                    pixels TALL would be 180 KB)
+// 20 tiles per board in four classes, each in its own region of V / Z so that a GEMM block of 64 tiles is of one class:
+//     A   tx = 2, ty < 4    4 x 4 outputs, F(4) x F(4), 36 positions  p = 6 i + j
+//     B   tx = 3, ty < 4    4 x 3, F(4) vertically, F(3) horizontally: 6 x 5 positions stored transposed, p = 6 j + i (j < 5)
+//     B'  ty = 4, tx >= 2   3 x 4 (and the 3 x 3 corner as 3 x 4): F(3) vertically, F(4) horizontally: p = 6 i + j (i < 5)
+//     D   tx < 2            4 x 6 (ty = 4: 3 x 6 as 4 x 6), F(4) vertically, F(6) horizontally: 6 x 8 positions stored transposed,
+//                           p = 6 j + i (j < 8)
+// The 6-long direction (F(4)'s six patch points) always runs INSIDE a row of positions, so the GEMM kernel's register half of the output
+// transform is the one F(4) A^T of conv_wino4.hip for every class; a D block simply has 8 rows of positions and its own set of transformed
+// weights.  804 instead of 846 positions per board (-5 % matrix work and V bytes), 536 instead of 564 row sums (Z).
+// And a board has FOUR tile columns: the boundary kernels run 4 waves per workgroup, one per SIMD with the whole register file each --
+// room to fetch the next tile row's Z while the current one is transformed (conv_wino4.hip's five waves share SIMDs and cannot).
+//
+// Kernels (the tower of a net with >= 2 residual blocks: net_kernels.hip):
+//   c6_w6_stem_in_kernel   boards -> V of the first layer (the stem computed in place)
+//   c6_w6_gemm_kernel      conv_wino4.hip's GEMM schedule over the four classes
+//   c6_w6_mid_kernel       Z of layer l -> (activations) -> V of layer l + 1, software-pipelined
+//   c6_w6_out_kernel       Z of the last layer -> the heads' 1x1 filters
+// Rounding: F(6,3)'s matrices (entries up to 32 and 21/4) in ONE direction: a layer's error ~3e-6 rms of activations of order 1; the net's
+// outputs stay within 1e-5 of a float64 model (tests/test_gpu_net.py).
+#include "c6_wino.h"
+
+#define W6_BT 64          // tiles per block
+#define W6_C 256
+#define W6_N 19
+#define W6_TWX 4
+#define W6_TWY 5
+#define W6_T 20           // tiles per board
+#define W6_NPV 49         // 1-KiB rows of a tile's slot in V: 48 positions (class D uses all of them) + one of padding -- tile rows of a GEMM slab
+#define W6_NZ 33          // and of its slot in Z: 32 row sums + one of padding -- then lie an ODD number of KiB apart (48 / 32 KiB strides
+                          // put the 64 rows of a slab on a fraction of the memory channels)
+#define W6_COLS 22        // window columns: board columns -1 .. 20
+#define W6_ROWF (W6_COLS * W6_C)
+#define W6_PF 7
+enum { W6_CLS_A = 0, W6_CLS_B = 1, W6_CLS_BP = 2, W6_CLS_D = 3 };
+#define W6_NA 4
+#define W6_NB 4
+#define W6_NBP 2
+#define W6_ND 10
+#define W6_SETS_POS (36 + 30 + 30 + 48)      // position matrices of the four weight sets
+
+__host__ __device__ __forceinline__ int w6_x0(int tx) { return tx == 0 ? 0 : tx == 1 ? 6 : tx == 2 ? 12 : 16; }
+__host__ __device__ __forceinline__ int w6_width(int tx) { return tx < 2 ? 6 : tx == 2 ? 4 : 3; }
+__host__ __device__ __forceinline__ int w6_cls(int ty, int tx) { return tx < 2 ? W6_CLS_D : ty == W6_TWY - 1 ? W6_CLS_BP : tx == 2 ? W6_CLS_A : W6_CLS_B; }
+struct W6Map {
+    long blkB, blkBP, blkD, nblocks;
+    __host__ __device__ explicit W6Map(long nboards) {
+        blkB = (nboards * W6_NA + W6_BT - 1) / W6_BT;
+        blkBP = blkB + (nboards * W6_NB + W6_BT - 1) / W6_BT;
+        blkD = blkBP + (nboards * W6_NBP + W6_BT - 1) / W6_BT;
+        nblocks = blkD + (nboards * W6_ND + W6_BT - 1) / W6_BT;
+    }
+    // the tile's slot: block slot / 64, tile slot % 64 of the block
+    __host__ __device__ __forceinline__ long slot(long bd, int ty, int tx) const {
+        if (tx < 2) return blkD * W6_BT + bd * W6_ND + ty * 2 + tx;
+        if (ty == W6_TWY - 1) return blkBP * W6_BT + bd * W6_NBP + (tx - 2);
+        if (tx == 2) return bd * W6_NA + ty;
+        return blkB * W6_BT + bd * W6_NB + ty;
+    }
+};
+#define W6_VTILE ((size_t)W6_NPV * W6_C)
+#define W6_VBLOCK ((size_t)W6_BT * W6_NPV * W6_C)
+#define W6_ZTILE ((size_t)W6_NZ * W6_C)
+#define W6_ZBLOCK ((size_t)W6_BT * W6_NZ * W6_C)
+
+// ---- F(6,3), points 0, +-1, +-2, +-1/2, inf (the matrices of Lavin & Gray's generator) ---------------------------------------------
+// row i of B^T (8 x 8) applied along the first index of x[8]:
+//   [1 0 -21/4 0 21/4 0 -1 0; 0 1 1 -17/4 -17/4 1 1 0; 0 -1 1 17/4 -17/4 -1 1 0; 0 1/2 1/4 -5/2 -5/4 2 1 0; 0 -1/2 1/4 5/2 -5/4 -2 1 0;
+//    0 2 4 -5/2 -5 1/2 1 0; 0 -2 4 5/2 -5 -1/2 1 0; 0 -1 0 21/4 0 -21/4 0 1]
+// all eight at once, through the even / odd parts the rows share
+template <typename V>
+__device__ __forceinline__ void w6_bt6(const V (&x)[8], V (&r)[8]) {
+    r[0] = w4_fma(5.25f, x[4] - x[2], x[0] - x[6]);
+    r[7] = w4_fma(5.25f, x[3] - x[5], x[7] - x[1]);
+    const V e1 = w4_fma(-4.25f, x[4], x[2] + x[6]), o1 = w4_fma(-4.25f, x[3], x[1] + x[5]);
+    r[1] = e1 + o1;
+    r[2] = e1 - o1;
+    const V e2 = w4_fma(0.25f, x[2], w4_fma(-1.25f, x[4], x[6])), o2 = w4_fma(0.5f, x[1], w4_fma(-2.5f, x[3], x[5] + x[5]));
+    r[3] = e2 + o2;
+    r[4] = e2 - o2;
+    const V e3 = w4_fma(4.f, x[2], w4_fma(-5.f, x[4], x[6])), o3 = w4_fma(2.f, x[1], w4_fma(-2.5f, x[3], 0.5f * x[5]));
+    r[5] = e3 + o3;
+    r[6] = e3 - o3;
+}
+// B^T d B of one patch -> the tile's positions in V (2 channels per pass, every window value read from LDS once: conv_wino4.hip).
+// The patch's rows lie in the window slots slot[0 .. 5] (float offsets), wc = its first column (channel 0), vt = the tile in V.
+__device__ __forceinline__ void w6_patch_transform(const float *wc, const int (&slot)[6], float *vt, int lane, int cls) {
+    constexpr int C = W6_C;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int co = h * (C / 2) + lane * 2;
+        const float *wl = wc + co;
+        float *vl = vt + co;
+#define W6_D(a, b) (*reinterpret_cast<const f32x2 *>(wl + slot[a] + (b) * C))
+#define W6_VST(pos, val) *reinterpret_cast<f32x2 *>(vl + (size_t)(pos) * C) = (val)
+        if (cls == W6_CLS_D) {      // 6 patch rows (F(4) vertically) x 8 columns (F(6) horizontally), stored transposed: p = 6 j + i
+            f32x2 t[6][8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const f32x2 d0 = W6_D(0, b), d1 = W6_D(1, b), d2 = W6_D(2, b), d3 = W6_D(3, b), d4 = W6_D(4, b), d5 = W6_D(5, b);
+#pragma unroll
+                for (int i = 0; i < 6; i++) t[i][b] = W4_BT_ROW(i, d0, d1, d2, d3, d4, d5);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                f32x2 r[8];
+                w6_bt6(t[i], r);
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) W6_VST(jj * 6 + i, r[jj]);
+            }
+        } else if (cls == W6_CLS_A) {
+            f32x2 t[6][6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const f32x2 d0 = W6_D(0, b), d1 = W6_D(1, b), d2 = W6_D(2, b), d3 = W6_D(3, b), d4 = W6_D(4, b), d5 = W6_D(5, b);
+#pragma unroll
+                for (int i = 0; i < 6; i++) t[i][b] = W4_BT_ROW(i, d0, d1, d2, d3, d4, d5);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int jj = 0; jj < 6; jj++) W6_VST(i * 6 + jj, W4_BT_ROW(jj, t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5]));
+        } else if (cls == W6_CLS_BP) {      // 5 patch rows (F(3) vertically) x 6 columns
+            f32x2 t[5][6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const f32x2 d0 = W6_D(0, b), d1 = W6_D(1, b), d2 = W6_D(2, b), d3 = W6_D(3, b), d4 = W6_D(4, b);
+#pragma unroll
+                for (int i = 0; i < 5; i++) t[i][b] = W4_BT3_ROW(i, d0, d1, d2, d3, d4);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int jj = 0; jj < 6; jj++) W6_VST(i * 6 + jj, W4_BT_ROW(jj, t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5]));
+        } else {                            // B: 6 patch rows x 5 columns (F(3) horizontally), positions stored transposed
+            f32x2 t[6][5];
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+                const f32x2 d0 = W6_D(0, b), d1 = W6_D(1, b), d2 = W6_D(2, b), d3 = W6_D(3, b), d4 = W6_D(4, b), d5 = W6_D(5, b);
+#pragma unroll
+                for (int i = 0; i < 6; i++) t[i][b] = W4_BT_ROW(i, d0, d1, d2, d3, d4, d5);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int jj = 0; jj < 5; jj++) W6_VST(jj * 6 + i, W4_BT3_ROW(jj, t[i][0], t[i][1], t[i][2], t[i][3], t[i][4]));
+        }
+#undef W6_D
+#undef W6_VST
+        __builtin_amdgcn_sched_barrier(0);      // one pass at a time
+    }
+}
+// window slot offsets of the six patch rows of tile row ty (board rows 4 ty - 1 .. 4 ty + 4; row y lives in slot (y + 1) % 6)
+__device__ __forceinline__ void w6_slots(int ty, int (&slot)[6]) {
+#pragma unroll
+    for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * W6_ROWF;
+}
+
+// The boundary kernels' barriers order accesses to the LDS window only: wait for the wave's LDS operations, not for its global loads and
+// stores (__syncthreads() also drains vmcnt: every V store and every prefetched Z load would have to land before the workgroup moves on)
+#define W6_LDS_BARRIER()                                        \
+    do {                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();                           \
+        asm volatile("" ::: "memory");                          \
+    } while (0)
+
+// ---- first layer: the stem computed into the window, input transform -> V -----------------------------------------------------------
+#define W6_THREADS 256      // 4 waves: wave = tile column
+__global__ __launch_bounds__(W6_THREADS) void c6_w6_stem_in_kernel(C6StemSrc S, float *__restrict__ V, int nboards) {
+    constexpr int C = W6_C, N = W6_N, LPT = C / 4, P = N + 2, ROWF = W6_ROWF;
+    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] + the player-plane sums [9][C] + the board plane [P][P]
+    float *s0 = win + 6 * ROWF, *bd = s0 + 9 * C;
+    const int tid = threadIdx.x, cq = tid % LPT, tx = tid / LPT;
+    const W6Map map(nboards);
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = tid; k < 6 * ROWF / 4; k += W6_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
+    for (int k = tid; k < P * P; k += W6_THREADS) bd[k] = 0.f;
+    f32x4 sw[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) sw[t] = *reinterpret_cast<const f32x4 *>(S.w + (t * 2 + 1) * C + cq * 4);
+    if (tid < LPT) w4_stem_player_sums(S.w, C, tid * 4, s0);
+    const f32x4 sb = *reinterpret_cast<const f32x4 *>(S.bias + cq * 4);
+    float pv = 0.f;
+    // rows y0 .. y0 + nr - 1 of the stem's output into the window (rows outside the board are zeros)
+    auto fill = [&](int y0, int nr) {
+        for (int k = tid; k < nr * N * LPT; k += W6_THREADS) {
+            const int r = k / (N * LPT), px = (k / LPT) % N, y = y0 + r;
+            const bool inb = y >= 0 && y < N;
+            const f32x4 v = inb ? w4_stem_pixel<N>(bd, w4_fma(pv, *reinterpret_cast<const f32x4 *>(s0 + w4_border_class(y, px, N) * C + cq * 4), zero4), y, px, sb,
+                                                   [&](int t) { return sw[t]; })
+                                : zero4;
+            *reinterpret_cast<f32x4 *>(win + ((y + 1) % 6) * ROWF + (px + 1) * C + cq * 4) = v;
+        }
+    };
+#pragma unroll 1
+    for (int b = blockIdx.x; b < nboards; b += gridDim.x) {
+        W6_LDS_BARRIER();                                            // the previous board's last reads (and the zero fills)
+        pv = w4_stem_plane<N>(S, b, bd, tid, W6_THREADS);
+        W6_LDS_BARRIER();
+        fill(-1, 6);
+#pragma unroll 1
+        for (int ty = 0; ty < W6_TWY; ty++) {
+            W6_LDS_BARRIER();                                        // rows 4 ty - 1 .. 4 ty + 4 are in the window
+            {
+                const long t = map.slot(b, ty, tx);
+                float *vb = V + (size_t)(t / W6_BT) * W6_VBLOCK + (size_t)(t % W6_BT) * W6_VTILE;
+                int slot[6];
+                w6_slots(ty, slot);
+                w6_patch_transform(win + w6_x0(tx) * C, slot, vb, cq, w6_cls(ty, tx));
+            }
+            if (ty + 1 < W6_TWY) {
+                W6_LDS_BARRIER();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more
+                fill(4 * ty + 5, 4);
+            }
+        }
+    }
+}
+
+// the tail of a region's last block (tiles beyond the batch) is never written by the kernels above: zero it once per launch
+__global__ void c6_w6_tail_kernel(float *__restrict__ V, int nboards) {
+    const W6Map map(nboards);
+    const long first_blk[4] = {0, map.blkB, map.blkBP, map.blkD}, count[4] = {(long)nboards * W6_NA, (long)nboards * W6_NB, (long)nboards * W6_NBP, (long)nboards * W6_ND};
+    for (int r = 0; r < 4; r++) {
+        const int used = (int)(count[r] % W6_BT);
+        if (used == 0) continue;
+        float *blk = V + (size_t)(first_blk[r] + count[r] / W6_BT) * W6_VBLOCK + (size_t)used * W6_VTILE;
+        const size_t n = (size_t)(W6_BT - used) * W6_VTILE;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) blk[i] = 0.f;
+    }
+}
+static bool w6_has_tail(int nboards) {
+    return ((long)nboards * W6_NA) % W6_BT || ((long)nboards * W6_NB) % W6_BT || ((long)nboards * W6_NBP) % W6_BT || ((long)nboards * W6_ND) % W6_BT;
+}
+
+// ---- the GEMMs of a block, with the column half of the output transform ("Z rows"): conv_wino4.hip's c6_wino4_gemm_kernel ----------
+// over four classes: rows of positions 6 / 5 / 5 / 8, weight sets at 0 / 36 / 66 / 96 C^2, tile slots of 48 positions in V and 32 row
+// sums in Z.  The schedule, the hand-issued memory operations and their wait counts are the original's (see there).
+constexpr int w6_store_group(int k) { return 8 + k; }
+constexpr int w6_wait(int i, bool stores) {
+    const int nd = 8;
+    const int lo = i - W6_PF > 0 ? i - W6_PF : 0, hi = (nd - 1 < i - 1) ? nd - 1 : i - 1;
+    const int dmas = hi >= lo ? hi - lo + 1 : 0;
+    int st = 0;
+    if (stores)
+        for (int k = 0; k < 16; k++)
+            if (w6_store_group(k) < i && w6_store_group(k) >= i - W6_PF) st++;
+    return W6_PF + dmas + st;
+}
+static_assert(w6_store_group(15) < 32 - W6_PF, "a position's stores are older than every request that is waited for in the next one");
+
+__global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo,
+                                                                      int nblocks, int blkB, int blkBP, int blkD) {
+    constexpr int C = W6_C, CP = C + 4, SLAB = W6_BT * CP, WAVES = C / 32, NG = C / 8, PF = W6_PF;
+    constexpr int ND = W6_BT / WAVES;
+    static_assert(PF == 7 && NG == 32 && ND == 8, "ring of 8 weight groups; 8 DMAs per position");
+    constexpr int RM = PF;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int n4 = wave * 32 + 4 * h;
+    int b = blockIdx.x;
+    if (b >= nblocks) return;
+
+    auto rows_of = [&](int blk) { return blk < blkB ? 6 : blk < blkD ? 5 : 8; };
+    auto wbase_of = [&](int blk) {
+        const int first = blk < blkB ? 0 : blk < blkBP ? 36 : blk < blkD ? 66 : 96, npos = blk < blkB ? 36 : blk < blkD ? 30 : 48;
+        return U + (size_t)first * C * C + (size_t)wave * ((size_t)npos * NG * 256);
+    };
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned zoff0 = (unsigned)(((size_t)j * W6_ZTILE + n4) * 4), zoff1 = zoff0 + (unsigned)((size_t)32 * W6_ZTILE * 4);
+
+    auto dma_chunk = [&](const float *src, int buf, int c0) {
+        const int c = c0 * WAVES + wave;
+        const float *gp = src + (size_t)c * W6_VTILE;
+        const int lds_off = (buf * SLAB + c * CP) * 4;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lds_off) : "memory");
+    };
+#pragma unroll
+    for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * W6_VBLOCK, 0, c0);
+    f32x4 ring[PF + 1];
+    int ub = b, ungt = rows_of(b) * 6 * NG;      // the weight stream runs ahead of the multiplications: its own block and group counters
+    const float *uptr = wbase_of(b);
+    int gi = 0;
+#define W6_UNEXT()                                                       \
+    {                                                                    \
+        gi += 1; uptr += 256;                                            \
+        if (gi == ungt) {                                                \
+            gi = 0;                                                      \
+            ub = ub + (int)gridDim.x < nblocks ? ub + (int)gridDim.x : ub; \
+            ungt = rows_of(ub) * 6 * NG;                                 \
+            uptr = wbase_of(ub);                                         \
+        }                                                                \
+    }
+#pragma unroll
+    for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W6_UNEXT() }
+
+    f32x16 z00, z01, z10, z11, z20, z21, z30, z31, m0, m1;
+    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    z20 = z16; z21 = z16; z30 = z16; z31 = z16;
+    const float *zprev = Zo + (size_t)b * W6_ZBLOCK;          // row base of the row whose Z_2, Z_3 are still to be stored
+    const float *zcur = zprev;                                  // row base of the row being accumulated
+
+#define W6Z_STORE1(SET0, SET1, BIDX, DST, k)                                                                     \
+    {                                                                                                            \
+        const f32x16 &sv = ((k) & 4) ? SET1 : SET0;                                                              \
+        const f32x4 a = {sv[4 * ((k) & 3)], sv[4 * ((k) & 3) + 1], sv[4 * ((k) & 3) + 2], sv[4 * ((k) & 3) + 3]}; \
+        const float *d_ = (DST) + (size_t)(BIDX) * C;                                                            \
+        if (((k) & 3) == 0) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 0);                                       \
+        else if (((k) & 3) == 1) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 32);                                 \
+        else if (((k) & 3) == 2) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 64);                                 \
+        else W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 96);                                                     \
+        asm volatile("s_nop 1" ::: "memory");                                                                    \
+    }
+#define W6Z_GROUP(q, u, NWAIT, DMA, JJ, BUF)                                                                     \
+            {                                                                                                    \
+                W4_ULOAD(ring[((q) + PF) & RM], lane16, uptr);                                                   \
+                W6_UNEXT()                                                                                       \
+                if ((u) + 1 < NG) {                                                                              \
+                    va[((u) + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(vb + 8 * ((u) + 1));                 \
+                    va[((u) + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP + 8 * ((u) + 1));       \
+                }                                                                                                \
+                W4_UWAIT(ring[(q)], NWAIT);                                                                      \
+                const f32x4 w = ring[(q)];                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                if ((JJ) == 0) {                                                                                 \
+                    z00 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : z00, 0, 0, 0); \
+                    z01 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : z01, 0, 0, 0); \
+                } else if ((JJ) == 5) {                                                                          \
+                    z30 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], z30, 0, 0, 0);           \
+                    z31 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], z31, 0, 0, 0);           \
+                } else {                                                                                         \
+                    m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : m0, 0, 0, 0); \
+                    m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : m1, 0, 0, 0); \
+                }                                                                                                \
+                if ((DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (BUF) ^ 1, (DMA));                                 \
+                if ((JJ) == 5 && (u) >= 8 && (u) < 24) {      /* Z_0, Z_1 of this row */                          \
+                    if ((u) < 16) W6Z_STORE1(z00, z01, 0, zcur, (u) - 8)                                         \
+                    else W6Z_STORE1(z10, z11, 1, zcur, (u) - 16)                                                 \
+                }                                                                                                \
+                if ((JJ) == 0 && (u) >= 8 && (u) < 24) {      /* Z_2, Z_3 of the previous row */                  \
+                    if ((u) < 16) W6Z_STORE1(z20, z21, 2, zprev, (u) - 8)                                        \
+                    else W6Z_STORE1(z30, z31, 3, zprev, (u) - 16)                                                \
+                }                                                                                                \
+                _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                  \
+                    if ((JJ) == 0) {                                                                             \
+                        z00 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], z00, 0, 0, 0);       \
+                        z01 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], z01, 0, 0, 0);       \
+                    } else if ((JJ) == 5) {                                                                      \
+                        z30 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], z30, 0, 0, 0);       \
+                        z31 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], z31, 0, 0, 0);       \
+                    } else {                                                                                     \
+                        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], m0, 0, 0, 0);         \
+                        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], m1, 0, 0, 0);         \
+                    }                                                                                            \
+                }                                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+            }
+#define W6GZ_(i, JJ, BUF) W6Z_GROUP((i) & RM, (i), w6_wait((i), (JJ) == 0 || (JJ) == 5), (i), JJ, BUF)
+#define W6Z_POSITION(i_, JJ)                                                                                     \
+        {                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");                                            \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            const float *nsrc;                                                                                   \
+            {                                                                                                    \
+                const int pp = 6 * (i_) + (JJ);                                                                  \
+                int nb = pp < 6 * R - 1 ? b : b + (int)gridDim.x;                                                \
+                nb = nb < nblocks ? nb : b;                                                                      \
+                nsrc = V + (size_t)nb * W6_VBLOCK + (size_t)(pp < 6 * R - 1 ? pp + 1 : 0) * C;                   \
+            }                                                                                                    \
+            const float *vb = wsm + ((JJ) & 1) * SLAB + j * CP + 4 * h;                                          \
+            f32x4 va[2][2];                                                                                      \
+            va[0][0] = *reinterpret_cast<const f32x4 *>(vb);                                                     \
+            va[0][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP);                                           \
+            W6GZ_(0, JJ, (JJ) & 1) W6GZ_(1, JJ, (JJ) & 1) W6GZ_(2, JJ, (JJ) & 1) W6GZ_(3, JJ, (JJ) & 1)                 \
+            W6GZ_(4, JJ, (JJ) & 1) W6GZ_(5, JJ, (JJ) & 1) W6GZ_(6, JJ, (JJ) & 1) W6GZ_(7, JJ, (JJ) & 1)                 \
+            W6GZ_(8, JJ, (JJ) & 1) W6GZ_(9, JJ, (JJ) & 1) W6GZ_(10, JJ, (JJ) & 1) W6GZ_(11, JJ, (JJ) & 1)               \
+            W6GZ_(12, JJ, (JJ) & 1) W6GZ_(13, JJ, (JJ) & 1) W6GZ_(14, JJ, (JJ) & 1) W6GZ_(15, JJ, (JJ) & 1)             \
+            W6GZ_(16, JJ, (JJ) & 1) W6GZ_(17, JJ, (JJ) & 1) W6GZ_(18, JJ, (JJ) & 1) W6GZ_(19, JJ, (JJ) & 1)             \
+            W6GZ_(20, JJ, (JJ) & 1) W6GZ_(21, JJ, (JJ) & 1) W6GZ_(22, JJ, (JJ) & 1) W6GZ_(23, JJ, (JJ) & 1)             \
+            W6GZ_(24, JJ, (JJ) & 1) W6GZ_(25, JJ, (JJ) & 1) W6GZ_(26, JJ, (JJ) & 1) W6GZ_(27, JJ, (JJ) & 1)             \
+            W6GZ_(28, JJ, (JJ) & 1) W6GZ_(29, JJ, (JJ) & 1) W6GZ_(30, JJ, (JJ) & 1) W6GZ_(31, JJ, (JJ) & 1)             \
+        }
+#define W6Z_UPDATE(JJ)                                                                                           \
+        _Pragma("unroll") for (int v = 0; v < 16; v++) {                                                         \
+            z00[v] += m0[v]; z01[v] += m1[v];                                                                    \
+            if ((JJ) == 1) { z10[v] = m0[v]; z11[v] = m1[v]; z20[v] = m0[v]; z21[v] = m1[v]; z30[v] = m0[v]; z31[v] = m1[v]; } \
+            if ((JJ) == 2) { z10[v] -= m0[v]; z11[v] -= m1[v]; z20[v] += m0[v]; z21[v] += m1[v]; z30[v] -= m0[v]; z31[v] -= m1[v]; } \
+            if ((JJ) == 3) {                                                                                     \
+                z10[v] = __builtin_fmaf(2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(2.f, m1[v], z11[v]);        \
+                z20[v] = __builtin_fmaf(4.f, m0[v], z20[v]); z21[v] = __builtin_fmaf(4.f, m1[v], z21[v]);        \
+                z30[v] = __builtin_fmaf(8.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(8.f, m1[v], z31[v]);        \
+            }                                                                                                    \
+            if ((JJ) == 4) {                                                                                     \
+                z10[v] = __builtin_fmaf(-2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(-2.f, m1[v], z11[v]);      \
+                z20[v] = __builtin_fmaf(4.f, m0[v], z20[v]); z21[v] = __builtin_fmaf(4.f, m1[v], z21[v]);        \
+                z30[v] = __builtin_fmaf(-8.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(-8.f, m1[v], z31[v]);      \
+            }                                                                                                    \
+        }
+
+#pragma unroll 1
+    for (; b < nblocks; b += gridDim.x) {
+        const int R = rows_of(b);
+#pragma unroll 1
+        for (int i = 0; i < R; i++) {
+            zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
+            W6Z_POSITION(i, 0)            // (stores Z_2, Z_3 of the previous row to zprev)
+            W6Z_POSITION(i, 1) W6Z_UPDATE(1)
+            W6Z_POSITION(i, 2) W6Z_UPDATE(2)
+            W6Z_POSITION(i, 3) W6Z_UPDATE(3)
+            W6Z_POSITION(i, 4) W6Z_UPDATE(4)
+            W6Z_POSITION(i, 5)            // (stores Z_0, Z_1 of this row to zcur)
+            zprev = zcur;
+        }
+    }
+    // the last row's Z_2, Z_3
+#pragma unroll
+    for (int k = 0; k < 8; k++) W6Z_STORE1(z20, z21, 2, zprev, k)
+#pragma unroll
+    for (int k = 0; k < 8; k++) W6Z_STORE1(z30, z31, 3, zprev, k)
+#undef W6Z_UPDATE
+#undef W6Z_POSITION
+#undef W6GZ_
+#undef W6Z_GROUP
+#undef W6Z_STORE1
+#undef W6_UNEXT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- output transform, the half the GEMM kernel left ------------------------------------------------------------------------------
+// A tile's outputs (before bias) for this lane's 4 channels from its row sums, which are in registers (z[row][b], fetched ahead):
+//   A   y[a][b] = sum_i A4^T[a][i] Z_i[b]            (6 rows)      B'  the same with F(3)'s A^T over 5 rows -> output rows 0 .. 2
+//   B   stored transposed: Z's row index is the patch COLUMN j (5 of them), b the output ROW: y[b][c] = sum_j A3^T[c][j] Z_j[b]
+//   D   transposed, 8 rows: y[b][c] = sum_j A6^T[c][j] Z_j[b],  A6^T = [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 0; 0 1 1 4 4 1/4 1/4 0;
+//       0 1 -1 8 -8 1/8 -1/8 0; 0 1 1 16 16 1/16 1/16 0; 0 1 -1 32 -32 1/32 -1/32 1]
+// y[a][c]: output row a (4), column c (6; narrower tiles leave the rest untouched).  Pixels beyond the board are dropped by the callers.
+__device__ __forceinline__ void w6_tile_outputs(const f32x4 (&z)[8][4], f32x4 (&y)[4][6], int cls) {
+    if (cls == W6_CLS_D) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const f32x4 e1 = z[1][b] + z[2][b], o1 = z[1][b] - z[2][b], e2 = z[3][b] + z[4][b], o2 = z[3][b] - z[4][b], e3 = z[5][b] + z[6][b], o3 = z[5][b] - z[6][b];
+            y[b][0] = (z[0][b] + e1) + (e2 + e3);
+            y[b][1] = w4_fma(2.f, o2, w4_fma(0.5f, o3, o1));
+            y[b][2] = w4_fma(4.f, e2, w4_fma(0.25f, e3, e1));
+            y[b][3] = w4_fma(8.f, o2, w4_fma(0.125f, o3, o1));
+            y[b][4] = w4_fma(16.f, e2, w4_fma(0.0625f, e3, e1));
+            y[b][5] = w4_fma(32.f, o2, w4_fma(0.03125f, o3, o1)) + z[7][b];
+        }
+    } else if (cls == W6_CLS_A) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const f32x4 s12 = z[1][b] + z[2][b], d12 = z[1][b] - z[2][b], s34 = z[3][b] + z[4][b], d34 = z[3][b] - z[4][b];
+            y[0][b] = z[0][b] + s12 + s34;
+            y[1][b] = w4_fma(2.f, d34, d12);
+            y[2][b] = w4_fma(4.f, s34, s12);
+            y[3][b] = w4_fma(8.f, d34, d12) + z[5][b];
+        }
+    } else {
+        f32x4 e[3][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const f32x4 s12 = z[1][b] + z[2][b], d12 = z[1][b] - z[2][b];
+            e[0][b] = z[0][b] + s12 + z[3][b];
+            e[1][b] = w4_fma(2.f, z[3][b], d12);
+            e[2][b] = w4_fma(4.f, z[3][b], s12) + z[4][b];
+        }
+        const bool tr = cls == W6_CLS_B;
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const f32x4 rowwise = a < 3 ? e[a < 3 ? a : 0][b] : zero4, colwise = b < 3 ? e[b < 3 ? b : 0][a] : zero4;
+                y[a][b] = tr ? colwise : rowwise;
+            }
+    }
+}
+// the tile's row sums: rows (8 / 6 / 5) x 4 runs of 1 KiB, one contiguous piece of Z
+__device__ __forceinline__ void w6_load_z(const float *zb, f32x4 (&z)[8][4], int cls) {
+    const int rows = cls == W6_CLS_D ? 8 : cls == W6_CLS_A ? 6 : 5;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (i < rows) z[i][b] = *reinterpret_cast<const f32x4 *>(zb + (size_t)(i * 4 + b) * W6_C);
+}
+
+// ---- output transform of one layer + input transform of the next, in one pass (conv_wino4.hip's c6_wino4_mid_kernel) ----------------
+// One workgroup per board at a time, wave = tile column (4 waves: one per SIMD, the whole register file each), lane = 4 channels.
+// Software-pipelined: while a wave transforms the patches of tile row t - 1 (LDS reads, arithmetic, V stores), the row sums of ITS tile
+// of row t + 1 are already on their way into registers -- the load latency and the arithmetic no longer add up.
+// Step t: (a) the tile (t, tx) of Z, fetched during step t - 1, becomes pixels (A^T Z + bias (+ residual), ReLU); their first row goes into
+// the rolling 6-row window, the other three wait in registers; (b) Z of tile (t + 1, tx) is requested, then the window's rows 4t - 5 .. 4t
+// = the patches of tile row t - 1 go out as V; (c) the kept rows take the slots (b) read last.
+// RS: the residual is the STEM's output, computed here from the board.
+template <bool RS>
+__global__ __launch_bounds__(W6_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void c6_w6_mid_kernel(
+    const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res, float *__restrict__ act, float *__restrict__ V, int nboards, C6StemSrc S) {
+    constexpr int C = W6_C, N = W6_N, ROWF = W6_ROWF, NT = W6_THREADS;
+    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C]
+    const int tid = threadIdx.x, lane = tid & 63, tx = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = w6_x0(tx), wd = w6_width(tx);
+    const W6Map map(nboards);
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + lane * 4) : zero4;
+    for (int k = tid; k < 6 * ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
+    float *wpix = win + (x0 + 1) * C + lane * 4;           // window column of this wave's first pixel column (board column x0)
+    float *swl = win + 6 * ROWF, *s0 = swl + 9 * C, *bdp = s0 + 9 * C;     // RS: the stem's board-plane weights [9][C], its player-plane sums [9][C], the board plane [(N+2)^2]
+    f32x4 sb = zero4;
+    float pv = 0.f;
+    if (RS) {
+        for (int k = tid; k < 9 * C / 4; k += NT) reinterpret_cast<f32x4 *>(swl)[k] = *reinterpret_cast<const f32x4 *>(S.w + ((k / (C / 4)) * 2 + 1) * C + (k % (C / 4)) * 4);
+        if (tid < C / 4) w4_stem_player_sums(S.w, C, tid * 4, s0);
+        for (int k = tid; k < (N + 2) * (N + 2); k += NT) bdp[k] = 0.f;
+        sb = *reinterpret_cast<const f32x4 *>(S.bias + lane * 4);
+    }
+    f32x4 z[8][4];      // the tile of Z that is fetched ahead
+    int bd = blockIdx.x;
+    if (bd < nboards) w6_load_z(M + (size_t)map.slot(bd, 0, tx) * W6_ZTILE + lane * 4, z, w6_cls(0, tx));
+#pragma unroll 1
+    for (; bd < nboards; bd += gridDim.x) {
+        W6_LDS_BARRIER();                                    // the previous board's last window reads (and the zero fill)
+        for (int k = tid; k < ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // slot 0 = board row -1
+        if (RS) {
+            pv = w4_stem_plane<N>(S, bd, bdp, tid, NT);
+            W6_LDS_BARRIER();
+        }
+#pragma unroll 1
+        for (int t = 0; t <= W6_TWY; t++) {
+            f32x4 keep[3][6];
+            if (t < W6_TWY) {
+                f32x4 yv[4][6];
+                w6_tile_outputs(z, yv, w6_cls(t, tx));
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const int py = 4 * t + a;
+#pragma unroll
+                    for (int bb = 0; bb < 6; bb++) {
+                        if (bb >= wd) continue;                              // (uniform over the wave)
+                        f32x4 v = yv[a][bb] + bi;
+                        const bool inb = py < N;
+                        const size_t o = ((size_t)bd * (N * N) + (size_t)((inb ? py : 0) * N + x0 + bb)) * C + lane * 4;
+                        if (RS) {
+                            if (inb) v = v + w4_stem_pixel<N>(bdp, w4_fma(pv, *reinterpret_cast<const f32x4 *>(s0 + w4_border_class(py, x0 + bb, N) * C + lane * 4), zero4), py, x0 + bb, sb,
+                                                              [&](int t_) { return *reinterpret_cast<const f32x4 *>(swl + t_ * C + lane * 4); });
+                        } else if (res && inb) v = v + *reinterpret_cast<const f32x4 *>(res + o);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                        if (!inb) v = zero4;                             // beyond the board: the next layer's zero padding
+                        else if (act) *reinterpret_cast<f32x4 *>(act + o) = v;      // a block's output is also the next block's residual
+                        if (a == 0) *reinterpret_cast<f32x4 *>(wpix + ((py + 1) % 6) * ROWF + bb * C) = v;
+                        else keep[a - 1][bb] = v;
+                    }
+                }
+                if (tx == W6_TWX - 1) {      // window column 20 (beyond the board; the corner tile's fourth patch column reads it): stays zero
+                }
+            } else {
+#pragma unroll
+                for (int bb = 0; bb < 6; bb++)
+                    if (bb < wd) *reinterpret_cast<f32x4 *>(wpix + ((4 * t + 1) % 6) * ROWF + bb * C) = zero4;      // row 4 TWY: below the board
+            }
+            W6_LDS_BARRIER();                                // board rows 4t - 5 .. 4t are in the window
+            // the next tile of Z: (t + 1, tx) of this board, or (0, tx) of the workgroup's next board
+            {
+                long nbd = bd;
+                int nt = t + 1;
+                if (nt >= W6_TWY) { nt = 0; nbd = bd + gridDim.x; }
+                if (t < W6_TWY && nbd < nboards) w6_load_z(M + (size_t)map.slot(nbd, nt, tx) * W6_ZTILE + lane * 4, z, w6_cls(nt, tx));
+            }
+            if (t >= 1) {
+                const int ty = t - 1;
+                const long tt = map.slot(bd, ty, tx);
+                float *vb = V + (size_t)(tt / W6_BT) * W6_VBLOCK + (size_t)(tt % W6_BT) * W6_VTILE;
+                int slot[6];
+                w6_slots(ty, slot);
+                w6_patch_transform(win + x0 * C, slot, vb, lane, w6_cls(ty, tx));
+            }
+            W6_LDS_BARRIER();                                // rows 4t - 5 .. 4t - 3 are read no more: their slots take rows 4t + 1 .. 4t + 3
+            if (t < W6_TWY) {
+#pragma unroll
+                for (int a = 1; a < 4; a++)
+#pragma unroll
+                    for (int bb = 0; bb < 6; bb++)
+                        if (bb < wd) *reinterpret_cast<f32x4 *>(wpix + ((4 * t + a + 1) % 6) * ROWF + bb * C) = keep[a - 1][bb];
+            }
+        }
+    }
+}
+
+// ---- the tower's last output transform, with the heads' 1x1 filters (conv_wino4.hip's c6_wino4_out_kernel<N, true>) -----------------
+// One wave per tile at a time, lane = 4 channels; a pixel's three filter sums are wave sums; nothing but the heads' inputs is written.
+// A tile is processed in four SLICES -- the transform is independent for every value of Z's second index b: a slice takes the 8 / 6 / 5
+// row sums Z[.][b] and yields up to six pixels (a row of the tile for the transposed classes D and B, a column for A and B') -- so that
+// only one slice's pixels and filter sums are alive at a time beside the tile's row sums.
+__device__ __forceinline__ void w6_slice_outputs(const f32x4 (&z)[8], f32x4 (&y)[6], int cls) {
+    if (cls == W6_CLS_D) {
+        const f32x4 e1 = z[1] + z[2], o1 = z[1] - z[2], e2 = z[3] + z[4], o2 = z[3] - z[4], e3 = z[5] + z[6], o3 = z[5] - z[6];
+        y[0] = (z[0] + e1) + (e2 + e3);
+        y[1] = w4_fma(2.f, o2, w4_fma(0.5f, o3, o1));
+        y[2] = w4_fma(4.f, e2, w4_fma(0.25f, e3, e1));
+        y[3] = w4_fma(8.f, o2, w4_fma(0.125f, o3, o1));
+        y[4] = w4_fma(16.f, e2, w4_fma(0.0625f, e3, e1));
+        y[5] = w4_fma(32.f, o2, w4_fma(0.03125f, o3, o1)) + z[7];
+    } else if (cls == W6_CLS_A) {
+        const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
+        y[0] = z[0] + s12 + s34;
+        y[1] = w4_fma(2.f, d34, d12);
+        y[2] = w4_fma(4.f, s34, s12);
+        y[3] = w4_fma(8.f, d34, d12) + z[5];
+    } else {
+        const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2];
+        y[0] = z[0] + s12 + z[3];
+        y[1] = w4_fma(2.f, z[3], d12);
+        y[2] = w4_fma(4.f, z[3], s12) + z[4];
+    }
+}
+struct W6OutCtx {
+    f32x4 bi, hw0, hw1, hw2;
+    const float *res;
+    C6HeadFuse hd;
+};
+// one tile of class CLS: everything about the class is a constant here (no run-time indexing of the register arrays)
+template <int CLS>
+__device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, long bd, int ty, int x0, int wd, int lane, int b0) {
+    constexpr int C = W6_C, N = W6_N;
+    constexpr int rows = CLS == W6_CLS_D ? 8 : CLS == W6_CLS_A ? 6 : 5;
+    constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_B;      // the slice's pixels run along a row of the tile (else: along a column)
+    constexpr int npx = CLS == W6_CLS_D ? 6 : CLS == W6_CLS_A ? 4 : 3;
+    // two slices per wave (b = b0, b0 + 1): their row sums are requested at once (up to 16 KiB in flight per wave), then consumed one by one
+    f32x4 zt[2][8];
+#pragma unroll
+    for (int i = 0; i < rows; i++)
+#pragma unroll
+        for (int bq = 0; bq < 2; bq++) zt[bq][i] = *reinterpret_cast<const f32x4 *>(zb + (size_t)(i * 4 + b0 + bq) * C);
+#pragma unroll
+    for (int bq = 0; bq < 2; bq++) {
+        const int b = b0 + bq;
+        f32x4 y[6];
+        w6_slice_outputs(zt[bq], y, CLS);
+        float hs[npx][3];
+#pragma unroll
+        for (int k = 0; k < npx; k++) {
+            hs[k][0] = 0.f; hs[k][1] = 0.f; hs[k][2] = 0.f;
+            const int py = 4 * ty + (along_row ? b : k), cx = along_row ? k : b, px = x0 + cx;
+            if (py >= N || cx >= wd) continue;
+            f32x4 v = y[k] + X.bi;
+            if (X.res) v = v + *reinterpret_cast<const f32x4 *>(X.res + ((size_t)bd * (N * N) + (size_t)(py * N + px)) * C + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                v[r] = v[r] > 0.f ? v[r] : 0.f;
+                hs[k][0] = __builtin_fmaf(v[r], X.hw0[r], hs[k][0]);
+                hs[k][1] = __builtin_fmaf(v[r], X.hw1[r], hs[k][1]);
+                hs[k][2] = __builtin_fmaf(v[r], X.hw2[r], hs[k][2]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < npx; k++)
+#pragma unroll
+            for (int f = 0; f < 3; f++) hs[k][f] = w4_wave_sum_row3(hs[k][f]);
+        // lanes 48 .. have the sums: lane 48 + k writes pixel k of the slice
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < npx; k++)
+            if ((lane & 15) == k) { m0 = hs[k][0]; m1 = hs[k][1]; m2 = hs[k][2]; }
+        const int k = lane & 15, py = 4 * ty + (along_row ? b : k), cx = along_row ? k : b, px = x0 + cx;
+        if (lane >= 48 && k < npx && py < N && cx < wd) {
+            const int p = py * N + px;
+            const float y0 = m0 + X.hd.pc_b[0], y1 = m1 + X.hd.pc_b[1];
+            X.hd.ph[(size_t)bd * (2 * N * N) + p] = y0 > 0.f ? y0 : 0.f;             // flatten is channel-major (NCHW view)
+            X.hd.ph[(size_t)bd * (2 * N * N) + N * N + p] = y1 > 0.f ? y1 : 0.f;
+            const float vv = (m2 + X.hd.vc_b) * X.hd.vn_scale[p] + X.hd.vn_shift[p];
+            X.hd.vh[(size_t)bd * (N * N) + p] = vv > 0.f ? vv : 0.f;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void c6_w6_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
+                                                        long total_tiles, C6HeadFuse hd) {
+    constexpr int C = W6_C;
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    W6OutCtx X;
+    X.bi = *reinterpret_cast<const f32x4 *>(bias + lane * 4);
+    X.hw0 = *reinterpret_cast<const f32x4 *>(hd.w + lane * 4);
+    X.hw1 = *reinterpret_cast<const f32x4 *>(hd.w + C + lane * 4);
+    X.hw2 = *reinterpret_cast<const f32x4 *>(hd.w + 2 * C + lane * 4);
+    X.res = res;
+    X.hd = hd;
+    const W6Map map(total_tiles / W6_T);
+#pragma unroll 1
+    for (long it = wave0; it < 2 * total_tiles; it += nwaves) {      // item = half a tile: two of its four slices
+        const long t = it >> 1;
+        const int b0 = (int)(it & 1) * 2;
+        const long bd = t / W6_T;
+        const int tt = (int)(t - bd * W6_T), ty = tt / W6_TWX, tx = tt - ty * W6_TWX, cls = w6_cls(ty, tx);
+        const int x0 = w6_x0(tx), wd = w6_width(tx);
+        const float *zb = M + (size_t)map.slot(bd, ty, tx) * W6_ZTILE + lane * 4;
+        if (cls == W6_CLS_D) w6_out_tile<W6_CLS_D>(X, zb, bd, ty, x0, wd, lane, b0);
+        else if (cls == W6_CLS_A) w6_out_tile<W6_CLS_A>(X, zb, bd, ty, x0, wd, lane, b0);
+        else if (cls == W6_CLS_B) w6_out_tile<W6_CLS_B>(X, zb, bd, ty, x0, wd, lane, b0);
+        else w6_out_tile<W6_CLS_BP>(X, zb, bd, ty, x0, wd, lane, b0);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+bool c6_w6_available(int C, int N, int blocks) { return C == W6_C && N == W6_N && blocks - 1 >= 2; }
+size_t c6_w6_packed_floats(void) { return (size_t)W6_SETS_POS * W6_C * W6_C; }
+static long w6_nblocks(int nboards) { return W6Map(nboards).nblocks; }
+// V and Z, one behind the other
+size_t c6_w6_vbuf_floats(int nboards) { return (size_t)w6_nblocks(nboards) * (W6_VBLOCK + W6_ZBLOCK); }
+
+// Transformed weights U = G_v g G_h^T (double, rounded once), four sets one behind the other: A (36 positions p = 6 i + j: F(4)'s G both
+// ways), B (30, p = 6 j + i: G4 vertically, G3 horizontally), B' (30, p = 6 i + j: G3 vertically, G4 horizontally), D (48, p = 6 j + i: G4
+// vertically, F(6)'s G horizontally).  A set is packed [wave][position][group u][lane][r]: U_p[cout = 32 wave + (lane & 31)][cin = 8u + 4(lane >> 5) + r].
+void c6_w6_pack_weights(const float *w, float *packed) {
+    const double G4[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const double G3[5][3] = {{1.0 / 2, 0.0, 0.0}, {-1.0 / 2, -1.0 / 2, -1.0 / 2}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0.0, 0.0, 1.0}};
+    const double G6[8][3] = {{1.0, 0.0, 0.0},
+                             {-2.0 / 9, -2.0 / 9, -2.0 / 9},
+                             {-2.0 / 9, 2.0 / 9, -2.0 / 9},
+                             {1.0 / 90, 1.0 / 45, 2.0 / 45},
+                             {1.0 / 90, -1.0 / 45, 2.0 / 45},
+                             {32.0 / 45, 16.0 / 45, 8.0 / 45},
+                             {32.0 / 45, -16.0 / 45, 8.0 / 45},
+                             {0.0, 0.0, 1.0}};
+    constexpr int C = W6_C, NG = C / 8;
+    const int npos[4] = {36, 30, 30, 48}, first[4] = {0, 36, 66, 96};
+    for (int set = 0; set < 4; set++)
+        for (int wv = 0; wv < C / 32; wv++)
+            for (int pos = 0; pos < npos[set]; pos++) {
+                const int p = pos / 6, q = pos % 6;
+                const double *gv = set == 0 ? G4[p] : set == 1 ? G4[q] : set == 2 ? G3[p] : G4[q];      // the row of G on the vertical side
+                const double *gh = set == 0 ? G4[q] : set == 1 ? G3[p] : set == 2 ? G4[q] : G6[p];      // ... and on the horizontal side
+                for (int u = 0; u < NG; u++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int r = 0; r < 4; r++) {
+                            const int co = wv * 32 + (lane & 31), ci = 8 * u + 4 * (lane >> 5) + r;
+                            const float *g = w + ((size_t)co * C + ci) * 9;
+                            double sum = 0.0;
+                            for (int a = 0; a < 3; a++)
+                                for (int b = 0; b < 3; b++) sum += gv[a] * (double)g[a * 3 + b] * gh[b];
+                            packed[(size_t)first[set] * C * C + ((((size_t)wv * npos[set] + pos) * NG + u) * 64 + lane) * 4 + r] = (float)sum;
+                        }
+            }
+}
+
+// steps: 1 the first layer's input transform from the boards, 2 the GEMMs, 16 the boundary kernel, 4 the last output transform + heads
+bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float *res, float *act, float *vbuf, int num_cus, hipStream_t s, int steps,
+                    const C6HeadFuse *heads, const C6StemSrc *stem) {
+    if (nboards <= 0) return true;
+    const W6Map map(nboards);
+    const int nblocks = (int)map.nblocks;
+    const bool tail = w6_has_tail(nboards);
+    float *Vb = vbuf, *Mb = vbuf + (size_t)nblocks * W6_VBLOCK;
+    constexpr size_t win_smem = (size_t)6 * W6_ROWF * 4;
+    const int grid_b = nboards < num_cus ? nboards : num_cus;
+    if (steps & 1) {
+        constexpr size_t smem = win_smem + (size_t)9 * W6_C * 4 + (size_t)(W6_N + 2) * (W6_N + 2) * 4;
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_stem_in_kernel), (int)smem);
+        hipLaunchKernelGGL(c6_w6_stem_in_kernel, dim3(grid_b), dim3(W6_THREADS), smem, s, *stem, Vb, nboards);
+        if (tail) hipLaunchKernelGGL(c6_w6_tail_kernel, dim3(256), dim3(256), 0, s, Vb, nboards);
+    }
+    if (steps & 2) {
+        constexpr size_t smem = (size_t)2 * W6_BT * (W6_C + 4) * 4;
+        const int grid = nblocks < num_cus ? nblocks : num_cus;
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel), (int)smem);
+        hipLaunchKernelGGL(c6_w6_gemm_kernel, dim3(grid), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD);
+    }
+    if (steps & 16) {
+        constexpr size_t rs_smem = win_smem + (size_t)18 * W6_C * 4 + (size_t)(W6_N + 2) * (W6_N + 2) * 4;
+        if (stem) {      // the residual is the stem's output, recomputed from the boards
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<true>), (int)rs_smem);
+            hipLaunchKernelGGL((c6_w6_mid_kernel<true>), dim3(grid_b), dim3(W6_THREADS), rs_smem, s, Mb, bias, res, act, Vb, nboards, *stem);
+        } else {
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<false>), (int)win_smem);
+            hipLaunchKernelGGL((c6_w6_mid_kernel<false>), dim3(grid_b), dim3(W6_THREADS), win_smem, s, Mb, bias, res, act, Vb, nboards, C6StemSrc{});
+        }
+        if (tail) hipLaunchKernelGGL(c6_w6_tail_kernel, dim3(256), dim3(256), 0, s, Vb, nboards);
+    }
+    if (steps & 4) {
+        const long tiles = (long)nboards * W6_T, want = (2 * tiles + 3) / 4;
+        const int grid_out = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
+        hipLaunchKernelGGL(c6_w6_out_kernel, dim3(grid_out), dim3(256), 0, s, Mb, bias, res, tiles, *heads);
+    }
+    return true;
+}
+// matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 / 30 / 30 / 48 positions x C x C MACs)
+double c6_w6_exec_flops(int nboards) {
+    const W6Map m(nboards);
+    return 2.0 * (36.0 * m.blkB + 30.0 * (m.blkD - m.blkB) + 48.0 * (m.nblocks - m.blkD)) * W6_BT * (double)W6_C * W6_C;
+}

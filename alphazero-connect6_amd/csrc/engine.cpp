@@ -390,7 +390,9 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
         std::vector<float> cw5, cww;
         std::vector<unsigned short> cw7;
         std::vector<unsigned char> cw9;
-        const size_t w5 = c6_conv_packed_f32n_floats(C), ww = c6_conv_packed_wino_floats(C), w7 = c6_conv_packed_b3s_units(C), w9 = c6_conv_packed_m8_bytes(C);
+        d.wino6 = d.variant == C6_CONV_WINO && c6_w6_available(C, n, nb);
+        const size_t w5 = c6_conv_packed_f32n_floats(C), ww = d.wino6 ? c6_w6_packed_floats() : c6_conv_packed_wino_floats(C), w7 = c6_conv_packed_b3s_units(C),
+                     w9 = c6_conv_packed_m8_bytes(C);
         if (d.variant == C6_CONV_F32N) cw5.resize((size_t)Lm * w5);
         else if (d.variant == C6_CONV_WINO) cww.resize((size_t)Lm * ww);
         else if (d.variant == C6_CONV_M8) cw9.resize((size_t)Lm * w9);
@@ -429,6 +431,7 @@ static int net_load(NetHost &nh, int n, int C, int nb, const float *blob, size_t
                 }
             }
             if (d.variant == C6_CONV_F32N) c6_pack_conv_weights_f32n(C, folded.data(), cw5.data() + (size_t)l * w5);
+            else if (d.wino6) c6_w6_pack_weights(folded.data(), cww.data() + (size_t)l * ww);
             else if (d.variant == C6_CONV_WINO) c6_pack_conv_weights_wino(C, folded.data(), cww.data() + (size_t)l * ww);
             else if (d.variant == C6_CONV_M8) c6_pack_conv_weights_m8(C, folded.data(), cw9.data() + (size_t)l * w9);
             else c6_pack_conv_weights_b3s(C, folded.data(), cw7.data() + (size_t)l * w7);
@@ -722,7 +725,8 @@ static int engine_alloc(c6_engine *e) {
         ALLOC(e->ph, nb * 2 * cells); ALLOC(e->vh, nb * cells);
         if (conv_variant(c.net_precision) == C6_CONV_WINO) {
             // the largest buffer of the net (16/4 of an activation): not zero-filled, every float the GEMM reads is written first
-            int rc_ = pool.alloc(&e->vbuf, c6_conv_wino_vbuf_floats(c.net_channels, N, (int)nb), false);
+            const size_t vf = c6_w6_available(c.net_channels, N, c.net_blocks) ? c6_w6_vbuf_floats((int)nb) : c6_conv_wino_vbuf_floats(c.net_channels, N, (int)nb);
+            int rc_ = pool.alloc(&e->vbuf, vf, false);
             if (rc_ != C6_OK) return rc_;
         }
     }
@@ -1541,7 +1545,7 @@ extern "C" int c6_net_forward_prec(int n, int C, int blocks, int precision, cons
     int16_t *dm = t.get<int16_t>(aug.size(), aug.data());
     float *a0 = t.get<float>(act), *a1 = t.get<float>(act), *a2 = t.get<float>(act), *ph = t.get<float>((size_t)num * 2 * cells),
           *vh = t.get<float>((size_t)num * cells), *dp = t.get<float>((size_t)num * cells), *dv = t.get<float>(num);
-    float *vb = nh.dev.variant == C6_CONV_WINO ? t.get<float>(c6_conv_wino_vbuf_floats(C, n, num)) : a0;
+    float *vb = nh.dev.variant == C6_CONV_WINO ? t.get<float>(nh.dev.wino6 ? c6_w6_vbuf_floats(num) : c6_conv_wino_vbuf_floats(C, n, num)) : a0;
     if (!db || !dpl || !dm || !a0 || !a1 || !a2 || !ph || !vh || !dp || !dv || !vb) { nh.pool.release(); return fail(C6_ERR_HIP, "hipMalloc failed"); }
     c6_net_forward_dev(nh.dev, num, 1, db, cells, dpl, 1, dm, a0, a1, a2, vb, ph, vh, dp, dv, nullptr, nullptr);
     hipError_t he = hipDeviceSynchronize();

@@ -304,6 +304,46 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
     if (!stem_inline)
         hipLaunchKernelGGL(c6_stem_kernel, dim3(nb), dim3(256), 0, s, boards, board_stride, player, player_stride, aug_map, images, net.stem_w,
                            net.stem_b, act0, net.N, C);
+    if (net.variant == C6_CONV_WINO && net.wino6) {
+        // 19x19, C = 256, >= 2 residual blocks: conv_wino6.hip (tiles six pixels wide, pipelined boundary kernel).  The chain of a pass:
+        //   stem-in -> [GEMM -> boundary]* -> GEMM -> last output transform + heads; activations are stored only at block ends (the next
+        //   block's residual), the stem's never (recomputed where it is the residual)
+        const int Lw = 2 * (net.blocks - 1);
+        const size_t wwf = c6_w6_packed_floats();
+        const C6HeadFuse hf{net.head_w, net.pc_b, net.vc_b, net.vn_scale, net.vn_shift, ph, vh};
+        for (int l = 0; l < Lw; l++) {
+            const int half = l & 1;
+            hipEvent_t e0 = nullptr, e1 = nullptr, em = nullptr, eg = nullptr;
+            if (timed) { e0 = timer_event(timers); e1 = timer_event(timers); hipEventRecord(e0, s); }
+            if (l == 0) c6_w6_dispatch(nb, nullptr, nullptr, nullptr, nullptr, vbuf, net.num_cus, s, 1, nullptr, &stem_src);
+            if (timed) {
+                em = timer_event(timers);
+                hipEventRecord(em, s);
+                timers->pre.emplace_back(e0, em);
+                timers->exec_flops += c6_w6_exec_flops(nb);
+            }
+            c6_w6_dispatch(nb, net.conv_ww + (size_t)l * wwf, nullptr, nullptr, nullptr, vbuf, net.num_cus, s, 2);
+            if (timed) { eg = timer_event(timers); hipEventRecord(eg, s); }
+            const float *cb = net.conv_b + (size_t)l * C;
+            // residual of the block's second convolution: the block's input = the previous block's output (x), or the stem for block 0
+            const float *cres = half == 0 ? nullptr : x;
+            if (l < Lw - 1) {
+                float *cout = half == 0 ? nullptr : z;      // a block's output is stored: the next block's residual
+                c6_w6_dispatch(nb, nullptr, cb, l == 1 ? nullptr : cres, cout, vbuf, net.num_cus, s, 16, nullptr, l == 1 ? &stem_src : nullptr);
+            } else
+                c6_w6_dispatch(nb, nullptr, cb, Lw == 2 ? nullptr : cres, nullptr, vbuf, net.num_cus, s, 4, &hf);
+            if (timed) {
+                hipEvent_t eo = timer_event(timers);
+                hipEventRecord(eo, s);
+                timers->post.emplace_back(eg, eo);
+                hipEventRecord(e1, s);
+                timers->conv.emplace_back(e0, e1);
+                timers->conv_flops += 2.0 * 9.0 * C * C * cells * (double)nb;
+            }
+            if (half == 1) { float *t = x; x = z; z = t; }
+        }
+        heads_done = true;
+    } else
     for (int i = 0; i < net.blocks - 1; i++) {     // res_block, model.hpp:61-78
         for (int half = 0; half < 2; half++) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
