@@ -8,7 +8,7 @@ Workload at every N (weak scaling: per-GPU work fixed): BASELINE.json configs[1]
 simulations/move, random-init policy/value net with "4 blocks" = stem + 3 residual blocks, C = 256.
 
 `value` runs on the REFERENCE's arithmetic: f32 operands, f32 products, f32 accumulate (AlphaZero/cpp_weighted/model.hpp:52-95 is an f32
-net) -- `--precision fp32`, the library default: Winograd F(4x4,3x3) on the FP32 matrix cores.  The same f32 arithmetic as a direct
+net) -- `--precision fp32`, the library default: Winograd (tiles 4 x {6, 6, 4, 3} of a 19x19 board) on the FP32 matrix cores.  The same f32 arithmetic as a direct
 convolution (`fp32_direct_path`) and the reduced-operand arithmetics (`bf16x3_path`, `f16f8_path`, `relaxed_bf16_path`) are measured in
 the same run at N = 1 and reported BESIDE it, never as `value`.
 
@@ -49,9 +49,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, description)
-    "fp32": ("c6_wino4_gemm_kernel<19>", "FP32 Winograd F(4x4,3x3) (F(3,3) in the last tile row / column): the 36 / 30 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, column half of the "
-             "output transform accumulated in registers; "
-             "the transforms between the layers' GEMMs are HBM-bound kernels of their own (c6_wino4_mid_kernel: output transform of a layer + "
+    "fp32": ("c6_w6_gemm_kernel", "FP32 Winograd, tiles 4 x {6, 6, 4, 3} across a 19-wide board (F(4,3) down, F(6,3) / F(4,3) / F(3,3) across; F(3,3) down in the "
+             "last tile row): the 48 / 36 / 30 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, the F(4) half of the output transform accumulated in "
+             "registers; the transforms between the layers' GEMMs are HBM-bound kernels of their own (c6_w6_mid_kernel: output transform of a layer + "
              "input transform of the next)"),
     "fp32_direct": ("c6_conv3x3_f32n_kernel<256, 19>", "FP32 direct implicit GEMM, v_mfma_f32_32x32x2_f32"),
     "bf16x3": ("c6_conv3x3_b3s_kernel<256, 19, true, false>", "split-bf16 implicit GEMM, v_mfma_f32_16x16x32_bf16, 3 MFMAs per product"),
@@ -354,7 +354,7 @@ def main():
         return r
 
     PRECS = {"fp32": pkg.PREC_FP32, "fp32_direct": pkg.PREC_FP32_DIRECT, "bf16x3": pkg.PREC_BF16X3, "f16f8": pkg.PREC_F16F8}
-    DTYPES = {"fp32": "f32 (f32 operands, f32 products, f32 accumulate on v_mfma_f32_32x32x2_f32; Winograd F(4x4,3x3) form)",
+    DTYPES = {"fp32": "f32 (f32 operands, f32 products, f32 accumulate on v_mfma_f32_32x32x2_f32; Winograd form: F(4,3) / F(3,3) down, F(6,3) / F(4,3) / F(3,3) across)",
               "fp32_direct": "f32 (the same arithmetic as a direct implicit GEMM)",
               "bf16x3": "bf16x3 (f32 operands split hi+mid in bf16, 3 bf16 MFMAs per product, f32 accumulate; net outputs within 1e-5)",
               "f16f8": "f16+f8 (f32 operands split hi+lo in fp16: x_hi*w_hi on fp16 MFMAs, cross terms on MX-scaled fp8 MFMAs, f32 accumulate; net outputs "
@@ -462,27 +462,30 @@ def main():
             r["layer_frac"] = prof["conv_exec_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 / peak
             if name == "fp32":
                 r["note"] = ("achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + "
-                             "boundary-kernel time; algorithmic_tflops / algorithmic_ratio count 2*9*C^2*N^2 per board and layer (SURVEY 8d), of which Winograd "
-                             "F(4x4,3x3) with F(3,3) edge tiles executes 1 / 3.84 (846 products per channel pair and board instead of 3249)")
+                             "boundary-kernel time; algorithmic_tflops / algorithmic_ratio count 2*9*C^2*N^2 per board and layer (SURVEY 8d), of which this Winograd "
+                             "tiling executes 1 / 4.04 (804 products per channel pair and board instead of 3249)")
                 nbd, Cc, tiles = min(G * 8, 32768), wl["channels"], ((n + 3) // 4) ** 2
                 # between the GEMM kernels: one input transform in front of the tower, then ONE kernel per layer boundary (output transform of
                 # layer l + input transform of layer l + 1; the activations between the two convolutions of a block are never stored), and
                 # the last output transform, which applies the heads' 1x1 filters.  HBM-bound kernels.
                 nl = 2 * (wl["blocks"] - 1)
                 tw = (n + 3) // 4
-                edge = 2 * tw - 1 if n % 4 == 3 else 0      # mixed tiling: the last tile row / column is F(3,3) in one direction, 30 positions / 20 row sums
-                act_b, v_b, z_b = n * n * Cc * 4 * nbd, (36 * (tiles - edge) + 30 * edge) * Cc * 4 * nbd, (24 * (tiles - edge) + 20 * edge) * Cc * 4 * nbd
-                # V: the 36 transformed positions of a tile, GEMM input; Z: the 24 row sums the GEMM kernel leaves (column half of the output
+                edge = 2 * tw - 1 if n % 4 == 3 else 0      # conv_wino4.hip's tiling: the last tile row / column is F(3,3) in one direction, 30 positions / 20 row sums
+                vpos, zrows = 36 * (tiles - edge) + 30 * edge, 24 * (tiles - edge) + 20 * edge
+                if n == 19 and Cc == 256 and wl["blocks"] - 1 >= 2:      # conv_wino6.hip: 10 tiles of 48 positions / 32 row sums, 4 of 36 / 24, 6 of 30 / 20
+                    vpos, zrows = 10 * 48 + 4 * 36 + 6 * 30, 10 * 32 + 4 * 24 + 6 * 20
+                act_b, v_b, z_b = n * n * Cc * 4 * nbd, vpos * Cc * 4 * nbd, zrows * Cc * 4 * nbd
+                # V: the transformed positions of a tile, GEMM input; Z: the row sums the GEMM kernel leaves (the F(4) half of the output
                 # transform applied in its registers).  First layer: V written from the boards (the stem is computed, not read); inside a block:
                 # Z in, V out; across blocks: Z + residual in, activations + V out -- except behind the first block, whose residual (the stem) is
                 # computed too; last layer: Z + residual in
                 tr_bytes = v_b + (nl // 2) * (z_b + v_b) + (nl // 2 - 1) * (z_b + v_b + 2 * act_b) - act_b + (z_b + act_b)
                 tr_ms = (prof["conv_pre_ms"] + prof.get("conv_post_ms", 0.0)) / L
-                r["transforms"] = {"kernels": "c6_wino4_stem_in_kernel<19> (first layer: stem + input transform), c6_wino4_mid_kernel<19> (between layers), "
-                                              "c6_wino4_out_kernel<19, true> (last layer + heads): HBM bound",
+                r["transforms"] = {"kernels": "c6_w6_stem_in_kernel (first layer: stem + input transform), c6_w6_mid_kernel (between layers), "
+                                              "c6_w6_out_kernel (last layer + heads): HBM bound",
                                    "avg_ms_per_layer": tr_ms, "algorithmic_bytes_per_layer": tr_bytes / nl,
                                    "achieved_gbs": tr_bytes / nl / max(tr_ms, 1e-9) / 1e6,
-                                   "traffic_mid_kernel": pmc_record("c6_wino4_mid_kernel<19, false>").get("hbm_bytes_per_launch") if std else None}
+                                   "traffic_mid_kernel": pmc_record("c6_w6_mid_kernel<false>").get("hbm_bytes_per_launch") if std else None}
                 r["conv_layer_tflops_algorithmic"] = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
             if name == "bf16x3":
                 r.update(mfma_flops_per_algorithmic_flop=3, executed_mfma_tflops=3 * alg, frac_executed=3 * alg / peak)
