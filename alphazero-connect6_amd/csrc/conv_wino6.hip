@@ -20,7 +20,7 @@
 // Kernels (the tower of a net with >= 2 residual blocks: net_kernels.hip):
 //   c6_w6_stem_in_kernel   boards -> V of the first layer (the stem computed in place)
 //   c6_w6_gemm_kernel      conv_wino4.hip's GEMM schedule over the four classes
-//   c6_w6_mid_kernel       Z of layer l -> (activations) -> V of layer l + 1, software-pipelined
+//   c6_w6_mid_kernel       Z of layer l -> (activations) -> V of layer l + 1; producer and consumer waves
 //   c6_w6_out_kernel       Z of the last layer -> the heads' 1x1 filters
 // Rounding: F(6,3)'s matrices (entries up to 32 and 21/4) in ONE direction: a layer's error ~3e-6 rms of activations of order 1; the net's
 // outputs stay within 1e-5 of a float64 model (tests/test_gpu_net.py).
@@ -434,173 +434,17 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
 }
 
 // ---- output transform, the half the GEMM kernel left ------------------------------------------------------------------------------
-// A tile's outputs (before bias) for this lane's 4 channels from its row sums, which are in registers (z[row][b], fetched ahead):
+// A tile's outputs (before bias) from its row sums Z_i[b] (i = Z's row, b = 0 .. 3 its second index):
 //   A   y[a][b] = sum_i A4^T[a][i] Z_i[b]            (6 rows)      B'  the same with F(3)'s A^T over 5 rows -> output rows 0 .. 2
 //   B   stored transposed: Z's row index is the patch COLUMN j (5 of them), b the output ROW: y[b][c] = sum_j A3^T[c][j] Z_j[b]
 //   D   transposed, 8 rows: y[b][c] = sum_j A6^T[c][j] Z_j[b],  A6^T = [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 0; 0 1 1 4 4 1/4 1/4 0;
 //       0 1 -1 8 -8 1/8 -1/8 0; 0 1 1 16 16 1/16 1/16 0; 0 1 -1 32 -32 1/32 -1/32 1]
-// y[a][c]: output row a (4), column c (6; narrower tiles leave the rest untouched).  Pixels beyond the board are dropped by the callers.
-__device__ __forceinline__ void w6_tile_outputs(const f32x4 (&z)[8][4], f32x4 (&y)[4][6], int cls) {
+// The transform is independent for every b: a SLICE takes the 8 / 6 / 5 row sums Z[.][b] and yields up to six pixels (a row of the tile
+// for the transposed classes D and B, a column for A and B').  Pixels beyond the board are dropped by the callers.
+template <typename VT>
+__device__ __forceinline__ void w6_slice_outputs(const VT (&z)[8], VT (&y)[6], int cls) {
     if (cls == W6_CLS_D) {
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const f32x4 e1 = z[1][b] + z[2][b], o1 = z[1][b] - z[2][b], e2 = z[3][b] + z[4][b], o2 = z[3][b] - z[4][b], e3 = z[5][b] + z[6][b], o3 = z[5][b] - z[6][b];
-            y[b][0] = (z[0][b] + e1) + (e2 + e3);
-            y[b][1] = w4_fma(2.f, o2, w4_fma(0.5f, o3, o1));
-            y[b][2] = w4_fma(4.f, e2, w4_fma(0.25f, e3, e1));
-            y[b][3] = w4_fma(8.f, o2, w4_fma(0.125f, o3, o1));
-            y[b][4] = w4_fma(16.f, e2, w4_fma(0.0625f, e3, e1));
-            y[b][5] = w4_fma(32.f, o2, w4_fma(0.03125f, o3, o1)) + z[7][b];
-        }
-    } else if (cls == W6_CLS_A) {
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const f32x4 s12 = z[1][b] + z[2][b], d12 = z[1][b] - z[2][b], s34 = z[3][b] + z[4][b], d34 = z[3][b] - z[4][b];
-            y[0][b] = z[0][b] + s12 + s34;
-            y[1][b] = w4_fma(2.f, d34, d12);
-            y[2][b] = w4_fma(4.f, s34, s12);
-            y[3][b] = w4_fma(8.f, d34, d12) + z[5][b];
-        }
-    } else {
-        f32x4 e[3][4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const f32x4 s12 = z[1][b] + z[2][b], d12 = z[1][b] - z[2][b];
-            e[0][b] = z[0][b] + s12 + z[3][b];
-            e[1][b] = w4_fma(2.f, z[3][b], d12);
-            e[2][b] = w4_fma(4.f, z[3][b], s12) + z[4][b];
-        }
-        const bool tr = cls == W6_CLS_B;
-        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const f32x4 rowwise = a < 3 ? e[a < 3 ? a : 0][b] : zero4, colwise = b < 3 ? e[b < 3 ? b : 0][a] : zero4;
-                y[a][b] = tr ? colwise : rowwise;
-            }
-    }
-}
-// the tile's row sums: rows (8 / 6 / 5) x 4 runs of 1 KiB, one contiguous piece of Z
-__device__ __forceinline__ void w6_load_z(const float *zb, f32x4 (&z)[8][4], int cls) {
-    const int rows = cls == W6_CLS_D ? 8 : cls == W6_CLS_A ? 6 : 5;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-            if (i < rows) z[i][b] = *reinterpret_cast<const f32x4 *>(zb + (size_t)(i * 4 + b) * W6_C);
-}
-
-// ---- output transform of one layer + input transform of the next, in one pass (conv_wino4.hip's c6_wino4_mid_kernel) ----------------
-// One workgroup per board at a time, wave = tile column (4 waves: one per SIMD, the whole register file each), lane = 4 channels.
-// Software-pipelined: while a wave transforms the patches of tile row t - 1 (LDS reads, arithmetic, V stores), the row sums of ITS tile
-// of row t + 1 are already on their way into registers -- the load latency and the arithmetic no longer add up.
-// Step t: (a) the tile (t, tx) of Z, fetched during step t - 1, becomes pixels (A^T Z + bias (+ residual), ReLU); their first row goes into
-// the rolling 6-row window, the other three wait in registers; (b) Z of tile (t + 1, tx) is requested, then the window's rows 4t - 5 .. 4t
-// = the patches of tile row t - 1 go out as V; (c) the kept rows take the slots (b) read last.
-// RS: the residual is the STEM's output, computed here from the board.
-template <bool RS>
-__global__ __launch_bounds__(W6_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void c6_w6_mid_kernel(
-    const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res, float *__restrict__ act, float *__restrict__ V, int nboards, C6StemSrc S) {
-    constexpr int C = W6_C, N = W6_N, ROWF = W6_ROWF, NT = W6_THREADS;
-    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C]
-    const int tid = threadIdx.x, lane = tid & 63, tx = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = w6_x0(tx), wd = w6_width(tx);
-    const W6Map map(nboards);
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 bi = bias ? *reinterpret_cast<const f32x4 *>(bias + lane * 4) : zero4;
-    for (int k = tid; k < 6 * ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
-    float *wpix = win + (x0 + 1) * C + lane * 4;           // window column of this wave's first pixel column (board column x0)
-    float *swl = win + 6 * ROWF, *s0 = swl + 9 * C, *bdp = s0 + 9 * C;     // RS: the stem's board-plane weights [9][C], its player-plane sums [9][C], the board plane [(N+2)^2]
-    f32x4 sb = zero4;
-    float pv = 0.f;
-    if (RS) {
-        for (int k = tid; k < 9 * C / 4; k += NT) reinterpret_cast<f32x4 *>(swl)[k] = *reinterpret_cast<const f32x4 *>(S.w + ((k / (C / 4)) * 2 + 1) * C + (k % (C / 4)) * 4);
-        if (tid < C / 4) w4_stem_player_sums(S.w, C, tid * 4, s0);
-        for (int k = tid; k < (N + 2) * (N + 2); k += NT) bdp[k] = 0.f;
-        sb = *reinterpret_cast<const f32x4 *>(S.bias + lane * 4);
-    }
-    f32x4 z[8][4];      // the tile of Z that is fetched ahead
-    int bd = blockIdx.x;
-    if (bd < nboards) w6_load_z(M + (size_t)map.slot(bd, 0, tx) * W6_ZTILE + lane * 4, z, w6_cls(0, tx));
-#pragma unroll 1
-    for (; bd < nboards; bd += gridDim.x) {
-        W6_LDS_BARRIER();                                    // the previous board's last window reads (and the zero fill)
-        for (int k = tid; k < ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // slot 0 = board row -1
-        if (RS) {
-            pv = w4_stem_plane<N>(S, bd, bdp, tid, NT);
-            W6_LDS_BARRIER();
-        }
-#pragma unroll 1
-        for (int t = 0; t <= W6_TWY; t++) {
-            f32x4 keep[3][6];
-            if (t < W6_TWY) {
-                f32x4 yv[4][6];
-                w6_tile_outputs(z, yv, w6_cls(t, tx));
-#pragma unroll
-                for (int a = 0; a < 4; a++) {
-                    const int py = 4 * t + a;
-#pragma unroll
-                    for (int bb = 0; bb < 6; bb++) {
-                        if (bb >= wd) continue;                              // (uniform over the wave)
-                        f32x4 v = yv[a][bb] + bi;
-                        const bool inb = py < N;
-                        const size_t o = ((size_t)bd * (N * N) + (size_t)((inb ? py : 0) * N + x0 + bb)) * C + lane * 4;
-                        if (RS) {
-                            if (inb) v = v + w4_stem_pixel<N>(bdp, w4_fma(pv, *reinterpret_cast<const f32x4 *>(s0 + w4_border_class(py, x0 + bb, N) * C + lane * 4), zero4), py, x0 + bb, sb,
-                                                              [&](int t_) { return *reinterpret_cast<const f32x4 *>(swl + t_ * C + lane * 4); });
-                        } else if (res && inb) v = v + *reinterpret_cast<const f32x4 *>(res + o);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) v[r] = v[r] > 0.f ? v[r] : 0.f;
-                        if (!inb) v = zero4;                             // beyond the board: the next layer's zero padding
-                        else if (act) *reinterpret_cast<f32x4 *>(act + o) = v;      // a block's output is also the next block's residual
-                        if (a == 0) *reinterpret_cast<f32x4 *>(wpix + ((py + 1) % 6) * ROWF + bb * C) = v;
-                        else keep[a - 1][bb] = v;
-                    }
-                }
-                if (tx == W6_TWX - 1) {      // window column 20 (beyond the board; the corner tile's fourth patch column reads it): stays zero
-                }
-            } else {
-#pragma unroll
-                for (int bb = 0; bb < 6; bb++)
-                    if (bb < wd) *reinterpret_cast<f32x4 *>(wpix + ((4 * t + 1) % 6) * ROWF + bb * C) = zero4;      // row 4 TWY: below the board
-            }
-            W6_LDS_BARRIER();                                // board rows 4t - 5 .. 4t are in the window
-            // the next tile of Z: (t + 1, tx) of this board, or (0, tx) of the workgroup's next board
-            {
-                long nbd = bd;
-                int nt = t + 1;
-                if (nt >= W6_TWY) { nt = 0; nbd = bd + gridDim.x; }
-                if (t < W6_TWY && nbd < nboards) w6_load_z(M + (size_t)map.slot(nbd, nt, tx) * W6_ZTILE + lane * 4, z, w6_cls(nt, tx));
-            }
-            if (t >= 1) {
-                const int ty = t - 1;
-                const long tt = map.slot(bd, ty, tx);
-                float *vb = V + (size_t)(tt / W6_BT) * W6_VBLOCK + (size_t)(tt % W6_BT) * W6_VTILE;
-                int slot[6];
-                w6_slots(ty, slot);
-                w6_patch_transform(win + x0 * C, slot, vb, lane, w6_cls(ty, tx));
-            }
-            W6_LDS_BARRIER();                                // rows 4t - 5 .. 4t - 3 are read no more: their slots take rows 4t + 1 .. 4t + 3
-            if (t < W6_TWY) {
-#pragma unroll
-                for (int a = 1; a < 4; a++)
-#pragma unroll
-                    for (int bb = 0; bb < 6; bb++)
-                        if (bb < wd) *reinterpret_cast<f32x4 *>(wpix + ((4 * t + a + 1) % 6) * ROWF + bb * C) = keep[a - 1][bb];
-            }
-        }
-    }
-}
-
-// ---- the tower's last output transform, with the heads' 1x1 filters (conv_wino4.hip's c6_wino4_out_kernel<N, true>) -----------------
-// One wave per tile at a time, lane = 4 channels; a pixel's three filter sums are wave sums; nothing but the heads' inputs is written.
-// A tile is processed in four SLICES -- the transform is independent for every value of Z's second index b: a slice takes the 8 / 6 / 5
-// row sums Z[.][b] and yields up to six pixels (a row of the tile for the transposed classes D and B, a column for A and B') -- so that
-// only one slice's pixels and filter sums are alive at a time beside the tile's row sums.
-__device__ __forceinline__ void w6_slice_outputs(const f32x4 (&z)[8], f32x4 (&y)[6], int cls) {
-    if (cls == W6_CLS_D) {
-        const f32x4 e1 = z[1] + z[2], o1 = z[1] - z[2], e2 = z[3] + z[4], o2 = z[3] - z[4], e3 = z[5] + z[6], o3 = z[5] - z[6];
+        const VT e1 = z[1] + z[2], o1 = z[1] - z[2], e2 = z[3] + z[4], o2 = z[3] - z[4], e3 = z[5] + z[6], o3 = z[5] - z[6];
         y[0] = (z[0] + e1) + (e2 + e3);
         y[1] = w4_fma(2.f, o2, w4_fma(0.5f, o3, o1));
         y[2] = w4_fma(4.f, e2, w4_fma(0.25f, e3, e1));
@@ -608,18 +452,21 @@ __device__ __forceinline__ void w6_slice_outputs(const f32x4 (&z)[8], f32x4 (&y)
         y[4] = w4_fma(16.f, e2, w4_fma(0.0625f, e3, e1));
         y[5] = w4_fma(32.f, o2, w4_fma(0.03125f, o3, o1)) + z[7];
     } else if (cls == W6_CLS_A) {
-        const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
+        const VT s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
         y[0] = z[0] + s12 + s34;
         y[1] = w4_fma(2.f, d34, d12);
         y[2] = w4_fma(4.f, s34, s12);
         y[3] = w4_fma(8.f, d34, d12) + z[5];
     } else {
-        const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2];
+        const VT s12 = z[1] + z[2], d12 = z[1] - z[2];
         y[0] = z[0] + s12 + z[3];
         y[1] = w4_fma(2.f, z[3], d12);
         y[2] = w4_fma(4.f, z[3], s12) + z[4];
     }
 }
+// ---- the tower's last output transform, with the heads' 1x1 filters (conv_wino4.hip's c6_wino4_out_kernel<N, true>) -----------------
+// One wave per half tile at a time (two slices), lane = 4 channels; a pixel's three filter sums are wave sums; nothing but the heads'
+// inputs is written.  Only one slice's pixels and filter sums are alive at a time beside the half tile's row sums and residual.
 struct W6OutCtx {
     f32x4 bi, hw0, hw1, hw2;
     const float *res;
@@ -633,6 +480,18 @@ __device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, 
     constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_B;      // the slice's pixels run along a row of the tile (else: along a column)
     constexpr int npx = CLS == W6_CLS_D ? 6 : CLS == W6_CLS_A ? 4 : 3;
     // two slices per wave (b = b0, b0 + 1): their row sums are requested at once (up to 16 KiB in flight per wave), then consumed one by one
+    // (the residual first: asked for where it is added, the load would wait behind its slice's arithmetic)
+    f32x4 rv[2][npx];
+    if (X.res) {
+#pragma unroll
+        for (int bq = 0; bq < 2; bq++)
+#pragma unroll
+            for (int k = 0; k < npx; k++) {
+                const int py = 4 * ty + (along_row ? b0 + bq : k), cx = along_row ? k : b0 + bq;
+                rv[bq][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (py < N && cx < wd) rv[bq][k] = *reinterpret_cast<const f32x4 *>(X.res + ((size_t)bd * (N * N) + (size_t)(py * N + x0 + cx)) * C + lane * 4);
+            }
+    }
     f32x4 zt[2][8];
 #pragma unroll
     for (int i = 0; i < rows; i++)
@@ -650,7 +509,7 @@ __device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, 
             const int py = 4 * ty + (along_row ? b : k), cx = along_row ? k : b, px = x0 + cx;
             if (py >= N || cx >= wd) continue;
             f32x4 v = y[k] + X.bi;
-            if (X.res) v = v + *reinterpret_cast<const f32x4 *>(X.res + ((size_t)bd * (N * N) + (size_t)(py * N + px)) * C + lane * 4);
+            if (X.res) v = v + rv[bq][k];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 v[r] = v[r] > 0.f ? v[r] : 0.f;
@@ -704,6 +563,196 @@ __global__ __launch_bounds__(256) void c6_w6_out_kernel(const float *__restrict_
         else if (cls == W6_CLS_A) w6_out_tile<W6_CLS_A>(X, zb, bd, ty, x0, wd, lane, b0);
         else if (cls == W6_CLS_B) w6_out_tile<W6_CLS_B>(X, zb, bd, ty, x0, wd, lane, b0);
         else w6_out_tile<W6_CLS_BP>(X, zb, bd, ty, x0, wd, lane, b0);
+    }
+}
+
+// ---- the boundary kernel with the two halves on different waves ---------------------------------------------------------------------
+// 12 waves per workgroup (three per SIMD, 168 registers each), one board at a time:
+//   waves 0 .. 7   PRODUCERS: wave = (tile column, channel half), lane = 2 channels.  Z tile -> pixels (A^T Z + bias (+ residual), ReLU),
+//                  activations out, the pixels into the rolling 6-row window
+//   waves 8 .. 11  CONSUMERS: wave = tile column, lane = 4 channels in two passes: window patch -> B^T d B -> V
+// so that one half's memory waits (Z / residual loads; V stores) overlap the other half's arithmetic inside the workgroup -- the two never
+// touch the matrix unit, the mutual exclusion profiles/r03_mfma_valu_coissue.txt measured does not apply.
+// A board takes six phases, each ending in two LDS barriers (X: the consumers' reads of the phase are done / Y: the producers' writes are):
+//   phase p  producers  compute the pixels of tile row p + 1 (p = 4: the zero row below the board; p = 5: tile row 0 of the NEXT board),
+//                       after X write the three rows kept from phase p - 1 and the first row of this phase's tile into the window
+//            consumers  transform the patches of tile row p - 1 (window rows 4p - 5 .. 4p), p >= 1
+template <int CLS, bool RS>
+__device__ __forceinline__ void w6_produce_tile(const float *zb, long bd, int t, int x0, int wd, int c, f32x2 bi, const float *res, float *act, const float *plane, float pv,
+                                                const float *swl, const float *s0, f32x2 sb, f32x2 (&r0)[6], f32x2 (&kn)[3][6]) {
+    constexpr int C = W6_C, N = W6_N;
+    constexpr int rows = CLS == W6_CLS_D ? 8 : CLS == W6_CLS_A ? 6 : 5;
+    constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_B;
+    constexpr int npx = CLS == W6_CLS_D ? 6 : CLS == W6_CLS_A ? 4 : 3;
+    const f32x2 zero2 = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        // the residual of the half's pixels is requested BEFORE the row sums: both are in flight together (asked for where it is added, the
+        // load waits behind the arithmetic of its slice -- a layer with a residual took 16.5 ms instead of 8.4)
+        f32x2 rv[2][along_row ? 6 : 4];
+        if (!RS && res) {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int k = 0; k < (along_row ? 6 : 4); k++) {
+                    const int a = along_row ? 2 * h + q : k, cx = along_row ? k : 2 * h + q, py = 4 * t + a;
+                    rv[q][k] = zero2;
+                    if (cx < wd && k < npx && py < N) rv[q][k] = *reinterpret_cast<const f32x2 *>(res + ((size_t)bd * (N * N) + (size_t)(py * N + x0 + cx)) * C + c);
+                }
+        }
+        f32x2 zt[2][8];
+#pragma unroll
+        for (int i = 0; i < rows; i++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) zt[q][i] = *reinterpret_cast<const f32x2 *>(zb + (size_t)(i * 4 + 2 * h + q) * C);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int b = 2 * h + q;
+            f32x2 y[6];
+            w6_slice_outputs(zt[q], y, CLS);
+#pragma unroll
+            for (int k = 0; k < (along_row ? 6 : 4); k++) {
+                const int a = along_row ? b : k, cx = along_row ? k : b;      // pixel (row a, column cx) of the tile
+                if (cx >= wd) continue;                                        // (uniform over the wave)
+                const int py = 4 * t + a;
+                f32x2 v = zero2;
+                if (k < npx && py < N) {
+                    v = y[k < npx ? k : 0] + bi;
+                    const size_t o = ((size_t)bd * (N * N) + (size_t)(py * N + x0 + cx)) * C + c;
+                    if (RS) {
+                        constexpr int P = N + 2;
+                        const f32x2 s0v = *reinterpret_cast<const f32x2 *>(s0 + w4_border_class(py, x0 + cx, N) * C + c);
+                        f32x2 acc = sb + w4_fma(pv, s0v, zero2);              // (w4_stem_pixel's order of operations)
+#pragma unroll
+                        for (int tp = 0; tp < 9; tp++) {
+                            const float bdv = plane[(py + tp / 3) * P + x0 + cx + tp % 3];
+                            const f32x2 w = *reinterpret_cast<const f32x2 *>(swl + tp * C + c);
+                            acc[0] = __builtin_fmaf(w[0], bdv, acc[0]);
+                            acc[1] = __builtin_fmaf(w[1], bdv, acc[1]);
+                        }
+                        v[0] += acc[0] > 0.f ? acc[0] : 0.f;
+                        v[1] += acc[1] > 0.f ? acc[1] : 0.f;
+                    } else if (res) v = v + rv[q][k];
+                    v[0] = v[0] > 0.f ? v[0] : 0.f;
+                    v[1] = v[1] > 0.f ? v[1] : 0.f;
+                    if (act) *reinterpret_cast<f32x2 *>(act + o) = v;      // a block's output is also the next block's residual
+                }                                                          // (else: beyond the board, the next layer's zero padding)
+                if (a == 0) r0[cx] = v;
+                else kn[a - 1][cx] = v;
+            }
+        }
+    }
+}
+#define W6_MID_THREADS 768
+template <bool RS>
+__global__ __launch_bounds__(W6_MID_THREADS) void c6_w6_mid_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
+                                                                      float *__restrict__ act, float *__restrict__ V, int nboards, C6StemSrc S) {
+    constexpr int C = W6_C, N = W6_N, ROWF = W6_ROWF, NT = W6_MID_THREADS, PP = (N + 2) * (N + 2);
+    extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] (+ RS: the stem's weights, sums and two board planes)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = w < 8;
+    const int tx = producer ? (w & 3) : (w - 8);
+    const int x0 = w6_x0(tx), wd = w6_width(tx);
+    const int c = ((w >> 2) & 1) * (C / 2) + lane * 2;                         // a producer's channel pair
+    const W6Map map(nboards);
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x2 zero2 = f32x2{0.f, 0.f};
+    const f32x2 bi = bias ? *reinterpret_cast<const f32x2 *>(bias + c) : zero2;
+    for (int k = tid; k < 6 * ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
+    float *wpix = win + (x0 + 1) * C + c;                  // window column of this producer's first pixel column (board column x0)
+    float *swl = win + 6 * ROWF, *s0 = swl + 9 * C, *planes = s0 + 9 * C;      // RS: board-plane weights [9][C], player-plane sums [9][C], board planes [2][(N+2)^2]
+    f32x2 sb = zero2;
+    if (RS) {
+        for (int k = tid; k < 9 * C / 4; k += NT) reinterpret_cast<f32x4 *>(swl)[k] = *reinterpret_cast<const f32x4 *>(S.w + ((k / (C / 4)) * 2 + 1) * C + (k % (C / 4)) * 4);
+        if (tid < C / 4) w4_stem_player_sums(S.w, C, tid * 4, s0);
+        for (int k = tid; k < 2 * PP; k += NT) planes[k] = 0.f;
+        sb = *reinterpret_cast<const f32x2 *>(S.bias + c);
+    }
+    long cur = -1, nxt = blockIdx.x;
+    int p = 5;
+    W6_LDS_BARRIER();
+    // The two roles run separate loops (nothing of one role's state is alive in the other's registers); both pass the same barriers:
+    // X = this phase's window reads are done, Y = the window holds the next phase's rows.
+    if (producer) {
+        constexpr int NP = 512;                              // the producers' threads: tid 0 .. 511
+        int pbuf = 0;
+        float pvc = 0.f, pvn = 0.f;
+        if (RS && nxt < nboards) pvn = w4_stem_plane<N>(S, nxt, planes + (pbuf ^ 1) * PP, tid, NP);
+        W6_LDS_BARRIER();
+        f32x2 r0[6], ko[3][6], kn[3][6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { r0[k] = zero2; ko[0][k] = zero2; ko[1][k] = zero2; ko[2][k] = zero2; kn[0][k] = zero2; kn[1][k] = zero2; kn[2][k] = zero2; }
+#pragma unroll 1
+        for (;;) {
+            const long b = p == 5 ? nxt : cur;
+            const int t = p == 5 ? 0 : p + 1;
+            if (p != 4 && b >= 0 && b < nboards) {
+                const int cls = w6_cls(t, tx);
+                const float *zb = M + (size_t)map.slot(b, t, tx) * W6_ZTILE + c;
+                const float *plane = planes + (p == 5 ? pbuf ^ 1 : pbuf) * PP;
+                const float pv = p == 5 ? pvn : pvc;
+                if (cls == W6_CLS_D) w6_produce_tile<W6_CLS_D, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+                else if (cls == W6_CLS_A) w6_produce_tile<W6_CLS_A, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+                else if (cls == W6_CLS_B) w6_produce_tile<W6_CLS_B, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+                else w6_produce_tile<W6_CLS_BP, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+            } else if (p == 4) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) r0[k] = zero2;                     // row 4 TWY: below the board
+                if (RS && nxt < nboards) pvn = w4_stem_plane<N>(S, nxt, planes + (pbuf ^ 1) * PP, tid, NP);      // (last read in phase 3 of the board before)
+            }
+            W6_LDS_BARRIER();                                // X
+            if (p == 5) {
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    if (k < wd) {
+                        *reinterpret_cast<f32x2 *>(wpix + 0 * ROWF + k * C) = zero2;      // slot 0 = board row -1
+                        *reinterpret_cast<f32x2 *>(wpix + 1 * ROWF + k * C) = r0[k];      // slot 1 = row 0
+                    }
+            } else {
+#pragma unroll
+                for (int a = 1; a < 4; a++)
+#pragma unroll
+                    for (int k = 0; k < 6; k++)
+                        if (k < wd) *reinterpret_cast<f32x2 *>(wpix + ((4 * p + a + 1) % 6) * ROWF + k * C) = ko[a - 1][k];
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    if (k < wd) *reinterpret_cast<f32x2 *>(wpix + ((4 * p + 5) % 6) * ROWF + k * C) = r0[k];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) ko[a][k] = kn[a][k];
+            W6_LDS_BARRIER();                                // Y
+            if (p == 5) {
+                if (nxt >= nboards) break;
+                cur = nxt;
+                nxt += gridDim.x;
+                pvc = pvn;
+                pbuf ^= 1;
+                p = 0;
+            } else p++;
+        }
+    } else {
+        W6_LDS_BARRIER();
+#pragma unroll 1
+        for (;;) {
+            if (p >= 1 && cur >= 0) {
+                const int ty = p - 1;
+                const long tt = map.slot(cur, ty, tx);
+                float *vb = V + (size_t)(tt / W6_BT) * W6_VBLOCK + (size_t)(tt % W6_BT) * W6_VTILE;
+                int slot[6];
+                w6_slots(ty, slot);
+                w6_patch_transform(win + x0 * C, slot, vb, lane, w6_cls(ty, tx));
+            }
+            W6_LDS_BARRIER();                                // X
+            W6_LDS_BARRIER();                                // Y
+            if (p == 5) {
+                if (nxt >= nboards) break;
+                cur = nxt;
+                nxt += gridDim.x;
+                p = 0;
+            } else p++;
+        }
     }
 }
 
@@ -775,11 +824,12 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
     if (steps & 16) {
         constexpr size_t rs_smem = win_smem + (size_t)18 * W6_C * 4 + (size_t)(W6_N + 2) * (W6_N + 2) * 4;
         if (stem) {      // the residual is the stem's output, recomputed from the boards
-            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<true>), (int)rs_smem);
-            hipLaunchKernelGGL((c6_w6_mid_kernel<true>), dim3(grid_b), dim3(W6_THREADS), rs_smem, s, Mb, bias, res, act, Vb, nboards, *stem);
+            constexpr size_t rs12 = rs_smem + (size_t)(W6_N + 2) * (W6_N + 2) * 4;
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<true>), (int)rs12);
+            hipLaunchKernelGGL((c6_w6_mid_kernel<true>), dim3(grid_b), dim3(W6_MID_THREADS), rs12, s, Mb, bias, res, act, Vb, nboards, *stem);
         } else {
             w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<false>), (int)win_smem);
-            hipLaunchKernelGGL((c6_w6_mid_kernel<false>), dim3(grid_b), dim3(W6_THREADS), win_smem, s, Mb, bias, res, act, Vb, nboards, C6StemSrc{});
+            hipLaunchKernelGGL((c6_w6_mid_kernel<false>), dim3(grid_b), dim3(W6_MID_THREADS), win_smem, s, Mb, bias, res, act, Vb, nboards, C6StemSrc{});
         }
         if (tail) hipLaunchKernelGGL(c6_w6_tail_kernel, dim3(256), dim3(256), 0, s, Vb, nboards);
     }
