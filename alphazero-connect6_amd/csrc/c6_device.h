@@ -322,13 +322,19 @@ __device__ __forceinline__ int c6_select_bit(unsigned long long m, int n) {
 // c6_gamma_draw per cell -- the attempt that is accepted for a cell does not depend on who evaluates it -- but the
 // rejection loops are not run in lockstep: the cells still without a variate are packed onto lanes 0..k-1 in every round
 // (occupied cells cost nothing: in the middle of a 9x9 game the 2 x 64 owned slots hold ~47 empty cells -- one pass instead of two).
-// `scratch` = cells 8-byte words of wave-private LDS: workers hand the variates (mantissa | exponent, or "rejected") back to the
-// owners.  Cells that need none come back as {0, C6_GAM_NONE}.
+// `scratch` = wave-private LDS: 64 J 8-byte words through which workers hand the variates (mantissa | exponent, or "rejected") back to
+// the owners, followed by 64 J 16-bit words for the list of pending cells (C6_GAM_SCRATCH_DOUBLES(J) doubles in all).  Cells that need
+// none come back as {0, C6_GAM_NONE}.
+// The packing costs no division and no bit search: a pending cell's rank is a popcount below its lane (v_mbcnt) and it writes its own
+// index into the list; every pending cell gets 2^s speculative attempt pairs, the largest power of two that fits the wave (item i ->
+// cell list[i >> s], attempt pair att + (i & (2^s - 1)): shifts and masks).
 #define C6_GAM_REJ 0x7fffffff
+#define C6_GAM_SCRATCH_DOUBLES(J) (64 * (J) + 16 * (J))
 template <int J>
 __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], c6_gam (&gam)[J], double *scratch_, int lane, double alpha,
                                               double d, double c, uint32_t k0, uint32_t k1, uint32_t search, uint32_t depth) {
     unsigned long long *scratch = reinterpret_cast<unsigned long long *>(scratch_);
+    unsigned short *list = reinterpret_cast<unsigned short *>(scratch_ + 64 * J);
     unsigned long long pend[J];
     bool any = false;
 #pragma unroll
@@ -341,23 +347,21 @@ __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], c6_gam (&ga
     for (uint32_t att = 0; any;) {
         int tot = 0;
 #pragma unroll
-        for (int j = 0; j < J; j++) tot += __popcll(pend[j]);
-        // k speculative attempt pairs (att .. att+k-1; c6_gamma_try2) per pending cell while they fit on the 64 lanes; the lowest accepted
-        // attempt of a cell wins, exactly as if they had been tried one after the other
-        const int k = tot >= 64 ? 1 : 64 / tot;
-        for (int base = 0; base < tot * k; base += 64) {
+        for (int j = 0; j < J; j++) {
+            if ((pend[j] >> lane) & 1ull)
+                list[tot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pend[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend[j], 0u))] = (unsigned short)(lane + 64 * j);
+            tot += __popcll(pend[j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS is in order within a wave; this binds the compiler
+        // 2^s speculative attempt pairs (att .. att + 2^s - 1; c6_gamma_try2) per pending cell while they fit on the 64 lanes; the lowest
+        // accepted attempt of a cell wins, exactly as if they had been tried one after the other
+        const int s = tot > 32 ? 0 : 6 - (tot > 1 ? 32 - __builtin_clz((unsigned)(tot - 1)) : 0);
+        const int k = 1 << s, items = tot << s;
+        for (int base = 0; base < items; base += 64) {
             const int item = base + lane;
-            const bool active = item < tot * k;
-            const int idx = item / k, sub = item - idx * k;
-            int rem = idx, cell = -1;
-#pragma unroll
-            for (int j = 0; j < J; j++) {
-                const int pc = __popcll(pend[j]);
-                if (active && cell < 0) {
-                    if (rem < pc) cell = c6_select_bit(pend[j], rem) + 64 * j;
-                    else rem -= pc;
-                }
-            }
+            const bool active = item < items;
+            const int sub = item & (k - 1);
+            const int cell = active ? (int)list[item >> s] : 0;
             c6_gam v = {0.f, 0};
             const bool ok = active && c6_gamma_try2(alpha, d, c, k0, k1, (uint32_t)cell, search, depth, att + (uint32_t)sub, v);
             // lanes of one cell are consecutive (sub = 0..k-1, one batch whenever k > 1): the first accepted one writes
@@ -367,7 +371,7 @@ __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], c6_gam (&ga
             if (ok && (mine & ((1ull << sub) - 1ull)) == 0ull) scratch[cell] = (unsigned long long)__float_as_uint(v.m) | ((unsigned long long)(uint32_t)v.k << 32);
         }
         att += (uint32_t)k;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS is in order within a wave; this binds the compiler
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         any = false;
 #pragma unroll
         for (int j = 0; j < J; j++) {

@@ -1248,7 +1248,7 @@ __device__ __noinline__ void move_call(const C6Dev *Es, int g, int lane, uint8_t
 // one on, the game's header, tag row, root row and root priors come out of the L2 instead of HBM.
 template <int J, int KIND>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? C6_OCC4 : 2)) void c6_search_kernel(C6Dev E, int nsims) {
-    __shared__ double gscratch[WAVES_PER_BLOCK][64 * J];    // c6_wave_gamma hand-back, then the leaf's prior / board: wave-private
+    __shared__ double gscratch[WAVES_PER_BLOCK][C6_GAM_SCRATCH_DOUBLES(J)];    // c6_wave_gamma hand-back + list, then the leaf's prior / board: wave-private
     __shared__ C6Dev Es;                                    // the descriptor for the rare paths (round_head_call / move_call)
     extern __shared__ __align__(16) uint8_t c6_tag_lds[];   // [WAVES_PER_BLOCK][tag_row_bytes(H)] the games' tag rows
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1321,7 +1321,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
 // Net / callback evaluators: the evaluator sits between select and expand, so the leaf travels through the leaf_* arrays.
 template <int J>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? 4 : (J <= 4 ? 3 : 2)) void c6_select_kernel(C6Dev E) {
-    __shared__ double gscratch[WAVES_PER_BLOCK][64 * J];
+    __shared__ double gscratch[WAVES_PER_BLOCK][C6_GAM_SCRATCH_DOUBLES(J)];
     extern __shared__ __align__(16) uint8_t c6_tag_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = blockIdx.x * WAVES_PER_BLOCK + wv;
@@ -1513,7 +1513,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_noise_op_kernel(int N
     if (b >= num) return;
     const int cells = N * N;
     const int8_t *board = boards + (size_t)b * cells;
-    __shared__ double gscratch[WAVES_PER_BLOCK][64 * C6_MAXJ];
+    __shared__ double gscratch[WAVES_PER_BLOCK][C6_GAM_SCRATCH_DOUBLES(C6_MAXJ)];
     c6_gam gam[C6_MAXJ];
     float nz[C6_MAXJ];
     bool need[C6_MAXJ];
