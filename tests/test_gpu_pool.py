@@ -155,6 +155,39 @@ def test_shared_pool_grows_by_mapping_and_pages_change_hands():
         assert list(games[uid]["moves"]) == [r * n + c for _, _, (r, c) in ref["path"]] and games[uid]["winner"] == ref["winner"], uid
 
 
+def test_page_churn_under_recycling_keeps_every_game_exact():
+    """Steady-state mode at scale: 2048 staggered 9x9 games that restart as they finish (recycle), every third on the stress evaluator, a pool
+    created for one move's worth per game -- pages and table chunks go back and forth between finishing shallow games and growing deep ones
+    for ~30 game lengths while the host side raises the per-game caps as it goes (the pool's first mapping is a whole VMM unit: large enough here).  No game is abandoned or left parked, and sampled games of
+    both kinds, from the second generation of their slots to the last, equal the oracle stone for stone."""
+    need_gpu()
+    n, G, S, seed, eps, every = 9, 2048, 40, 23, 0.001, 3
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_STRESS, stress_every=every,
+                     records_per_game=8, recycle=True, stagger=True)
+    st0 = eng.stats()
+    done = {}
+    for it in range(60):
+        eng.step(S * 20)
+        eng.maintain()
+        for g in eng.fetch_games():
+            done[g["uid"]] = g
+    st = eng.stats()
+    eng.close()
+    assert st["abandoned_games"] == 0 and st["overflow_games"] == st["parked_games"] and st["parked_games"] <= G // 100, st
+    assert st["cap_raises"] >= 1 and st["max_records_used"] > 3 * S and st["pool_pages_low"] < st0["pool_pages_free"] // 2, (st0, st)
+    assert len(done) > 8 * G and max(done) >= 8 * G                       # many generations of every slot
+    fn = stress_eval_fn(n)
+    uids = sorted(done)
+    # (a staggered slot's FIRST game starts its first move with uid % S simulations already counted -- connect6_amd.h: stagger -- so the
+    #  oracle's game of that uid is another one; every later generation of the slot is a whole game)
+    peaked = [u for u in uids if u % every == 0 and u >= G]
+    plain = [u for u in uids if u % every != 0 and u >= G]
+    for u in peaked[:2] + peaked[len(peaked) // 2:len(peaked) // 2 + 2] + peaked[-2:] + plain[:2] + plain[-2:]:
+        kind = dict(eval_kind=o.EVAL_CUSTOM, eval_fn=fn) if u % every == 0 else dict(eval_kind=o.EVAL_UNIFORM)
+        ref = o.self_play(n, num=1, threads=1, num_simulation=S, seed=seed, epsilon=eps, uid_base=u, **kind)[0]
+        assert list(done[u]["moves"]) == [r * n + c for _, _, (r, c) in ref["path"]] and done[u]["winner"] == ref["winner"], u
+
+
 def test_recycled_error_slots_stay_consistent_without_stagger():
     """recycle = 1, stagger = 0 and a host evaluator.  Games that cannot be served (max_records_per_game = 128) are abandoned
     and their slots restart OUT OF PHASE with the aligned move rounds; K1 runs every round, so every move of a restarted game is applied
