@@ -37,11 +37,11 @@ DROPIN_SYMBOLS = ["cpp_play", "cpp_self_play", "cpp_play_with", "test_new_raw_pa
 ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_config", "c6_engine_create",
                   "c6_engine_destroy", "c6_net_blob_floats", "c6_net_blob_header_floats", "c6_net_blob_write_header",
                   "c6_net_blob_check_header", "c6_engine_load_weights", "c6_engine_set_callback",
-                  "c6_engine_step", "c6_engine_run", "c6_engine_maintain", "c6_engine_sync", "c6_engine_stats", "c6_engine_fetch_games",
+                  "c6_engine_step", "c6_engine_run", "c6_engine_maintain", "c6_engine_sync", "c6_engine_stats", "c6_engine_pool_audit", "c6_engine_fetch_games",
                   "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_swap_tuple_buffer", "c6_engine_stream", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
                   "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
-                  "c6_bench_conv", "c6_bench_board", "c6_bench_board_scan", "c6_conv_pack_m8_bytes", "c6_conv_pack_m8", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
+                  "c6_bench_conv", "c6_bench_board", "c6_bench_board_scan", "c6_pool_ring_selftest", "c6_conv_pack_m8_bytes", "c6_conv_pack_m8", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
@@ -149,6 +149,7 @@ def lib():
     L.c6_engine_apply_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_last_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.c6_engine_pool_audit.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 12)]
     L.c6_engine_play_match.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_long]
     L.c6_engine_boards.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
     L.c6_rollout_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
@@ -239,6 +240,13 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+def pool_ring_selftest(ids=1000, waves=4096, tries=4, launches=50, seed=1):
+    """c6_pool_ring_selftest -> dict(dup, over, min_popped)"""
+    d, ov, mp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _chk(lib().c6_pool_ring_selftest(ids, waves, tries, launches, seed, C.byref(d), C.byref(ov), C.byref(mp)))
+    return dict(dup=d.value, over=ov.value, min_popped=mp.value)
+
+
 def device_count():
     return lib().c6_device_count()
 
@@ -261,7 +269,7 @@ class _Arena:
 
 
 def _vec_to_py(v):
-    """GameResult::from_vec (connect6.hpp:251-263) -> [(winner, [(turn, board[15][15], (row, col)), ...])]"""
+    """GameResult::from_vec (connect6.hpp:251-263) -> [(winner, [(turn, board[15][15], (row, col)), ...])] with numpy boards"""
     out = []
     for i in range(v.len):
         r = v.vec[i]
@@ -274,31 +282,89 @@ def _vec_to_py(v):
     return out
 
 
+def _result_to_ref(r):
+    """RunResultWrapper / PathWrapper (pybind/pybind_impl/mod.rs:66-105): `(winner: int, [(turn: int, board: list of N*N ints
+    in row-major order (pylist_from_board, :29-37), (row, col)), ...])` -- plain Python objects, as rust-cpython builds them"""
+    path = []
+    for k in range(r.len):
+        p = r.paths[k]
+        path.append((int(p.turn), np.ctypeslib.as_array(p.board).reshape(-1).tolist(), (int(p.row), int(p.col))))
+    return int(r.winner), path
+
+
+def board_size():
+    """pyconnect6.board_size (pybind/pyconnect6/__init__.py:5-6): the drop-in boundary is the reference's 15x15 build"""
+    return REF_N
+
+
 def default_param():
-    """pyconnect6.default_param (Connect6/pybind/pyconnect6/__init__.py:47-56)"""
-    return {"num_simulation": 800, "epsilon": 0.25, "dirichlet_alpha": 0.03, "c_puct": 1.0, "debug": False, "num_game_thread": 1}
+    """pyconnect6.default_param (Connect6/pybind/pyconnect6/__init__.py:46-55)"""
+    return {"num_simulation": 800, "epsilon": 0.25, "dirichlet_alpha": 0.03, "c_puct": 1, "debug": False, "num_game_thread": 1}
 
 
-def dump_param(path, param):
-    """pyconnect6.dump_param (pybind/pyconnect6/__init__.py:58-67): MCTS hyper-parameters as `<path>_mcts.json`"""
+def param_to_tuple(param):
+    """pyconnect6.param_to_tuple (pybind/pyconnect6/__init__.py:58-64); a missing key is a KeyError, as there"""
+    return (param["num_simulation"], param["epsilon"], param["dirichlet_alpha"], param["c_puct"], param["debug"],
+            param["num_game_thread"])
+
+
+def dump_param(path, param=None):
+    """pyconnect6.dump_param (pybind/pyconnect6/__init__.py:67-73): MCTS hyper-parameters as `<path>_mcts.json`"""
     import json
+    if param is None:
+        param = default_param()
     with open(path + "_mcts.json", "w") as f:
-        json.dump(param, f)
+        f.write(json.dumps(param))
 
 
 def load_param(path):
-    """pyconnect6.load_param (pybind/pyconnect6/__init__.py:69-79)"""
+    """pyconnect6.load_param (pybind/pyconnect6/__init__.py:76-78)"""
     import json
     with open(path + "_mcts.json") as f:
-        return json.load(f)
+        return json.loads(f.read())
+
+
+def _cpp_self_play(tramp, param):
+    cb = CALLBACK(tramp)
+    arena = _Arena()
+    ns, eps, alpha, cp, debug, threads = param_to_tuple(param)
+    v = lib().cpp_self_play(cb, arena.alloc_path, arena.alloc_result, int(ns), float(eps), float(alpha), float(cp), bool(debug), int(threads))
+    return v, arena
 
 
 def self_play(policy, param=None):
-    """pyconnect6.self_play (pybind/pyconnect6/__init__.py:9-33) through the reference C ABI cpp_self_play.
+    """pyconnect6.self_play (pybind/pyconnect6/__init__.py:9-35 over libpyconnect6/src/lib.rs:104-153) through the reference C
+    ABI cpp_self_play, with the reference's Python objects on both sides:
 
-    policy(turn:int, boards: np.ndarray[len, 225] of -1/0/1) -> (values[len], probs[len, 225]);
-    returns [(winner, [(turn, board, (row, col)), ...]), ...], one entry per game.
-    """
+    `policy(turn: int, boards: list[len] of list[N*N] of int in {-1, 0, 1}) -> (values[len], probs[len][N*N])` -- PyEval
+    (pybind/pyeval/mod.rs: `pylist_from_multiple` in, anything iterable back; numpy arrays are fine, as in
+    Connect6/sample/python/random_policy.py:22-26);
+
+    returns `(winner, path)` when `param['num_game_thread'] == 1` (lib.rs:119-128) and a tuple of `(winner, path)` -- one per
+    game, in any order -- otherwise (lib.rs:129-152); `path = [(turn, board: list[N*N] of int, (row, col)), ...]`
+    (pybind_impl/mod.rs:66-105).  `self_play_np` is the same call with numpy arrays and always a list of games."""
+    if param is None:
+        param = default_param()
+    cells = REF_N * REF_N
+
+    def tramp(player, values, policies, n):
+        pol = np.ctypeslib.as_array(policies, shape=(n, cells))
+        val = np.ctypeslib.as_array(values, shape=(n,))
+        v, p = policy(int(player), pol.astype(np.int32).tolist())
+        val[:] = np.asarray(v, dtype=np.float32).reshape(n)
+        pol[:] = np.asarray(p, dtype=np.float32).reshape(n, cells)
+
+    v, arena = _cpp_self_play(tramp, param)
+    games = tuple(_result_to_ref(v.vec[i]) for i in range(v.len))
+    if param["num_game_thread"] == 1:
+        return games[0]
+    return games
+
+
+def self_play_np(policy, param=None):
+    """the numpy face of the same boundary (not in the reference): `policy(turn, boards: int8 ndarray [len, 225]) -> (values,
+    probs)`; returns a LIST of `(winner, [(turn, board int8[15, 15], (row, col)), ...])`, one per game, whatever
+    `num_game_thread` is; missing keys of `param` take their defaults"""
     prm = default_param()
     prm.update(param or {})
 
@@ -309,10 +375,7 @@ def self_play(policy, param=None):
         val[:] = np.asarray(v, dtype=np.float32).reshape(n)
         pol[:] = np.asarray(p, dtype=np.float32).reshape(n, REF_N * REF_N)
 
-    cb = CALLBACK(tramp)
-    arena = _Arena()
-    v = lib().cpp_self_play(cb, arena.alloc_path, arena.alloc_result, prm["num_simulation"], prm["epsilon"],
-                            prm["dirichlet_alpha"], prm["c_puct"], bool(prm["debug"]), prm["num_game_thread"])
+    v, arena = _cpp_self_play(tramp, prm)
     return _vec_to_py(v)
 
 
@@ -348,29 +411,28 @@ def play(policy, debug=False, num_game_thread=1):
 
 
 def play_with(policy, param=None):
-    """Connect6::play_with (connect6.hpp:340-354) through cpp_play_with: AlphaZero over `policy` (the evaluator callback of
-    self_play) plays Black, a human on stdin/stdout plays White ("aB" = row a, column B).  Returns (winner, path)."""
-    prm = default_param()
-    prm.update(param or {})
+    """pyconnect6.play_with (pybind/pyconnect6/__init__.py:38-43 over lib.rs:170-192) through cpp_play_with: AlphaZero over
+    `policy` (the evaluator callable of self_play) plays Black, a human on stdin / stdout plays White ("aB" = row a, column B).
+    Returns `(winner, path)` in self_play's shapes."""
+    if param is None:
+        param = default_param()
+    cells = REF_N * REF_N
 
     def tramp(player, values, policies, n):
-        pol = np.ctypeslib.as_array(policies, shape=(n, REF_N * REF_N))
+        pol = np.ctypeslib.as_array(policies, shape=(n, cells))
         val = np.ctypeslib.as_array(values, shape=(n,))
-        v, p = policy(player, pol.astype(np.int8))
+        v, p = policy(int(player), pol.astype(np.int32).tolist())
         val[:] = np.asarray(v, dtype=np.float32).reshape(n)
-        pol[:] = np.asarray(p, dtype=np.float32).reshape(n, REF_N * REF_N)
+        pol[:] = np.asarray(p, dtype=np.float32).reshape(n, cells)
 
     cb = CALLBACK(tramp)
     arena = _Arena()
     L = lib()
     L.cpp_play_with.restype = PlayResult
     L.cpp_play_with.argtypes = [CALLBACK, ALLOC_PATH, C.c_int, C.c_float, C.c_double, C.c_float]
-    r = L.cpp_play_with(cb, arena.alloc_path, prm["num_simulation"], prm["epsilon"], prm["dirichlet_alpha"], prm["c_puct"])
-    paths = []
-    for k in range(r.len):
-        pth = r.paths[k]
-        paths.append((pth.turn, np.ctypeslib.as_array(pth.board).astype(np.int8).reshape(REF_N, REF_N).copy(), (pth.row, pth.col)))
-    return r.winner, paths
+    ns, eps, alpha, cp = param_to_tuple(param)[:-2]
+    r = L.cpp_play_with(cb, arena.alloc_path, int(ns), float(eps), float(alpha), float(cp))
+    return _result_to_ref(r)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -471,6 +533,13 @@ class Engine:
         s = Stats()
         _chk(lib().c6_engine_stats(self.h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def pool_audit(self):
+        """c6_engine_pool_audit: {pages,chunks}_{total,held,free,dup,leaked,bad}; dup / leaked / bad are 0 on a sound engine"""
+        a = (C.c_uint32 * 12)()
+        _chk(lib().c6_engine_pool_audit(self.h, C.byref(a)))
+        names = [f"{k}_{f}" for k in ("pages", "chunks") for f in ("total", "held", "free", "dup", "leaked", "bad")]
+        return dict(zip(names, [int(x) for x in a]))
 
     def fetch_games(self, cap=None):
         cap = cap or 4 * self.G

@@ -49,7 +49,8 @@ struct C6RootChild {
 #define C6_NOPAGE 0xFFFFFFFFu
 #define C6_MAX_RECORDS 65000      // per game: record indices travel as 16 bits (idx + 1)
 enum { C6_POOL_PAGE_HEAD = 0, C6_POOL_PAGE_TAIL, C6_POOL_PAGE_LIMIT, C6_POOL_CHUNK_HEAD, C6_POOL_CHUNK_TAIL, C6_POOL_CHUNK_LIMIT,
-       C6_POOL_PAGE_LOW, C6_POOL_N };      // PAGE_LOW: fewest free pages seen by a popper (statistics)
+       C6_POOL_PAGE_LOW, C6_POOL_PAGE_AVAIL, C6_POOL_CHUNK_AVAIL, C6_POOL_N };      // PAGE_LOW: fewest free pages seen by a popper (statistics);
+                                                                                  // *_AVAIL: the credits of this launch (signed; tree_kernels.hip ring_pop)
 enum { C6_PARK_NONE = 0, C6_PARK_POOL = 1, C6_PARK_CAPS = 2 };
 
 // C6_ST_OVERFLOW: the game is PARKED at a move boundary -- after a move / a reset it could not be given the records (>= S free ones)
@@ -176,6 +177,7 @@ void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s);
 // limit = tail of both pools' rings: launched in front of every kernel that may acquire pages (ids handed back by earlier launches
 // become available)
 void c6_launch_pool_snapshot(const C6Dev &d, hipStream_t s);
+void c6_launch_ring_selftest(const uint32_t *ring, uint32_t mask, unsigned long long *ctr, uint32_t *count, uint32_t *popped, int waves, int tries, uint32_t seed, hipStream_t s);
 // dynamic LDS of the kernels that keep a game's tag row / chunk list / page table per wave
 size_t c6_tree_lds_bytes(const C6Dev &d);
 // games in an error state -> the finished queue as they stand (winner 0, the stones played so far), agent_impl/mod.rs:163

@@ -614,6 +614,8 @@ static int pools_map(c6_engine *e, size_t pages, size_t chunks) {
     if (chunks > old_c && (rc = push(d.chunk_ring, d.chunk_ring_mask, ctr[C6_POOL_CHUNK_TAIL], old_c, chunks))) return rc;
     ctr[C6_POOL_PAGE_LIMIT] = ctr[C6_POOL_PAGE_TAIL];
     ctr[C6_POOL_CHUNK_LIMIT] = ctr[C6_POOL_CHUNK_TAIL];
+    ctr[C6_POOL_PAGE_AVAIL] = ctr[C6_POOL_PAGE_TAIL] - ctr[C6_POOL_PAGE_HEAD];
+    ctr[C6_POOL_CHUNK_AVAIL] = ctr[C6_POOL_CHUNK_TAIL] - ctr[C6_POOL_CHUNK_HEAD];
     if (old_p == 0) ctr[C6_POOL_PAGE_LOW] = pages;
     HIPCHK(hipMemcpy(d.pool_ctr, ctr, sizeof ctr, hipMemcpyHostToDevice));
     d.pages_total = (unsigned)pages;
@@ -1292,6 +1294,63 @@ extern "C" int c6_engine_enable_tuples(c6_engine *e, size_t capacity_records) {
     return ensure_own_tuples(e, capacity_records);
 }
 
+// Invariants of the two pools (a self-check for tests and soak runs): every page / chunk id below the pools' sizes is
+// either held by exactly one game (a valid slot of its page table below npages / of its chunk list below hslots / 1024) or sits
+// exactly once in its free ring between head and tail.  dup = ids seen more than once, leaked = ids seen nowhere.  Synchronises.
+extern "C" int c6_engine_pool_audit(c6_engine *e, c6_pool_audit *out) {
+    if (!e || !out) return fail(C6_ERR_BAD_ARG, "null argument");
+    C6Dev &d = e->d;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int G = d.G;
+    std::vector<C6GameHdr> hdr(G);
+    HIPCHK(hipMemcpy(hdr.data(), d.hdr, (size_t)G * sizeof(C6GameHdr), hipMemcpyDeviceToHost));
+    unsigned long long ctr[C6_POOL_N];
+    HIPCHK(hipMemcpy(ctr, d.pool_ctr, sizeof ctr, hipMemcpyDeviceToHost));
+    size_t wp = 1, wc = 1;
+    for (int g = 0; g < G; g++) { wp = std::max<size_t>(wp, hdr[g].npages); wc = std::max<size_t>(wc, hdr[g].hslots >> C6_CHUNK_SHIFT); }
+    wp = std::min<size_t>(wp, d.maxpages); wc = std::min<size_t>(wc, d.maxchunks);
+    std::vector<uint32_t> pt((size_t)G * wp), ct((size_t)G * wc);
+    HIPCHK(hipMemcpy2D(pt.data(), wp * 4, d.page_table, (size_t)d.maxpages * 4, wp * 4, G, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(ct.data(), wc * 4, d.chunk_table, (size_t)d.maxchunks * 4, wc * 4, G, hipMemcpyDeviceToHost));
+    auto ring_ids = [&](const uint32_t *ring, uint32_t mask, unsigned long long head, unsigned long long tail, std::vector<uint32_t> &ids) -> int {
+        std::vector<uint32_t> all((size_t)mask + 1);
+        HIPCHK(hipMemcpy(all.data(), ring, all.size() * 4, hipMemcpyDeviceToHost));
+        if (tail < head || tail - head > all.size()) return fail(C6_ERR_HIP, "pool ring: head beyond tail");
+        for (unsigned long long t = head; t < tail; t++) ids.push_back(all[(size_t)(t & mask)]);
+        return C6_OK;
+    };
+    memset(out, 0, sizeof *out);
+    int rc;
+    {
+        std::vector<uint8_t> seen(d.pages_total, 0);
+        std::vector<uint32_t> fr;
+        if ((rc = ring_ids(d.page_ring, d.page_ring_mask, ctr[C6_POOL_PAGE_HEAD], ctr[C6_POOL_PAGE_TAIL], fr))) return rc;
+        out->pages_total = d.pages_total;
+        out->pages_free = (uint32_t)fr.size();
+        auto mark = [&](uint32_t id) { if (id >= d.pages_total) out->pages_bad++; else if (seen[id]++) out->pages_dup++; };
+        for (uint32_t id : fr) mark(id);
+        for (int g = 0; g < G; g++)
+            for (size_t k = 0; k < std::min<size_t>(hdr[g].npages, wp); k++) {
+                const uint32_t id = pt[(size_t)g * wp + k];
+                if (id != C6_NOPAGE) { out->pages_held++; mark(id); }
+            }
+        for (uint8_t v : seen) out->pages_leaked += v == 0;
+    }
+    {
+        std::vector<uint8_t> seen(d.chunks_total, 0);
+        std::vector<uint32_t> fr;
+        if ((rc = ring_ids(d.chunk_ring, d.chunk_ring_mask, ctr[C6_POOL_CHUNK_HEAD], ctr[C6_POOL_CHUNK_TAIL], fr))) return rc;
+        out->chunks_total = d.chunks_total;
+        out->chunks_free = (uint32_t)fr.size();
+        auto mark = [&](uint32_t id) { if (id >= d.chunks_total) out->chunks_bad++; else if (seen[id]++) out->chunks_dup++; };
+        for (uint32_t id : fr) mark(id);
+        for (int g = 0; g < G; g++)
+            for (size_t k = 0; k < std::min<size_t>(hdr[g].hslots >> C6_CHUNK_SHIFT, wc); k++) { out->chunks_held++; mark(ct[(size_t)g * wc + k]); }
+        for (uint8_t v : seen) out->chunks_leaked += v == 0;
+    }
+    return C6_OK;
+}
+
 __global__ void c6_root_probe_kernel(C6Dev E, int g, int32_t *visits, float *q, float *prior, int *root_stats, float *root_f) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int cells = E.cells;
@@ -1637,4 +1696,43 @@ static int bench_board(int n, int G, int iters, bool scan_only, double *avg_ms) 
     return C6_OK;
 }
 extern "C" int c6_bench_board(int n, int G, int iters, double *avg_ms) { return bench_board(n, G, iters, false, avg_ms); }
+// The pools' pop protocol on its own (tests/test_gpu_pool.py): `launches` launches of `waves` waves, each wave asking `tries` times for
+// 1-8 ids from a ring of `ids` ids (ids << waves * tries * 4.5, so the ring runs dry early in every launch).  Out: ids handed out more
+// than once (dup), ids handed out beyond the ring's content (over = popped - ids when positive), and the fewest ids a launch handed out.
+extern "C" int c6_pool_ring_selftest(int ids, int waves, int tries, int launches, uint32_t seed, uint32_t *dup, uint32_t *over, uint32_t *min_popped) {
+    if (ids < 8 || waves < 1 || tries < 1 || launches < 1 || !dup || !over || !min_popped) return fail(C6_ERR_BAD_ARG, "bad self-test geometry");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return fail(C6_ERR_NO_GPU, "no gfx950 device");
+    uint32_t size = 64;
+    while (size < (uint32_t)ids) size <<= 1;
+    uint32_t *ring = nullptr, *count = nullptr, *popped = nullptr;
+    unsigned long long *ctr = nullptr;
+    HIPCHK(hipMalloc(&ring, size * 4)); HIPCHK(hipMalloc(&count, size * 4)); HIPCHK(hipMalloc(&popped, 4)); HIPCHK(hipMalloc(&ctr, C6_POOL_N * 8));
+    std::vector<uint32_t> h(size), cnt(size);
+    for (uint32_t i = 0; i < size; i++) h[i] = i;
+    HIPCHK(hipMemcpy(ring, h.data(), size * 4, hipMemcpyHostToDevice));
+    *dup = *over = 0; *min_popped = 0xffffffffu;
+    unsigned long long head = 0;
+    for (int l = 0; l < launches; l++) {
+        unsigned long long c[C6_POOL_N] = {};
+        c[C6_POOL_PAGE_HEAD] = head;                       // the ring keeps turning: launch l hands out ring[head .. head + ids)
+        c[C6_POOL_PAGE_TAIL] = c[C6_POOL_PAGE_LIMIT] = head + (unsigned long long)ids;
+        c[C6_POOL_PAGE_AVAIL] = (unsigned long long)ids;
+        c[C6_POOL_PAGE_LOW] = ~0ull;
+        HIPCHK(hipMemcpy(ctr, c, sizeof c, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(count, 0, size * 4)); HIPCHK(hipMemset(popped, 0, 4));
+        c6_launch_ring_selftest(ring, size - 1, ctr, count, popped, waves, tries, seed + (uint32_t)l * 7919u, 0);
+        HIPCHK(hipDeviceSynchronize());
+        uint32_t np = 0;
+        HIPCHK(hipMemcpy(cnt.data(), count, size * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&np, popped, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c, ctr, sizeof c, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < size; i++) if (cnt[i] > 1) *dup += cnt[i] - 1;
+        if (np > (uint32_t)ids) *over += np - (uint32_t)ids;
+        *min_popped = std::min(*min_popped, np);
+        head = (head + (unsigned long long)ids + 13) & 0xffffffull;
+    }
+    hipFree(ring); hipFree(count); hipFree(popped); hipFree(ctr);
+    return C6_OK;
+}
+
 extern "C" int c6_bench_board_scan(int n, int G, int iters, double *avg_ms) { return bench_board(n, G, iters, true, avg_ms); }

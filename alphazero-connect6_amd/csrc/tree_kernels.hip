@@ -810,17 +810,24 @@ __device__ __forceinline__ int move_select_wave(const C6Dev &E, int g, int lane,
 }
 
 // ---- pages and chunks: the pools' rings ---------------------------------------------------------------------------------
-// pop n ids (n <= 64): lane k < n gets id k; false (nothing taken) if fewer than n are available to this launch.  Tickets beyond
-// `limit` belong to ids pushed during this launch (by waves on other XCDs, possibly still in their caches): not ours yet.
-__device__ __forceinline__ bool ring_pop(const uint32_t *ring, uint32_t mask, unsigned long long *ctr, int head_i, int limit_i, int n, int lane, uint32_t &id) {
+// pop n ids (n <= 64): lane k < n gets id k; false (nothing taken) if fewer than n are available to this launch.  Ids pushed during
+// this launch (by waves on other XCDs, possibly still in their caches) are not ours yet: what a launch may take is fixed when it
+// starts (c6_pool_snapshot_kernel) as a number of CREDITS, avail = tail - head.  A popper first takes n credits and only with them in
+// hand a ticket from `head` (the earlier add-then-undo on head itself could hand one ring slot to two poppers once an undo
+// had landed between two failures).  Credits are conserved: a success removes n for good, a failure removes n for the moment and
+// returns them, so the credits handed out never exceed the snapshot and head never passes the snapshot's tail; what a failure in
+// flight can cause is only another popper's failure -- that game parks and asks again at the next round's head.
+__device__ __forceinline__ bool ring_pop(const uint32_t *ring, uint32_t mask, unsigned long long *ctr, int head_i, int avail_i, int n, int lane, uint32_t &id) {
     unsigned long long h = 0ull;
     int ok = 0;
     if (lane == 0) {
-        h = atomicAdd(&ctr[head_i], (unsigned long long)n);
-        const unsigned long long lim = ctr[limit_i];
-        ok = h + (unsigned long long)n <= lim;
-        if (!ok) atomicAdd(&ctr[head_i], 0ull - (unsigned long long)n);      // undo: tickets behind a failed one fail too, so nothing is lost
-        else if (head_i == C6_POOL_PAGE_HEAD) atomicMin(&ctr[C6_POOL_PAGE_LOW], lim - (h + (unsigned long long)n));
+        const long long a = (long long)atomicAdd(&ctr[avail_i], 0ull - (unsigned long long)n);
+        ok = a >= (long long)n;
+        if (!ok) atomicAdd(&ctr[avail_i], (unsigned long long)n);
+        else {
+            h = atomicAdd(&ctr[head_i], (unsigned long long)n);
+            if (head_i == C6_POOL_PAGE_HEAD) atomicMin(&ctr[C6_POOL_PAGE_LOW], (unsigned long long)(a - (long long)n));
+        }
     }
     ok = __shfl(ok, 0, 64);
     if (!ok) return false;
@@ -913,7 +920,7 @@ __device__ __forceinline__ int reprovision_wave(const C6Dev &E, int g, int lane,
         while (acquire > 0) {
             const int n = acquire < 64 ? acquire : 64;
             uint32_t nid = C6_NOPAGE;
-            if (!ring_pop(E.page_ring, E.page_ring_mask, E.pool_ctr, C6_POOL_PAGE_HEAD, C6_POOL_PAGE_LIMIT, n, lane, nid)) { park = C6_PARK_POOL; break; }
+            if (!ring_pop(E.page_ring, E.page_ring_mask, E.pool_ctr, C6_POOL_PAGE_HEAD, C6_POOL_PAGE_AVAIL, n, lane, nid)) { park = C6_PARK_POOL; break; }
             if (lane < n) E.page_free[nid] = ~0ull;      // (its records are level -1: a page is handed back only when it is empty)
             int placed = 0;
             while (placed < n && lp0 < E.pages_cap) {
@@ -962,7 +969,7 @@ __device__ __forceinline__ int reprovision_wave(const C6Dev &E, int g, int lane,
             while (have < nnew) {
                 const int n = nnew - have < 64 ? nnew - have : 64;
                 uint32_t nid = 0u;
-                if (!ring_pop(E.chunk_ring, E.chunk_ring_mask, E.pool_ctr, C6_POOL_CHUNK_HEAD, C6_POOL_CHUNK_LIMIT, n, lane, nid)) break;
+                if (!ring_pop(E.chunk_ring, E.chunk_ring_mask, E.pool_ctr, C6_POOL_CHUNK_HEAD, C6_POOL_CHUNK_AVAIL, n, lane, nid)) break;
                 if (lane < n) ckg[have + lane] = nid;
                 have += n;
             }
@@ -1408,9 +1415,33 @@ __global__ void c6_pool_snapshot_kernel(C6Dev E) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         E.pool_ctr[C6_POOL_PAGE_LIMIT] = E.pool_ctr[C6_POOL_PAGE_TAIL];
         E.pool_ctr[C6_POOL_CHUNK_LIMIT] = E.pool_ctr[C6_POOL_CHUNK_TAIL];
+        E.pool_ctr[C6_POOL_PAGE_AVAIL] = E.pool_ctr[C6_POOL_PAGE_TAIL] - E.pool_ctr[C6_POOL_PAGE_HEAD];
+        E.pool_ctr[C6_POOL_CHUNK_AVAIL] = E.pool_ctr[C6_POOL_CHUNK_TAIL] - E.pool_ctr[C6_POOL_CHUNK_HEAD];
     }
 }
 void c6_launch_pool_snapshot(const C6Dev &d, hipStream_t s) { hipLaunchKernelGGL(c6_pool_snapshot_kernel, dim3(1), dim3(64), 0, s, d); }
+
+// Self-test of the rings' pop protocol (c6_pool_ring_selftest, connect6_amd.h): every wave tries `tries` pops of 1-8 ids from a ring that
+// holds far fewer than all of them ask for, so that most of the launch runs with the ring nearly dry -- small requests succeeding beside
+// larger ones failing.  count[id] is how often an id was handed out.
+__global__ void c6_ring_selftest_kernel(const uint32_t *ring, uint32_t mask, unsigned long long *ctr, uint32_t *count, uint32_t *popped, int tries, uint32_t seed) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t x = (wave + 1u) * 2654435761u ^ seed;
+    for (int t = 0; t < tries; t++) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        const int n = (int)((0x84321111u >> ((x & 7u) * 4u)) & 15u);      // 1, 1, 1, 1, 2, 3, 4, 8: many single-id requests beside large ones
+        uint32_t id = C6_NOPAGE;
+        if (ring_pop(ring, mask, ctr, C6_POOL_PAGE_HEAD, C6_POOL_PAGE_AVAIL, n, lane, id)) {
+            if (lane < n) atomicAdd(&count[id & mask], 1u);
+            if (lane == 0) atomicAdd(popped, (uint32_t)n);
+        }
+        if (x >> 31) __builtin_amdgcn_s_sleep(2);
+    }
+}
+void c6_launch_ring_selftest(const uint32_t *ring, uint32_t mask, unsigned long long *ctr, uint32_t *count, uint32_t *popped, int waves, int tries, uint32_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(c6_ring_selftest_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, ring, mask, ctr, count, popped, tries, seed);
+}
 
 // Games that stopped in an error state leave as they stand: PlayResult{winner None, the path so far} -- what a caller of the
 // reference would hold had Agent::play returned its Err (agent_impl/mod.rs:163) instead of the bindings' unwrap().

@@ -273,6 +273,15 @@ typedef struct c6_stats {
 } c6_stats;
 int c6_engine_stats(c6_engine *e, c6_stats *out); /* synchronises */
 
+/* Invariants of the two pools (a self-check for soak tests): every record page / table chunk is held by exactly one game or sits
+ * exactly once in its free ring.  *_dup: ids seen more than once (two owners, or an owner and the ring), *_leaked: ids seen nowhere,
+ * *_bad: ids beyond the pool.  All three are 0 on a sound engine, whatever was parked, abandoned or recycled.  Synchronises. */
+typedef struct c6_pool_audit {
+    uint32_t pages_total, pages_held, pages_free, pages_dup, pages_leaked, pages_bad;
+    uint32_t chunks_total, chunks_held, chunks_free, chunks_dup, chunks_leaked, chunks_bad;
+} c6_pool_audit;
+int c6_engine_pool_audit(c6_engine *e, c6_pool_audit *out);
+
 /* finished games (winner, moves): agent::PlayResult, agent/agent_impl/mod.rs:41-44.
  * Copies up to `cap` finished, not yet fetched games: winners[i], lens[i], uids[i],
  * moves[i*N*N + k] = cell of stone k.  Returns the number copied in *count. */
@@ -370,6 +379,11 @@ int c6_conv_pack_m8(int channels, const float *w_oihw, unsigned char *packed, si
 int c6_bench_board(int board_size, int num_games, int iters, double *avg_ms);
 /* K1's search-only launch (is_game_end of every resident game, no stone: N*N bytes read + 1 written per board) */
 int c6_bench_board_scan(int board_size, int num_games, int iters, double *avg_ms);
+/* Self-test of the pools' free-id rings (the pop protocol of tree_kernels.hip on its own): `launches` launches of `waves` waves, each
+ * asking `tries` times for 1-8 ids from a ring of `ids` ids, so that nearly all of every launch runs on a ring that is almost dry.
+ * *dup: ids handed out more than once; *over: ids handed out beyond the ring's content; *min_popped: fewest ids one launch handed out
+ * (a sound protocol gives dup = over = 0 and hands out nearly all: failures in flight may leave at most a few behind). */
+int c6_pool_ring_selftest(int ids, int waves, int tries, int launches, uint32_t seed, uint32_t *dup, uint32_t *over, uint32_t *min_popped);
 /* C6RNG Dirichlet noise of select step (search, depth) for `num` boards (keys k0/k1 per board) */
 int c6_dirichlet_noise(int board_size, int num, double alpha, const uint32_t *k0, const uint32_t *k1,
                        const uint32_t *search, const uint32_t *depth, const int8_t *boards, float *noise);

@@ -157,3 +157,19 @@ def test_reference_sample_links(tmp_path):
     subprocess.check_call(cmd)
     und = subprocess.check_output(["nm", "-u", str(exe)], text=True)
     assert "cpp_self_play" in und and "cpp_play" in und      # imported from the shared library, resolved at link time
+
+
+def test_python_face_param_helpers(tmp_path):
+    """default_param / param_to_tuple / dump_param(path, param=None) / load_param / board_size (pyconnect6/__init__.py:5-79)"""
+    d = pkg.default_param()
+    assert d == {"num_simulation": 800, "epsilon": 0.25, "dirichlet_alpha": 0.03, "c_puct": 1, "debug": False, "num_game_thread": 1}
+    assert pkg.param_to_tuple(d) == (800, 0.25, 0.03, 1, False, 1)
+    assert pkg.board_size() == 15
+    base = str(tmp_path / "ckpt")
+    pkg.dump_param(base)                                     # param=None -> the defaults
+    assert os.path.exists(base + "_mcts.json") and pkg.load_param(base) == d
+    d["num_simulation"] = 17
+    pkg.dump_param(base, d)
+    assert pkg.load_param(base) == d
+    with pytest.raises(KeyError):
+        pkg.param_to_tuple({"num_simulation": 2})

@@ -39,14 +39,14 @@ def test_self_play_two_games():  # test_cppbind/main.cpp:46-52
         seen.append(boards.shape[0])
         return random_policy(turn, boards)
 
-    res = pkg.self_play(policy, {"num_simulation": 2, "num_game_thread": 2})
+    res = pkg.self_play_np(policy, {"num_simulation": 2, "num_game_thread": 2})
     assert len(res) == 2 and seen
     check_result(res)
 
 
 def test_self_play_single_game_more_sims():
     need_gpu()
-    res = pkg.self_play(random_policy, {"num_simulation": 12, "num_game_thread": 1})
+    res = pkg.self_play_np(random_policy, {"num_simulation": 12, "num_game_thread": 1})
     assert len(res) == 1
     check_result(res)
 
@@ -149,9 +149,13 @@ def test_cpp_play_with_scripted_human(tmp_path):
         from c6amd_loader import load_package
         pkg = load_package()
         def policy(turn, boards):
-            k = boards.shape[0]
+            k = len(boards)
+            assert isinstance(boards, list) and len(boards[0]) == 225
             return np.zeros(k, np.float32), np.full((k, 225), 1 / 225, np.float32)
-        winner, path = pkg.play_with(policy, dict(num_simulation=8))
+        param = pkg.default_param()
+        param["num_simulation"] = 8
+        winner, path = pkg.play_with(policy, param)
+        assert isinstance(path[0][1], list) and len(path[0][1]) == 225
         print("RESULT", winner, len(path), path[-1][0])
     """)
     ok = False
@@ -209,3 +213,63 @@ def test_cpp_play_with_random_policy():
             assert turn == winner
         turns = [t for t, _, _ in path]
         assert turns[0] == -1 and turns[1:3] == [1, 1]          # 1 stone, then 2 per turn
+
+
+# ---- the Python face with the reference's own objects ------------------------------
+
+def _check_ref_result(winner, path):
+    """(winner: int, [(turn: int, board: list[225] of int, (row, col))]) -- pybind_impl/mod.rs:66-105 -- replayed on the oracle"""
+    assert isinstance(winner, int) and isinstance(path, list) and len(path) > 0
+    g = o.new_game(N)
+    for turn, board, pos in path:
+        assert isinstance(turn, int) and isinstance(board, list) and len(board) == N * N and all(isinstance(x, int) for x in board)
+        assert isinstance(pos, tuple) and len(pos) == 2
+        assert turn == g.turn and board == g.np_board().reshape(-1).tolist()
+        assert o.game_set(g, pos[0], pos[1])[0] == o.OK
+    import ctypes as C
+    assert o.lib().c6o_game_is_end(C.byref(g)) == winner
+    if winner != 0:
+        assert path[-1][0] == winner
+
+
+@pytest.mark.parametrize("threads", [1, 2])
+def test_python_face_runs_the_reference_sample(threads, capfd):
+    """The body of Connect6/sample/python/random_policy.py:6-37 with `pyconnect6` = this package: class RandomPolicy built on
+    `board_size()`, called with `(turn, board)` where `board` is a list of `len` lists of N*N ints, returning numpy arrays;
+    `winner, path = self_play(policy, param)` with num_game_thread = 1 (lib.rs:119-128), a tuple of (winner, path) with 2
+    (lib.rs:129-152); debug = True prints the boards like the reference's sample run."""
+    need_gpu()
+    pyconnect6 = pkg
+    calls = []
+
+    class RandomPolicy:
+        def __init__(self):
+            self.board_size = pyconnect6.board_size()
+
+        def __call__(self, turn, board):
+            assert isinstance(turn, int) and turn in (-1, 1)
+            assert isinstance(board, list) and isinstance(board[0], list) and isinstance(board[0][0], int)
+            assert len(board[0]) == self.board_size ** 2 and set(board[0]) <= {-1, 0, 1}
+            calls.append(len(board))
+            size = len(board)
+            value = np.random.rand(size)
+            rand_policy = np.random.rand(size, self.board_size * self.board_size)
+            return value, rand_policy
+
+    policy = RandomPolicy()
+    param = pyconnect6.default_param()
+    param['num_simulation'] = 2
+    param['num_game_thread'] = threads
+    param['debug'] = True
+    if threads == 1:
+        winner, path = pyconnect6.self_play(policy, param)
+        print('winner {}, len {}'.format(winner, len(path)))
+        _check_ref_result(winner, path)
+        out = capfd.readouterr().out
+        assert "0 A B C D E F G H I J K L M N O" in out and "Black (" in out and f"winner {winner}, len {len(path)}" in out
+    else:
+        res = pyconnect6.self_play(policy, param)
+        assert isinstance(res, tuple) and len(res) == threads
+        for winner, path in res:
+            _check_ref_result(winner, path)
+    assert calls and all(k % 8 == 0 for k in calls)          # always the 8 dihedral images (x games that share the side to move)

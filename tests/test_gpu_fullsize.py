@@ -135,3 +135,39 @@ def test_config1_full_game_19x19_400_sims():
     assert st["overflow_games"] == 0 and st["simulations"] == S * len(mv)
     print(f"config1: winner {ref['winner']}, {len(mv)} stones, oracle {t_cpu:.1f} s, engine (1 game) {t_gpu:.1f} s, "
           f"max records {st['max_records_used']}, max depth {st['max_depth']}")
+
+
+def test_config2_exact():
+    """BASELINE config 2 EXACTLY as bench.py times it: Engine(n = 19, G = 4096, S = 400, EVAL_NET, C = 256, stem + 3
+    residual blocks, default precision = FP32 Winograd F(6,3), conv_wino6.hip), 3 rounds of 32 768 dihedral images each.  Every
+    root has visit R and children R - 1; six sampled games -- first / last leaves of the batch and the seams of the Winograd
+    scratch's 64-tile blocks -- equal the seeded oracle driven by its own FP32 net: visits exactly, priors / q / value to 1e-5."""
+    need_gpu()
+    import __graft_entry__ as ge
+    n, G, S, C, blocks, R, seed = 19, 4096, 400, 256, 4, 3, 2024
+    blob = ge.make_random_blob(n, C, blocks, np.random.default_rng(12))
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks)
+    eng.load_weights(blob)
+    eng.step(R)
+    st = eng.stats()
+    assert st["simulations"] == G * R and st["overflow_games"] == 0 and st["live_games"] == G
+    for g in list(range(0, G, 511)) + [G - 1]:
+        r = eng.root(g)
+        assert r["root_visit"] == R and r["visits"].sum() == R - 1 and r["stones"] == 0 and r["nsearch"] == R
+    net = o.Net(n, C, blocks, blob)
+    fn, ctx = net.eval_fn()
+    empty = np.zeros((n, n), np.int8)
+    for g in (0, 1, 799, 2048, 3333, G - 1):
+        az = o.AlphaZero(n, num_simulation=S, eval_kind=o.EVAL_CUSTOM, eval_fn=fn, ctx=ctx, seed=seed, game_uid=g)
+        s = o.sim_from_game(o.new_game(n))
+        az.init(s)
+        for _ in range(R):
+            az.search(s)
+        vis, q, p = az.children(empty)
+        r = eng.root(g)
+        assert (r["visits"] == vis).all(), (g, np.flatnonzero(r["visits"]), np.flatnonzero(vis))
+        assert np.abs(r["q"] - q).max() <= 1e-5 and np.abs(r["prior"] - p).max() <= 1e-5
+        assert abs(r["root_value"] - az.node_info(empty).value) <= 1e-5
+        az.close()
+    net.close()
+    eng.close()

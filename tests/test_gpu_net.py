@@ -369,3 +369,109 @@ def test_blob_header_rejects_a_permuted_blob():
     with pytest.raises(pkg.C6Error) as ei:
         pkg.net_forward(n, C, blocks + 1, np.concatenate([headed, np.zeros(pkg.blob_floats(n, C, blocks + 1) - want.size, np.float32)]), boards, 1)
     assert "another board size" in str(ei.value) or "payload" in str(ei.value)
+
+
+# ---- the BENCHMARK's own convolution kernels on hostile weights ---------------------------------------
+# conv_wino6.hip (F(6,3) across) runs only at N = 19, C = 256, >= 3 blocks; conv_wino4.hip's F(4x4) at C = 256 for 15x15 / 9x9.  The
+# robustness cases above sit on the C = 64 / 128 F(2x2) kernel, so every one of them is repeated here on the shapes the bench
+# (config 2: (19, 256, 4); config 3: (19, 256, 8)) and the other C = 256 towers run.
+
+BENCH_SHAPES = [pytest.param(19, 256, 4, id="w6-config2-net"), pytest.param(19, 256, 8, id="w6-config3-net"),
+                pytest.param(15, 256, 3, id="w4-15x15"), pytest.param(9, 256, 4, id="w4-9x9")]
+
+
+def _check_against_oracle(n, C, blocks, blob, boards, player, idx=None, prec=None):
+    pol, val = pkg.net_forward(n, C, blocks, blob, boards, player, precision=pkg.PREC_FP32 if prec is None else prec)
+    assert np.isfinite(pol).all() and np.isfinite(val).all()
+    net = o.Net(n, C, blocks, blob)
+    worst_p = worst_v = 0.0
+    pl = np.broadcast_to(np.asarray(player, np.int8), (boards.shape[0],))
+    for i in (range(boards.shape[0]) if idx is None else idx):
+        rp, rv = net.forward(float(pl[i]), boards[i].astype(np.float32))
+        worst_p = max(worst_p, float(np.abs(pol[i] - rp[0]).max()))
+        worst_v = max(worst_v, float(abs(val[i] - rv[0])))
+    net.close()
+    assert worst_p <= TOL and worst_v <= TOL, (worst_p, worst_v)
+    return pol, val, worst_p, worst_v
+
+
+@pytest.mark.parametrize("n,C,blocks", BENCH_SHAPES)
+def test_bench_kernels_channel_scales_spanning_six_decades(n, C, blocks):
+    """(a) BatchNorm scales from 1e-3 to 1e3 inside every block, on F(6,3) / F(4x4) at C = 256"""
+    need_gpu()
+    blob = _scaled_blob(n, C, blocks, spread=6.0, seed=50 + n + blocks)
+    boards = np.random.default_rng(80 + n).integers(-1, 2, size=(4, n * n)).astype(np.int8)
+    player = np.array([1, -1, 1, -1], np.int8)
+    _check_against_oracle(n, C, blocks, blob, boards, player)
+
+
+@pytest.mark.parametrize("n,C,blocks", BENCH_SHAPES)
+def test_bench_kernels_large_activations(n, C, blocks):
+    """(b) activations in the hundreds (stem gain x300, compensated in the heads' 1x1 filters) on F(6,3) / F(4x4) at C = 256"""
+    need_gpu()
+    gain, cells = 300.0, n * n
+    blob = rand_blob(n, C, blocks, seed=77 + n + blocks).copy()
+    stem_gamma = C * 18 + C
+    blob[stem_gamma:stem_gamma + C] *= gain
+    tower = C * 18 + C + 4 * C + 2 * (blocks - 1) * (C * C * 9 + C + 4 * C)
+    blob[tower:tower + 2 * C] /= gain
+    vconv = tower + 2 * C + 2 + 8 + cells * 2 * cells + cells
+    blob[vconv:vconv + C] /= gain
+    boards = np.random.default_rng(3 + n).integers(-1, 2, size=(3, cells)).astype(np.int8)
+    _check_against_oracle(n, C, blocks, blob, boards, np.array([1, -1, 1], np.int8))
+
+
+@pytest.mark.parametrize("n,C,blocks", BENCH_SHAPES)
+def test_bench_kernels_after_training_steps(n, C, blocks):
+    """(c) weights after 60 SGD steps of the HIP trainer AT C = 256 (every BatchNorm statistic moved, momentum spread the channel
+    scales), evaluated by the benchmark's kernels against the oracle's FP32 net"""
+    need_gpu()
+    import torch_ref as tr
+    B = 32
+    blob = rand_blob(n, C, blocks, seed=21 + n + blocks)
+    t = pkg.Trainer(n, C, blocks, B, lr=1e-2, momentum=0.9, precision=pkg.PREC_FP32)
+    t.load_weights(blob)
+    for k in range(60):
+        w, p, b, q = [x.numpy() for x in tr.make_batch(n, B, 300 + k)]
+        t.step(w, p, b, q)
+    trained = t.export_weights()
+    t.close()
+    assert np.isfinite(trained).all() and np.abs(trained - blob).max() > 1e-3
+    rng = np.random.default_rng(2 + n)
+    boards = rng.integers(-1, 2, size=(5, n * n)).astype(np.int8)
+    boards[0] = 0
+    player = rng.choice(np.array([-1, 1], np.int8), size=5)
+    _check_against_oracle(n, C, blocks, trained, boards, player)
+
+
+@pytest.mark.parametrize("n,C,blocks,num", [pytest.param(19, 256, 4, 333, id="w6-333-boards-every-region-partial"),
+                                            pytest.param(19, 256, 8, 320, id="w6-320-boards-every-region-exactly-full"),
+                                            pytest.param(15, 256, 3, 301, id="w4-15x15-301"), pytest.param(9, 256, 4, 500, id="w4-9x9-500")])
+def test_bench_kernels_many_distinct_boards(n, C, blocks, num):
+    """(d) >= 300 DISTINCT boards in one net_forward: every tile class (w6: D 10, A 4, B 4, B' 2 tiles per board in regions of
+    their own, 64-tile blocks) has full blocks and -- at 333 -- a partial last block, blocks straddle boards; >= 16 sampled
+    boards (first / last, the block seams of every class) against the oracle; boards of every density from empty to full"""
+    need_gpu()
+    rng = np.random.default_rng(1000 + num)
+    dens = rng.uniform(0, 1, size=(num, 1))
+    u = rng.uniform(0, 1, size=(num, n * n))
+    boards = np.where(u < dens, rng.choice(np.array([-1, 1], np.int8), size=(num, n * n)), 0).astype(np.int8)
+    boards[0] = 0
+    boards[1] = 1
+    boards[2] = -1
+    seen = set()
+    for i in range(num):                                  # sparse boards repeat: redraw until all are distinct
+        while boards[i].tobytes() in seen:
+            boards[i] = rng.integers(-1, 2, size=n * n)
+        seen.add(boards[i].tobytes())
+    assert len(seen) == num
+    player = rng.choice(np.array([-1, 1], np.int8), size=num)
+    blob = rand_blob(n, C, blocks, seed=5 + num)
+    # seams: 64-tile blocks end inside boards 6 / 12 / 16 / 32 (classes of 10 / 4 / 4 / 2 tiles per board at 19x19)
+    idx = sorted({0, 1, 2, 5, 6, 7, 12, 13, 15, 16, 31, 32, 63, 64, 160, 255, 256, num // 2, num - 3, num - 2, num - 1})
+    assert len(idx) >= 16
+    pol, _, _, _ = _check_against_oracle(n, C, blocks, blob, boards, player, idx=idx)
+    assert np.allclose(pol.sum(axis=1), 1.0, atol=1e-5)
+    # every board's answer is independent of the batch it travels in: the sampled ones again, alone, bit for bit
+    p1, v1 = pkg.net_forward(n, C, blocks, blob, boards[idx[-4:]], player[idx[-4:]], precision=pkg.PREC_FP32)
+    assert (p1 == pol[idx[-4:]]).all()

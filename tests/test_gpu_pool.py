@@ -233,8 +233,75 @@ def test_dropin_self_play_survives_an_exhausted_pool(monkeypatch, capfd):
 
     param = pkg.default_param()
     param.update(num_simulation=40, epsilon=0.001, num_game_thread=2)
-    res = pkg.self_play(pol, param)
+    res = pkg.self_play_np(pol, param)
     err = capfd.readouterr().err
     assert len(res) == 2 and "partial" in err
     for winner, path in res:
         assert winner == 0 and 1 <= len(path) < n * n
+
+
+DRY_POOL_CHILD = r"""
+import json, sys
+sys.path.insert(0, sys.argv[2])
+from c6amd_loader import load_package
+pkg = load_package()
+n, G, S, seed, eps, every = 9, 4096, 40, 29, 0.001, 2
+eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_STRESS, stress_every=every,
+                 records_per_game=8, recycle=True, stagger=True)
+audits, done = [], {}
+for it in range(48):
+    eng.step(S * 6 + 7)
+    eng.maintain()
+    audits.append(eng.pool_audit())
+    for g in eng.fetch_games():
+        done[g["uid"]] = (int(g["winner"]), [int(m) for m in g["moves"]])
+st = eng.stats()
+eng.close()
+keep = sorted(u for u in done if u >= G)
+pick = keep[:3] + keep[len(keep) // 2:len(keep) // 2 + 3] + keep[-3:]
+json.dump(dict(audits=audits, st=st, ndone=len(done), games={str(u): done[u] for u in pick}), open(sys.argv[1], "w"))
+"""
+
+
+def test_nearly_dry_pool_never_hands_a_page_to_two_games(tmp_path):
+    """with the pool nearly dry many parked waves retry ring_pop at every round's head.  The pool here cannot grow
+    (C6_NO_VMM=1: plain allocations of the initial two pages per game) while every second of 4096 recycling games grows a deep tree:
+    games park, are abandoned and restarted, pages and chunks change hands all the time.  After every chunk of rounds
+    c6_engine_pool_audit must find every page / chunk id exactly once -- held by one game or in its free ring: no id twice (two
+    owners), none lost -- and the games that do finish are still the oracle's games."""
+    need_gpu()
+    import json
+    import subprocess
+    import sys
+    out = str(tmp_path / "out.json")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", DRY_POOL_CHILD, out, root], check=True, env=dict(os.environ, C6_NO_VMM="1"), timeout=600)
+    d = json.load(open(out))
+    st = d["st"]
+    assert st["pool_grows"] == 0 and st["pool_pages_low"] <= 4 and st["abandoned_games"] >= 10, st          # the pool did run dry
+    for k, a in enumerate(d["audits"]):
+        assert a["pages_dup"] == a["pages_leaked"] == a["pages_bad"] == 0, (k, a)
+        assert a["chunks_dup"] == a["chunks_leaked"] == a["chunks_bad"] == 0, (k, a)
+        assert a["pages_held"] + a["pages_free"] == a["pages_total"] and a["chunks_held"] + a["chunks_free"] == a["chunks_total"], (k, a)
+    assert d["ndone"] > 4096 and len(d["games"]) >= 6
+    n, S, seed, eps, every = 9, 40, 29, 0.001, 2
+    fn = stress_eval_fn(n)
+    for u, (winner, moves) in d["games"].items():
+        u = int(u)
+        kind = dict(eval_kind=o.EVAL_CUSTOM, eval_fn=fn) if u % every == 0 else dict(eval_kind=o.EVAL_UNIFORM)
+        ref = o.self_play(n, num=1, threads=1, num_simulation=S, seed=seed, epsilon=eps, uid_base=u, **kind)[0]
+        assert moves == [r * n + c for _, _, (r, c) in ref["path"]] and winner == ref["winner"], u
+
+
+def test_ring_pop_protocol_selftest():
+    """The pop protocol on its own (c6_pool_ring_selftest): thousands of launches in which a few / many waves ask for 1-8 ids from a
+    ring that holds far fewer -- almost all of every launch runs on a nearly dry ring, single-id requests succeeding beside larger
+    ones failing.  No id is handed out twice, none beyond the ring's content, and nearly all are handed out (a failure in flight can
+    only make another request fail).  Round 3's add-then-undo protocol hands out duplicates in the first three geometries (4352 /
+    286 / 205 of them: profiles/r04_ring_selftest.txt, A/B build tools/ab_patches/tree_ring_pop_add_undo.sed)."""
+    need_gpu()
+    for geo, least in ((dict(ids=16, waves=4, tries=8, launches=30000, seed=3), 8), (dict(ids=16, waves=8, tries=6, launches=30000, seed=4), 8),
+                       (dict(ids=24, waves=16, tries=4, launches=30000, seed=6), 12), (dict(ids=1000, waves=4096, tries=4, launches=200, seed=5), 900),
+                       (dict(ids=37, waves=2048, tries=8, launches=1000, seed=9), 20)):
+        r = pkg.pool_ring_selftest(**geo)
+        assert r["dup"] == 0 and r["over"] == 0 and r["min_popped"] >= least, (geo, r)

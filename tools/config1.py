@@ -28,7 +28,7 @@ def sample_callback(turn, boards):     # random values / policies like the refer
     k = boards.shape[0]
     return rng.uniform(-1, 1, k).astype(np.float32), rng.uniform(0, 1, (k, 225)).astype(np.float32)
 param = pkg.default_param(); param.update(num_simulation=400, num_game_thread=1)
-t0 = time.time(); res = pkg.self_play(sample_callback, param); t_drop = time.time() - t0
+t0 = time.time(); res = pkg.self_play_np(sample_callback, param); t_drop = time.time() - t0
 winner, path = res[0] if isinstance(res, (list, tuple)) and not isinstance(res[0], (int, np.integer)) else res
 out["cases"].append({"board": 15, "entry": "cpp_self_play (drop-in ABI, host callback)", "winner": int(winner), "stones": len(path), "wall_s": round(t_drop, 2)})
 print(json.dumps(out))

@@ -15,7 +15,7 @@ def cb(turn, boards):
     calls[0] += 1; calls[1] += boards.shape[0]
     return np.zeros(boards.shape[0], np.float32), np.full((boards.shape[0], 225), 1.0 / 225, np.float32)
 param = pkg.default_param(); param.update(num_simulation=a.sims, num_game_thread=a.games)
-t0 = time.time(); res = pkg.self_play(cb, param); dt = time.time() - t0
+t0 = time.time(); res = pkg.self_play_np(cb, param); dt = time.time() - t0
 stones = sum(len(p) for _, p in res)
 sims = stones * a.sims
 print(json.dumps({"games": a.games, "sims_per_move": a.sims, "stones": stones, "wall_s": round(dt, 2), "sims_per_s": round(sims / dt), "boards_per_s": round(calls[1] / dt),
