@@ -996,6 +996,8 @@ __global__ void c6_match_moves_kernel(int G, int Gpad, const uint8_t *active, co
     if (g < Gpad) move[g] = g < G && active[g] ? pos[g] : -2;
 }
 
+static int live_games(c6_engine *e, int *live, int *errors, int *overflow);
+static int maintain(c6_engine *e);
 extern "C" int c6_engine_play_match(c6_engine *e, int engine_colour, int opponent, c6_rollout *r, uint64_t opp_seed, long max_stones) {
     if (!e || (engine_colour != -1 && engine_colour != 1)) return fail(C6_ERR_BAD_ARG, "c6_engine_play_match: engine_colour is -1 (Black) or +1 (White)");
     if (opponent != C6_OPP_RANDOM && opponent != C6_OPP_ROLLOUT) return fail(C6_ERR_BAD_ARG, "c6_engine_play_match: opponent is C6_OPP_RANDOM or C6_OPP_ROLLOUT");
@@ -1010,9 +1012,40 @@ extern "C" int c6_engine_play_match(c6_engine *e, int engine_colour, int opponen
     int *live = t.get<int>(1);
     if (!boards || !active || !pos || !move || !live) return fail(C6_ERR_HIP, "hipMalloc failed");
     const unsigned gb = (unsigned)((d.Gpad + 255) / 256);
-    // every game is at the same stone of the same turn: Black 1, then 2 each (game_impl/mod.rs:125-169)
+    // Every game is at the same stone of the same turn -- Black 1, then 2 each (game_impl/mod.rs:125-169) -- and the loop below keeps
+    // them there: the precondition is CHECKED (no stone placed, Black to move, every game playing), and a game that is
+    // parked at a move boundary (C6_ST_OVERFLOW: it waits for pages, chunks or higher caps, tree_kernels.hip reprovision_wave) is
+    // served before the next stone is played -- otherwise it would resume a move late and the engine would search for the
+    // opponent's colour in that game.
+    {
+        int live = 0, errs = 0;
+        int rc = live_games(e, &live, &errs, nullptr);
+        if (rc != C6_OK) return rc;
+        std::vector<int8_t> h_turn((size_t)d.G);
+        HIPCHK(hipMemcpy(h_turn.data(), d.turn, (size_t)d.G, hipMemcpyDeviceToHost));
+        for (int g = 0; g < d.G; g++)
+            if (e->h_hdr[g].status != C6_ST_PLAYING || e->h_hdr[g].nstones != 0 || e->h_hdr[g].sim_in_move != 0 || h_turn[g] != C6_BLACK)
+                return fail(C6_ERR_BAD_ARG, "c6_engine_play_match: the engine must be at the start of its games (no stone placed, no search made, Black to move); create a fresh engine per match");
+    }
+    auto serve_parked = [&]() -> int {
+        for (int attempt = 0;; attempt++) {
+            int live = 0, errs = 0, ov = 0;
+            int rc = live_games(e, &live, &errs, &ov);
+            if (rc != C6_OK) return rc;
+            if (ov == 0) return C6_OK;
+            if (attempt >= 8 || e->grow_failed)
+                return fail(C6_ERR_OVERFLOW, "c6_engine_play_match: a game's tree outgrew the pools (max_records_per_game / device memory); the match stops with that game unfinished");
+            if ((rc = maintain(e)) != C6_OK) return rc;      // raise the caps / map more pool memory
+            c6_launch_pool_snapshot(d, e->stream);
+            c6_launch_post_move(d, e->stream);              // the round head: parked games ask again, nothing else happens
+        }
+    };
     int turn = C6_BLACK, remain = 1;
     for (long stone = 0; max_stones <= 0 || stone < max_stones; stone++) {
+        {
+            int rc = serve_parked();
+            if (rc != C6_OK) return rc;
+        }
         HIPCHK(hipMemsetAsync(live, 0, sizeof(int), e->stream));
         hipLaunchKernelGGL(c6_match_prepare_kernel, dim3(gb), dim3(256), 0, e->stream, d, -engine_colour, boards, active, live);
         int h_live = 0;
@@ -1035,6 +1068,10 @@ extern "C" int c6_engine_play_match(c6_engine *e, int engine_colour, int opponen
             if (rc != C6_OK) return rc;
         }
         if (--remain <= 0) { remain = 2; turn = -turn; }
+    }
+    {
+        int rc = serve_parked();      // the last stone's move boundary as well: no game is left waiting when the call says C6_OK
+        if (rc != C6_OK) return rc;
     }
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
@@ -1069,7 +1106,7 @@ static int range_status(const NetHost &net) {
     return C6_OK;
 }
 
-static int live_games(c6_engine *e, int *live, int *errors, int *overflow = nullptr) {
+static int live_games(c6_engine *e, int *live, int *errors, int *overflow) {
     e->h_hdr.resize(e->d.G);
     HIPCHK(hipMemcpyAsync(e->h_hdr.data(), e->d.hdr, (size_t)e->d.G * sizeof(C6GameHdr), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1201,7 +1238,7 @@ extern "C" int c6_engine_stats(c6_engine *e, c6_stats *out) {
     unsigned long long c[C6_CNT_N];
     HIPCHK(hipMemcpyAsync(c, e->d.counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
     int live = 0, errs = 0;
-    int rc = live_games(e, &live, &errs);
+    int rc = live_games(e, &live, &errs, nullptr);
     if (rc != C6_OK) return rc;
     c[C6_CNT_SIMS] = c[C6_CNT_SELECT] = c[C6_CNT_STONES] = c[C6_CNT_MAXDEPTH] = c[C6_CNT_MAXREC] = 0;
     for (const C6GameHdr &h : e->h_hdr) {      // refreshed by live_games above

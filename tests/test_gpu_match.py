@@ -97,3 +97,41 @@ def test_play_match_rejects_bad_arguments():
     with pytest.raises(pkg.C6Error, match="engine_colour"):
         eng.play_match(0, "random")
     eng.close()
+
+
+def test_play_match_checks_that_the_engine_is_at_the_start():
+    """the match loop tracks turn / remain on the host, so the precondition is checked: a second call (stones on the boards),
+    or an engine that has already searched, is refused instead of playing the opponent's stones with the engine's search"""
+    need_gpu()
+    eng = pkg.Engine(board_size=9, num_games=3, num_simulation=6, seed=2, evaluator=pkg.EVAL_RANDOM)
+    eng.play_match(-1, "random", opp_seed=5, max_stones=3)
+    with pytest.raises(pkg.C6Error, match="start of its games"):
+        eng.play_match(-1, "random", opp_seed=5)
+    eng.close()
+    eng = pkg.Engine(board_size=9, num_games=3, num_simulation=6, seed=2, evaluator=pkg.EVAL_RANDOM)
+    eng.step(2)
+    with pytest.raises(pkg.C6Error, match="start of its games"):
+        eng.play_match(1, "random", opp_seed=5)
+    eng.close()
+
+
+@pytest.mark.parametrize("colour", [-1, 1])
+def test_play_match_serves_parked_games_before_the_next_stone(colour):
+    """a game whose tree outgrows the per-game caps is parked at its move boundary.  The match loop now raises the caps /
+    grows the pool and lets the game ask again BEFORE the next stone, so every game stays in step: an engine created for 8 records
+    per game (caps raised again and again under the stress evaluator's deep trees) plays exactly the games of an engine whose
+    pool never runs short."""
+    need_gpu()
+    n, G, S, seed, eps, opp_seed = 9, 16, 60, 7, 0.001, 77
+    res = []
+    for rpg in (0, 8):
+        eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, epsilon=eps, evaluator=pkg.EVAL_STRESS, stress_every=1, records_per_game=rpg)
+        eng.play_match(colour, "random", opp_seed=opp_seed)
+        st = eng.stats()
+        assert st["live_games"] == 0 and st["overflow_games"] == 0 and st["parked_games"] == 0, st
+        res.append(({g["uid"]: g for g in eng.fetch_games()}, st))
+        eng.close()
+    assert res[1][1]["cap_raises"] >= 1 and res[0][1]["cap_raises"] == 0, (res[0][1], res[1][1])
+    same_games(res[0][0], res[1][0], G)
+    # (inside play_match the caps are raised only for a game that IS parked -- serve_parked, engine.cpp -- so cap_raises >= 1 above
+    #  means that games did wait at a move boundary and were resumed in step)
