@@ -34,7 +34,7 @@ REF_N = 15
 DROPIN_SYMBOLS = ["cpp_play", "cpp_self_play", "cpp_play_with", "test_new_raw_path", "test_with_raw_path",
                   "test_echo_raw_path", "test_with_raw_play_result", "test_echo_raw_play_result", "test_with_raw_vec",
                   "test_echo_raw_vec", "test_echo_cppeval", "test_cpp_policy"]
-ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_device_count", "c6_default_config", "c6_engine_create",
+ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_rng_spec", "c6_device_count", "c6_default_config", "c6_engine_create",
                   "c6_engine_destroy", "c6_net_blob_floats", "c6_net_blob_header_floats", "c6_net_blob_write_header",
                   "c6_net_blob_check_header", "c6_engine_load_weights", "c6_engine_set_callback",
                   "c6_engine_step", "c6_engine_run", "c6_engine_maintain", "c6_engine_sync", "c6_engine_stats", "c6_engine_pool_audit", "c6_engine_fetch_games",
@@ -132,6 +132,7 @@ def lib():
     i8p, u8p, f32p, i32p, u32p, i16p = (C.POINTER(t) for t in (C.c_int8, C.c_uint8, C.c_float, C.c_int32, C.c_uint32, C.c_int16))
     L.c6_last_error.restype = C.c_char_p
     L.c6_version.restype = C.c_char_p
+    L.c6_rng_spec.restype = C.c_char_p
     L.c6_default_config.argtypes = [C.POINTER(Config)]
     L.c6_engine_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.c6_engine_destroy.argtypes = [C.c_void_p]
@@ -245,6 +246,10 @@ def pool_ring_selftest(ids=1000, waves=4096, tries=4, launches=50, seed=1):
     d, ov, mp = C.c_uint32(), C.c_uint32(), C.c_uint32()
     _chk(lib().c6_pool_ring_selftest(ids, waves, tries, launches, seed, C.byref(d), C.byref(ov), C.byref(mp)))
     return dict(dup=d.value, over=ov.value, min_popped=mp.value)
+
+
+def rng_spec():
+    return lib().c6_rng_spec().decode()
 
 
 def device_count():

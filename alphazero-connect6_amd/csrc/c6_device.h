@@ -13,6 +13,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// the specification the random stream follows: games are a function of (this, the net's arithmetic, weights, seed, S) -- the
+// whole-game parity tests pin engine and oracle to the same games for one specification
+#define C6_RNG_SPEC "C6RNG v4"
+
 #define C6_BLACK (-1)
 #define C6_NONE 0
 #define C6_WHITE 1

@@ -51,7 +51,7 @@ struct C6RootChild {
 enum { C6_POOL_PAGE_HEAD = 0, C6_POOL_PAGE_TAIL, C6_POOL_PAGE_LIMIT, C6_POOL_CHUNK_HEAD, C6_POOL_CHUNK_TAIL, C6_POOL_CHUNK_LIMIT,
        C6_POOL_PAGE_LOW, C6_POOL_PAGE_AVAIL, C6_POOL_CHUNK_AVAIL, C6_POOL_N };      // PAGE_LOW: fewest free pages seen by a popper (statistics);
                                                                                   // *_AVAIL: the credits of this launch (signed; tree_kernels.hip ring_pop)
-enum { C6_PARK_NONE = 0, C6_PARK_POOL = 1, C6_PARK_CAPS = 2 };
+enum { C6_PARK_NONE = 0, C6_PARK_POOL = 1, C6_PARK_CAPS = 2, C6_PARK_CHUNKS = 4 };      // bits: C6Dev.abandon_parked is a mask of them
 
 // C6_ST_OVERFLOW: the game is PARKED at a move boundary -- after a move / a reset it could not be given the records (>= S free ones)
 // or the table (>= 2 x (live records + S) slots) its next move may need: the pool had no free page (hdr.park = C6_PARK_POOL; other
@@ -114,7 +114,9 @@ struct C6Dev {
     int maxpages, maxchunks, pages_cap, hcap;
     unsigned int pages_total, chunks_total, page_ring_mask, chunk_ring_mask;
     int stress_every;        // C6_EVAL_STRESS: games with uid % stress_every == 0 get the peaked evaluator
-    int abandon_parked;      // steady-state mode: a parked game whose request cannot be met is abandoned (counted) -- set once growth has failed
+    int abandon_parked;      // steady-state mode: mask of C6_PARK_* -- a game parked for one of these reasons is abandoned (counted) at the next round's
+                             // head: the host sets a bit while that request cannot be met (caps at their maximum; a pool that could not grow at the last
+                             // c6_engine_maintain) and clears it when it can again
     float eps, cpuct;
     double alpha, gam_d, gam_c;
     uint32_t seed_lo, seed_hi, uid_base, uid_stride;
@@ -176,6 +178,12 @@ void c6_launch_post_move(const C6Dev &d, hipStream_t s);
 void c6_launch_reset_games(const C6Dev &d, int stagger, hipStream_t s);
 // limit = tail of both pools' rings: launched in front of every kernel that may acquire pages (ids handed back by earlier launches
 // become available)
+// A launch helper that cannot run its kernel -- hipFuncSetAttribute refused an LDS request, a launch was rejected -- would leave the data
+// of an earlier pass behind for whoever reads its outputs (the search would expand on stale priors).  The first such failure is kept
+// (c6_note_hip) and every entry point that enqueues work -- c6_engine_step, c6_net_forward* -- ends with c6_launch_status(), which turns it
+// into C6_ERR_HIP naming the call.
+void c6_note_hip(hipError_t e, const char *what);
+int c6_launch_status();      // C6_OK, or c6_set_error(C6_ERR_HIP, ...) for the failure noted since the last call (and forgets it)
 void c6_launch_pool_snapshot(const C6Dev &d, hipStream_t s);
 void c6_launch_ring_selftest(const uint32_t *ring, uint32_t mask, unsigned long long *ctr, uint32_t *count, uint32_t *popped, int waves, int tries, uint32_t seed, hipStream_t s);
 // dynamic LDS of the kernels that keep a game's tag row / chunk list / page table per wave

@@ -102,5 +102,5 @@ static inline void w4_smem_once(const void *fn, int bytes) {
     int dev = 0;
     hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
-    if (done.insert({fn, dev}).second) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (done.insert({fn, dev}).second) c6_note_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) of a Winograd kernel");
 }

@@ -838,7 +838,9 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
         const int grid_out = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
         hipLaunchKernelGGL(c6_w6_out_kernel, dim3(grid_out), dim3(256), 0, s, Mb, bias, res, tiles, *heads);
     }
-    return true;
+    const hipError_t le = hipGetLastError();      // a rejected launch (e.g. its LDS request): noted for c6_launch_status, and the caller stops the pass
+    c6_note_hip(le, "launch of a c6_w6 kernel");
+    return le == hipSuccess;
 }
 // matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 / 30 / 30 / 48 positions x C x C MACs)
 double c6_w6_exec_flops(int nboards) {

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,9 +33,24 @@ static int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess) return fail(C6_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
+static std::mutex g_launch_mu;
+static std::string g_launch_err;
+void c6_note_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    if (g_launch_err.empty()) g_launch_err = std::string(what) + ": " + hipGetErrorString(e);
+}
+int c6_launch_status() {
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    if (g_launch_err.empty()) return C6_OK;
+    const std::string m = "a kernel could not be launched (" + g_launch_err + "): the outputs of this call are not valid";
+    g_launch_err.clear();
+    return fail(C6_ERR_HIP, m);
+}
 int c6_set_error(int code, const char *msg) { return fail(code, msg); }   // for the other translation units (c6_engine.h)
 extern "C" const char *c6_last_error(void) { return g_err.c_str(); }
 extern "C" const char *c6_version(void) { return "connect6_amd 0.1 (gfx950)"; }
+extern "C" const char *c6_rng_spec(void) { return C6_RNG_SPEC; }
 extern "C" int c6_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -554,7 +570,8 @@ struct c6_engine {
     int pages_per_game0 = 0;
     uint32_t pool_grows = 0;                   // times memory was added to the pools
     uint32_t cap_raises = 0;                   // times the per-game caps were raised
-    bool grow_failed = false;
+    bool grow_failed = false;      // the last c6_engine_maintain found parked games it could not help (caps at their maximum / the pools cannot grow)
+    bool said_full = false;
 };
 
 extern "C" void c6_default_config(c6_config *cfg) {
@@ -897,7 +914,7 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
             e->rounds += k;
         }
         HIPCHK(hipGetLastError());
-        return C6_OK;
+        return c6_launch_status();
     }
     for (int r = 0; r < rounds; r++) {
         { Scoped t(&e->t_select, e->stream, e->profiling); c6_launch_select(d, e->stream); }
@@ -925,7 +942,7 @@ extern "C" int c6_engine_step(c6_engine *e, int rounds) {
         c6_launch_post_move(d, e->stream);
     }
     HIPCHK(hipGetLastError());
-    return C6_OK;
+    return c6_launch_status();
 }
 
 // Stones placed from OUTSIDE the engine's policy (MultiPolicy: another policy plays one colour, multi_policy/mod.rs:61-71;
@@ -1128,64 +1145,82 @@ static int live_games(c6_engine *e, int *live, int *errors, int *overflow) {
 //   * a pool that runs low (or a game parked with C6_PARK_POOL) gets more memory MAPPED behind the same addresses (VmRange):
 //     nothing is copied, nothing is allocated twice, games in progress are not touched.
 // A parked game has lost nothing -- it waits at a move boundary and asks again at the head of every round.
-static int grow_pools(c6_engine *e, size_t need_pages) {
+static int grow_pools(c6_engine *e, size_t need_pages, size_t need_chunks) {
     C6Dev &d = e->d;
-    if (d.pages_total >= e->pages_max || !e->vm_prior.vmm) return fail(C6_ERR_OVERFLOW, "record pool is at its maximum");
-    size_t add = std::max<size_t>(need_pages, d.pages_total / 4);
-    add = std::max(add, std::min<size_t>(e->pages_max, ((size_t)1 << 30) / ((size_t)C6_PAGE_RECS * d.cells * 4)));      // >= 1 GiB of priors a step
-    add = (add + e->page_quantum - 1) / e->page_quantum * e->page_quantum;
-    size_t pages = std::min(e->pages_max, d.pages_total + add);
+    if (!e->vm_prior.vmm) return fail(C6_ERR_OVERFLOW, "the pools are plain allocations (no virtual memory management): they cannot grow");
+    const bool pages_full = d.pages_total >= e->pages_max, chunks_full = d.chunks_total >= e->chunks_max;
+    if ((need_pages == 0 || pages_full) && (need_chunks == 0 || chunks_full))
+        return fail(C6_ERR_OVERFLOW, need_pages > 0 ? "record pool is at its maximum" : "table-chunk pool is at its maximum");
+    size_t pages = d.pages_total, chunks = d.chunks_total;
+    if (need_pages > 0 && !pages_full) {
+        size_t add = std::max<size_t>(need_pages, d.pages_total / 4);
+        add = std::max(add, std::min<size_t>(e->pages_max, ((size_t)1 << 30) / ((size_t)C6_PAGE_RECS * d.cells * 4)));      // >= 1 GiB of priors a step
+        add = (add + e->page_quantum - 1) / e->page_quantum * e->page_quantum;
+        pages = std::min(e->pages_max, d.pages_total + add);
+        // chunks follow the pages in proportion
+        chunks = std::min(e->chunks_max, (size_t)((double)pages / (double)d.pages_total * (double)d.chunks_total));
+    }
+    // ... and grow on their own when it is table chunks that games wait for (keyed on pages alone, a chunk shortage with the
+    // pages at their maximum could never be served)
+    if (need_chunks > 0 && !chunks_full) chunks = std::max(chunks, d.chunks_total + std::max<size_t>(need_chunks, d.chunks_total / 4));
+    chunks = std::min(e->chunks_max, (chunks + e->chunk_quantum - 1) / e->chunk_quantum * e->chunk_quantum);
     size_t fr = 0, tot = 0;
     hipMemGetInfo(&fr, &tot);
     const size_t page_bytes = (size_t)C6_PAGE_RECS * ((size_t)d.cells * 4 + sizeof(C6RecStat)), chunk_bytes = (size_t)C6_CHUNK_SLOTS * (sizeof(C6HtEntry) + 1);
     const size_t reserve = (size_t)1 << 30;      // left to the rest of the process
-    // chunks follow the pages in proportion
-    size_t chunks = std::min(e->chunks_max, (size_t)((double)pages / (double)d.pages_total * (double)d.chunks_total));
-    chunks = std::min(e->chunks_max, (chunks + e->chunk_quantum - 1) / e->chunk_quantum * e->chunk_quantum);
-    while (pages > d.pages_total && (pages - d.pages_total) * page_bytes + (chunks - d.chunks_total) * chunk_bytes + reserve > fr) {
-        pages = pages - d.pages_total > e->page_quantum ? d.pages_total + (pages - d.pages_total) / 2 / e->page_quantum * e->page_quantum : d.pages_total;
-        chunks = d.chunks_total;
+    auto fits = [&]() { return (pages - d.pages_total) * page_bytes + (chunks - d.chunks_total) * chunk_bytes + reserve <= fr; };
+    while (!fits() && (pages > d.pages_total || chunks > d.chunks_total)) {      // tight memory: halve the step, pages first (a chunk is 17 KB, a page >= 23 KB)
+        if (pages > d.pages_total) pages = pages - d.pages_total > e->page_quantum ? d.pages_total + (pages - d.pages_total) / 2 / e->page_quantum * e->page_quantum : d.pages_total;
+        else chunks = chunks - d.chunks_total > e->chunk_quantum ? d.chunks_total + (chunks - d.chunks_total) / 2 / e->chunk_quantum * e->chunk_quantum : d.chunks_total;
     }
-    if (pages <= d.pages_total) return fail(C6_ERR_OVERFLOW, "not enough device memory to grow the record pool");
+    if (pages <= d.pages_total && chunks <= d.chunks_total) return fail(C6_ERR_OVERFLOW, "not enough device memory to grow the pools");
     int rc = pools_map(e, pages, chunks);
     if (rc != C6_OK) return rc;
     e->pool_grows++;
     return C6_OK;
 }
 
-// raise the caps / map more memory if games are waiting for it or the pool is running low; C6_OK also when there was nothing to do.
+// raise the caps / map more memory if games are waiting for it or the pools are running low; C6_OK also when there was nothing to do.
 // (live_games has just refreshed e->h_hdr; the stream is idle.)
 static int maintain(c6_engine *e) {
     C6Dev &d = e->d;
-    int parked_caps = 0, parked_pool = 0, near_cap = 0;
+    int parked_caps = 0, parked_pages = 0, parked_chunks = 0, near_cap = 0;
     for (const C6GameHdr &h : e->h_hdr) {
-        if (h.status == C6_ST_OVERFLOW) { parked_caps += h.park == C6_PARK_CAPS; parked_pool += h.park != C6_PARK_CAPS; }
+        if (h.status == C6_ST_OVERFLOW) { parked_caps += h.park == C6_PARK_CAPS; parked_chunks += h.park == C6_PARK_CHUNKS; parked_pages += h.park != C6_PARK_CAPS && h.park != C6_PARK_CHUNKS; }
         else if (h.status == C6_ST_PLAYING && ((size_t)h.live_pages * 4 > (size_t)d.pages_cap * 3 || (size_t)h.hslots * 2 > (size_t)d.hcap)) near_cap++;
     }
+    // Why a parked game cannot be served is a statement about NOW (one failed growth used to condemn every later parked game):
+    // the bits are recomputed at every call.
+    int cannot = 0;
     if (parked_caps > 0 || near_cap > 0) {
         const int pc = std::min(d.maxpages, 2 * d.pages_cap);
         const int hc = std::min(e->hmax, pow2_at_least(2L * ((long)pc * C6_PAGE_RECS + d.S), C6_CHUNK_SLOTS));
         if (pc != d.pages_cap || hc != d.hcap) { d.pages_cap = pc; d.hcap = hc; e->cap_raises++; }
-        else if (parked_caps > 0) e->grow_failed = true;      // a game at max_records_per_game: it stays parked (steady state: abandoned)
+        else if (parked_caps > 0) cannot |= C6_PARK_CAPS;      // a game at max_records_per_game: it stays parked (steady state: abandoned)
     }
     unsigned long long ctr[C6_POOL_N];
     HIPCHK(hipMemcpy(ctr, d.pool_ctr, sizeof ctr, hipMemcpyDeviceToHost));
-    const size_t free_pages = (size_t)(ctr[C6_POOL_PAGE_TAIL] - ctr[C6_POOL_PAGE_HEAD]);
+    const size_t free_pages = (size_t)(ctr[C6_POOL_PAGE_TAIL] - ctr[C6_POOL_PAGE_HEAD]), free_chunks = (size_t)(ctr[C6_POOL_CHUNK_TAIL] - ctr[C6_POOL_CHUNK_HEAD]);
     const size_t move_pages = (size_t)(d.S + C6_PAGE_RECS - 1) / C6_PAGE_RECS + 1;
-    const size_t low_water = std::max<size_t>(64, (size_t)d.G * move_pages / 8);      // an eighth of the games could start a move
-    if (parked_pool > 0 || free_pages < low_water) {
-        int rc = grow_pools(e, (size_t)parked_pool * move_pages + low_water);
+    const size_t move_chunks = (size_t)pow2_at_least(2L * d.S, C6_CHUNK_SLOTS) >> C6_CHUNK_SHIFT;      // what a fresh game's table takes
+    const size_t low_pages = std::max<size_t>(64, (size_t)d.G * move_pages / 8);      // an eighth of the games could start a move
+    const size_t low_chunks = std::max<size_t>(16, (size_t)d.G * move_chunks / 8);
+    const bool want_pages = parked_pages > 0 || free_pages < low_pages, want_chunks = parked_chunks > 0 || free_chunks < low_chunks;
+    if (want_pages || want_chunks) {
+        int rc = grow_pools(e, want_pages ? (size_t)parked_pages * move_pages + low_pages : 0, want_chunks ? (size_t)parked_chunks * move_chunks + low_chunks : 0);
         if (rc != C6_OK) {
             // not an error of this call: the games wait, or leave as partial results (c6_engine_run).  Said once, on stderr.
-            if (parked_pool > 0) {
-                if (!e->grow_failed) fprintf(stderr, "[connect6_amd] the record pool cannot grow any further: %s\n", g_err.c_str());
-                e->grow_failed = true;
+            if (parked_pages > 0 || parked_chunks > 0) {
+                if (!e->said_full) fprintf(stderr, "[connect6_amd] the pools cannot grow any further: %s\n", g_err.c_str());
+                e->said_full = true;
+                cannot |= (parked_pages > 0 ? C6_PARK_POOL : 0) | (parked_chunks > 0 ? C6_PARK_CHUNKS : 0);
             }
             g_err.clear();
             (void)hipGetLastError();
         }
     }
-    if (e->grow_failed && d.recycle) d.abandon_parked = 1;
+    e->grow_failed = cannot != 0;
+    d.abandon_parked = d.recycle ? cannot : 0;
     return C6_OK;
 }
 
@@ -1644,6 +1679,8 @@ extern "C" int c6_net_forward_prec(int n, int C, int blocks, int precision, cons
     float *vb = nh.dev.variant == C6_CONV_WINO ? t.get<float>(nh.dev.wino6 ? c6_w6_vbuf_floats(num) : c6_conv_wino_vbuf_floats(C, n, num)) : a0;
     if (!db || !dpl || !dm || !a0 || !a1 || !a2 || !ph || !vh || !dp || !dv || !vb) { nh.pool.release(); return fail(C6_ERR_HIP, "hipMalloc failed"); }
     c6_net_forward_dev(nh.dev, num, 1, db, cells, dpl, 1, dm, a0, a1, a2, vb, ph, vh, dp, dv, nullptr, nullptr);
+    c6_note_hip(hipGetLastError(), "c6_net_forward");
+    if ((rc = c6_launch_status()) != C6_OK) { hipDeviceSynchronize(); nh.pool.release(); return rc; }
     hipError_t he = hipDeviceSynchronize();
     if (he == hipSuccess && (rc = range_status(nh)) != C6_OK) { nh.pool.release(); return rc; }
     if (he == hipSuccess) he = hipMemcpy(policy, dp, (size_t)num * cells * 4, hipMemcpyDeviceToHost);

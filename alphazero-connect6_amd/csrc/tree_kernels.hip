@@ -978,7 +978,7 @@ __device__ __forceinline__ int reprovision_wave(const C6Dev &E, int g, int lane,
                     const int k = base + lane;
                     ring_push(E.chunk_ring, E.chunk_ring_mask, E.pool_ctr, C6_POOL_CHUNK_TAIL, __ballot(k < have), lane, k < have ? ckg[k] : 0u);
                 }
-                park = C6_PARK_POOL;
+                park = C6_PARK_CHUNKS;
                 Hn = Hold;
             }
         }
@@ -1180,8 +1180,8 @@ __device__ __forceinline__ void post_move_wave(const C6Dev &E, int g, int lane, 
 
 // head of every round for game g: the move K1 applied last round, if any; a parked game asks the pools again (pages come back from
 // other games all the time, and the host may have mapped more memory or raised the caps).  Steady-state mode also abandons -- counted,
-// never silently -- a slot whose game stopped with NaN scores, and a parked one once the host has said that nothing more can be done
-// (E.abandon_parked: growth failed).
+// never silently -- a slot whose game stopped with NaN scores, and a parked one while the host says that its request cannot be met
+// (E.abandon_parked: a mask of C6_PARK_* reasons -- caps at their maximum, a pool that could not grow).
 template <int J>
 __device__ __forceinline__ void round_head_wave(const C6Dev &E, int g, int lane) {
     const int pos = E.move_pos[g];
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void round_head_wave(const C6Dev &E, int g, int lane)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         stt = E.hdr[g].status;
-        if (!(stt == C6_ST_OVERFLOW && E.recycle && E.abandon_parked)) return;
+        if (!(stt == C6_ST_OVERFLOW && E.recycle && (E.abandon_parked & (int)E.hdr[g].park))) return;
     }
     if (E.recycle && (stt == C6_ST_ERROR || stt == C6_ST_OVERFLOW)) {
         const uint32_t uid_ = E.hdr[g].game_uid;
@@ -1483,7 +1483,7 @@ static void tree_smem(const void *fn, size_t dyn) {
     int dev = 0;
     hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
-    if (done.insert({fn, dev}).second) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (done.insert({fn, dev}).second) c6_note_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) of a tree kernel");
 }
 // J = cells owned by one lane: 2 (9x9), 4 (15x15), 6 (19x19)
 #define C6_LAUNCH_ONE(KERNEL, d, s, ...)                                                                              \

@@ -96,10 +96,14 @@ def pmc_record(kernel_substr):
     return {}
 
 
-def committed_stones_probe(workload, sims=None, ignored=None):
-    """profiles/r*_stones_probe*.json (tools/stones_probe.py): complete games of the benchmark's net.  The probe taken at the workload's
-    own simulation budget wins; otherwise the one with the most games.  Only probes of THESE kernel sources in the reference's f32
-    arithmetic count (`src_hash`, `precision`): the others are listed in `ignored`."""
+def committed_stones_probe(workload, sims, rng, ignored=None):
+    """profiles/r*_stones_probe*.json (tools/stones_probe.py): complete games of the benchmark's net.  A probe turns simulations/s into
+    `value` only if it was played (i) at the workload's OWN simulation budget -- the game length depends on it, and not monotonically --
+    (ii) in the reference's f32 arithmetic and (iii) under the random-stream specification this library implements (c6_rng_spec): the
+    games an engine plays are a function of (specification, seed, weights, arithmetic, hyper-parameters), pinned to the CPU oracle stone
+    for stone by the whole-game parity tests, so a probe stays valid across kernel edits that keep the specification and is void after
+    one that changes it.  Among the qualifying probes the one taken on exactly these kernel sources wins (`src_hash`), then the newest.
+    Records from before round 4 carry no `rng` field: they were played under C6RNG v4.  Everything else is listed in `ignored`."""
     best = None
     h = kernel_source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stones_probe*.json"))):
@@ -109,12 +113,19 @@ def committed_stones_probe(workload, sims=None, ignored=None):
             continue
         if d.get("workload") != workload:
             continue
-        if d.get("src_hash") != h or d.get("precision") != "fp32":
+        why = None
+        if d.get("num_simulation") != sims:
+            why = f"played at {d.get('num_simulation')} simulations per move, not the workload's {sims}"
+        elif d.get("precision") != "fp32":
+            why = f"precision {d.get('precision')}"
+        elif d.get("rng", "C6RNG v4") != rng:
+            why = f"random-stream specification {d.get('rng', 'C6RNG v4')}, this library implements {rng}"
+        if why:
             if ignored is not None:
-                ignored.append(f"{os.path.basename(f)}: " + ("taken on other kernel sources" if d.get("src_hash") != h else f"precision {d.get('precision')}"))
+                ignored.append(f"{os.path.basename(f)}: {why}")
             continue
-        d = dict(d, file=os.path.basename(f))
-        key = (d.get("num_simulation") == sims, d.get("games", 0))
+        d = dict(d, file=os.path.basename(f), same_sources=d.get("src_hash") == h)
+        key = (d["same_sources"], os.path.basename(f))
         if best is None or key > best[0]:
             best = (key, d)
     return best[1] if best else None
@@ -217,9 +228,9 @@ def cpu_baseline(wl, stones, seconds_budget=20.0):
     sims = sum(done)
     net.close()
     sims_s = sims / dt
-    return {"value": sims_s / (wl["sims"] * stones), "unit": "games/s", "cores": cores, "kind": "port", "sims_per_s": sims_s,
+    return {"value": sims_s / (wl["sims"] * stones) if stones else None, "unit": "games/s", "cores": cores, "kind": "port", "sims_per_s": sims_s,
             "sample": f"{sims} searches of the opening move ({cores} games, one per core, {dt:.1f} s) with the oracle's FP32 net; "
-                      f"games/s = searches/s / ({wl['sims']} * {stones:.1f} measured stones/game)"}
+                      + (f"games/s = searches/s / ({wl['sims']} * {stones:.1f} measured stones/game)" if stones else "no game length measured at this budget: searches/s only")}
 
 
 def under_profiler():
@@ -383,18 +394,21 @@ def main():
 
     # ---- stones per game: measured --------------------------------------------------------------------------------------
     probes_ignored = []
-    probe_file = committed_stones_probe(args.workload if args.workload != "config4" else "config2", S, probes_ignored)
+    probe_file = committed_stones_probe(args.workload if args.workload != "config4" else "config2", S, pkg.rng_spec(), probes_ignored) if is_net else None
     live = None
     if world == 1 and is_net and not args.no_probe:
         live = stones_probe(pkg, wl, args.probe_games, 8, prec, device=local_rank)
     if is_net:
         if probe_file:
             stones, stones_src = probe_file["stones_per_game"], (f"measured: {probe_file['games']} complete games of this net at {probe_file['num_simulation']} "
-                                                                  f"simulations/move on MI355X (profiles/{probe_file['file']}, tools/stones_probe.py)")
-        elif live:
-            stones, stones_src = live["stones_per_game"], f"measured in this run: {live['games']} complete games of this net at {live['num_simulation']} simulations/move"
+                                                                  f"simulations/move on MI355X (profiles/{probe_file['file']}, tools/stones_probe.py; {pkg.rng_spec()}, "
+                                                                  + ("these kernel sources)" if probe_file["same_sources"] else
+                                                                     "played on earlier kernel sources under the same random-stream specification and arithmetic: the same games)"))
         else:
-            stones, stones_src = wl["stones_prior"], "PRIOR (SURVEY 8d: uniform-random play), no measurement available in this run"
+            # No probe at this workload's own budget: `value` is NOT derived from a probe at another budget (game length at 8 simulations
+            # per move is 106 stones, at 400 it is 136) -- simulations/s is the measurement, games/s stays null
+            stones, stones_src = None, (f"none: no committed probe of complete games at {S} simulations/move for this net under {pkg.rng_spec()}; value is null, "
+                                        "sims_per_s is the measurement (value_with_live_probe: the 8-simulation live probe, for orientation only)")
     else:
         # tree-only workload: complete games are cheap -- play a batch to the end (no recycling: every game counts, short and long alike).
         # The ratio stones / finished games inside a timed window is NOT the game length while the games' phases are still correlated
@@ -410,7 +424,7 @@ def main():
     if world == 1 and is_net and not args.no_probe:
         k = 200
         op = measure(0, k, 20, evaluator=pkg.EVAL_UNIFORM)
-        ss = measure(0, k, 20, evaluator=pkg.EVAL_UNIFORM, settle_rounds=min(int(S * stones), 60000))
+        ss = measure(0, k, 20, evaluator=pkg.EVAL_UNIFORM, settle_rounds=min(int(S * (stones or live["stones_per_game"])), 60000))
         tree_steady = {"evaluator": "uniform (tree + board kernels only, same G / N / S)", "opening_ms_per_round": 1000.0 * op["dt"] / k,
                        "steady_ms_per_round": 1000.0 * ss["dt"] / k, "steady_max_records_used": ss["st"]["max_records_used"],
                        "records_per_game": ss["st"]["records_per_game"], "pool_grows": ss["st"]["pool_grows"],
@@ -444,7 +458,7 @@ def main():
     if rank == 0:
         def line(m):
             sims = m["sims_in_window"] * world / m["dt"] if world == 1 else args.steps * G * world / m["dt"]
-            return sims, sims / (S * stones)
+            return sims, (sims / (S * stones) if stones else None)
 
         def conv_roofline(m, name):
             prof, dt_ = m["prof"], m["dt"]
@@ -560,7 +574,7 @@ def main():
             if tree_steady:
                 d_ms = tree_steady["steady_ms_per_round"] - tree_steady["opening_ms_per_round"]
                 tree_steady["steady_state_ms_per_step_estimate"] = out["ms_per_step"] + d_ms
-                tree_steady["value_at_steady_state_estimate"] = games_s * out["ms_per_step"] / (out["ms_per_step"] + d_ms)
+                tree_steady["value_at_steady_state_estimate"] = games_s * out["ms_per_step"] / (out["ms_per_step"] + d_ms) if games_s is not None else None
                 out["steady_state"] = tree_steady
         else:
             # tree-bound workload: algorithmic bytes per simulation, SURVEY 8d: (12*d + 13) * N^2
@@ -582,7 +596,7 @@ def main():
             out["tree_kernel"] = tree_side
         out["phase_ms"] = {k: head["prof"][k] for k in ("conv_ms", "conv_pre_ms", "conv_post_ms", "select_ms", "expand_ms", "eval_other_ms", "move_ms")}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, stones, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(wl, stones, args.cpu_seconds)      # (stones None: its value is null too, sims_per_s stays)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -64,7 +64,7 @@ def main():
     st = eng.stats()
     games = eng.fetch_games()
     allrec = np.concatenate(records, axis=0) if records else np.zeros((0, pool.stride), np.uint8)
-    np.savez(out, records=allrec, finished=st["games_finished"], overflow=st["overflow_games"],
+    np.savez(out, records=allrec, finished=st["games_finished"], overflow=st["overflow_games"], dropped=pool.dropped,
              uids=np.array(sorted(g["uid"] for g in games), np.int64))
     eng.close()
     dist.barrier()

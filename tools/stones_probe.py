@@ -1,7 +1,8 @@
 """Measured stones per game for bench.py: complete self-play games of the benchmark's net (random-init weights, Dirichlet noise) at a
 short simulation budget, on the GPU engine.  Writes one JSON line (commit it as profiles/rNN_stones_probe.json).
     python tools/stones_probe.py [workload=config2] [games=4096] [sims=8] [also_sims=0] [seed=7] [precision=fp32]
-The record carries the hash of the kernel sources it was taken on (bench.kernel_source_hash): bench.py ignores a probe of other sources."""
+The record carries the random-stream specification it was played under (c6_rng_spec) and the hash of the kernel sources: bench.py uses a probe
+only at the workload's own budget and under the library's current specification (bench.committed_stones_probe)."""
 import json
 import os
 import sys
@@ -21,7 +22,7 @@ prec = {"fp32": pkg.PREC_FP32, "bf16x3": pkg.PREC_BF16X3}[pname]
 wl = bench.WORKLOADS[name]
 r = bench.stones_probe(pkg, wl, games, sims, prec, seed=seed, progress=True)
 r["seed"] = seed
-r.update(workload=name, precision=pname, board=wl["n"], net_blocks=wl["blocks"], net_channels=wl["channels"], src_hash=bench.kernel_source_hash())
+r.update(workload=name, precision=pname, board=wl["n"], net_blocks=wl["blocks"], net_channels=wl["channels"], src_hash=bench.kernel_source_hash(), rng=pkg.rng_spec())
 if also:      # how the game length moves with the simulation budget: further budgets on fewer games
     r["other_budgets"] = [bench.stones_probe(pkg, wl, 256, b, prec, seed=8 + b, progress=True) for b in (2, also)]
 print(json.dumps(r))
