@@ -69,7 +69,7 @@ def _worker(rank, world, port, n, total_games, S, seed, q):
 def test_ranks_gather_pools_all_tuples(world, total):
     """world 8 = the rank count of BASELINE config 4 / the driver's 8-GPU run: uid_plan with 8 ranks and the all-gather over 8
     gloo ranks (the GPU box's process guard admits at most 6 processes on the card, so 8 REAL engines cannot share it: the
-    6-rank rehearsal with engines is tools/share_rehearsal.sh, the 4-rank test tests/test_gpu_configs.py)"""
+    4-rank rehearsal of bench.py with engines is tools/share_rehearsal.sh, the 4-rank test tests/test_gpu_configs.py)"""
     import c6oracle as o
     n, S, seed = 9, 6, 13
     ctx = mp.get_context("spawn")

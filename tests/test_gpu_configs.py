@@ -212,7 +212,7 @@ def test_multi_process_engine_shard_on_one_gpu(tmp_path, world, per_rank):
     same pooled set, and that set must equal the single-process run of all the games -- a concatenation in any order, as
     AsyncAgent::run collects results (agent/async_agent/mod.rs:100-137).  world 4 x 8 games = the 32 uids VERDICT r3 asked for
     as 8 x 4: the GPU box admits at most 6 processes on its card (this one included), so 4 ranks is what a test may spawn; the
-    8-rank sharding plan and all-gather run over gloo on the CPU (tests/test_dist_gloo.py) and 6 ranks x bench.py in
+    8-rank sharding plan and all-gather run over gloo on the CPU (tests/test_dist_gloo.py) and 4 ranks x bench.py in
     tools/share_rehearsal.sh."""
     need_gpu()
     n, S, seed = 9, 12, 77
