@@ -60,7 +60,7 @@ __device__ __forceinline__ float c6_u11(uint32_t w) { return 2.0f * ((float)(w >
 __device__ __forceinline__ float c6_open01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // m * 2^k for a normal float m and -126 <= k <= 127 with a normal result: exact
-__device__ __forceinline__ float c6_scale2f(float m, int k) { return m * __uint_as_float((uint32_t)(k + 127) << 23); }
+__device__ __forceinline__ float c6_scale2f(float m, int k) { return __builtin_amdgcn_ldexpf(m, k); }      // v_ldexp_f32: one instruction, the same bits
 
 // ---- C6RNG v4: the Gamma sampler -------------------------------------------------------------------------------------------
 // log and exp of the sampler: polynomial forms (Cephes' logf / expf coefficients) on explicitly fused multiply-adds -- no division, no

@@ -894,7 +894,9 @@ static int evaluate(c6_engine *e) {
     }
 }
 
-#define C6_SEARCH_ROUNDS_PER_LAUNCH 16
+#ifndef C6_SEARCH_ROUNDS_PER_LAUNCH
+#define C6_SEARCH_ROUNDS_PER_LAUNCH 64      // r4: 16 -> 64 (config 5, same box: 8 rounds per launch 0.146 ms per round, 16 0.139, 32 0.134, 64 0.130: a wave's start -- game
+#endif                                      // registers, tag row, page table into LDS -- is paid once per launch; parked games ask again at every launch's head)
 extern "C" int c6_engine_step(c6_engine *e, int rounds) {
     if (!e) return fail(C6_ERR_BAD_ARG, "null engine");
     HIPCHK(hipSetDevice(e->cfg.device));

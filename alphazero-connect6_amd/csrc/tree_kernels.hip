@@ -41,7 +41,39 @@
 #include "c6_device.h"
 #include "c6_engine.h"
 
-#define WAVES_PER_BLOCK 4
+// Diagnostic builds only (tools/ab_build.sh stamps tree_kernels.hip -DC6_AB_STAMPS; tools/tree_stamps.py): where a wave's cycles go.  C6_STAMP(a, b) ends
+// phase a and begins phase b: lane 0 adds s_memtime to one accumulator and subtracts it from the other, so acc[p] = sum over waves of the cycles
+// (waits included) spent in p.  No stamp exists in the product.
+#ifdef C6_AB_STAMPS
+__device__ unsigned long long c6_stamp_acc[16];
+__shared__ unsigned long long c6_stamp_lds[16];      // one wave per workgroup (WAVES_PER_BLOCK 1): the wave's own accumulators, flushed once
+#define C6_STAMP(a, b)                                                                    \
+    do {                                                                                  \
+        if (lane == 0) {                                                                  \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                   \
+            c6_stamp_lds[a] += t_;                                                        \
+            c6_stamp_lds[b] -= t_;                                                        \
+        }                                                                                 \
+    } while (0)
+#define C6_STAMP_INIT() do { if (lane < 16) c6_stamp_lds[lane] = 0ull; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); } while (0)
+#define C6_STAMP_FLUSH() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); if (lane < 16) atomicAdd(&c6_stamp_acc[lane], c6_stamp_lds[lane]); } while (0)
+extern "C" int c6_debug_stamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(c6_stamp_acc), 16 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(c6_stamp_acc), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define C6_STAMP(a, b) do { } while (0)
+#define C6_STAMP_INIT() do { } while (0)
+#define C6_STAMP_FLUSH() do { } while (0)
+#endif
+enum { C6_PH_HEAD = 0, C6_PH_SCAN, C6_PH_NOISE, C6_PH_SCORE, C6_PH_STEP, C6_PH_EVAL, C6_PH_EXPAND, C6_PH_MOVE, C6_PH_TAIL, C6_PH_OUT };
+
+// One wave = one game = one workgroup (r4).  With four waves per workgroup a CU's slot came free only when the slowest of four games had
+// finished its rounds: config 5 ran 0.1507 ms per round; two waves 0.143; one wave 0.139 (same box, tools/ab_many.sh).
+#ifndef WAVES_PER_BLOCK
+#define WAVES_PER_BLOCK 1
+#endif
 #ifndef C6_OCC2
 #define C6_OCC2 3      // c6_search_kernel<2, .>: at 4 blocks per SIMD it spills 19 registers and is 17 % slower (tools/ab_build.sh -DC6_OCC2=4)
 #endif
@@ -269,6 +301,7 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
     int kind = C6_LEAF_EVAL;
     L.my_path = 0;
     while (p >= 0) {
+        C6_STAMP(C6_PH_STEP, C6_PH_SCAN);
         const int nchild = cells - level;
         if (nchild == 0) break;                 // cannot happen: full boards are never records
         if (d >= E.maxd) { kind = -1; break; }  // cannot happen: a path adds a stone per step and maxd >= cells
@@ -363,8 +396,10 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
 #pragma unroll
             for (int j = 0; j < J; j++) asm volatile("" ::"v"(noise_[j]));
 #endif
+            C6_STAMP(C6_PH_SCAN, C6_PH_NOISE);
             c6_wave_gamma<J>(need, gam, gscratch, lane, E.alpha, E.gam_d, E.gam_c, k0, k1, t, (uint32_t)d);
             c6_wave_dirichlet<J>(gam, noise_);
+            C6_STAMP(C6_PH_NOISE, C6_PH_SCORE);
             float sc[J], best = -INFINITY;
 #pragma unroll
             for (int j = 0; j < J; j++) {
@@ -404,14 +439,16 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
                 }
             }
             if (chosen < 0) { kind = -1; break; }   // NaN scores: the reference panics (partial_cmp().unwrap())
+            C6_STAMP(C6_PH_SCORE, C6_PH_SCAN);
         }
+        C6_STAMP(C6_PH_SCAN, C6_PH_STEP);
 
         // step into the child: diff_board + simulate_in (mod.rs:417-420)
         const int cl = chosen & 63, cj = chosen >> 6;
         int child = -1;
 #pragma unroll
         for (int j = 0; j < J; j++) if (j == cj) child = cidx[j];
-        child = __shfl(child, cl, 64);
+        child = __builtin_amdgcn_readlane(child, __builtin_amdgcn_readfirstlane(cl));      // `chosen` is wave-uniform: a register read, not an LDS permute
         const int step = p | (chosen << 16);
         if (d < 64) { if (lane == d) L.my_path = step; }
         else if (lane == 0) E.path_rec[(size_t)g * E.maxd + d] = (uint32_t)step;      // beyond 64 steps: through memory
@@ -626,7 +663,7 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         bk_visit = E.rec_stat[my_at].visit;
         bk_qsum = E.rec_stat[my_at].qsum;
     }
-    const int cell0 = __shfl(my_cell, 0, 64);      // the root's move of this path (len >= 1): its rootc entry follows the child
+    const int cell0 = __builtin_amdgcn_readfirstlane(my_cell);      // the root's move of this path (len >= 1): its rootc entry follows the child
     C6RootChild *rootc = E.rootc + (size_t)g * E.cellsP;
 
     if (kind == C6_LEAF_TERMINAL) {   // mod.rs:338-348: value by winner, no visit increment, no children
@@ -703,7 +740,7 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
             while (cand) {
                 const int src_lane = __ffsll((long long)cand) - 1;
                 cand &= cand - 1;
-                const int i = __shfl(mcell, src_lane, 64);
+                const int i = __builtin_amdgcn_readlane(mcell, src_lane);
                 const unsigned long long kq = key ^ zk[i];
 #pragma unroll
                 for (int j = 0; j < J; j++) {
@@ -1289,9 +1326,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
     free_record_prefetch<J>(E, T, R);
     float *probs = reinterpret_cast<float *>(gscratch[wv]);
     int8_t *lboard = reinterpret_cast<int8_t *>(probs + 64 * J);
+    C6_STAMP_INIT();
+    C6_STAMP(C6_PH_OUT, C6_PH_HEAD);
     for (int it = 0;;) {
         C6Leaf<J> L;
+        C6_STAMP(C6_PH_HEAD, C6_PH_STEP);
         select_wave<J>(E, g, lane, gscratch[wv], T, R, L);
+        C6_STAMP(C6_PH_STEP, C6_PH_EVAL);
         if (L.kind < 0) { select_failed(E, g, lane, L.kind); return; }
         if (lane == 0) {
             E.hdr[g].g_select += (unsigned long long)L.len;      // per-game statistics: no shared-address atomics
@@ -1308,7 +1349,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (L.len > 64) __threadfence();      // path steps beyond 64 went through memory
+        C6_STAMP(C6_PH_EVAL, C6_PH_EXPAND);
         const bool spent = expand_wave<J>(E, g, lane, T, R, L, value, probs, lboard);
+        C6_STAMP(C6_PH_EXPAND, C6_PH_MOVE);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // what this round wrote is read back below / by the next round
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (spent) {
@@ -1316,6 +1359,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
+        C6_STAMP(C6_PH_MOVE, C6_PH_HEAD);
         if (++it >= nsims) break;
         // the next round of the same game: its state as this wave left it
         if (E.hdr[g].status != C6_ST_PLAYING) break;
@@ -1323,6 +1367,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
         if (spent) tags_load(E, g, lane, tag_row, T);      // the table was rebuilt, pages may have changed hands
         free_record_prefetch<J>(E, T, R);
     }
+    C6_STAMP(C6_PH_HEAD, C6_PH_OUT);
+    C6_STAMP_FLUSH();
 }
 
 // Net / callback evaluators: the evaluator sits between select and expand, so the leaf travels through the leaf_* arrays.

@@ -584,7 +584,7 @@ def main():
             bytes_sim = (12.0 * d + 13.0) * n * n
             ach = bytes_sim * G * args.steps / max(tree_ms * 1e-3, 1e-9) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "c6_search_kernel<2, 2> (a whole round -- search, and the move when its budget is spent -- per game and wave; "
-                                                          "up to 16 rounds of every game per launch)", "achieved": ach, "peak": PEAK_HBM_GBS,
+                                                          "up to 64 rounds of every game per launch)", "achieved": ach, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_sim": bytes_sim,
                                "avg_launch_ms": tree_ms / max(prof["select_launches"], 1), "rounds_per_launch": args.steps / max(prof["select_launches"], 1),
                                "note": "algorithmic bytes (SURVEY 8d: (12 d + 13) N^2 per simulation) over the kernel's time; the kernel is bound by the vector "
