@@ -38,27 +38,31 @@
 #define W6_COLS 22        // window columns: board columns -1 .. 20
 #define W6_ROWF (W6_COLS * W6_C)
 #define W6_PF 7
-enum { W6_CLS_A = 0, W6_CLS_B = 1, W6_CLS_BP = 2, W6_CLS_D = 3 };
+enum { W6_CLS_A = 0, W6_CLS_B = 1, W6_CLS_BP = 2, W6_CLS_D = 3, W6_CLS_DP = 4 };
 #define W6_NA 4
 #define W6_NB 4
 #define W6_NBP 2
-#define W6_ND 10
-#define W6_SETS_POS (36 + 30 + 30 + 48)      // position matrices of the four weight sets
+#define W6_ND 8
+#define W6_NDP 2
+#define W6_SETS_POS (36 + 30 + 30 + 48 + 40)      // position matrices of the five weight sets
 
 __host__ __device__ __forceinline__ int w6_x0(int tx) { return tx == 0 ? 0 : tx == 1 ? 6 : tx == 2 ? 12 : 16; }
 __host__ __device__ __forceinline__ int w6_width(int tx) { return tx < 2 ? 6 : tx == 2 ? 4 : 3; }
-__host__ __device__ __forceinline__ int w6_cls(int ty, int tx) { return tx < 2 ? W6_CLS_D : ty == W6_TWY - 1 ? W6_CLS_BP : tx == 2 ? W6_CLS_A : W6_CLS_B; }
+__host__ __device__ __forceinline__ int w6_cls(int ty, int tx) {
+    return tx < 2 ? (ty == W6_TWY - 1 ? W6_CLS_DP : W6_CLS_D) : ty == W6_TWY - 1 ? W6_CLS_BP : tx == 2 ? W6_CLS_A : W6_CLS_B;
+}
 struct W6Map {
-    long blkB, blkBP, blkD, nblocks;
+    long blkB, blkBP, blkD, blkDP, nblocks;
     __host__ __device__ explicit W6Map(long nboards) {
         blkB = (nboards * W6_NA + W6_BT - 1) / W6_BT;
         blkBP = blkB + (nboards * W6_NB + W6_BT - 1) / W6_BT;
         blkD = blkBP + (nboards * W6_NBP + W6_BT - 1) / W6_BT;
-        nblocks = blkD + (nboards * W6_ND + W6_BT - 1) / W6_BT;
+        blkDP = blkD + (nboards * W6_ND + W6_BT - 1) / W6_BT;
+        nblocks = blkDP + (nboards * W6_NDP + W6_BT - 1) / W6_BT;
     }
     // the tile's slot: block slot / 64, tile slot % 64 of the block
     __host__ __device__ __forceinline__ long slot(long bd, int ty, int tx) const {
-        if (tx < 2) return blkD * W6_BT + bd * W6_ND + ty * 2 + tx;
+        if (tx < 2) return ty == W6_TWY - 1 ? blkDP * W6_BT + bd * W6_NDP + tx : blkD * W6_BT + bd * W6_ND + ty * 2 + tx;
         if (ty == W6_TWY - 1) return blkBP * W6_BT + bd * W6_NBP + (tx - 2);
         if (tx == 2) return bd * W6_NA + ty;
         return blkB * W6_BT + bd * W6_NB + ty;
@@ -113,6 +117,21 @@ __device__ __forceinline__ void w6_patch_transform(const float *wc, const int (&
                 w6_bt6(t[i], r);
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++) W6_VST(jj * 6 + i, r[jj]);
+            }
+        } else if (cls == W6_CLS_DP) {      // 5 patch rows (F(3) vertically) x 8 columns (F(6) horizontally), stored transposed: p = 5 j + i
+            f32x2 t[5][8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const f32x2 d0 = W6_D(0, b), d1 = W6_D(1, b), d2 = W6_D(2, b), d3 = W6_D(3, b), d4 = W6_D(4, b);
+#pragma unroll
+                for (int i = 0; i < 5; i++) t[i][b] = W4_BT3_ROW(i, d0, d1, d2, d3, d4);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                f32x2 r[8];
+                w6_bt6(t[i], r);
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) W6_VST(jj * 5 + i, r[jj]);
             }
         } else if (cls == W6_CLS_A) {
             f32x2 t[6][6];
@@ -226,8 +245,9 @@ __global__ __launch_bounds__(W6_THREADS) void c6_w6_stem_in_kernel(C6StemSrc S, 
 // the tail of a region's last block (tiles beyond the batch) is never written by the kernels above: zero it once per launch
 __global__ void c6_w6_tail_kernel(float *__restrict__ V, int nboards) {
     const W6Map map(nboards);
-    const long first_blk[4] = {0, map.blkB, map.blkBP, map.blkD}, count[4] = {(long)nboards * W6_NA, (long)nboards * W6_NB, (long)nboards * W6_NBP, (long)nboards * W6_ND};
-    for (int r = 0; r < 4; r++) {
+    const long first_blk[5] = {0, map.blkB, map.blkBP, map.blkD, map.blkDP},
+               count[5] = {(long)nboards * W6_NA, (long)nboards * W6_NB, (long)nboards * W6_NBP, (long)nboards * W6_ND, (long)nboards * W6_NDP};
+    for (int r = 0; r < 5; r++) {
         const int used = (int)(count[r] % W6_BT);
         if (used == 0) continue;
         float *blk = V + (size_t)(first_blk[r] + count[r] / W6_BT) * W6_VBLOCK + (size_t)used * W6_VTILE;
@@ -236,7 +256,8 @@ __global__ void c6_w6_tail_kernel(float *__restrict__ V, int nboards) {
     }
 }
 static bool w6_has_tail(int nboards) {
-    return ((long)nboards * W6_NA) % W6_BT || ((long)nboards * W6_NB) % W6_BT || ((long)nboards * W6_NBP) % W6_BT || ((long)nboards * W6_ND) % W6_BT;
+    return ((long)nboards * W6_NA) % W6_BT || ((long)nboards * W6_NB) % W6_BT || ((long)nboards * W6_NBP) % W6_BT || ((long)nboards * W6_ND) % W6_BT ||
+           ((long)nboards * W6_NDP) % W6_BT;
 }
 
 // ---- the GEMMs of a block, with the column half of the output transform ("Z rows"): conv_wino4.hip's c6_wino4_gemm_kernel ----------
@@ -255,8 +276,11 @@ constexpr int w6_wait(int i, bool stores) {
 }
 static_assert(w6_store_group(15) < 32 - W6_PF, "a position's stores are older than every request that is waited for in the next one");
 
+// DP = false: the blocks [first, nblocks) of the classes with rows of six positions (A, B, B', D); DP = true: the blocks of class D' (rows of
+// five).  Two instantiations, two launches: with both row forms in one kernel the register allocator spilled 121 registers of the accumulators.
+template <bool DP>
 __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo,
-                                                                      int nblocks, int blkB, int blkBP, int blkD) {
+                                                                      int first, int nblocks, int blkB, int blkBP, int blkD) {
     constexpr int C = W6_C, CP = C + 4, SLAB = W6_BT * CP, WAVES = C / 32, NG = C / 8, PF = W6_PF;
     constexpr int ND = W6_BT / WAVES;
     static_assert(PF == 7 && NG == 32 && ND == 8, "ring of 8 weight groups; 8 DMAs per position");
@@ -265,13 +289,16 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int n4 = wave * 32 + 4 * h;
-    int b = blockIdx.x;
+    int b = first + (int)blockIdx.x;
     if (b >= nblocks) return;
 
-    auto rows_of = [&](int blk) { return blk < blkB ? 6 : blk < blkD ? 5 : 8; };
+    // blocks [0, blkB): class A, 6 rows of 6 positions; [blkB, blkD): B and B', 5 rows of 6; [blkD, ...): D, 8 rows of 6; the DP instantiation: D', 8 rows
+    // of FIVE positions (r4: F(3) down the board in the six-wide tiles of the last tile row -- 40 instead of 48 positions)
+    auto rows_of = [&](int blk) { return DP ? 8 : blk < blkB ? 6 : blk < blkD ? 5 : 8; };
+    auto npos_of = [&](int blk) { return DP ? 40 : blk < blkB ? 36 : blk < blkD ? 30 : 48; };
     auto wbase_of = [&](int blk) {
-        const int first = blk < blkB ? 0 : blk < blkBP ? 36 : blk < blkD ? 66 : 96, npos = blk < blkB ? 36 : blk < blkD ? 30 : 48;
-        return U + (size_t)first * C * C + (size_t)wave * ((size_t)npos * NG * 256);
+        const int fs = DP ? 144 : blk < blkB ? 0 : blk < blkBP ? 36 : blk < blkD ? 66 : 96;
+        return U + (size_t)fs * C * C + (size_t)wave * ((size_t)npos_of(blk) * NG * 256);
     };
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned zoff0 = (unsigned)(((size_t)j * W6_ZTILE + n4) * 4), zoff1 = zoff0 + (unsigned)((size_t)32 * W6_ZTILE * 4);
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
 #pragma unroll
     for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * W6_VBLOCK, 0, c0);
     f32x4 ring[PF + 1];
-    int ub = b, ungt = rows_of(b) * 6 * NG;      // the weight stream runs ahead of the multiplications: its own block and group counters
+    int ub = b, ungt = npos_of(b) * NG;      // the weight stream runs ahead of the multiplications: its own block and group counters
     const float *uptr = wbase_of(b);
     int gi = 0;
 #define W6_UNEXT()                                                       \
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
         if (gi == ungt) {                                                \
             gi = 0;                                                      \
             ub = ub + (int)gridDim.x < nblocks ? ub + (int)gridDim.x : ub; \
-            ungt = rows_of(ub) * 6 * NG;                                 \
+            ungt = npos_of(ub) * NG;                                     \
             uptr = wbase_of(ub);                                         \
         }                                                                \
     }
@@ -363,29 +390,45 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }
 #define W6GZ_(i, JJ, BUF) W6Z_GROUP((i) & RM, (i), w6_wait((i), (JJ) == 0 || (JJ) == 5), (i), JJ, BUF)
-#define W6Z_POSITION(i_, JJ)                                                                                     \
+// one position of a block: JJ = its role in the row (0: the first point, accumulates into Z_0; 5: the last point, accumulates into the last
+// row sum; 1 .. 4: aside, folded in by W6Z_UPDATE / W6Z_UPDATE3), BUF = the LDS slab it reads (positions alternate), PP = its index in the
+// block, LAST = the block's last index
+#define W6Z_POSITION_AT(JJ, BUF, PP, LAST)                                                                       \
         {                                                                                                        \
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");                                            \
             __builtin_amdgcn_s_barrier();                                                                        \
             const float *nsrc;                                                                                   \
             {                                                                                                    \
-                const int pp = 6 * (i_) + (JJ);                                                                  \
-                int nb = pp < 6 * R - 1 ? b : b + (int)gridDim.x;                                                \
+                const int pp = (PP);                                                                             \
+                int nb = pp < (LAST) ? b : b + (int)gridDim.x;                                                   \
                 nb = nb < nblocks ? nb : b;                                                                      \
-                nsrc = V + (size_t)nb * W6_VBLOCK + (size_t)(pp < 6 * R - 1 ? pp + 1 : 0) * C;                   \
+                nsrc = V + (size_t)nb * W6_VBLOCK + (size_t)(pp < (LAST) ? pp + 1 : 0) * C;                      \
             }                                                                                                    \
-            const float *vb = wsm + ((JJ) & 1) * SLAB + j * CP + 4 * h;                                          \
+            const float *vb = wsm + (BUF) * SLAB + j * CP + 4 * h;                                               \
             f32x4 va[2][2];                                                                                      \
             va[0][0] = *reinterpret_cast<const f32x4 *>(vb);                                                     \
             va[0][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP);                                           \
-            W6GZ_(0, JJ, (JJ) & 1) W6GZ_(1, JJ, (JJ) & 1) W6GZ_(2, JJ, (JJ) & 1) W6GZ_(3, JJ, (JJ) & 1)                 \
-            W6GZ_(4, JJ, (JJ) & 1) W6GZ_(5, JJ, (JJ) & 1) W6GZ_(6, JJ, (JJ) & 1) W6GZ_(7, JJ, (JJ) & 1)                 \
-            W6GZ_(8, JJ, (JJ) & 1) W6GZ_(9, JJ, (JJ) & 1) W6GZ_(10, JJ, (JJ) & 1) W6GZ_(11, JJ, (JJ) & 1)               \
-            W6GZ_(12, JJ, (JJ) & 1) W6GZ_(13, JJ, (JJ) & 1) W6GZ_(14, JJ, (JJ) & 1) W6GZ_(15, JJ, (JJ) & 1)             \
-            W6GZ_(16, JJ, (JJ) & 1) W6GZ_(17, JJ, (JJ) & 1) W6GZ_(18, JJ, (JJ) & 1) W6GZ_(19, JJ, (JJ) & 1)             \
-            W6GZ_(20, JJ, (JJ) & 1) W6GZ_(21, JJ, (JJ) & 1) W6GZ_(22, JJ, (JJ) & 1) W6GZ_(23, JJ, (JJ) & 1)             \
-            W6GZ_(24, JJ, (JJ) & 1) W6GZ_(25, JJ, (JJ) & 1) W6GZ_(26, JJ, (JJ) & 1) W6GZ_(27, JJ, (JJ) & 1)             \
-            W6GZ_(28, JJ, (JJ) & 1) W6GZ_(29, JJ, (JJ) & 1) W6GZ_(30, JJ, (JJ) & 1) W6GZ_(31, JJ, (JJ) & 1)             \
+            W6GZ_(0, JJ, BUF) W6GZ_(1, JJ, BUF) W6GZ_(2, JJ, BUF) W6GZ_(3, JJ, BUF)                                     \
+            W6GZ_(4, JJ, BUF) W6GZ_(5, JJ, BUF) W6GZ_(6, JJ, BUF) W6GZ_(7, JJ, BUF)                                     \
+            W6GZ_(8, JJ, BUF) W6GZ_(9, JJ, BUF) W6GZ_(10, JJ, BUF) W6GZ_(11, JJ, BUF)                                   \
+            W6GZ_(12, JJ, BUF) W6GZ_(13, JJ, BUF) W6GZ_(14, JJ, BUF) W6GZ_(15, JJ, BUF)                                 \
+            W6GZ_(16, JJ, BUF) W6GZ_(17, JJ, BUF) W6GZ_(18, JJ, BUF) W6GZ_(19, JJ, BUF)                                 \
+            W6GZ_(20, JJ, BUF) W6GZ_(21, JJ, BUF) W6GZ_(22, JJ, BUF) W6GZ_(23, JJ, BUF)                                 \
+            W6GZ_(24, JJ, BUF) W6GZ_(25, JJ, BUF) W6GZ_(26, JJ, BUF) W6GZ_(27, JJ, BUF)                                 \
+            W6GZ_(28, JJ, BUF) W6GZ_(29, JJ, BUF) W6GZ_(30, JJ, BUF) W6GZ_(31, JJ, BUF)                                 \
+        }
+#define W6Z_POSITION(i_, JJ) W6Z_POSITION_AT(JJ, (JJ) & 1, 6 * (i_) + (JJ), 6 * R - 1)
+// rows of FIVE positions (class D': F(3)'s points 0, 1, -1, 2, inf; A3^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1]): the first point takes the JJ = 0
+// path, the last the JJ = 5 path -- F(3)'s third row sum lives in the registers (and in Z's slot b = 3) of F(4)'s fourth; b = 2 is not used
+#define W6Z_UPDATE3(IDX)                                                                                         \
+        _Pragma("unroll") for (int v = 0; v < 16; v++) {                                                         \
+            z00[v] += m0[v]; z01[v] += m1[v];                                                                    \
+            if ((IDX) == 1) { z10[v] = m0[v]; z11[v] = m1[v]; z30[v] = m0[v]; z31[v] = m1[v]; }                  \
+            if ((IDX) == 2) { z10[v] -= m0[v]; z11[v] -= m1[v]; z30[v] += m0[v]; z31[v] += m1[v]; }              \
+            if ((IDX) == 3) {                                                                                    \
+                z10[v] = __builtin_fmaf(2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(2.f, m1[v], z11[v]);        \
+                z30[v] = __builtin_fmaf(4.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(4.f, m1[v], z31[v]);        \
+            }                                                                                                    \
         }
 #define W6Z_UPDATE(JJ)                                                                                           \
         _Pragma("unroll") for (int v = 0; v < 16; v++) {                                                         \
@@ -407,6 +450,26 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
 #pragma unroll 1
     for (; b < nblocks; b += gridDim.x) {
         const int R = rows_of(b);
+        if (DP) {      // D': two rows of five positions per trip, so that the LDS slab of every position is a constant
+#pragma unroll 1
+            for (int i = 0; i < 8; i += 2) {
+                zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
+                W6Z_POSITION_AT(0, 0, 5 * i + 0, 39)
+                W6Z_POSITION_AT(1, 1, 5 * i + 1, 39) W6Z_UPDATE3(1)
+                W6Z_POSITION_AT(2, 0, 5 * i + 2, 39) W6Z_UPDATE3(2)
+                W6Z_POSITION_AT(3, 1, 5 * i + 3, 39) W6Z_UPDATE3(3)
+                W6Z_POSITION_AT(5, 0, 5 * i + 4, 39)
+                zprev = zcur;
+                zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)(i + 1) * (4 * C);
+                W6Z_POSITION_AT(0, 1, 5 * i + 5, 39)
+                W6Z_POSITION_AT(1, 0, 5 * i + 6, 39) W6Z_UPDATE3(1)
+                W6Z_POSITION_AT(2, 1, 5 * i + 7, 39) W6Z_UPDATE3(2)
+                W6Z_POSITION_AT(3, 0, 5 * i + 8, 39) W6Z_UPDATE3(3)
+                W6Z_POSITION_AT(5, 1, 5 * i + 9, 39)
+                zprev = zcur;
+            }
+            continue;
+        }
 #pragma unroll 1
         for (int i = 0; i < R; i++) {
             zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
@@ -425,7 +488,9 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
 #pragma unroll
     for (int k = 0; k < 8; k++) W6Z_STORE1(z30, z31, 3, zprev, k)
 #undef W6Z_UPDATE
+#undef W6Z_UPDATE3
 #undef W6Z_POSITION
+#undef W6Z_POSITION_AT
 #undef W6GZ_
 #undef W6Z_GROUP
 #undef W6Z_STORE1
@@ -443,7 +508,7 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
 // for the transposed classes D and B, a column for A and B').  Pixels beyond the board are dropped by the callers.
 template <typename VT>
 __device__ __forceinline__ void w6_slice_outputs(const VT (&z)[8], VT (&y)[6], int cls) {
-    if (cls == W6_CLS_D) {
+    if (cls == W6_CLS_D || cls == W6_CLS_DP) {
         const VT e1 = z[1] + z[2], o1 = z[1] - z[2], e2 = z[3] + z[4], o2 = z[3] - z[4], e3 = z[5] + z[6], o3 = z[5] - z[6];
         y[0] = (z[0] + e1) + (e2 + e3);
         y[1] = w4_fma(2.f, o2, w4_fma(0.5f, o3, o1));
@@ -472,13 +537,18 @@ struct W6OutCtx {
     const float *res;
     C6HeadFuse hd;
 };
+// Class D' (the six-wide tiles of the last tile row: F(3) down) shares D's slot layout of 4 row sums per row of positions, of which the
+// GEMM kernel fills b = 0, 1 and 3 (c6_w6_gemm_kernel: F(3)'s third row sum lives where F(4)'s fourth does): slice b = 2 does not exist and
+// slice 3 is output row 2.
+#define W6_SLICE_OK(CLS, b) (!((CLS) == W6_CLS_DP && (b) == 2))
+#define W6_SLICE_ROW(CLS, b) ((CLS) == W6_CLS_DP && (b) == 3 ? 2 : (b))
 // one tile of class CLS: everything about the class is a constant here (no run-time indexing of the register arrays)
 template <int CLS>
 __device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, long bd, int ty, int x0, int wd, int lane, int b0) {
     constexpr int C = W6_C, N = W6_N;
-    constexpr int rows = CLS == W6_CLS_D ? 8 : CLS == W6_CLS_A ? 6 : 5;
-    constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_B;      // the slice's pixels run along a row of the tile (else: along a column)
-    constexpr int npx = CLS == W6_CLS_D ? 6 : CLS == W6_CLS_A ? 4 : 3;
+    constexpr int rows = CLS == W6_CLS_D || CLS == W6_CLS_DP ? 8 : CLS == W6_CLS_A ? 6 : 5;
+    constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_DP || CLS == W6_CLS_B;      // the slice's pixels run along a row of the tile (else: along a column)
+    constexpr int npx = CLS == W6_CLS_D || CLS == W6_CLS_DP ? 6 : CLS == W6_CLS_A ? 4 : 3;
     // two slices per wave (b = b0, b0 + 1): their row sums are requested at once (up to 16 KiB in flight per wave), then consumed one by one
     // (the residual first: asked for where it is added, the load would wait behind its slice's arithmetic)
     f32x4 rv[2][npx];
@@ -487,9 +557,9 @@ __device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, 
         for (int bq = 0; bq < 2; bq++)
 #pragma unroll
             for (int k = 0; k < npx; k++) {
-                const int py = 4 * ty + (along_row ? b0 + bq : k), cx = along_row ? k : b0 + bq;
+                const int py = 4 * ty + (along_row ? W6_SLICE_ROW(CLS, b0 + bq) : k), cx = along_row ? k : b0 + bq;
                 rv[bq][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (py < N && cx < wd) rv[bq][k] = *reinterpret_cast<const f32x4 *>(X.res + ((size_t)bd * (N * N) + (size_t)(py * N + x0 + cx)) * C + lane * 4);
+                if (py < N && cx < wd && W6_SLICE_OK(CLS, b0 + bq)) rv[bq][k] = *reinterpret_cast<const f32x4 *>(X.res + ((size_t)bd * (N * N) + (size_t)(py * N + x0 + cx)) * C + lane * 4);
             }
     }
     f32x4 zt[2][8];
@@ -500,13 +570,14 @@ __device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, 
 #pragma unroll
     for (int bq = 0; bq < 2; bq++) {
         const int b = b0 + bq;
+        if (!W6_SLICE_OK(CLS, b)) continue;      // (uniform over the wave)
         f32x4 y[6];
         w6_slice_outputs(zt[bq], y, CLS);
         float hs[npx][3];
 #pragma unroll
         for (int k = 0; k < npx; k++) {
             hs[k][0] = 0.f; hs[k][1] = 0.f; hs[k][2] = 0.f;
-            const int py = 4 * ty + (along_row ? b : k), cx = along_row ? k : b, px = x0 + cx;
+            const int py = 4 * ty + (along_row ? W6_SLICE_ROW(CLS, b) : k), cx = along_row ? k : b, px = x0 + cx;
             if (py >= N || cx >= wd) continue;
             f32x4 v = y[k] + X.bi;
             if (X.res) v = v + rv[bq][k];
@@ -527,7 +598,7 @@ __device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, 
 #pragma unroll
         for (int k = 0; k < npx; k++)
             if ((lane & 15) == k) { m0 = hs[k][0]; m1 = hs[k][1]; m2 = hs[k][2]; }
-        const int k = lane & 15, py = 4 * ty + (along_row ? b : k), cx = along_row ? k : b, px = x0 + cx;
+        const int k = lane & 15, py = 4 * ty + (along_row ? W6_SLICE_ROW(CLS, b) : k), cx = along_row ? k : b, px = x0 + cx;
         if (lane >= 48 && k < npx && py < N && cx < wd) {
             const int p = py * N + px;
             const float y0 = m0 + X.hd.pc_b[0], y1 = m1 + X.hd.pc_b[1];
@@ -560,6 +631,7 @@ __global__ __launch_bounds__(256) void c6_w6_out_kernel(const float *__restrict_
         const int x0 = w6_x0(tx), wd = w6_width(tx);
         const float *zb = M + (size_t)map.slot(bd, ty, tx) * W6_ZTILE + lane * 4;
         if (cls == W6_CLS_D) w6_out_tile<W6_CLS_D>(X, zb, bd, ty, x0, wd, lane, b0);
+        else if (cls == W6_CLS_DP) w6_out_tile<W6_CLS_DP>(X, zb, bd, ty, x0, wd, lane, b0);
         else if (cls == W6_CLS_A) w6_out_tile<W6_CLS_A>(X, zb, bd, ty, x0, wd, lane, b0);
         else if (cls == W6_CLS_B) w6_out_tile<W6_CLS_B>(X, zb, bd, ty, x0, wd, lane, b0);
         else w6_out_tile<W6_CLS_BP>(X, zb, bd, ty, x0, wd, lane, b0);
@@ -581,10 +653,14 @@ template <int CLS, bool RS>
 __device__ __forceinline__ void w6_produce_tile(const float *zb, long bd, int t, int x0, int wd, int c, f32x2 bi, const float *res, float *act, const float *plane, float pv,
                                                 const float *swl, const float *s0, f32x2 sb, f32x2 (&r0)[6], f32x2 (&kn)[3][6]) {
     constexpr int C = W6_C, N = W6_N;
-    constexpr int rows = CLS == W6_CLS_D ? 8 : CLS == W6_CLS_A ? 6 : 5;
-    constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_B;
-    constexpr int npx = CLS == W6_CLS_D ? 6 : CLS == W6_CLS_A ? 4 : 3;
+    constexpr int rows = CLS == W6_CLS_D || CLS == W6_CLS_DP ? 8 : CLS == W6_CLS_A ? 6 : 5;
+    constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_DP || CLS == W6_CLS_B;
+    constexpr int npx = CLS == W6_CLS_D || CLS == W6_CLS_DP ? 6 : CLS == W6_CLS_A ? 4 : 3;
     const f32x2 zero2 = f32x2{0.f, 0.f};
+    if (CLS == W6_CLS_DP) {      // three output rows: the tile's fourth pixel row lies below the board (the next layer's zero padding)
+#pragma unroll
+        for (int k = 0; k < 6; k++) kn[2][k] = zero2;
+    }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         // the residual of the half's pixels is requested BEFORE the row sums: both are in flight together (asked for where it is added, the
@@ -595,9 +671,9 @@ __device__ __forceinline__ void w6_produce_tile(const float *zb, long bd, int t,
             for (int q = 0; q < 2; q++)
 #pragma unroll
                 for (int k = 0; k < (along_row ? 6 : 4); k++) {
-                    const int a = along_row ? 2 * h + q : k, cx = along_row ? k : 2 * h + q, py = 4 * t + a;
+                    const int a = along_row ? W6_SLICE_ROW(CLS, 2 * h + q) : k, cx = along_row ? k : 2 * h + q, py = 4 * t + a;
                     rv[q][k] = zero2;
-                    if (cx < wd && k < npx && py < N) rv[q][k] = *reinterpret_cast<const f32x2 *>(res + ((size_t)bd * (N * N) + (size_t)(py * N + x0 + cx)) * C + c);
+                    if (cx < wd && k < npx && py < N && W6_SLICE_OK(CLS, 2 * h + q)) rv[q][k] = *reinterpret_cast<const f32x2 *>(res + ((size_t)bd * (N * N) + (size_t)(py * N + x0 + cx)) * C + c);
                 }
         }
         f32x2 zt[2][8];
@@ -608,11 +684,12 @@ __device__ __forceinline__ void w6_produce_tile(const float *zb, long bd, int t,
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int b = 2 * h + q;
+            if (!W6_SLICE_OK(CLS, b)) continue;
             f32x2 y[6];
             w6_slice_outputs(zt[q], y, CLS);
 #pragma unroll
             for (int k = 0; k < (along_row ? 6 : 4); k++) {
-                const int a = along_row ? b : k, cx = along_row ? k : b;      // pixel (row a, column cx) of the tile
+                const int a = along_row ? W6_SLICE_ROW(CLS, b) : k, cx = along_row ? k : b;      // pixel (row a, column cx) of the tile
                 if (cx >= wd) continue;                                        // (uniform over the wave)
                 const int py = 4 * t + a;
                 f32x2 v = zero2;
@@ -692,6 +769,7 @@ __global__ __launch_bounds__(W6_MID_THREADS) void c6_w6_mid_kernel(const float *
                 const float *plane = planes + (p == 5 ? pbuf ^ 1 : pbuf) * PP;
                 const float pv = p == 5 ? pvn : pvc;
                 if (cls == W6_CLS_D) w6_produce_tile<W6_CLS_D, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+                else if (cls == W6_CLS_DP) w6_produce_tile<W6_CLS_DP, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
                 else if (cls == W6_CLS_A) w6_produce_tile<W6_CLS_A, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
                 else if (cls == W6_CLS_B) w6_produce_tile<W6_CLS_B, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
                 else w6_produce_tile<W6_CLS_BP, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
@@ -765,7 +843,7 @@ size_t c6_w6_vbuf_floats(int nboards) { return (size_t)w6_nblocks(nboards) * (W6
 
 // Transformed weights U = G_v g G_h^T (double, rounded once), four sets one behind the other: A (36 positions p = 6 i + j: F(4)'s G both
 // ways), B (30, p = 6 j + i: G4 vertically, G3 horizontally), B' (30, p = 6 i + j: G3 vertically, G4 horizontally), D (48, p = 6 j + i: G4
-// vertically, F(6)'s G horizontally).  A set is packed [wave][position][group u][lane][r]: U_p[cout = 32 wave + (lane & 31)][cin = 8u + 4(lane >> 5) + r].
+// vertically, F(6)'s G horizontally), D' (40, p = 5 j + i: G3 vertically, F(6)'s G horizontally).  A set is packed [wave][position][group u][lane][r]: U_p[cout = 32 wave + (lane & 31)][cin = 8u + 4(lane >> 5) + r].
 void c6_w6_pack_weights(const float *w, float *packed) {
     const double G4[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                              {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
@@ -779,13 +857,13 @@ void c6_w6_pack_weights(const float *w, float *packed) {
                              {32.0 / 45, -16.0 / 45, 8.0 / 45},
                              {0.0, 0.0, 1.0}};
     constexpr int C = W6_C, NG = C / 8;
-    const int npos[4] = {36, 30, 30, 48}, first[4] = {0, 36, 66, 96};
-    for (int set = 0; set < 4; set++)
+    const int npos[5] = {36, 30, 30, 48, 40}, first[5] = {0, 36, 66, 96, 144};
+    for (int set = 0; set < 5; set++)
         for (int wv = 0; wv < C / 32; wv++)
             for (int pos = 0; pos < npos[set]; pos++) {
-                const int p = pos / 6, q = pos % 6;
-                const double *gv = set == 0 ? G4[p] : set == 1 ? G4[q] : set == 2 ? G3[p] : G4[q];      // the row of G on the vertical side
-                const double *gh = set == 0 ? G4[q] : set == 1 ? G3[p] : set == 2 ? G4[q] : G6[p];      // ... and on the horizontal side
+                const int L = set == 4 ? 5 : 6, p = pos / L, q = pos % L;      // D': rows of five positions, p = 5 j + i
+                const double *gv = set == 0 ? G4[p] : set == 1 ? G4[q] : set == 2 ? G3[p] : set == 3 ? G4[q] : G3[q];      // the row of G on the vertical side
+                const double *gh = set == 0 ? G4[q] : set == 1 ? G3[p] : set == 2 ? G4[q] : G6[p];                          // ... and on the horizontal side
                 for (int u = 0; u < NG; u++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int r = 0; r < 4; r++) {
@@ -817,9 +895,13 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
     }
     if (steps & 2) {
         constexpr size_t smem = (size_t)2 * W6_BT * (W6_C + 4) * 4;
-        const int grid = nblocks < num_cus ? nblocks : num_cus;
-        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel), (int)smem);
-        hipLaunchKernelGGL(c6_w6_gemm_kernel, dim3(grid), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD);
+        const int n6 = (int)map.blkDP, n5 = nblocks - n6;      // blocks of the classes with rows of six positions / of class D'
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false>), (int)smem);
+        hipLaunchKernelGGL(c6_w6_gemm_kernel<false>, dim3(n6 < num_cus ? n6 : num_cus), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB, (int)map.blkBP,
+                           (int)map.blkD);
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true>), (int)smem);
+        hipLaunchKernelGGL(c6_w6_gemm_kernel<true>, dim3(n5 < num_cus ? n5 : num_cus), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, n6, nblocks, (int)map.blkB, (int)map.blkBP,
+                           (int)map.blkD);
     }
     if (steps & 16) {
         constexpr size_t rs_smem = win_smem + (size_t)18 * W6_C * 4 + (size_t)(W6_N + 2) * (W6_N + 2) * 4;
@@ -842,8 +924,8 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
     c6_note_hip(le, "launch of a c6_w6 kernel");
     return le == hipSuccess;
 }
-// matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 / 30 / 30 / 48 positions x C x C MACs)
+// matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 / 30 / 30 / 48 / 40 positions x C x C MACs)
 double c6_w6_exec_flops(int nboards) {
     const W6Map m(nboards);
-    return 2.0 * (36.0 * m.blkB + 30.0 * (m.blkD - m.blkB) + 48.0 * (m.nblocks - m.blkD)) * W6_BT * (double)W6_C * W6_C;
+    return 2.0 * (36.0 * m.blkB + 30.0 * (m.blkD - m.blkB) + 48.0 * (m.blkDP - m.blkD) + 40.0 * (m.nblocks - m.blkDP)) * W6_BT * (double)W6_C * W6_C;
 }

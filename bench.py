@@ -50,7 +50,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, de
 PEAK_HBM_GBS = 8000.0
 KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, description)
     "fp32": ("c6_w6_gemm_kernel", "FP32 Winograd, tiles 4 x {6, 6, 4, 3} across a 19-wide board (F(4,3) down, F(6,3) / F(4,3) / F(3,3) across; F(3,3) down in the "
-             "last tile row): the 48 / 36 / 30 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, the F(4) half of the output transform accumulated in "
+             "last tile row): the 48 / 40 / 36 / 30 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, the F(4) half of the output transform accumulated in "
              "registers; the transforms between the layers' GEMMs are HBM-bound kernels of their own (c6_w6_mid_kernel: output transform of a layer + "
              "input transform of the next)"),
     "fp32_direct": ("c6_conv3x3_f32n_kernel<256, 19>", "FP32 direct implicit GEMM, v_mfma_f32_32x32x2_f32"),
@@ -486,7 +486,7 @@ def main():
             if name == "fp32":
                 r["note"] = ("achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + "
                              "boundary-kernel time; algorithmic_tflops / algorithmic_ratio count 2*9*C^2*N^2 per board and layer (SURVEY 8d), of which this Winograd "
-                             "tiling executes 1 / 4.04 (804 products per channel pair and board instead of 3249)")
+                             "tiling executes 1 / 4.12 (788 products per channel pair and board instead of 3249)")
                 nbd, Cc, tiles = min(G * 8, 32768), wl["channels"], ((n + 3) // 4) ** 2
                 # between the GEMM kernels: one input transform in front of the tower, then ONE kernel per layer boundary (output transform of
                 # layer l + input transform of layer l + 1; the activations between the two convolutions of a block are never stored), and
@@ -495,8 +495,8 @@ def main():
                 tw = (n + 3) // 4
                 edge = 2 * tw - 1 if n % 4 == 3 else 0      # conv_wino4.hip's tiling: the last tile row / column is F(3,3) in one direction, 30 positions / 20 row sums
                 vpos, zrows = 36 * (tiles - edge) + 30 * edge, 24 * (tiles - edge) + 20 * edge
-                if n == 19 and Cc == 256 and wl["blocks"] - 1 >= 2:      # conv_wino6.hip: 10 tiles of 48 positions / 32 row sums, 4 of 36 / 24, 6 of 30 / 20
-                    vpos, zrows = 10 * 48 + 4 * 36 + 6 * 30, 10 * 32 + 4 * 24 + 6 * 20
+                if n == 19 and Cc == 256 and wl["blocks"] - 1 >= 2:      # conv_wino6.hip: 8 tiles of 48 positions / 32 row sums, 2 of 40 / 32, 4 of 36 / 24, 6 of 30 / 20
+                    vpos, zrows = 8 * 48 + 2 * 40 + 4 * 36 + 6 * 30, 10 * 32 + 4 * 24 + 6 * 20
                 act_b, v_b, z_b = n * n * Cc * 4 * nbd, vpos * Cc * 4 * nbd, zrows * Cc * 4 * nbd
                 # V: the transformed positions of a tile, GEMM input; Z: the row sums the GEMM kernel leaves (the F(4) half of the output
                 # transform applied in its registers).  First layer: V written from the boards (the stem is computed, not read); inside a block:

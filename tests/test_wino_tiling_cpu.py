@@ -1,7 +1,7 @@
 """The Winograd constants of the FP32 evaluator (csrc/c6_wino.h, csrc/conv_wino6.hip, csrc/conv_wino4.hip), written out here as the kernels
 use them, against the direct 3x3 convolution in float64 (model.hpp:61-78: conv3x3, padding 1) -- one channel pair, every tile class of the
-19x19 tiling of conv_wino6.hip (columns 6 + 6 + 4 + 3, rows 4 + 4 + 4 + 4 + 3; the six-wide tiles keep F(4,3) in the last tile row) and of the
-F(4,3) / F(3,3) tiling of conv_wino4.hip.  Host arithmetic only: it pins the matrices and the position counts (804 / 846 per channel pair and
+19x19 tiling of conv_wino6.hip (columns 6 + 6 + 4 + 3, rows 4 + 4 + 4 + 4 + 3) and of the
+F(4,3) / F(3,3) tiling of conv_wino4.hip.  Host arithmetic only: it pins the matrices and the position counts (788 / 846 per channel pair and
 19x19 board, 534 at 15x15), the kernels themselves are held to 1e-5 against the oracle in tests/test_gpu_net.py."""
 import numpy as np
 
@@ -58,11 +58,14 @@ def test_wino6_tiling_of_the_19_board():
     ref, xp = direct(x, g)
     cols = [(0, 6, 6), (6, 6, 6), (12, 4, 4), (16, 3, 3)]
     rows = [(0, 4, 4), (4, 4, 4), (8, 4, 4), (12, 4, 4), (16, 3, 3)]
-    # class D (six wide) keeps F(4,3) down the board in the last tile row too (its fourth output row lies beyond the board); the corner tile is
-    # class B' (F(3,3) down, F(4,3) across, three of its four columns used)
-    out, npos = tiled(xp, g, n, rows, cols, lambda ty, tx, mv, mh: (4 if tx < 2 else mv, 4 if (ty == 4 and tx == 3) else mh))
-    assert npos == 804 == 10 * 48 + 4 * 36 + 4 * 30 + 2 * 30
+    # r4: the six-wide tiles of the last tile row are class D' (F(3,3) down, F(6,3) across: 5 x 8 positions); the corner tile is class B'
+    # (F(3,3) down, F(4,3) across, three of its four columns used)
+    out, npos = tiled(xp, g, n, rows, cols, lambda ty, tx, mv, mh: (mv, 4 if (ty == 4 and tx == 3) else mh))
+    assert npos == 788 == 8 * 48 + 2 * 40 + 4 * 36 + 4 * 30 + 2 * 30
     assert np.abs(out - ref).max() < 1e-11
+    # round 3's tiling (class D kept F(4,3) down the board in the last tile row: its fourth output row lies beyond the board)
+    out, npos = tiled(xp, g, n, rows, cols, lambda ty, tx, mv, mh: (4 if tx < 2 else mv, 4 if (ty == 4 and tx == 3) else mh))
+    assert npos == 804 and np.abs(out - ref).max() < 1e-11
 
 
 def test_wino4_tiling_of_the_19_and_15_boards():
@@ -88,3 +91,10 @@ def test_z_rows_are_half_of_the_output_transform():
         z = m @ F[4][0].T                                   # [rows of positions][b = 4]
         assert z.shape == (mv + 2, 4)
         assert np.abs(F[mv][0] @ z - F[mv][0] @ m @ F[4][0].T).max() < 1e-12
+    # class D' (r4): rows of FIVE positions, Z_i[b] = sum_j A3^T[b][j] M[i][j], three row sums per row of positions; the GEMM kernel keeps the third in
+    # the registers (and in Z's slot b = 3) of F(4)'s fourth: built from the points (0, 1, -1, 2, inf) exactly as W6Z_UPDATE3 does
+    m = rng.standard_normal((8, 5))
+    z0 = m[:, 0] + m[:, 1] + m[:, 2] + m[:, 3]
+    z1 = m[:, 1] - m[:, 2] + 2 * m[:, 3]
+    z3 = m[:, 1] + m[:, 2] + 4 * m[:, 3] + m[:, 4]
+    assert np.abs(np.stack([z0, z1, z3], 1) - m @ F[3][0].T).max() < 1e-12
