@@ -310,7 +310,8 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
 
         int cidx[J], cvis[J];
         float cq[J], cpr[J];
-        int vs = 0;
+        unsigned long long zmine[J];      // the Zobrist keys of the lane's cells: the chosen one's is read from its owner's register below (r4: `zk[chosen]`
+        int vs = 0;                       // after the choice was a memory round trip of its own on the way to the next level)
         if (d == 0 && R.rootc_ok) {
             // the root: its children are one contiguous row
             const uint2 *rc = reinterpret_cast<const uint2 *>(E.rootc + (size_t)g * E.cellsP);
@@ -321,6 +322,7 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
                 const bool mine = L.st[j] == 0;
                 v[j] = rc[mine ? c : 0];
                 cpr[j] = mine ? prior[c] : 0.f;
+                zmine[j] = zk[mine ? c : 0];
             }
 #pragma unroll
             for (int j = 0; j < J; j++) {
@@ -343,7 +345,8 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
             for (int j = 0; j < J; j++) {
                 const int c = lane + 64 * j;
                 const bool mine = L.st[j] == 0;
-                ck[j] = key ^ zk[mine ? c : 0];
+                zmine[j] = zk[mine ? c : 0];
+                ck[j] = key ^ zmine[j];
                 cslot[j] = ht_home(ck[j], H);
                 budget[j] = H;
                 hit[j] = mine && tag_seek(T, c6_ht_tag_of(ck[j]), cslot[j], budget[j]);
@@ -453,7 +456,13 @@ __device__ __forceinline__ void select_wave(const C6Dev &E, int g, int lane, dou
         if (d < 64) { if (lane == d) L.my_path = step; }
         else if (lane == 0) E.path_rec[(size_t)g * E.maxd + d] = (uint32_t)step;      // beyond 64 steps: through memory
         d++;
-        key ^= zk[chosen];
+        {
+            unsigned long long zc = 0ull;
+#pragma unroll
+            for (int j = 0; j < J; j++) if (j == cj) zc = zmine[j];
+            const int cls_ = __builtin_amdgcn_readfirstlane(cl);
+            key ^= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(zc >> 32), cls_) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)zc, cls_);
+        }
 #pragma unroll
         for (int j = 0; j < J; j++) if (j == cj && lane == cl) L.st[j] = (int8_t)turn;
         next_turn(turn, remain);
@@ -639,10 +648,20 @@ __device__ __forceinline__ int wave_winner(const int8_t *board, int N, int lane)
 // strictly increase along a path).  `prob` = the evaluated prior of the leaf, cells floats (global eval_prior, or the wave's LDS
 // scratch inside the fused search kernel); `board` = the leaf position as bytes (terminal leaves only); L.st = the same in registers.
 // Returns true when the game's simulation budget for this move is spent (the caller then runs policy()).
+// what expand_wave changed of the game's registers (C6GameRegs), for a caller that plays the next round of the same game without reading the
+// header back (c6_search_kernel): ok = the round took the ordinary path (nothing but the counters, the allocation mask and possibly the root's record
+// changed); took = records allocated (0 for a terminal leaf); left = the allocation page's free mask afterwards; new_root = the root's record if
+// this round created it, else -1
+struct C6Carry {
+    bool ok;
+    int took, new_root;
+    unsigned long long left;
+};
 template <int J>
 __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, const C6Tags &T, const C6GameRegs<J> &R, const C6Leaf<J> &L, float evalue,
-                                            const float *prob, const int8_t *board) {
+                                            const float *prob, const int8_t *board, C6Carry &K) {
     const int cells = E.cells;
+    K.ok = true; K.took = 0; K.new_root = -1; K.left = R.alloc_mask;
     const int kind = L.kind, len = L.len, level = L.level, turn = L.turn;
     const unsigned long long key = L.key;
     const int top = R.top, sim_in_move = R.sim_in_move;
@@ -675,6 +694,7 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         // (reprovision_wave), so this cannot run dry; if it ever did, the game stops with an error instead of writing anywhere.
         if (top <= 0 || R.alloc_mask == 0ull) {
             if (lane == 0) E.hdr[g].status = C6_ST_ERROR;
+            K.ok = false;
             return false;
         }
         const int bit = __ffsll((long long)R.alloc_mask) - 1;
@@ -684,11 +704,12 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
         value = evalue;
         float *prior = E.rec_prior + at * (size_t)cells;
         for (int c = lane; c < cells; c += 64) prior[c] = prob[c];      // child.n_prob = prob[r][c], mod.rs:370
+        int inserted = 1;
         if (lane == 0) {
             E.hdr[g].free_top = top - 1;
             E.page_free[T.pt[R.alloc_page]] = left;
             const int slot = ht_insert(T, key, idx, 1, 0.f);
-            if (slot < 0) E.hdr[g].status = C6_ST_ERROR;
+            if (slot < 0) { E.hdr[g].status = C6_ST_ERROR; inserted = 0; }
             C6RecStat rs;
             rs.visit = 1;             // parent_node.visit += 1, mod.rs:356 (was 0: never expanded)
             rs.value = value; rs.qsum = 0.f; rs.q = 0.f;
@@ -703,6 +724,10 @@ __device__ __forceinline__ bool expand_wave(const C6Dev &E, int g, int lane, con
             const uint32_t used = (uint32_t)(held * C6_PAGE_RECS - (top - 1));
             if (used > maxrec) E.hdr[g].g_maxrec = used;
         }
+        K.took = 1;
+        K.left = left;
+        K.new_root = len == 0 ? idx : -1;
+        K.ok = left != 0ull && __builtin_amdgcn_readfirstlane(inserted) != 0;      // (a used-up allocation page: the header names the next one)
         if (left == 0ull && top - 1 > 0) {
             // the allocation page is used up: the next page (in logical order, wrapping) that has a free record.  Once in 64 expansions.
             int next = -1;
@@ -1350,8 +1375,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, J <= 2 ? C6_OCC2 : (J <= 4 ? 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (L.len > 64) __threadfence();      // path steps beyond 64 went through memory
         C6_STAMP(C6_PH_EVAL, C6_PH_EXPAND);
-        const bool spent = expand_wave<J>(E, g, lane, T, R, L, value, probs, lboard);
+        const bool had_root = R.root_rec >= 0;
+        C6Carry K;
+        const bool spent = expand_wave<J>(E, g, lane, T, R, L, value, probs, lboard, K);
         C6_STAMP(C6_PH_EXPAND, C6_PH_MOVE);
+        if (K.ok && !spent) {
+            // The ordinary round (r4): the game belongs to this wave alone, so what the next round needs of the header is known without reading it
+            // back -- two dependent memory round trips (the header line, then the allocation page's free mask) per round.  What this round wrote
+            // (records, table entries, the root's row) is read by the same wave: wavefront scope orders it, no wait for the stores to land.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            C6_STAMP(C6_PH_MOVE, C6_PH_HEAD);
+            if (++it >= nsims) break;
+            R.nsearch += 1u;
+            R.sim_in_move += 1;
+            R.top -= K.took;
+            R.alloc_mask = K.left;
+            if (K.new_root >= 0) R.root_rec = K.new_root;
+            if (had_root) R.rootc_ok = 1;      // select's first scan of a root writes its row (select_wave, d == 0)
+            continue;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // what this round wrote is read back below / by the next round
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (spent) {
@@ -1433,7 +1476,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void c6_expand_kernel(C6Dev E
     C6Tags T;
     tags_load(E, g, lane, c6_tag_lds + (size_t)wv * c6_wave_lds(E.hcap, E.pages_cap), T);
     free_record_prefetch<J>(E, T, R);
-    if (expand_wave<J>(E, g, lane, T, R, L, evalue, E.eval_prior + (size_t)g * E.cells, E.leaf_board + (size_t)g * E.cellsP)) {
+    C6Carry K;
+    if (expand_wave<J>(E, g, lane, T, R, L, evalue, E.eval_prior + (size_t)g * E.cells, E.leaf_board + (size_t)g * E.cellsP, K)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         move_select_wave<J>(E, g, lane, T);
