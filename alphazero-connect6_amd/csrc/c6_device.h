@@ -76,12 +76,11 @@ __device__ __forceinline__ c6_f2 c6_log4(c6_f2 x) {
     c6_f2 m, fe;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        const uint32_t b = __float_as_uint(x[i]);
-        int e = (int)((b >> 23) & 0xff) - 127;
-        float mm = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
-        if (mm > 1.41421356f) { mm = mm * 0.5f; e += 1; }
-        m[i] = mm;
-        fe[i] = (float)e;
+        // the spec's split -- e = exponent, mm = mantissa in [1, 2); mm > 1.41421356f (bits above 0x3fb504f3): mm / 2, e + 1 -- in three integer
+        // operations (r4): with the bias 0x3f3504f4 the subtraction carries into the exponent exactly for the mantissas that are halved
+        const uint32_t t = __float_as_uint(x[i]) - 0x3f3504f4u;
+        m[i] = __uint_as_float((t & 0x007fffffu) + 0x3f3504f4u);
+        fe[i] = (float)((int)t >> 23);
     }
     const c6_f2 y = m - 1.0f, z = y * y;
     c6_f2 p = c6_f2{7.0376836292e-2f, 7.0376836292e-2f};
@@ -105,7 +104,7 @@ __device__ __forceinline__ c6_f2 c6_exp4(c6_f2 t, c6_i2 &k) {
     c6_f2 fk;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        k[i] = (int)(tt[i] + (tt[i] >= 0.0f ? 0.5f : -0.5f));
+        k[i] = (int)(tt[i] + __builtin_copysignf(0.5f, tt[i]));      // (= tt >= 0 ? +0.5 : -0.5 wherever it matters: (int)(-0.0f +- 0.5f) is 0 either way)
         fk[i] = (float)k[i];
     }
     c6_f2 r = c6_fma2(fk, -0.693359375f, t);

@@ -49,7 +49,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, description)
-    "fp32": ("c6_w6_gemm_kernel", "FP32 Winograd, tiles 4 x {6, 6, 4, 3} across a 19-wide board (F(4,3) down, F(6,3) / F(4,3) / F(3,3) across; F(3,3) down in the "
+    "fp32": ("c6_w6_gemm_kernel<false>", "FP32 Winograd, tiles 4 x {6, 6, 4, 3} across a 19-wide board (F(4,3) down, F(6,3) / F(4,3) / F(3,3) across; F(3,3) down in the "
              "last tile row): the 48 / 40 / 36 / 30 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, the F(4) half of the output transform accumulated in "
              "registers; the transforms between the layers' GEMMs are HBM-bound kernels of their own (c6_w6_mid_kernel: output transform of a layer + "
              "input transform of the next)"),
@@ -66,11 +66,15 @@ def net_flops_per_board(n, C, blocks):
     return 2 * 9 * 2 * C * n2 + (blocks - 1) * 2 * (2 * 9 * C * C * n2) + heads
 
 
-def kernel_source_hash():
-    """identity of the kernel sources: a committed PMC summary is only replayed while it describes THESE kernels"""
+CONV_SOURCES = ("conv_wino6.hip", "c6_wino.h", "net_kernels.hip")      # what the FP32 tower's kernels (the ones the PMC summary describes) are compiled from
+
+
+def kernel_source_hash(names=None):
+    """identity of kernel sources (all of csrc/, or the named files): a committed PMC summary is only replayed while it describes THESE kernels
+    (`names=CONV_SOURCES`: an edit of the tree kernels does not make the convolution kernels' counters stale)"""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "alphazero-connect6_amd", "csrc", "*"))):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h", ".cpp")) and (names is None or os.path.basename(f) in names):
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -86,7 +90,7 @@ def pmc_record(kernel_substr):
         return {}
     try:
         d = json.load(open(files[-1]))
-        if d.get("src_hash") != kernel_source_hash():
+        if d.get("src_hash") != kernel_source_hash(CONV_SOURCES) and d.get("src_hash") != kernel_source_hash():
             return {}
         for k, v in d["kernels"].items():
             if kernel_substr in k:
@@ -443,8 +447,8 @@ def main():
                 board_side["cases"].append({"games": games, "launch": "search-only" if scan else "board-step", "us_per_launch": 1e3 * ms,
                                             "algorithmic_gbs": b / ms / 1e6, "frac": b / ms / 1e6 / PEAK_HBM_GBS})
         c5 = WORKLOADS["config5"]
-        k = 256
-        tm = measure(0, k, 32, evaluator=pkg.EVAL_UNIFORM, settle_rounds=int(c5["sims"] * c5["stones_prior"]), geom=(c5["n"], c5["games"], c5["sims"]), chunk=64)
+        k = 2048      # (r4: 256 rounds were 32 ms -- the ~2 ms of synchronisation around the timed region read as +7 % per round)
+        tm = measure(0, k, 64, evaluator=pkg.EVAL_UNIFORM, settle_rounds=int(c5["sims"] * c5["stones_prior"]), geom=(c5["n"], c5["games"], c5["sims"]), chunk=64)
         d_ = tm["st"]["select_steps"] / max(tm["st"]["simulations"], 1)
         bsim = (12.0 * d_ + 13.0) * c5["n"] ** 2
         tree_ms = tm["prof"]["select_ms"] + tm["prof"]["expand_ms"]
@@ -474,8 +478,11 @@ def main():
             # a fraction of a roof, <= 1).  The algorithmic count of SURVEY 8d (2*9*C^2*N^2 per board and layer) is reported beside it:
             # Winograd executes 3.8x fewer products than that, so algorithmic / peak is a ratio, not a roofline fraction.
             ach = exe if name.startswith("fp32") else alg
+            traffic = rec.get("hbm_bytes_per_launch")
+            if name == "fp32" and traffic is not None:      # a layer's GEMM is two launches: the blocks with rows of six positions (<false>, 98.7 % of the work) and of five (<true>)
+                traffic += pmc_record("c6_w6_gemm_kernel<true>").get("hbm_bytes_per_launch", 0.0)
             r = {"bound": "mfma", "kernel": f"{kern} ({desc})", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                 "traffic": rec.get("hbm_bytes_per_launch"), "avg_launch_ms": gemm_ms / L, "launches": prof["conv_launches"],
+                 "traffic": traffic, "avg_launch_ms": gemm_ms / L, "launches": prof["conv_launches"],
                  "algorithmic_flops_per_launch": prof["conv_flops"] / L, "executed_flops_per_launch": prof["conv_exec_flops"] / L,
                  "algorithmic_tflops": alg, "algorithmic_ratio": alg / peak,
                  "executed_mfma_tflops": exe, "conv_share_of_step": prof["conv_ms"] / (1000.0 * dt_)}
@@ -484,7 +491,9 @@ def main():
             # alternate: their times add)
             r["layer_frac"] = prof["conv_exec_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 / peak
             if name == "fp32":
-                r["note"] = ("achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + "
+                r["note"] = ("a layer's GEMM is two launches of one kernel template -- c6_w6_gemm_kernel<false> (the tile classes with rows of six positions: 98.7 % of the "
+                             "products) then <true> (class D', rows of five) -- timed together: avg_launch_ms, achieved and traffic are per layer = the pair; "
+                             "achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + "
                              "boundary-kernel time; algorithmic_tflops / algorithmic_ratio count 2*9*C^2*N^2 per board and layer (SURVEY 8d), of which this Winograd "
                              "tiling executes 1 / 4.12 (788 products per channel pair and board instead of 3249)")
                 nbd, Cc, tiles = min(G * 8, 32768), wl["channels"], ((n + 3) // 4) ** 2

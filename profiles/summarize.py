@@ -18,7 +18,7 @@ import bench  # noqa: E402  (kernel_source_hash: bench.py replays this summary o
 stats = max(glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
 out = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-probe",
-       "src_hash": bench.kernel_source_hash(),
+       "src_hash": bench.kernel_source_hash(bench.CONV_SOURCES), "src_hash_of": list(bench.CONV_SOURCES),
        "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE counts 128-B requests at 64 B, so "
                     "hbm_read_bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM); WRITE_SIZE * 1024 is exact", "kernels": {}}
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
