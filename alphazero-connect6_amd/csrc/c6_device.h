@@ -6,7 +6,7 @@
 //    (reference call sites: policy/alphazero_policy/mod.rs:262,283,294,145,163).
 //    Only IEEE +,-,*,/ and sqrt are used (no fma contraction: this translation unit
 //    is compiled with -ffp-contract=off) plus explicitly written fused multiply-adds (v4: correctly rounded on both
-//    sides), so the stream is bit-reproducible.  C6RNG v4: Gamma variates are (float mantissa, integer exponent) pairs,
+//    sides), so the stream is bit-reproducible.  C6RNG v4 / v5: Gamma variates are (float mantissa, integer exponent) pairs,
 //    their normaliser is single precision on exponents relative to the largest of the vector -- no double anywhere.
 //  * wave64 reductions used by the tree kernels.
 #pragma once
@@ -15,7 +15,7 @@
 
 // the specification the random stream follows: games are a function of (this, the net's arithmetic, weights, seed, S) -- the
 // whole-game parity tests pin engine and oracle to the same games for one specification
-#define C6_RNG_SPEC "C6RNG v4"
+#define C6_RNG_SPEC "C6RNG v5"
 
 #define C6_BLACK (-1)
 #define C6_NONE 0
@@ -32,9 +32,10 @@
 
 struct c6_u4 { uint32_t x, y, z, w; };
 
+template <int ROUNDS = 10>
 __device__ __forceinline__ c6_u4 c6_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32) instead of a high and a low multiplication
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
         uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -62,7 +63,7 @@ __device__ __forceinline__ float c6_open01f(uint32_t w) { return ((float)(w >> 8
 // m * 2^k for a normal float m and -126 <= k <= 127 with a normal result: exact
 __device__ __forceinline__ float c6_scale2f(float m, int k) { return __builtin_amdgcn_ldexpf(m, k); }      // v_ldexp_f32: one instruction, the same bits
 
-// ---- C6RNG v4: the Gamma sampler -------------------------------------------------------------------------------------------
+// ---- C6RNG v5: the Gamma sampler -------------------------------------------------------------------------------------------
 // log and exp of the sampler: polynomial forms (Cephes' logf / expf coefficients) on explicitly fused multiply-adds -- no division, no
 // table; a value pair at a time (the two attempts of a Philox block) on the packed f32 instructions.  |error| ~ 1e-7: what the
 // sampler owes the reference is a DISTRIBUTION (below); the routines are part of the spec, the oracle evaluates the same operations.
@@ -127,48 +128,49 @@ __device__ __forceinline__ float c6_exp4(float t, int &k) { c6_i2 kk; const c6_f
 struct c6_gam { float m; int k; };
 #define C6_GAM_NONE (-(1 << 30))      // exponent of "no variate" (a cell that needs none): never the largest, scales to 0
 
-// Gamma(alpha, 1).  C6RNG v4.  Attempts 2 i and 2 i + 1 of a cell come out of ONE Philox block (counter word c1 = i; words x, y serve
-// the even attempt, z, w the odd one) and are evaluated TOGETHER, a pair of values per packed instruction; a cell's variate is that of
-// its first accepted attempt.  Attempts are independent of one another, so who evaluates them, and in which order, is free
-// (c6_wave_gamma below spreads them over the wave).  Single precision (the reference casts the noise to f32 before it is used,
-// alphazero_policy/mod.rs:283).
-//  * alpha < 1 (the reference's 0.03): Ahrens-Dieter GS.  b = 1 + alpha/e, p = b u1, E = -log(u2) (an Exp(1) variate).
-//      p <= 1:  x = p^(1/alpha) = exp(log(p) / alpha), accepted iff x <= E           (<=> u2 <= exp(-x))
-//      p >  1:  x = -log((b - p) / alpha),            accepted iff E >= (1 - alpha) log(x)   (<=> u2 <= x^(alpha - 1))
-//    One log of the branch's argument, one log of u2 and one exp per attempt; 97 % of the attempts are accepted, a pair fails once
-//    in ~1000.  (v3 evaluated the attempts one after the other with a division in its log, unfused polynomials, a second exp for the
-//    acceptance test and variates in double; v2 drew Marsaglia-Tsang at alpha + 1 times U^(1/alpha) as rand 0.6 does for small shapes.
-//    The distribution is the same -- tests/test_oracle_rng.py: Kolmogorov-Smirnov and moments on both branches; the select kernel
-//    spends its arithmetic here.)
+// Gamma(alpha, 1).  C6RNG v5.  Attempts 2 i and 2 i + 1 of a cell come out of ONE Philox block (counter word c1 = i; words x, y serve
+// the even attempt, z, w the odd one; the noise draws' blocks are Philox4x32-SEVEN) and are evaluated TOGETHER, a pair of values per packed
+// instruction; a cell's variate is that of its first accepted attempt.  Attempts are independent of one another, so who evaluates them, and
+// in which order, is free (c6_wave_gamma below spreads them over the wave).  Single precision (the reference casts the noise to f32 before it
+// is used, alphazero_policy/mod.rs:283).
+//  * alpha < 1 (the reference's 0.03): rejection from a two-piece proposal ("GS with a Pareto tail"): q1 = alpha x^(alpha-1) on (0, 1], q2 = beta
+//    x^(-beta-1) on (1, inf), beta = 1 - alpha, weights 1 : alpha / (e beta).  b = 1 + alpha / (e beta), p = b u1, E = -log(u2) (an Exp(1) variate).
+//      p <= 1:  x = p^(1/alpha)  = exp(log(p) / alpha),                                    accepted iff x <= E                (<=> u2 <= e^-x)
+//      p >  1:  x = u'^(-1/beta) = exp(-log(u') / beta), u' = (b - p) e beta / alpha,     accepted iff E >= (x - 1) - log(x)  (<=> u2 <= x e^(1-x))
+//    ONE sequence for both branches: a log of the branch's argument, a multiplication by the branch's constant, an exp, a comparison against
+//    E.  97 % of the attempts are accepted, a pair fails once in ~1000.  (v4 was Ahrens-Dieter GS: its tail x = -log((b - p) / alpha), accepted iff
+//    E >= (1 - alpha) log(x), needs a second logarithm -- executed by the whole wave whenever one of its ~94 attempts fell into the tail, 6 passes in
+//    10.  The distribution is the same: tests/test_oracle_rng.py, Kolmogorov-Smirnov and moments on both branches.)
 //  * alpha >= 1: Marsaglia-Tsang at shape alpha + 1 times U^(1/alpha) with polar normals (words: v1, v2, squeeze u, power u), one
 //    attempt per Philox block (counter word c1 = attempt).
-__device__ __forceinline__ bool c6_gamma_gs2(float a, float ia, float b, c6_u4 w, c6_gam &out) {
+struct c6_gs_consts { float ia, ib, b, ct; };      // 1 / alpha, -1 / beta, b, e beta / alpha: IEEE single precision (the oracle computes the same bits)
+__device__ __forceinline__ c6_gs_consts c6_gs_setup(float a) {
+    const float beta = 1.0f - a, eb = 2.7182817f * beta;
+    return c6_gs_consts{1.0f / a, -1.0f / beta, 1.0f + a / eb, eb / a};
+}
+__device__ __forceinline__ bool c6_gamma_gs2(const c6_gs_consts &G, c6_u4 w, c6_gam &out) {
     const c6_f2 u1 = {c6_open01f(w.x), c6_open01f(w.z)}, u2 = {c6_open01f(w.y), c6_open01f(w.w)};
-    const c6_f2 p = u1 * b;
-    const c6_f2 y = (b - p) * ia;
-    const bool b1[2] = {p[0] <= 1.0f, p[1] <= 1.0f};
-    c6_f2 arg = {b1[0] ? p[0] : y[0], b1[1] ? p[1] : y[1]};
+    const c6_f2 p = u1 * G.b;
+    const c6_f2 y = (G.b - p) * G.ct;
+    const bool tl[2] = {!(p[0] <= 1.0f), !(p[1] <= 1.0f)};
+    c6_f2 arg = {tl[0] ? y[0] : p[0], tl[1] ? y[1] : p[1]};
     const bool bad[2] = {!(arg[0] > 0.0f), !(arg[1] > 0.0f)};      // p rounded up to b: the attempt is rejected
     if (bad[0]) arg[0] = 1.0f;
     if (bad[1]) arg[1] = 1.0f;
     const c6_f2 L = c6_log4(arg), E = 0.0f - c6_log4(u2);
+    const c6_f2 t = L * c6_f2{tl[0] ? G.ib : G.ia, tl[1] ? G.ib : G.ia};
     c6_i2 k;
-    const c6_f2 m = c6_exp4(L * ia, k);
+    const c6_f2 m = c6_exp4(t, k);
     bool acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; i++) acc[i] = k[i] < -30 || c6_scale2f(m[i], k[i] < -30 ? -30 : k[i]) <= E[i];      // below 2^-30 every E (>= 2^-25) accepts
-    c6_f2 x2 = {1.0f, 1.0f};
-    if (!(b1[0] && b1[1])) {      // 1 % of the attempts
-        x2 = 0.0f - L;
-        const c6_f2 lx = c6_log4(c6_f2{b1[0] ? 1.0f : x2[0], b1[1] ? 1.0f : x2[1]});
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-            if (!b1[i]) acc[i] = !bad[i] && E[i] >= (1.0f - a) * lx[i];
+    for (int i = 0; i < 2; i++) {
+        const float x = c6_scale2f(m[i], !tl[i] && k[i] < -30 ? -30 : k[i]);      // body: below 2^-30 every E (>= 2^-25) accepts; tail: k <= 18
+        acc[i] = !bad[i] && (tl[i] ? E[i] >= (x - 1.0f) - t[i] : (k[i] < -30 || x <= E[i]));
     }
     const int i = acc[0] ? 0 : 1;
     if (!acc[i]) return false;
-    out.m = b1[i] ? m[i] : x2[i];
-    out.k = b1[i] ? k[i] : 0;
+    out.m = m[i];
+    out.k = k[i];
     return true;
 }
 
@@ -177,7 +179,7 @@ __device__ __forceinline__ bool c6_gamma_mt(double alpha, double d_, double c_, 
                                             uint32_t search, uint32_t depth, uint32_t att, c6_gam &out) {
     const uint32_t tag = C6_TAG_NOISE | (depth << 8);
     const float inv_alpha = 1.0f / (float)alpha;
-    const c6_u4 w = c6_philox(cell, att, search, tag, k0, k1);
+    const c6_u4 w = c6_philox<7>(cell, att, search, tag, k0, k1);
     const float d = (float)d_, c = (float)c_;
     const float v1 = 2.0f * c6_open01f(w.x) - 1.0f, v2 = 2.0f * c6_open01f(w.y) - 1.0f;
     const float s = v1 * v1 + v2 * v2;
@@ -198,12 +200,9 @@ __device__ __forceinline__ bool c6_gamma_mt(double alpha, double d_, double c_, 
 }
 
 // attempts 2 * pair and 2 * pair + 1 of a cell: true and the variate of the first accepted one
-__device__ __forceinline__ bool c6_gamma_try2(double alpha, double d_, double c_, uint32_t k0, uint32_t k1, uint32_t cell,
+__device__ __forceinline__ bool c6_gamma_try2(double alpha, const c6_gs_consts &G, double d_, double c_, uint32_t k0, uint32_t k1, uint32_t cell,
                                               uint32_t search, uint32_t depth, uint32_t pair, c6_gam &out) {
-    if (alpha < 1.0) {
-        const float a = (float)alpha, ia = 1.0f / a, b = __builtin_fmaf(a, 0.36787944f, 1.0f);
-        return c6_gamma_gs2(a, ia, b, c6_philox(cell, pair, search, C6_TAG_NOISE | (depth << 8), k0, k1), out);
-    }
+    if (alpha < 1.0) return c6_gamma_gs2(G, c6_philox<7>(cell, pair, search, C6_TAG_NOISE | (depth << 8), k0, k1), out);
     if (c6_gamma_mt(alpha, d_, c_, k0, k1, cell, search, depth, 2u * pair, out)) return true;
     return c6_gamma_mt(alpha, d_, c_, k0, k1, cell, search, depth, 2u * pair + 1u, out);
 }
@@ -211,8 +210,9 @@ __device__ __forceinline__ bool c6_gamma_try2(double alpha, double d_, double c_
 __device__ __forceinline__ c6_gam c6_gamma_draw(double alpha, double d, double c, uint32_t k0, uint32_t k1, uint32_t cell,
                                                 uint32_t search, uint32_t depth) {
     c6_gam g;
+    const c6_gs_consts G = c6_gs_setup((float)alpha);
     for (uint32_t pair = 0;; pair++)
-        if (c6_gamma_try2(alpha, d, c, k0, k1, cell, search, depth, pair, g)) return g;
+        if (c6_gamma_try2(alpha, G, d, c, k0, k1, cell, search, depth, pair, g)) return g;
 }
 
 // ---- wave64 helpers ---------------------------------------------------------
@@ -340,6 +340,7 @@ __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], c6_gam (&ga
     unsigned short *list = reinterpret_cast<unsigned short *>(scratch_ + 64 * J);
     unsigned long long pend[J];
     bool any = false;
+    const c6_gs_consts G = c6_gs_setup((float)alpha);      // (wave-uniform: three divisions, hoisted out of the round loop by the compiler)
 #pragma unroll
     for (int j = 0; j < J; j++) {
         gam[j].m = 0.f;
@@ -366,7 +367,7 @@ __device__ __forceinline__ void c6_wave_gamma(const bool (&need)[J], c6_gam (&ga
             const int sub = item & (k - 1);
             const int cell = active ? (int)list[item >> s] : 0;
             c6_gam v = {0.f, 0};
-            const bool ok = active && c6_gamma_try2(alpha, d, c, k0, k1, (uint32_t)cell, search, depth, att + (uint32_t)sub, v);
+            const bool ok = active && c6_gamma_try2(alpha, G, d, c, k0, k1, (uint32_t)cell, search, depth, att + (uint32_t)sub, v);
             // lanes of one cell are consecutive (sub = 0..k-1, one batch whenever k > 1): the first accepted one writes
             const unsigned long long okm = __ballot(ok);
             const unsigned long long mine = (okm >> (lane - sub)) & (k >= 64 ? ~0ull : ((1ull << k) - 1ull));

@@ -240,12 +240,12 @@ void c6o_recover_way8(float *probs8, int n, float *out) {
 }
 
 /* ===================================================================== */
-/* C6RNG (spec in DESIGN.md): Philox4x32-10 + deterministic f64 math       */
+/* C6RNG (spec in DESIGN.md): Philox4x32-10 / -7 + deterministic f32 math   */
 /* ===================================================================== */
 
-void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+static void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < rounds; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -255,6 +255,10 @@ void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32(ctr, key, out, 10); }
+/* C6RNG v5: the Dirichlet-noise draws (tag 1) -- one block per pair of attempts and empty cell at every tree level, the bulk of all draws -- use
+ * the seven-round form (Salmon et al. 2011: Philox4x32-7 is the fewest rounds that pass BigCrush; 10 is the margin the other tags keep) */
+void c6o_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32(ctr, key, out, 7); }
 
 static inline double bits2d(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 static inline uint64_t d2bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
@@ -318,51 +322,57 @@ static inline float open01f(uint32_t w) { return ((float)(w >> 8) + 0.5f) * (1.0
 /* m * 2^k, exact for a normal m and a normal result */
 static inline float scale2f(float m, int k) { return m * bits2f((uint32_t)(k + 127) << 23); }
 
-/* one Ahrens-Dieter GS attempt on the uniforms (u1, u2); 1 and the variate m 2^k if it is accepted (spec: c6_device.h, C6RNG v4) */
-static int gs_attempt(float a, float ia, float b, float u1, float u2, float *m_out, int *k_out) {
+/* One attempt of the alpha < 1 sampler on the uniforms (u1, u2); 1 and the variate m 2^k if it is accepted.  C6RNG v5 ("GS with a Pareto tail"):
+ * rejection from the mixture of q1(x) = alpha x^(alpha-1) on (0, 1] and q2(x) = beta x^(-beta-1) on (1, inf), beta = 1 - alpha, with the weights
+ * 1 : alpha / (e beta) -- then target / proposal is proportional to e^-x on the body and to x e^(1-x) on the tail, both <= 1:
+ *     p = b u1, b = 1 + alpha / (e beta), E = -log(u2) (an Exp(1) variate)
+ *     p <= 1 (98.9 %):  x = p^(1/alpha)  = exp(log(p) / alpha),              accepted iff x <= E                (<=> u2 <= e^-x)
+ *     p >  1:           x = u'^(-1/beta) = exp(-log(u') / beta), u' = (b - p) e beta / alpha,
+ *                                                                           accepted iff E >= (x - 1) - log(x)  (<=> u2 <= x e^(1-x))
+ * Both branches are ONE sequence -- log of the branch's argument, times the branch's constant, exp, one comparison against E -- where v4's
+ * Ahrens-Dieter tail (x = -log((b - p) / alpha), accepted iff E >= (1 - alpha) log x) needed a second logarithm that a wave executed whenever one
+ * of its ~94 attempts fell into the tail.  Acceptance 0.972 (GS: 0.973). */
+static int gs_attempt(float ia, float ib, float b, float ct, float u1, float u2, float *m_out, int *k_out) {
     const float p = b * u1;
-    const float E = 0.0f - c6o_log4(u2);
-    if (p <= 1.0f) {
-        int k;
-        const float m = c6o_exp4(c6o_log4(p) * ia, &k);
-        if (!(k < -30 || scale2f(m, k) <= E)) return 0;
-        *m_out = m;
-        *k_out = k;
-        return 1;
-    }
-    const float y = (b - p) * ia;
-    if (!(y > 0.0f)) return 0;
-    const float x = 0.0f - c6o_log4(y);
-    if (!(E >= (1.0f - a) * c6o_log4(x))) return 0;
-    *m_out = x;
-    *k_out = 0;
+    const int tail = !(p <= 1.0f);
+    const float arg = tail ? (b - p) * ct : p;
+    if (!(arg > 0.0f)) return 0;      /* p rounded up to b */
+    const float L = c6o_log4(arg), E = 0.0f - c6o_log4(u2);
+    const float t = L * (tail ? ib : ia);
+    int k;
+    const float m = c6o_exp4(t, &k);
+    if (!tail) {
+        if (!(k < -30 || scale2f(m, k) <= E)) return 0;      /* below 2^-30 every E (>= 2^-25) accepts */
+    } else if (!(E >= (scale2f(m, k) - 1.0f) - t)) return 0;  /* (k <= 18: u' >= 2^-18) */
+    *m_out = m;
+    *k_out = k;
     return 1;
 }
 
 /*
  * Gamma(alpha, 1): what `Dirichlet::new_with_param(alpha, n).sample` draws per component
  * (rand 0.6, called from alphazero_policy/mod.rs:262,283).  The reference's generator is unseeded and rand's own
- * stream cannot be reproduced, so only the DISTRIBUTION is the reference's; the algorithm is C6RNG's (v4), in single
+ * stream cannot be reproduced, so only the DISTRIBUTION is the reference's; the algorithm is C6RNG's (v5), in single
  * precision (the reference casts the noise to f32 before use, mod.rs:283); a variate is m * 2^k:
- *   alpha < 1:  Ahrens-Dieter GS (1974).  b = 1 + alpha/e, p = b u1, E = -log(u2).  p <= 1: x = p^(1/alpha), accept iff
- *               x <= E; else x = -log((b - p)/alpha), accept iff E >= (1 - alpha) log(x).  Attempts 2i and 2i + 1
- *               share the Philox block with counter word c1 = i (words 0, 1 and 2, 3).
+ *   alpha < 1:  gs_attempt above.  Attempts 2i and 2i + 1 share the Philox block with counter word c1 = i (words 0, 1 and 2, 3).
  *   alpha >= 1: Marsaglia-Tsang for shape alpha+1 times U^(1/alpha) (rand's GammaSmallShape form) with polar-method
  *               normals.  Words: polar v1, polar v2, squeeze u, power u.
+ * Every block of these draws is Philox4x32-7 (c6o_philox4x32_7).
  */
 void c6o_gamma_draw4(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth, float *m_out, int *k_out) {
     const double shape = alpha + 1.0;
     const double dd = shape - 1.0 / 3.0;
     const double cd = 1.0 / sqrt(9.0 * dd);
     const float d = (float)dd, c = (float)cd, inv_alpha = 1.0f / (float)alpha;
-    const float a = (float)alpha, b = fmaf(a, 0.36787944f, 1.0f);
+    /* the launch's constants of gs_attempt (IEEE single precision, as the kernels compute them: c6_gs_consts, c6_device.h) */
+    const float a = (float)alpha, beta = 1.0f - a, eb = 2.7182817f * beta, b = 1.0f + a / eb, ct = eb / a, ib = -1.0f / beta;
     uint32_t key[2] = {k0, k1};
     for (uint32_t att = 0;; att++) {
         /* alpha < 1: one Philox block serves the attempts 2i (words 0, 1) and 2i + 1 (words 2, 3) */
         uint32_t ctr[4] = {cell, alpha < 1.0 ? att >> 1 : att, search, (uint32_t)C6O_TAG_NOISE | (depth << 8)}, w[4];
-        c6o_philox4x32_10(ctr, key, w);
+        c6o_philox4x32_7(ctr, key, w);
         if (alpha < 1.0) {
-            if (gs_attempt(a, inv_alpha, b, open01f(w[2 * (att & 1)]), open01f(w[2 * (att & 1) + 1]), m_out, k_out)) return;
+            if (gs_attempt(inv_alpha, ib, b, ct, open01f(w[2 * (att & 1)]), open01f(w[2 * (att & 1) + 1]), m_out, k_out)) return;
             continue;
         }
         const float v1 = 2.0f * open01f(w[0]) - 1.0f, v2 = 2.0f * open01f(w[1]) - 1.0f;

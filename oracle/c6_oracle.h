@@ -109,6 +109,7 @@ enum {
     C6O_TAG_ROLL_POLICY = 7 /* DefaultPolicy::policy fallback,  ctr = (0, 0, searches so far, tag) word 0 */
 };
 void c6o_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void c6o_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);      /* the noise draws (C6RNG v5) */
 float c6o_log4(float x);            /* log / exp of the Gamma sampler (C6RNG v4): fused polynomial forms, no division */
 float c6o_exp4(float t, int *k);    /* exp(t) = return value * 2^k */
 void c6o_gamma_draw4(double alpha, uint32_t k0, uint32_t k1, uint32_t cell, uint32_t search, uint32_t depth, float *m, int *k); /* variate m 2^k */

@@ -1,6 +1,6 @@
 """C6RNG: the documented random stream the oracle (and, independently, the HIP kernels) implement.
 The reference draws from unseeded thread_rng (alphazero_policy/mod.rs:145,163,262,283,294), so the
-stream itself is unpinned; what is checked here is the published Philox4x32-10 known answers and that
+stream itself is unpinned; what is checked here is the published Philox4x32-10 known answers (and the 7-round form of the noise draws) and that
 the sampled distributions are the reference's: Gamma(alpha,1)/Dirichlet(alpha) and U[-1,1)."""
 import math
 
@@ -17,8 +17,32 @@ def test_philox_known_answers():
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
+def _philox_py(ctr, key, rounds):
+    """Philox4x32 as published (Salmon, Moraes, Dror, Shaw 2011), any number of rounds"""
+    c, k = list(ctr), list(key)
+    for _ in range(rounds):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+        k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+    return c
+
+
+def test_philox_seven_rounds_is_the_same_round_function():
+    """C6RNG v5 draws the Dirichlet noise from Philox4x32-7 (the fewest rounds that pass BigCrush in the paper; the other tags keep 10).  The
+    library's 7-round form against an independent statement of the round function -- which reproduces the published 10-round known answers"""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    cases = [([0, 0, 0, 0], [0, 0]), ([0xffffffff] * 4, [0xffffffff] * 2)] + [(rng.integers(0, 2**32, 4).tolist(), rng.integers(0, 2**32, 2).tolist()) for _ in range(50)]
+    for ctr, key in cases:
+        assert _philox_py(ctr, key, 10) == o.philox(ctr, key)
+        c, k, out = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        o.lib().c6o_philox4x32_7(c, k, out)
+        assert list(out) == _philox_py(ctr, key, 7)
+    assert _philox_py([0, 0, 0, 0], [0, 0], 7) != _philox_py([0, 0, 0, 0], [0, 0], 10)
+
+
 def test_log4_exp4_accuracy():
-    """the single-precision pair of the Gamma sampler (C6RNG v4: division-free fused polynomials): a few ulp of float over the ranges
+    """the single-precision pair of the Gamma sampler (C6RNG v4 / v5: division-free fused polynomials): a few ulp of float over the ranges
     the sampler uses -- far more than the sampler needs (its distribution is tested below)"""
     L = o.lib()
     rng = np.random.default_rng(0)
@@ -45,8 +69,30 @@ def test_gamma_moments():
         assert (xs >= 0).all()
 
 
+def test_gamma_tail_branch():
+    """the Pareto-tail branch of the alpha < 1 sampler (C6RNG v5: p > 1, x = u'^(-1/(1-alpha)), accepted with probability x e^(1-x)) on its own:
+    the share of variates above 1 is P(X > 1) = Gamma(alpha, 1) / Gamma(alpha), and CONDITIONED on X > 1 they follow the Gamma tail
+    (Kolmogorov-Smirnov at the 0.1 % level) -- at alpha = 0.3 and 0.5, where a third to a sixth of the variates come from that branch"""
+    from scipy import stats
+    L = o.lib()
+    for alpha in (0.3, 0.5):
+        xs = np.array([L.c6o_gamma_draw(alpha, 21, 9, c, s, 1) for s in range(60) for c in range(361)])
+        n = xs.size
+        p_tail = stats.gamma.sf(1.0, alpha)
+        k = int((xs > 1.0).sum())
+        assert abs(k - n * p_tail) < 4.5 * math.sqrt(n * p_tail * (1 - p_tail)), (alpha, k, n * p_tail)
+        t = np.sort(xs[xs > 1.0])
+        cdf = (stats.gamma.cdf(t, alpha) - (1 - p_tail)) / p_tail
+        dmax = max(np.abs(cdf - np.arange(1, k + 1) / k).max(), np.abs(cdf - np.arange(0, k) / k).max())
+        assert dmax < 1.95 / math.sqrt(k), (alpha, dmax, k)
+        body = np.sort(xs[xs <= 1.0])
+        cdfb = stats.gamma.cdf(body, alpha) / (1 - p_tail)
+        nb = body.size
+        assert max(np.abs(cdfb - np.arange(1, nb + 1) / nb).max(), np.abs(cdfb - np.arange(0, nb) / nb).max()) < 1.95 / math.sqrt(nb)
+
+
 def test_gamma_distribution_ks():
-    """Kolmogorov-Smirnov against Gamma(alpha, 1) on both branches of the sampler (alpha < 1: Ahrens-Dieter GS,
+    """Kolmogorov-Smirnov against Gamma(alpha, 1) on both branches of the sampler (alpha < 1: the two-piece rejection sampler of C6RNG v5,
     alpha >= 1: Marsaglia-Tsang): the distribution is what the reference's Dirichlet noise pins (mod.rs:262)"""
     from scipy import stats
     L = o.lib()
