@@ -391,6 +391,7 @@ def _check_against_oracle(n, C, blocks, blob, boards, player, idx=None, prec=Non
         worst_p = max(worst_p, float(np.abs(pol[i] - rp[0]).max()))
         worst_v = max(worst_v, float(abs(val[i] - rv[0])))
     net.close()
+    print(f"[net-vs-oracle] n={n} C={C} blocks={blocks} boards={boards.shape[0]}: worst |policy diff| {worst_p:.3e}, worst |value diff| {worst_v:.3e}")      # (pytest -s: profiles/r04_hostile_errors.txt)
     assert worst_p <= TOL and worst_v <= TOL, (worst_p, worst_v)
     return pol, val, worst_p, worst_v
 
