@@ -132,7 +132,8 @@ def lib():
     i8p, u8p, f32p, i32p, u32p, i16p = (C.POINTER(t) for t in (C.c_int8, C.c_uint8, C.c_float, C.c_int32, C.c_uint32, C.c_int16))
     L.c6_last_error.restype = C.c_char_p
     L.c6_version.restype = C.c_char_p
-    L.c6_rng_spec.restype = C.c_char_p
+    if hasattr(L, "c6_rng_spec"):      # (absent from the A/B libraries built from earlier rounds' sources: tools/ab_many.sh)
+        L.c6_rng_spec.restype = C.c_char_p
     L.c6_default_config.argtypes = [C.POINTER(Config)]
     L.c6_engine_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.c6_engine_destroy.argtypes = [C.c_void_p]
@@ -150,7 +151,8 @@ def lib():
     L.c6_engine_apply_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_last_moves.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.c6_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
-    L.c6_engine_pool_audit.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 12)]
+    if hasattr(L, "c6_engine_pool_audit"):
+        L.c6_engine_pool_audit.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 12)]
     L.c6_engine_play_match.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_long]
     L.c6_engine_boards.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
     L.c6_rollout_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
@@ -249,7 +251,9 @@ def pool_ring_selftest(ids=1000, waves=4096, tries=4, launches=50, seed=1):
 
 
 def rng_spec():
-    return lib().c6_rng_spec().decode()
+    """c6_rng_spec: the random-stream specification the library implements (libraries from before round 4 do not say: they are C6RNG v4)"""
+    L = lib()
+    return L.c6_rng_spec().decode() if hasattr(L, "c6_rng_spec") else "C6RNG v4"
 
 
 def device_count():

@@ -135,6 +135,32 @@ def committed_stones_probe(workload, sims, rng, ignored=None):
     return best[1] if best else None
 
 
+SAME_LAW = ("C6RNG v4", "C6RNG v5")      # specifications whose noise / tie-break / evaluator draws follow the same distributions (v5 changed the
+                                         # Gamma sampler's tail proposal and the noise draws' round count, not a law; tests/test_oracle_rng.py)
+
+
+def pooled_stones_probes(workload, sims):
+    """every committed probe at the workload's own budget in f32 arithmetic under a specification of SAME_LAW, pooled by games: the game
+    length is a statistic of (net, budget, noise LAW), not of the stream -- reported BESIDE `value`, which uses the current specification's probe only"""
+    n, s1, s2, files = 0, 0.0, 0.0, []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stones_probe*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != workload or d.get("num_simulation") != sims or d.get("precision") != "fp32" or d.get("rng", "C6RNG v4") not in SAME_LAW:
+            continue
+        g = d["games"]
+        n += g
+        s1 += g * d["stones_per_game"]
+        s2 += g * (d["stones_std"] ** 2 + d["stones_per_game"] ** 2)
+        files.append(f"{os.path.basename(f)} ({d.get('rng', 'C6RNG v4')}: {g} games, {d['stones_per_game']:.1f})")
+    if n == 0:
+        return None
+    mean = s1 / n
+    return {"games": n, "stones_per_game": mean, "standard_error": (max(s2 / n - mean * mean, 0.0) / n) ** 0.5, "probes": files}
+
+
 def usable_cores():
     """host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
     logical CPUs but grants cpu.max = 16 CPUs of time; more threads than that only fight over the quota)"""
@@ -565,6 +591,11 @@ def main():
                 out["value_with_live_probe"] = sims_s / (S * live["stones_per_game"])
         if probes_ignored:
             out["config"]["stones_probes_ignored"] = probes_ignored
+        if is_net:
+            pooled_p = pooled_stones_probes(args.workload if args.workload != "config4" else "config2", S)
+            if pooled_p and len(pooled_p["probes"]) > 1:
+                out["config"]["stones_per_game_all_probes_at_this_budget"] = pooled_p
+                out["value_with_all_probes_at_this_budget"] = sims_s / (S * pooled_p["stones_per_game"])
         if is_net and head["prof"]["conv_launches"]:
             out["roofline"] = conv_roofline(head, args.precision)
             out["net_tflops_end_to_end"] = net_flops_per_board(n, wl["channels"], wl["blocks"]) * 8 * sims_s / 1e12
