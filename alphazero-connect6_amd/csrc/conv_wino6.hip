@@ -276,8 +276,8 @@ constexpr int w6_wait(int i, bool stores) {
 }
 static_assert(w6_store_group(15) < 32 - W6_PF, "a position's stores are older than every request that is waited for in the next one");
 
-// DP = false: the blocks [first, nblocks) of the classes with rows of six positions (A, B, B', D); DP = true: the blocks of class D' (rows of
-// five).  Two instantiations, two launches: with both row forms in one kernel the register allocator spilled 121 registers of the accumulators.
+// DP = false: the blocks [first, nblocks) of the classes with rows of six positions (A, B, B', D: 708 of a board's 788 positions); DP = true: the blocks of
+// class D' (rows of five: 80 positions).  Two instantiations, two launches: with both row forms in one kernel the register allocator spilled 121 registers of the accumulators.
 template <bool DP>
 __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo,
                                                                       int first, int nblocks, int blkB, int blkBP, int blkD) {
@@ -918,10 +918,11 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
         const int n6 = (int)map.blkDP, n5 = nblocks - n6;      // blocks of the classes with rows of six positions / of class D'
         w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false>), (int)smem);
         w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true>), (int)smem);
-        // The D' launch (1.3 % of the layer's products) does not wait for the other one: it goes to a side stream (fork / join by events) and its
-        // workgroups take whatever CUs are free -- all of them beside a SMALL batch, where in order on one stream the second launch cost one block's
-        // time after the other's (0.71 + 0.56 ms per layer at 64 games: 8.9 -> 5.5 ms per round); the tail of the big launch at the benchmark's batch.
-        W6Side *side = n5 > 0 ? w6_side_of(s) : nullptr;
+        // Beside a SMALL batch (the first launch leaves CUs idle: fewer than two rounds of blocks) the D' launch -- a tenth of the layer's products -- does
+        // not wait for the other one: it goes to a side stream (fork / join by events) and takes the free CUs.  In order on one stream the second launch
+        // cost one block's time after the other's (0.71 + 0.56 ms per layer at 64 games: 8.9 -> 5.5 ms per round; 128 games: 13.2 -> 9.8).  At the
+        // benchmark's batch the chip is full either way and the launches stay in order on the caller's stream (21.7 + 2.5 ms).
+        W6Side *side = n5 > 0 && n6 < 2 * num_cus ? w6_side_of(s) : nullptr;
         if (side) hipEventRecord(side->fork, s);
         hipLaunchKernelGGL(c6_w6_gemm_kernel<false>, dim3(n6 < num_cus ? n6 : num_cus), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB, (int)map.blkBP,
                            (int)map.blkD);

@@ -505,7 +505,7 @@ def main():
             # Winograd executes 3.8x fewer products than that, so algorithmic / peak is a ratio, not a roofline fraction.
             ach = exe if name.startswith("fp32") else alg
             traffic = rec.get("hbm_bytes_per_launch")
-            if name == "fp32" and traffic is not None:      # a layer's GEMM is two launches: the blocks with rows of six positions (<false>, 98.7 % of the work) and of five (<true>)
+            if name == "fp32" and traffic is not None:      # a layer's GEMM is two launches: the blocks with rows of six positions (<false>, 708 of a board's 788 positions) and of five (<true>, 80)
                 traffic += pmc_record("c6_w6_gemm_kernel<true>").get("hbm_bytes_per_launch", 0.0)
             r = {"bound": "mfma", "kernel": f"{kern} ({desc})", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                  "traffic": traffic, "avg_launch_ms": gemm_ms / L, "launches": prof["conv_launches"],
@@ -517,8 +517,8 @@ def main():
             # alternate: their times add)
             r["layer_frac"] = prof["conv_exec_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 / peak
             if name == "fp32":
-                r["note"] = ("a layer's GEMM is two launches of one kernel template -- c6_w6_gemm_kernel<false> (the tile classes with rows of six positions: 98.7 % of the "
-                             "products) then <true> (class D', rows of five) -- timed together: avg_launch_ms, achieved and traffic are per layer = the pair; "
+                r["note"] = ("a layer's GEMM is two launches of one kernel template -- c6_w6_gemm_kernel<false> (the tile classes with rows of six positions: 708 of a board's "
+                             "788 products) then <true> (class D', rows of five: 80) -- timed together: avg_launch_ms, achieved and traffic are per layer = the pair; "
                              "achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + "
                              "boundary-kernel time; algorithmic_tflops / algorithmic_ratio count 2*9*C^2*N^2 per board and layer (SURVEY 8d), of which this Winograd "
                              "tiling executes 1 / 4.12 (788 products per channel pair and board instead of 3249)")
