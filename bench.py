@@ -433,7 +433,8 @@ def main():
             stones, stones_src = probe_file["stones_per_game"], (f"measured: {probe_file['games']} complete games of this net at {probe_file['num_simulation']} "
                                                                   f"simulations/move on MI355X (profiles/{probe_file['file']}, tools/stones_probe.py; {pkg.rng_spec()}, "
                                                                   + ("these kernel sources)" if probe_file["same_sources"] else
-                                                                     "played on earlier kernel sources under the same random-stream specification and arithmetic: the same games)"))
+                                                                     "played on earlier kernel sources under the same random-stream specification and arithmetic: the same process -- the parity tests pin the engine's "
+                                                                     "games to the oracle's, stone for stone with the built-in evaluators, to 1e-5 in the priors with the net)"))
         else:
             # No probe at this workload's own budget: `value` is NOT derived from a probe at another budget (game length at 8 simulations
             # per move is 106 stones, at 400 it is 136) -- simulations/s is the measurement, games/s stays null
