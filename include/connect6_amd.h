@@ -190,7 +190,7 @@ typedef struct c6_engine c6_engine;
 
 const char *c6_last_error(void);
 const char *c6_version(void);
-/* the random-stream specification the engine's noise / tie-breaks / built-in evaluators follow ("C6RNG v4": DESIGN.md 3).  The games an
+/* the random-stream specification the engine's noise / tie-breaks / built-in evaluators follow ("C6RNG v5": DESIGN.md 3).  The games an
  * engine plays are a function of (this, seed, weights, arithmetic, hyper-parameters): records of played games carry it. */
 const char *c6_rng_spec(void);
 int c6_device_count(void);
