@@ -143,3 +143,25 @@ def test_noise_survives_tiny_variates():
         o.lib().c6o_gamma_draw4(0.03, 5, 6, 0, s, 0, C.byref(mm), C.byref(kk))
         worst = min(worst, kk.value)
     assert worst < -126          # the range a float alone could not hold
+
+
+def test_dirichlet_order_statistics():
+    """The noise VECTOR's law, not only its components': the means of the three largest of 78 components at alpha = 0.03 (a 9x9 board with three
+    stones) against Dirichlet(alpha, ..., alpha) -- 0.4506 / 0.2119 / 0.12165, from a float64 construction Gamma(1 + alpha) U^(1/alpha) over 2 M
+    vectors (standard errors 1e-4 / 5e-5 / 4e-5).  Sensitive to the sampler's tail branch, to the normaliser and to the 100-binade cut-off, which the
+    component-wise tests above are not (r4: checked at 300 000 vectors when C6RNG v5 replaced the tail proposal: 0.45049 / 0.21204 / 0.12170)."""
+    import ctypes as C
+    L = o.lib()
+    n, m, alpha, N = 9, 78, 0.03, 40000
+    b = np.zeros(n * n, np.int8)
+    b[0], b[40], b[65] = 1, -1, 1
+    out = np.zeros(n * n, np.float32)
+    top = np.zeros((N, 3))
+    L.c6o_dirichlet_noise.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int8), C.c_int, C.POINTER(C.c_float)]
+    for s in range(N):
+        L.c6o_dirichlet_noise(alpha, 23, 5, s, 1, b.ctypes.data_as(C.POINTER(C.c_int8)), n, out.ctypes.data_as(C.POINTER(C.c_float)))
+        e = np.sort(out[b == 0].astype(np.float64))
+        top[s] = e[-1], e[-2], e[-3]
+    want = np.array([0.4506, 0.2119, 0.12165])
+    se = top.std(0) / math.sqrt(N)
+    assert (np.abs(top.mean(0) - want) < 4.0 * se + 3e-4).all(), (top.mean(0), se)
