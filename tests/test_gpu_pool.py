@@ -300,8 +300,10 @@ def test_ring_pop_protocol_selftest():
     only make another request fail).  Round 3's add-then-undo protocol hands out duplicates in the first three geometries (4352 /
     286 / 205 of them: profiles/r04_ring_selftest.txt, A/B build tools/ab_patches/tree_ring_pop_add_undo.sed)."""
     need_gpu()
-    for geo, least in ((dict(ids=16, waves=4, tries=8, launches=30000, seed=3), 8), (dict(ids=16, waves=8, tries=6, launches=30000, seed=4), 8),
-                       (dict(ids=24, waves=16, tries=4, launches=30000, seed=6), 12), (dict(ids=1000, waves=4096, tries=4, launches=200, seed=5), 900),
-                       (dict(ids=37, waves=2048, tries=8, launches=1000, seed=9), 20)):
+    # `least`: a loose floor under the fewest ids one launch handed out (observed 13 / 9 / 17 / 993 / 30: which requests meet a momentarily
+    # depressed credit count depends on the waves' timing) -- the invariants are dup == over == 0
+    for geo, least in ((dict(ids=16, waves=4, tries=8, launches=30000, seed=3), 4), (dict(ids=16, waves=8, tries=6, launches=30000, seed=4), 4),
+                       (dict(ids=24, waves=16, tries=4, launches=30000, seed=6), 8), (dict(ids=1000, waves=4096, tries=4, launches=200, seed=5), 900),
+                       (dict(ids=37, waves=2048, tries=8, launches=1000, seed=9), 16)):
         r = pkg.pool_ring_selftest(**geo)
         assert r["dup"] == 0 and r["over"] == 0 and r["min_popped"] >= least, (geo, r)
