@@ -94,10 +94,11 @@ __device__ __forceinline__ void w6_bt6(const V (&x)[8], V (&r)[8]) {
 }
 // B^T d B of one patch -> the tile's positions in V (2 channels per pass, every window value read from LDS once: conv_wino4.hip).
 // The patch's rows lie in the window slots slot[0 .. 5] (float offsets), wc = its first column (channel 0), vt = the tile in V.
-__device__ __forceinline__ void w6_patch_transform(const float *wc, const int (&slot)[6], float *vt, int lane, int cls) {
+// h0 .. h1 - 1: the channel halves this wave transforms (0, 2: both, one pass after the other; the first layer's kernel gives each half a wave)
+__device__ __forceinline__ void w6_patch_transform(const float *wc, const int (&slot)[6], float *vt, int lane, int cls, int h0 = 0, int h1 = 2) {
     constexpr int C = W6_C;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
+#pragma unroll 1
+    for (int h = h0; h < h1; h++) {
         const int co = h * (C / 2) + lane * 2;
         const float *wl = wc + co;
         float *vl = vt + co;
@@ -191,12 +192,13 @@ __device__ __forceinline__ void w6_slots(int ty, int (&slot)[6]) {
     } while (0)
 
 // ---- first layer: the stem computed into the window, input transform -> V -----------------------------------------------------------
-#define W6_THREADS 256      // 4 waves: wave = tile column
+#define W6_THREADS 512      // 8 waves: wave = (tile column, channel half).  r4: with four waves (a wave per tile column, both halves) the kernel kept ONE
+                            // wave per SIMD, not waiting 69 % of the time -- the stem's arithmetic, the transform and the store issue all hung on it
 __global__ __launch_bounds__(W6_THREADS) void c6_w6_stem_in_kernel(C6StemSrc S, float *__restrict__ V, int nboards) {
     constexpr int C = W6_C, N = W6_N, LPT = C / 4, P = N + 2, ROWF = W6_ROWF;
     extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] + the player-plane sums [9][C] + the board plane [P][P]
     float *s0 = win + 6 * ROWF, *bd = s0 + 9 * C;
-    const int tid = threadIdx.x, cq = tid % LPT, tx = tid / LPT;
+    const int tid = threadIdx.x, cq = tid % LPT, wv = tid / LPT, tx = wv & 3, hh = wv >> 2;
     const W6Map map(nboards);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = tid; k < 6 * ROWF / 4; k += W6_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(W6_THREADS) void c6_w6_stem_in_kernel(C6StemSrc S, 
                 float *vb = V + (size_t)(t / W6_BT) * W6_VBLOCK + (size_t)(t % W6_BT) * W6_VTILE;
                 int slot[6];
                 w6_slots(ty, slot);
-                w6_patch_transform(win + w6_x0(tx) * C, slot, vb, cq, w6_cls(ty, tx));
+                w6_patch_transform(win + w6_x0(tx) * C, slot, vb, cq, w6_cls(ty, tx), hh, hh + 1);
             }
             if (ty + 1 < W6_TWY) {
                 W6_LDS_BARRIER();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more
