@@ -25,6 +25,7 @@
 // Rounding: F(6,3)'s matrices (entries up to 32 and 21/4) in ONE direction: a layer's error ~3e-6 rms of activations of order 1; the net's
 // outputs stay within 1e-5 of a float64 model (tests/test_gpu_net.py).
 #include "c6_wino.h"
+#include <cstdlib>
 
 #define W6_BT 64          // tiles per block
 #define W6_C 256
@@ -277,10 +278,17 @@ constexpr int w6_wait(int i, bool stores) {
     return W6_PF + dmas + st;
 }
 static_assert(w6_store_group(15) < 32 - W6_PF, "a position's stores are older than every request that is waited for in the next one");
+// the LAST position of a split job (below): the weight stream ends with the row -- groups i + 1 .. 31 are the only weight requests younger than group i's
+constexpr int w6_wait_last(int i, bool stores) { return w6_wait(i, stores) - W6_PF + (31 - i < W6_PF ? 31 - i : W6_PF); }
 
 // DP = false: the blocks [first, nblocks) of the classes with rows of six positions (A, B, B', D: 708 of a board's 788 positions); DP = true: the blocks of
 // class D' (rows of five: 80 positions).  Two instantiations, two launches: with both row forms in one kernel the register allocator spilled 121 registers of the accumulators.
-template <bool DP>
+//
+// SPLIT (r5): the unit of work is a ROW of positions instead of a block (a row's four row sums depend on nothing but its own six -- D': two rows' ten --
+// positions).  A block on one CU is a chain of 48 positions x 13.7 us, whatever the batch: one game's eight boards took 0.66 ms per layer on 4 of the
+// 256 CUs.  Split, its 28 rows run on 28 CUs at once.  Same instruction stream per position (same waits), only the addresses of the V rows, of the
+// weight groups and of Z differ; the launcher takes this form while the blocks do not fill the chip a few times over (c6_w6_dispatch).
+template <bool DP, bool SPLIT>
 __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo,
                                                                       int first, int nblocks, int blkB, int blkBP, int blkD) {
     constexpr int C = W6_C, CP = C + 4, SLAB = W6_BT * CP, WAVES = C / 32, NG = C / 8, PF = W6_PF;
@@ -291,8 +299,10 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int n4 = wave * 32 + 4 * h;
+    // SPLIT: blockIdx.y is the row this workgroup multiplies in each of its blocks
     int b = first + (int)blockIdx.x;
     if (b >= nblocks) return;
+    const int row0 = SPLIT ? (int)blockIdx.y : 0;
 
     // blocks [0, blkB): class A, 6 rows of 6 positions; [blkB, blkD): B and B', 5 rows of 6; [blkD, ...): D, 8 rows of 6; the DP instantiation: D', 8 rows
     // of FIVE positions (r4: F(3) down the board in the six-wide tiles of the last tile row -- 40 instead of 48 positions)
@@ -311,24 +321,35 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
         const int lds_off = (buf * SLAB + c * CP) * 4;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lds_off) : "memory");
     };
-#pragma unroll
-    for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * W6_VBLOCK, 0, c0);
+    constexpr int RL = DP ? 5 : 6;      // positions per row
     f32x4 ring[PF + 1];
     int ub = b, ungt = npos_of(b) * NG;      // the weight stream runs ahead of the multiplications: its own block and group counters
     const float *uptr = wbase_of(b);
     int gi = 0;
+    // SPLIT: every (block, row) is a job of its own and nothing wraps -- the weight stream ends with the row (W6Z_GROUP's LP), the row's last position
+    // fetches the tile slots' next row of V (behind a block's last position: the slots' padding row W6_NPV - 1), which nobody reads
 #define W6_UNEXT()                                                       \
     {                                                                    \
-        gi += 1; uptr += 256;                                            \
-        if (gi == ungt) {                                                \
-            gi = 0;                                                      \
-            ub = ub + (int)gridDim.x < nblocks ? ub + (int)gridDim.x : ub; \
-            ungt = npos_of(ub) * NG;                                     \
-            uptr = wbase_of(ub);                                         \
+        uptr += 256;                                                     \
+        if (!SPLIT) {                                                    \
+            gi += 1;                                                     \
+            if (gi == ungt) {                                            \
+                gi = 0;                                                  \
+                ub = ub + (int)gridDim.x < nblocks ? ub + (int)gridDim.x : ub; \
+                ungt = npos_of(ub) * NG;                                 \
+                uptr = wbase_of(ub);                                     \
+            }                                                            \
         }                                                                \
     }
-#pragma unroll
-    for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W6_UNEXT() }
+    // the first position's V rows into slab 0, the first seven weight groups into the ring
+#define W6_PROLOGUE(ROW)                                                                                         \
+    {                                                                                                            \
+        _Pragma("unroll") for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * W6_VBLOCK + (size_t)(RL * (ROW)) * C, 0, c0); \
+        uptr = wbase_of(b) + (size_t)(RL * (ROW)) * (NG * 256);                                                  \
+        if (SPLIT) asm volatile("" : "+s"(uptr));      /* (D': the same for every block of the loop -- hoisted, the row's 160 group addresses took every scalar register and 568 spill lanes) */ \
+        _Pragma("unroll") for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W6_UNEXT() }           \
+    }
+    if (!SPLIT) W6_PROLOGUE(0)
 
     f32x16 z00, z01, z10, z11, z20, z21, z30, z31, m0, m1;
     const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -340,17 +361,26 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
     {                                                                                                            \
         const f32x16 &sv = ((k) & 4) ? SET1 : SET0;                                                              \
         const f32x4 a = {sv[4 * ((k) & 3)], sv[4 * ((k) & 3) + 1], sv[4 * ((k) & 3) + 2], sv[4 * ((k) & 3) + 3]}; \
-        const float *d_ = (DST) + (size_t)(BIDX) * C;                                                            \
-        if (((k) & 3) == 0) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 0);                                       \
-        else if (((k) & 3) == 1) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 32);                                 \
-        else if (((k) & 3) == 2) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 64);                                 \
-        else W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 96);                                                     \
+        /* SPLIT: the second tile half's offset rides in the scalar base (one vector register less: that kernel has none to spare) */ \
+        const float *d_ = (DST) + (size_t)(BIDX) * C + (SPLIT && ((k) & 4) ? (size_t)32 * W6_ZTILE : (size_t)0); \
+        const unsigned zo_ = SPLIT ? zoff0 : ((k) & 4) ? zoff1 : zoff0;                                          \
+        if (((k) & 3) == 0) W4_STORE(zo_, a, d_, 0);                                                             \
+        else if (((k) & 3) == 1) W4_STORE(zo_, a, d_, 32);                                                       \
+        else if (((k) & 3) == 2) W4_STORE(zo_, a, d_, 64);                                                       \
+        else W4_STORE(zo_, a, d_, 96);                                                                           \
         asm volatile("s_nop 1" ::: "memory");                                                                    \
     }
-#define W6Z_GROUP(q, u, NWAIT, DMA, JJ, BUF)                                                                     \
+#define W6Z_LAST_ROW()                                                                                           \
+    {                                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) W6Z_STORE1(z20, z21, 2, zprev, k)                           \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) W6Z_STORE1(z30, z31, 3, zprev, k)                           \
+    }
+#define W6Z_GROUP(q, u, NWAIT, DMA, JJ, BUF, LP)                                                                 \
             {                                                                                                    \
-                W4_ULOAD(ring[((q) + PF) & RM], lane16, uptr);                                                   \
-                W6_UNEXT()                                                                                       \
+                if (!(LP) || (u) + PF < NG) {      /* (LP: a split job's last position requests nothing beyond its row -- a request nobody waits for lands in */ \
+                    W4_ULOAD(ring[((q) + PF) & RM], lane16, uptr);      /* registers the compiler has long given to something else) */ \
+                    W6_UNEXT()                                                                                   \
+                }                                                                                                \
                 if ((u) + 1 < NG) {                                                                              \
                     va[((u) + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(vb + 8 * ((u) + 1));                 \
                     va[((u) + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP + 8 * ((u) + 1));       \
@@ -373,7 +403,7 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
                     if ((u) < 16) W6Z_STORE1(z00, z01, 0, zcur, (u) - 8)                                         \
                     else W6Z_STORE1(z10, z11, 1, zcur, (u) - 16)                                                 \
                 }                                                                                                \
-                if ((JJ) == 0 && (u) >= 8 && (u) < 24) {      /* Z_2, Z_3 of the previous row */                  \
+                if (!SPLIT && (JJ) == 0 && (u) >= 8 && (u) < 24) {      /* Z_2, Z_3 of the previous row (SPLIT: one row, no previous one) */ \
                     if ((u) < 16) W6Z_STORE1(z20, z21, 2, zprev, (u) - 8)                                        \
                     else W6Z_STORE1(z30, z31, 3, zprev, (u) - 16)                                                \
                 }                                                                                                \
@@ -391,35 +421,39 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }
-#define W6GZ_(i, JJ, BUF) W6Z_GROUP((i) & RM, (i), w6_wait((i), (JJ) == 0 || (JJ) == 5), (i), JJ, BUF)
+#define W6GZ_(i, JJ, BUF, LP) W6Z_GROUP((i) & RM, (i), (LP) ? w6_wait_last((i), true) : w6_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5), (i), JJ, BUF, LP)
 // one position of a block: JJ = its role in the row (0: the first point, accumulates into Z_0; 5: the last point, accumulates into the last
 // row sum; 1 .. 4: aside, folded in by W6Z_UPDATE / W6Z_UPDATE3), BUF = the LDS slab it reads (positions alternate), PP = its index in the
 // block, LAST = the block's last index
-#define W6Z_POSITION_AT(JJ, BUF, PP, LAST)                                                                       \
+#define W6Z_POSITION_AT(JJ, BUF, PP, LAST) W6Z_POSITION_LP(JJ, BUF, PP, LAST, false)
+#define W6Z_POSITION_LP(JJ, BUF, PP, LAST, LP)                                                                   \
         {                                                                                                        \
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");                                            \
             __builtin_amdgcn_s_barrier();                                                                        \
             const float *nsrc;                                                                                   \
             {                                                                                                    \
                 const int pp = (PP);                                                                             \
-                int nb = pp < (LAST) ? b : b + (int)gridDim.x;                                                   \
-                nb = nb < nblocks ? nb : b;                                                                      \
-                nsrc = V + (size_t)nb * W6_VBLOCK + (size_t)(pp < (LAST) ? pp + 1 : 0) * C;                      \
+                if (SPLIT) nsrc = V + (size_t)b * W6_VBLOCK + (size_t)(pp + 1) * C;                              \
+                else {                                                                                           \
+                    int nb = pp < (LAST) ? b : b + (int)gridDim.x;                                               \
+                    nb = nb < nblocks ? nb : b;                                                                  \
+                    nsrc = V + (size_t)nb * W6_VBLOCK + (size_t)(pp < (LAST) ? pp + 1 : 0) * C;                  \
+                }                                                                                                \
             }                                                                                                    \
             const float *vb = wsm + (BUF) * SLAB + j * CP + 4 * h;                                               \
             f32x4 va[2][2];                                                                                      \
             va[0][0] = *reinterpret_cast<const f32x4 *>(vb);                                                     \
             va[0][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP);                                           \
-            W6GZ_(0, JJ, BUF) W6GZ_(1, JJ, BUF) W6GZ_(2, JJ, BUF) W6GZ_(3, JJ, BUF)                                     \
-            W6GZ_(4, JJ, BUF) W6GZ_(5, JJ, BUF) W6GZ_(6, JJ, BUF) W6GZ_(7, JJ, BUF)                                     \
-            W6GZ_(8, JJ, BUF) W6GZ_(9, JJ, BUF) W6GZ_(10, JJ, BUF) W6GZ_(11, JJ, BUF)                                   \
-            W6GZ_(12, JJ, BUF) W6GZ_(13, JJ, BUF) W6GZ_(14, JJ, BUF) W6GZ_(15, JJ, BUF)                                 \
-            W6GZ_(16, JJ, BUF) W6GZ_(17, JJ, BUF) W6GZ_(18, JJ, BUF) W6GZ_(19, JJ, BUF)                                 \
-            W6GZ_(20, JJ, BUF) W6GZ_(21, JJ, BUF) W6GZ_(22, JJ, BUF) W6GZ_(23, JJ, BUF)                                 \
-            W6GZ_(24, JJ, BUF) W6GZ_(25, JJ, BUF) W6GZ_(26, JJ, BUF) W6GZ_(27, JJ, BUF)                                 \
-            W6GZ_(28, JJ, BUF) W6GZ_(29, JJ, BUF) W6GZ_(30, JJ, BUF) W6GZ_(31, JJ, BUF)                                 \
+            W6GZ_(0, JJ, BUF, LP) W6GZ_(1, JJ, BUF, LP) W6GZ_(2, JJ, BUF, LP) W6GZ_(3, JJ, BUF, LP)                                     \
+            W6GZ_(4, JJ, BUF, LP) W6GZ_(5, JJ, BUF, LP) W6GZ_(6, JJ, BUF, LP) W6GZ_(7, JJ, BUF, LP)                                     \
+            W6GZ_(8, JJ, BUF, LP) W6GZ_(9, JJ, BUF, LP) W6GZ_(10, JJ, BUF, LP) W6GZ_(11, JJ, BUF, LP)                                   \
+            W6GZ_(12, JJ, BUF, LP) W6GZ_(13, JJ, BUF, LP) W6GZ_(14, JJ, BUF, LP) W6GZ_(15, JJ, BUF, LP)                                 \
+            W6GZ_(16, JJ, BUF, LP) W6GZ_(17, JJ, BUF, LP) W6GZ_(18, JJ, BUF, LP) W6GZ_(19, JJ, BUF, LP)                                 \
+            W6GZ_(20, JJ, BUF, LP) W6GZ_(21, JJ, BUF, LP) W6GZ_(22, JJ, BUF, LP) W6GZ_(23, JJ, BUF, LP)                                 \
+            W6GZ_(24, JJ, BUF, LP) W6GZ_(25, JJ, BUF, LP) W6GZ_(26, JJ, BUF, LP) W6GZ_(27, JJ, BUF, LP)                                 \
+            W6GZ_(28, JJ, BUF, LP) W6GZ_(29, JJ, BUF, LP) W6GZ_(30, JJ, BUF, LP) W6GZ_(31, JJ, BUF, LP)                                 \
         }
-#define W6Z_POSITION(i_, JJ) W6Z_POSITION_AT(JJ, (JJ) & 1, 6 * (i_) + (JJ), 6 * R - 1)
+#define W6Z_POSITION(i_, JJ) W6Z_POSITION_LP(JJ, (JJ) & 1, 6 * (i_) + (JJ), SPLIT ? 6 * (i_) + 5 : 6 * R - 1, SPLIT && (JJ) == 5)
 // rows of FIVE positions (class D': F(3)'s points 0, 1, -1, 2, inf; A3^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1]): the first point takes the JJ = 0
 // path, the last the JJ = 5 path -- F(3)'s third row sum lives in the registers (and in Z's slot b = 3) of F(4)'s fourth; b = 2 is not used
 #define W6Z_UPDATE3(IDX)                                                                                         \
@@ -431,7 +465,8 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
                 z10[v] = __builtin_fmaf(2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(2.f, m1[v], z11[v]);        \
                 z30[v] = __builtin_fmaf(4.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(4.f, m1[v], z31[v]);        \
             }                                                                                                    \
-        }
+        }                                                                                                        \
+        if (SPLIT) __builtin_amdgcn_sched_barrier(0);
 #define W6Z_UPDATE(JJ)                                                                                           \
         _Pragma("unroll") for (int v = 0; v < 16; v++) {                                                         \
             z00[v] += m0[v]; z01[v] += m1[v];                                                                    \
@@ -447,33 +482,54 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
                 z20[v] = __builtin_fmaf(4.f, m0[v], z20[v]); z21[v] = __builtin_fmaf(4.f, m1[v], z21[v]);        \
                 z30[v] = __builtin_fmaf(-8.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(-8.f, m1[v], z31[v]);      \
             }                                                                                                    \
-        }
+        }                                                                                                        \
+        if (SPLIT) __builtin_amdgcn_sched_barrier(0);
 
+    // SPLIT: one trip (the grid has a workgroup per item; an item's last position fetches its own first one again -- the same instruction stream, nothing
+    // waits for it)
 #pragma unroll 1
     for (; b < nblocks; b += gridDim.x) {
-        const int R = rows_of(b);
+        const int i_lo = row0, i_hi = SPLIT ? row0 + 1 : DP ? 8 : rows_of(b);
+        if (SPLIT) {
+            if (row0 >= (DP ? 8 : rows_of(b))) continue;      // (a class with fewer rows than the grid has: uniform over the workgroup)
+            W6_PROLOGUE(row0)      // (what the previous job left in flight -- its last Z stores, the stream's seven groups, its last position's fetch into slab 0 -- is
+        }                          //  older than these requests and retires before them)
+        const int R = SPLIT ? 0 : i_hi;      // (the macros' LAST: 6 R - 1 = the block's last position; SPLIT passes the item's own)
+        if (DP && SPLIT) {      // one row of five positions: the job's first position is in slab 0 (its own prologue put it there)
+            const int i = row0, last5 = 5 * i + 4;
+            zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
+            W6Z_POSITION_AT(0, 0, 5 * i + 0, last5)
+            W6Z_POSITION_AT(1, 1, 5 * i + 1, last5) W6Z_UPDATE3(1)
+            W6Z_POSITION_AT(2, 0, 5 * i + 2, last5) W6Z_UPDATE3(2)
+            W6Z_POSITION_AT(3, 1, 5 * i + 3, last5) W6Z_UPDATE3(3)
+            W6Z_POSITION_LP(5, 0, 5 * i + 4, last5, true)
+            zprev = zcur;
+            W6Z_LAST_ROW()
+            continue;
+        }
         if (DP) {      // D': two rows of five positions per trip, so that the LDS slab of every position is a constant
 #pragma unroll 1
-            for (int i = 0; i < 8; i += 2) {
+            for (int i = i_lo; i < i_hi; i += 2) {
                 zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
-                W6Z_POSITION_AT(0, 0, 5 * i + 0, 39)
-                W6Z_POSITION_AT(1, 1, 5 * i + 1, 39) W6Z_UPDATE3(1)
-                W6Z_POSITION_AT(2, 0, 5 * i + 2, 39) W6Z_UPDATE3(2)
-                W6Z_POSITION_AT(3, 1, 5 * i + 3, 39) W6Z_UPDATE3(3)
-                W6Z_POSITION_AT(5, 0, 5 * i + 4, 39)
+                const int last5 = 39;
+                W6Z_POSITION_AT(0, 0, 5 * i + 0, last5)
+                W6Z_POSITION_AT(1, 1, 5 * i + 1, last5) W6Z_UPDATE3(1)
+                W6Z_POSITION_AT(2, 0, 5 * i + 2, last5) W6Z_UPDATE3(2)
+                W6Z_POSITION_AT(3, 1, 5 * i + 3, last5) W6Z_UPDATE3(3)
+                W6Z_POSITION_AT(5, 0, 5 * i + 4, last5)
                 zprev = zcur;
                 zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)(i + 1) * (4 * C);
-                W6Z_POSITION_AT(0, 1, 5 * i + 5, 39)
-                W6Z_POSITION_AT(1, 0, 5 * i + 6, 39) W6Z_UPDATE3(1)
-                W6Z_POSITION_AT(2, 1, 5 * i + 7, 39) W6Z_UPDATE3(2)
-                W6Z_POSITION_AT(3, 0, 5 * i + 8, 39) W6Z_UPDATE3(3)
-                W6Z_POSITION_AT(5, 1, 5 * i + 9, 39)
+                W6Z_POSITION_AT(0, 1, 5 * i + 5, last5)
+                W6Z_POSITION_AT(1, 0, 5 * i + 6, last5) W6Z_UPDATE3(1)
+                W6Z_POSITION_AT(2, 1, 5 * i + 7, last5) W6Z_UPDATE3(2)
+                W6Z_POSITION_AT(3, 0, 5 * i + 8, last5) W6Z_UPDATE3(3)
+                W6Z_POSITION_AT(5, 1, 5 * i + 9, last5)
                 zprev = zcur;
             }
             continue;
         }
 #pragma unroll 1
-        for (int i = 0; i < R; i++) {
+        for (int i = i_lo; i < i_hi; i++) {
             zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
             W6Z_POSITION(i, 0)            // (stores Z_2, Z_3 of the previous row to zprev)
             W6Z_POSITION(i, 1) W6Z_UPDATE(1)
@@ -483,19 +539,20 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
             W6Z_POSITION(i, 5)            // (stores Z_0, Z_1 of this row to zcur)
             zprev = zcur;
         }
+        if (SPLIT) W6Z_LAST_ROW()
     }
     // the last row's Z_2, Z_3
-#pragma unroll
-    for (int k = 0; k < 8; k++) W6Z_STORE1(z20, z21, 2, zprev, k)
-#pragma unroll
-    for (int k = 0; k < 8; k++) W6Z_STORE1(z30, z31, 3, zprev, k)
+    if (!SPLIT) W6Z_LAST_ROW()
 #undef W6Z_UPDATE
 #undef W6Z_UPDATE3
 #undef W6Z_POSITION
 #undef W6Z_POSITION_AT
+#undef W6Z_POSITION_LP
 #undef W6GZ_
 #undef W6Z_GROUP
 #undef W6Z_STORE1
+#undef W6Z_LAST_ROW
+#undef W6_PROLOGUE
 #undef W6_UNEXT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -918,21 +975,36 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
     if (steps & 2) {
         constexpr size_t smem = (size_t)2 * W6_BT * (W6_C + 4) * 4;
         const int n6 = (int)map.blkDP, n5 = nblocks - n6;      // blocks of the classes with rows of six positions / of class D'
-        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false>), (int)smem);
-        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true>), (int)smem);
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false, false>), (int)smem);
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, false>), (int)smem);
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false, true>), (int)smem);
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, true>), (int)smem);
+        // r5 -- rows instead of blocks as the unit of work while the blocks do not fill the chip four times over (up to ~400 games): a block is a chain of
+        // 36 .. 48 positions on ONE CU whatever the batch (one game: 0.66 ms per layer on 4 CUs; split: 28 rows on 28 CUs)
+        // (C6_W6_SPLIT = 0 / 1: a test hook that forces one form -- tests/test_gpu_net.py compares the two bit for bit)
+        static const int force = [] { const char *e = getenv("C6_W6_SPLIT"); return e ? atoi(e) : -1; }();
+        const bool split = force >= 0 ? force != 0 : n6 < 4 * num_cus;
         // Beside a SMALL batch (the first launch leaves CUs idle: fewer than two rounds of blocks) the D' launch -- a tenth of the layer's products -- does
         // not wait for the other one: it goes to a side stream (fork / join by events) and takes the free CUs.  In order on one stream the second launch
         // cost one block's time after the other's (0.71 + 0.56 ms per layer at 64 games: 8.9 -> 5.5 ms per round; 128 games: 13.2 -> 9.8).  At the
         // benchmark's batch the chip is full either way and the launches stay in order on the caller's stream (21.7 + 2.5 ms).
         W6Side *side = n5 > 0 && n6 < 2 * num_cus ? w6_side_of(s) : nullptr;
         if (side) hipEventRecord(side->fork, s);
-        hipLaunchKernelGGL(c6_w6_gemm_kernel<false>, dim3(n6 < num_cus ? n6 : num_cus), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB, (int)map.blkBP,
-                           (int)map.blkD);
+        if (split) {
+            hipLaunchKernelGGL((c6_w6_gemm_kernel<false, true>), dim3(n6 < num_cus ? n6 : num_cus, 8), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB,
+                               (int)map.blkBP, (int)map.blkD);
+        } else
+            hipLaunchKernelGGL((c6_w6_gemm_kernel<false, false>), dim3(n6 < num_cus ? n6 : num_cus), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB, (int)map.blkBP,
+                               (int)map.blkD);
         if (n5 > 0) {
             hipStream_t s5 = side ? side->stream : s;
             if (side) hipStreamWaitEvent(s5, side->fork, 0);
-            hipLaunchKernelGGL(c6_w6_gemm_kernel<true>, dim3(n5 < num_cus ? n5 : num_cus), dim3(64 * (W6_C / 32)), smem, s5, Vb, wp, Mb, n6, nblocks, (int)map.blkB, (int)map.blkBP,
-                               (int)map.blkD);
+            if (split)
+                hipLaunchKernelGGL((c6_w6_gemm_kernel<true, true>), dim3(n5 < num_cus ? n5 : num_cus, 8), dim3(64 * (W6_C / 32)), smem, s5, Vb, wp, Mb, n6, nblocks, (int)map.blkB,
+                                   (int)map.blkBP, (int)map.blkD);
+            else
+                hipLaunchKernelGGL((c6_w6_gemm_kernel<true, false>), dim3(n5 < num_cus ? n5 : num_cus), dim3(64 * (W6_C / 32)), smem, s5, Vb, wp, Mb, n6, nblocks, (int)map.blkB, (int)map.blkBP,
+                                   (int)map.blkD);
             if (side) {
                 hipEventRecord(side->join, s5);
                 hipStreamWaitEvent(s, side->join, 0);

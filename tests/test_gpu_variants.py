@@ -10,6 +10,10 @@
 * C6_NO_VMM=1 (child process) -- the record pools as plain allocations of their initial size, what a device without HIP virtual memory
   management gets (engine.cpp: VmRange): the pool cannot grow, so deep trees end as partial games with the reason said -- never silently.
 
+* C6_W6_SPLIT=0 / 1 (child processes) -- the two work decompositions of conv_wino6.hip's GEMM kernel: a block of 64 tiles per workgroup (the
+  benchmark's batches) or one ROW of a block's positions per workgroup (small batches: a block is a chain of up to 48 positions on one CU).
+  The same instruction stream per position, so the net's outputs are equal BIT FOR BIT at every batch size.
+
 (The forms that lost their A/B comparisons -- separate transform kernels, a stem kernel of its own, unfused heads, the two-workgroup
 weight-gradient kernel -- are no longer in the product: compile-time options of A/B builds only, tools/ab_build.sh.)
 """
@@ -164,3 +168,38 @@ def test_trainer_default_precision_is_the_engines():
         out.append((float(t.step(*batch)), t.gradients(), t.export_weights()))
         t.close()
     assert out[0][0] == out[1][0] and (out[0][1] == out[1][1]).all() and (out[0][2] == out[1][2]).all()
+
+
+W6_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from c6amd_loader import load_package
+import __graft_entry__ as ge
+pkg = load_package()
+out = {}
+for blocks in (4, 8):
+    blob = ge.make_random_blob(19, 256, blocks, np.random.default_rng(5))
+    for num in (1, 13, 40, 333, 1100):
+        boards = np.random.default_rng(num).integers(-1, 2, size=(num, 361)).astype(np.int8)
+        pol, val = pkg.net_forward(19, 256, blocks, blob, boards, 1 if num %% 2 else -1, precision=pkg.PREC_FP32)
+        out["p%%d_%%d" %% (blocks, num)] = pol
+        out["v%%d_%%d" %% (blocks, num)] = val
+np.savez(sys.argv[1], **out)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_w6_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
+    """conv_wino6.hip: c6_w6_gemm_kernel<., true> (r5: a row of positions per workgroup -- one game's boards on 28 CUs instead of 4) against
+    <., false> (a block per workgroup) through c6_net_forward at 1 .. 1100 boards (1 board: every region's block nearly empty; 333: full and
+    partial blocks; 1100 boards: 344 + 35 blocks -- the block loop of both forms runs more than once), stem + 3 and stem + 7 blocks."""
+    need_gpu()
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for form in ("0", "1"):
+            out = os.path.join(td, f"w6_{form}.npz")
+            subprocess.run([sys.executable, "-c", W6_CHILD, out], check=True, env=dict(os.environ, C6_W6_SPLIT=form), timeout=600)
+            res[form] = dict(np.load(out))
+    assert sorted(res["0"]) == sorted(res["1"]) and len(res["0"]) == 20
+    for k in res["0"]:
+        assert np.isfinite(res["0"][k]).all()
+        assert np.array_equal(res["0"][k], res["1"][k]), k

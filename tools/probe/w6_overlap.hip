@@ -1,5 +1,5 @@
 // Probe (round 5): do the REAL kernels of the FP32 Winograd tower overlap when they share a CU?
-//   G  = c6_w6_gemm_kernel<true> (the 200-register instantiation: 8 waves, 133 KB of LDS -- leaves 112 registers per SIMD lane)
+//   G  = c6_w6_gemm_kernel<true, false> (the 200-register instantiation: 8 waves, 133 KB of LDS -- leaves 112 registers per SIMD lane)
 //   O  = the tower's last output transform (c6_w6_out_kernel's body) compiled for <= 112 registers, 4 waves per workgroup, persistent grid
 // so that one workgroup of each fits on a CU together.  Times: G alone, O alone, O launched first (its waves are the OLDER ones) then G on
 // another stream, G first then O.  together ~ max => the boundary kernel's memory time hides under the matrix work; ~ sum => it does not.
@@ -9,6 +9,12 @@
 #include <thread>
 #include <cstdio>
 #include <vector>
+#include <atomic>
+#include <fstream>
+#include <glob.h>
+#include <climits>
+#include <cstdlib>
+#include <string>
 void c6_note_hip(hipError_t, const char *) {}
 
 // one slice (b) of a tile at a time: 8 row sums of 1 KiB per wave instruction in flight, slice transform, bias, ReLU, the heads' three filters
@@ -123,6 +129,37 @@ __global__ void fill_kernel(float *p, size_t n, unsigned seed) {
         p[i] = ((int)(x & 0xffff) - 32768) * (1.f / 65536.f);
     }
 }
+// ---- power / clock of the card while a kernel mix runs: the hwmon files of the amdgpu driver, sampled by a host thread every 10 ms -----------
+struct Sampler {
+    std::vector<std::string> pw, fq;
+    std::atomic<bool> run{false};
+    std::thread th;
+    double psum = 0, pmax = 0, fsum = 0, fmin = 1e30; long n = 0;
+    static std::vector<std::string> g(const char *pat) { glob_t gl; std::vector<std::string> r; if (glob(pat, 0, nullptr, &gl) == 0) for (size_t i = 0; i < gl.gl_pathc; i++) r.push_back(gl.gl_pathv[i]); globfree(&gl); return r; }
+    static double rd(const std::string &f) { std::ifstream i(f); double v = -1; i >> v; return v; }
+    Sampler() {
+        // the card this process computes on: by its PCI address (the host shows every card's files)
+        char bus[64] = {0};
+        hipDeviceGetPCIBusId(bus, sizeof bus, 0);
+        std::string want(bus);
+        for (auto &ch : want) ch = (char)tolower(ch);
+        std::string base;
+        for (auto &d : g("/sys/class/drm/card*/device")) {
+            char real[512];
+            if (realpath(d.c_str(), real) && std::string(real).find(want) != std::string::npos) base = d;
+        }
+        printf("device 0 at %s -> %s\n", bus, base.c_str());
+        if (!base.empty()) {
+            for (const char *f : {"/hwmon/hwmon*/power1_average", "/hwmon/hwmon*/power1_input"}) { pw = g((base + f).c_str()); if (!pw.empty()) break; }
+            fq = g((base + "/hwmon/hwmon*/freq1_input").c_str());
+            for (auto &c : g((base + "/hwmon/hwmon*/power1_cap").c_str())) printf("power cap %.0f W\n", rd(c) / 1e6);
+        }
+    }
+    void start() { psum = pmax = fsum = 0; fmin = 1e30; n = 0; run = true; th = std::thread([this] {
+        while (run) { double p = 0, f = 0; for (auto &x : pw) p = std::max(p, rd(x)); for (auto &x : fq) f = std::max(f, rd(x));
+            psum += p; pmax = std::max(pmax, p); fsum += f; fmin = std::min(fmin, f); n++; std::this_thread::sleep_for(std::chrono::milliseconds(10)); } }); }
+    void stop(const char *what, double ms_per_iter) { run = false; th.join(); printf("%-58s %8.3f ms per iteration; power avg %6.0f W max %6.0f W; sclk avg %5.0f MHz min %5.0f MHz (%ld samples)\n", what, ms_per_iter, psum / n / 1e6, pmax / 1e6, fsum / n / 1e6, fmin / 1e6, n); }
+};
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
 int main(int argc, char **argv) {
@@ -144,11 +181,11 @@ int main(int argc, char **argv) {
     const C6HeadFuse hd{hw, scal, 0.1f, scal + 8, scal + 512, ph, vh};
     const long tiles = (long)nboards * W6_T;
     constexpr size_t gsmem = (size_t)2 * W6_BT * (W6_C + 4) * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gsmem));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gsmem));
     hipStream_t sg, so; CK(hipStreamCreateWithFlags(&sg, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&so, hipStreamNonBlocking));
     const size_t osmem = 24 * 1024;
     // every block treated as a D' block (rows of five positions, 40 per tile): the instantiation that leaves registers free
-    auto gemm = [&]() { hipLaunchKernelGGL(c6_w6_gemm_kernel<true>, dim3(cus), dim3(512), gsmem, sg, V, U, Z, 0, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD); };
+    auto gemm = [&]() { hipLaunchKernelGGL(c6_w6_gemm_kernel<true, false>, dim3(cus), dim3(512), gsmem, sg, V, U, Z, 0, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD); };
     auto outp = [&](int grid) { for (int r = 0; r < out_reps; r++) hipLaunchKernelGGL(out_lo_kernel, dim3(grid), dim3(256), osmem, so, Z2, bias, (const float *)nullptr, tiles, hd, 0); };
     auto outfull = [&]() { for (int r = 0; r < out_reps; r++) hipLaunchKernelGGL(c6_w6_out_kernel, dim3(cus * 8), dim3(256), 0, so, Z2, bias, (const float *)nullptr, tiles, hd); };
     auto timeit = [&](auto &&f) {
@@ -164,9 +201,28 @@ int main(int argc, char **argv) {
         return best;
     };
     printf("CUs %d, %d boards, %d blocks; out kernel x %d\n", cus, nboards, nblocks, out_reps);
+    if (argc > 3 && atoi(argv[3]) == 1) {      // power / clock under each kernel mix, ~2.5 s each
+        Sampler S;
+        float *V2; CK(hipMalloc(&V2, zfl * 4 * 3 / 2 + (1 << 20)));
+        const size_t n4 = zfl / 4;
+        auto loop = [&](const char *what, auto &&f) {
+            hipDeviceSynchronize();
+            S.start();
+            auto t0 = std::chrono::steady_clock::now(); int it = 0;
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5) { f(); hipStreamSynchronize(sg); hipStreamSynchronize(so); it++; }
+            S.stop(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / it);
+        };
+        loop("idle (host sleeps 50 ms)", [&] { std::this_thread::sleep_for(std::chrono::milliseconds(50)); });
+        loop("G: c6_w6_gemm_kernel<true, false>, all blocks", [&] { gemm(); });
+        loop("O: c6_w6_out_kernel x reps (reads Z)", [&] { outfull(); });
+        loop("X: read-transform-write stand-in x reps", [&] { for (int r = 0; r < out_reps; r++) hipLaunchKernelGGL(xcopy_kernel<6>, dim3(cus * 8), dim3(256), 0, so, (const f32x4 *)Z2, (f32x4 *)V2, n4, 0); });
+        loop("G then X, one stream's worth (a layer: matrix phase + HBM phase)", [&] { gemm(); hipStreamSynchronize(sg); for (int r = 0; r < 2; r++) hipLaunchKernelGGL(xcopy_kernel<6>, dim3(cus * 8), dim3(256), 0, so, (const f32x4 *)Z2, (f32x4 *)V2, n4, 0); });
+        return 0;
+    }
+
     const double tg = timeit([&] { gemm(); });
     const double flops = 2.0 * 40.0 * nblocks * W6_BT * 256.0 * 256.0;
-    printf("G alone (c6_w6_gemm_kernel<true>, all blocks as rows of five): %8.3f ms  %6.1f TFLOP/s\n", tg, flops / tg / 1e9);
+    printf("G alone (c6_w6_gemm_kernel<true, false>, all blocks as rows of five): %8.3f ms  %6.1f TFLOP/s\n", tg, flops / tg / 1e9);
     const double zbytes = (double)tiles * 32 * 1024 * out_reps;
     const double tof = timeit([&] { outfull(); });
     printf("the product's c6_w6_out_kernel (8 workgroups per CU) alone:     %8.3f ms  %5.2f TB/s\n", tof, zbytes / tof / 1e9);
