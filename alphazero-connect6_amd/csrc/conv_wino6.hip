@@ -541,8 +541,12 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
         }
         if (SPLIT) W6Z_LAST_ROW()
     }
-    // the last row's Z_2, Z_3
-    if (!SPLIT) W6Z_LAST_ROW()
+    // the last row's Z_2, Z_3 (first the weight stream's last seven requests land: nobody waits for them, and a register the compiler hands to
+    // something else while a request into it is in flight is overwritten when it arrives -- r5, found in the split form)
+    if (!SPLIT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W6Z_LAST_ROW()
+    }
 #undef W6Z_UPDATE
 #undef W6Z_UPDATE3
 #undef W6Z_POSITION

@@ -537,6 +537,37 @@ struct PhaseTimer {
     }
 };
 
+// Host staging of the callback evaluator (8 G boards down, 8 G policies + values up, every simulation round): page-locked, so that the copies are
+// DMA transfers at the link's rate instead of the runtime's pageable path through a bounce buffer (r5).  Grows, never shrinks; pageable if locking fails.
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t cap = 0, n = 0;
+    bool pinned = false;
+    T *data() { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    void release() {
+        if (p) { if (pinned) hipHostFree(p); else free(p); }
+        p = nullptr; cap = n = 0;
+    }
+    bool resize(size_t want) {
+        if (want > cap) {
+            release();
+            void *q = nullptr;
+            if (hipHostMalloc(&q, want * sizeof(T), hipHostMallocDefault) == hipSuccess) pinned = true;
+            else { (void)hipGetLastError(); q = malloc(want * sizeof(T)); pinned = false; }
+            if (!q) return false;
+            memset(q, 0, want * sizeof(T));
+            p = static_cast<T *>(q);
+            cap = want;
+        }
+        n = want;
+        return true;
+    }
+    ~PinnedBuf() { release(); }
+};
+
 struct c6_engine {
     c6_config cfg{};
     C6Dev d{};
@@ -553,7 +584,8 @@ struct c6_engine {
     int chunk_leaves = 0;
     // callback scratch
     float *img_boards = nullptr;   // device [G][8][cells]
-    std::vector<float> h_img, h_pol, h_val, h_cbp, h_cbv;
+    PinnedBuf<float> h_img, h_pol, h_val;
+    std::vector<float> h_cbp, h_cbv;
     std::vector<int8_t> h_kind, h_turn;
     std::vector<C6GameHdr> h_hdr;      // host copy of the game headers (statistics, states)
     // owned tuple buffer
@@ -846,13 +878,24 @@ static int evaluate_callback(c6_engine *e) {
     if (!e->cb) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_CALLBACK but no callback is set");
     c6_launch_augment(d, e->img_boards, e->stream);
     e->h_kind.resize(G); e->h_turn.resize(G);
-    e->h_img.resize((size_t)G * 8 * cells); e->h_pol.resize((size_t)G * 8 * cells); e->h_val.resize((size_t)G * 8);
+    if (!e->h_img.resize((size_t)G * 8 * cells) || !e->h_pol.resize((size_t)G * 8 * cells) || !e->h_val.resize((size_t)G * 8)) return fail(C6_ERR_HIP, "callback staging: out of host memory");
     e->h_hdr.resize(G);
     HIPCHK(hipMemcpyAsync(e->h_hdr.data(), d.hdr, (size_t)G * sizeof(C6GameHdr), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(e->h_img.data(), e->img_boards, e->h_img.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int g = 0; g < G; g++) { e->h_kind[g] = e->h_hdr[g].leaf_kind; e->h_turn[g] = e->h_hdr[g].leaf_turn; }
-    // the callback takes ONE `player` for all boards (cppeval/mod.rs:8-13): batch per side to move
+    // the callback takes ONE `player` for all boards (cppeval/mod.rs:8-13): batch per side to move.  Games of one call start together, so as a rule
+    // every game waits for an evaluation for the same side: the callback then works on the staging buffers in place (no gather / scatter copies)
+    bool uniform = G > 0;
+    for (int g = 0; g < G && uniform; g++) uniform = e->h_kind[g] == C6_LEAF_EVAL && e->h_turn[g] == e->h_turn[0];
+    if (uniform) {
+        memset(e->h_val.data(), 0, e->h_val.size() * sizeof(float));      // values zero-filled, cppeval/mod.rs:34
+        e->cb(e->h_turn[0], e->h_val.data(), e->h_img.data(), G * 8);     // (boards in, policies out: the same buffer, as the reference passes it)
+        HIPCHK(hipMemcpyAsync(d.img_pol, e->h_img.data(), e->h_img.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(d.img_val, e->h_val.data(), e->h_val.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        c6_launch_recover(d, e->stream);
+        return C6_OK;
+    }
     for (int player = -1; player <= 1; player += 2) {
         std::vector<int> idx;
         for (int g = 0; g < G; g++)
