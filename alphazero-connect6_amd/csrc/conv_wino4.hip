@@ -20,6 +20,7 @@
 // Rounding: a layer's error is ~6x that of the direct f32 kernel (2.4e-6 rms of activations of order 1); over the benchmark's net
 // the outputs move by < 1e-7 (tests/test_gpu_net.py holds every arithmetic to 1e-5 against the oracle and a float64 PyTorch model).
 #include "c6_wino.h"
+#include <cstdlib>
 
 
 #define W4_BT 64        // tiles per block
@@ -336,8 +337,19 @@ constexpr int w4_wait(int i, bool stores) {
     return W4_PF + dmas + st;
 }
 static_assert(w4_store_group(15) < 32 - W4_PF, "a position's stores are older than every request that is waited for in the next one");
+// the LAST position of a split job (SPLIT below, r5): the weight stream ends with the row and no next position is fetched -- younger than group i's
+// request are only the groups i + 1 .. 31 and the result stores issued since
+constexpr int w4_wait_last(int i) {
+    int st = 0;
+    for (int k = 0; k < 16; k++)
+        if (w4_store_group(k) < i && w4_store_group(k) >= i - W4_PF) st++;
+    return (31 - i < W4_PF ? 31 - i : W4_PF) + st;
+}
 
-template <int N>
+// SPLIT (r5, as conv_wino6.hip's c6_w6_gemm_kernel<., true>): the job is a ROW of a block's positions (blockIdx.y), not the block -- a row's four row
+// sums depend on its own six positions only, and a block is a chain of up to 36 positions on one CU whatever the batch.  Same instruction stream per
+// position, bit-identical sums; every job has its own prologue, its last position requests nothing beyond the row (LP).  For small batches.
+template <int N, bool SPLIT>
 __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
                                                                          float *__restrict__ Zo, int nblocks, int blkB, int blkBP) {
     using G = W4Geom<N>;
@@ -353,6 +365,7 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
     const int n4 = wave * 32 + 4 * h;
     int b = blockIdx.x;
     if (b >= nblocks) return;
+    const int row0 = SPLIT ? (int)blockIdx.y : 0;
 
     // blocks [0, blkB) are of class A (6 rows of positions, weight set 0), [blkB, blkBP) of class B, [blkBP, nblocks) of class B' (5 rows,
     // weight sets at 36 C^2 and 66 C^2); a set is packed [wave][position][group][lane][4]
@@ -370,24 +383,33 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
         const int lds_off = (buf * SLAB + c * CP) * 4;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lds_off) : "memory");
     };
-#pragma unroll
-    for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * G::BLOCK_FLOATS, 0, c0);
     f32x4 ring[PF + 1];
     int ub = b, ungt = rows_of(b) * 6 * NG;      // the weight stream runs ahead of the multiplications: its own block and group counters
     const float *uptr = wbase_of(b);
     int gi = 0;
 #define W4_UNEXT()                                                       \
     {                                                                    \
-        gi += 1; uptr += 256;                                            \
-        if (gi == ungt) {                                                \
-            gi = 0;                                                      \
-            ub = ub + (int)gridDim.x < nblocks ? ub + (int)gridDim.x : ub; \
-            ungt = rows_of(ub) * 6 * NG;                                 \
-            uptr = wbase_of(ub);                                         \
+        uptr += 256;                                                     \
+        if (!SPLIT) {                                                    \
+            gi += 1;                                                     \
+            if (gi == ungt) {                                            \
+                gi = 0;                                                  \
+                ub = ub + (int)gridDim.x < nblocks ? ub + (int)gridDim.x : ub; \
+                ungt = rows_of(ub) * 6 * NG;                             \
+                uptr = wbase_of(ub);                                     \
+            }                                                            \
         }                                                                \
     }
-#pragma unroll
-    for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W4_UNEXT() }
+    // the first position's V rows into slab 0, the first seven weight groups into the ring (SPLIT: per job; the empty asm keeps the job's group
+    // addresses from being hoisted out of the block loop into scalar registers)
+#define W4_PROLOGUE(ROW)                                                                                         \
+    {                                                                                                            \
+        _Pragma("unroll") for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * G::BLOCK_FLOATS + (size_t)(6 * (ROW)) * G::POS_STRIDE, 0, c0); \
+        uptr = wbase_of(b) + (size_t)(6 * (ROW)) * (NG * 256);                                                   \
+        if (SPLIT) asm volatile("" : "+s"(uptr));                                                                \
+        _Pragma("unroll") for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W4_UNEXT() }           \
+    }
+    if (!SPLIT) W4_PROLOGUE(0)
 
     // z[b][tile half]; the very first "previous row" is this block's row 0 itself (zeros, overwritten one row later)
     f32x16 z00, z01, z10, z11, z20, z21, z30, z31, m0, m1;
@@ -401,18 +423,27 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
     {                                                                                                            \
         const f32x16 &sv = ((k) & 4) ? SET1 : SET0;                                                              \
         const f32x4 a = {sv[4 * ((k) & 3)], sv[4 * ((k) & 3) + 1], sv[4 * ((k) & 3) + 2], sv[4 * ((k) & 3) + 3]}; \
-        const float *d_ = (DST) + (size_t)(BIDX) * C;                                                            \
-        if (((k) & 3) == 0) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 0);                                       \
-        else if (((k) & 3) == 1) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 32);                                 \
-        else if (((k) & 3) == 2) W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 64);                                 \
-        else W4_STORE(((k) & 4) ? zoff1 : zoff0, a, d_, 96);                                                     \
+        /* SPLIT: the second tile half's offset rides in the scalar base (one vector register less) */         \
+        const float *d_ = (DST) + (size_t)(BIDX) * C + (SPLIT && ((k) & 4) ? (size_t)32 * ZTILE : (size_t)0);   \
+        const unsigned zo_ = SPLIT ? zoff0 : ((k) & 4) ? zoff1 : zoff0;                                          \
+        if (((k) & 3) == 0) W4_STORE(zo_, a, d_, 0);                                                             \
+        else if (((k) & 3) == 1) W4_STORE(zo_, a, d_, 32);                                                       \
+        else if (((k) & 3) == 2) W4_STORE(zo_, a, d_, 64);                                                       \
+        else W4_STORE(zo_, a, d_, 96);                                                                           \
         asm volatile("s_nop 1" ::: "memory");                                                                    \
     }
+#define W4Z_LAST_ROW()                                                                                           \
+    {                                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) W4Z_STORE1(z20, z21, 2, zprev, k)                           \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) W4Z_STORE1(z30, z31, 3, zprev, k)                           \
+    }
     // JJ = position's column j: 0 accumulates into z0 from zero, 5 into z3 on top of it, 1 .. 4 into m from zero
-#define W4Z_GROUP(q, u, NWAIT, DMA, JJ, BUF)                                                                     \
+#define W4Z_GROUP(q, u, NWAIT, DMA, JJ, BUF, LP)                                                                 \
             {                                                                                                    \
-                W4_ULOAD(ring[((q) + PF) & RM], lane16, uptr);                                                   \
-                W4_UNEXT()                                                                                       \
+                if (!(LP) || (u) + PF < NG) {      /* (LP: a request nobody waits for lands in registers the compiler has given to something else) */ \
+                    W4_ULOAD(ring[((q) + PF) & RM], lane16, uptr);                                               \
+                    W4_UNEXT()                                                                                   \
+                }                                                                                                \
                 if ((u) + 1 < NG) {                                                                              \
                     va[((u) + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(vb + 8 * ((u) + 1));                 \
                     va[((u) + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP + 8 * ((u) + 1));       \
@@ -430,12 +461,12 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
                     m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : m0, 0, 0, 0); \
                     m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : m1, 0, 0, 0); \
                 }                                                                                                \
-                if ((DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (BUF) ^ 1, (DMA));                                 \
+                if (!(LP) && (DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (BUF) ^ 1, (DMA));                        \
                 if ((JJ) == 5 && (u) >= 8 && (u) < 24) {      /* Z_0, Z_1 of this row */                          \
                     if ((u) < 16) W4Z_STORE1(z00, z01, 0, zcur, (u) - 8)                                         \
                     else W4Z_STORE1(z10, z11, 1, zcur, (u) - 16)                                                 \
                 }                                                                                                \
-                if ((JJ) == 0 && (u) >= 8 && (u) < 24) {      /* Z_2, Z_3 of the previous row */                  \
+                if (!SPLIT && (JJ) == 0 && (u) >= 8 && (u) < 24) {      /* Z_2, Z_3 of the previous row (SPLIT: one row, no previous one) */ \
                     if ((u) < 16) W4Z_STORE1(z20, z21, 2, zprev, (u) - 8)                                        \
                     else W4Z_STORE1(z30, z31, 3, zprev, (u) - 16)                                                \
                 }                                                                                                \
@@ -453,7 +484,7 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }
-#define WGZ_(i, JJ, BUF) W4Z_GROUP((i) & RM, (i), w4_wait((i), (JJ) == 0 || (JJ) == 5), (i), JJ, BUF)
+#define WGZ_(i, JJ, BUF) W4Z_GROUP((i) & RM, (i), (SPLIT && (JJ) == 5) ? w4_wait_last((i)) : w4_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5), (i), JJ, BUF, SPLIT && (JJ) == 5)
     // one position (row i_, column JJ): slab in LDS buffer JJ & 1
 #define W4Z_POSITION(i_, JJ)                                                                                     \
         {                                                                                                        \
@@ -462,9 +493,12 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
             const float *nsrc;                                                                                   \
             {                                                                                                    \
                 const int pp = 6 * (i_) + (JJ);                                                                  \
-                int nb = pp < 6 * R - 1 ? b : b + (int)gridDim.x;                                                \
-                nb = nb < nblocks ? nb : b;                                                                      \
-                nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)(pp < 6 * R - 1 ? pp + 1 : 0) * G::POS_STRIDE; \
+                if (SPLIT) nsrc = V + (size_t)b * G::BLOCK_FLOATS + (size_t)(pp + 1) * G::POS_STRIDE;      /* (not used by the job's last position) */ \
+                else {                                                                                           \
+                    int nb = pp < 6 * R - 1 ? b : b + (int)gridDim.x;                                            \
+                    nb = nb < nblocks ? nb : b;                                                                  \
+                    nsrc = V + (size_t)nb * G::BLOCK_FLOATS + (size_t)(pp < 6 * R - 1 ? pp + 1 : 0) * G::POS_STRIDE; \
+                }                                                                                                \
             }                                                                                                    \
             const float *vb = wsm + ((JJ) & 1) * SLAB + j * CP + 4 * h;                                          \
             f32x4 va[2][2];                                                                                      \
@@ -500,8 +534,12 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
 #pragma unroll 1
     for (; b < nblocks; b += gridDim.x) {
         const int R = rows_of(b);
+        if (SPLIT) {
+            if (row0 >= R) continue;      // (an edge class has five rows: uniform over the workgroup)
+            W4_PROLOGUE(row0)             // (what the previous job left in flight -- its last Z stores -- is older than these requests and retires before them)
+        }
 #pragma unroll 1
-        for (int i = 0; i < R; i++) {
+        for (int i = row0; i < (SPLIT ? row0 + 1 : R); i++) {
             zcur = Zo + (size_t)b * ZBLOCK + (size_t)i * (4 * C);
             W4Z_POSITION(i, 0)            // (stores Z_2, Z_3 of the previous row to zprev)
             W4Z_POSITION(i, 1) W4Z_UPDATE(1)
@@ -511,12 +549,15 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
             W4Z_POSITION(i, 5)            // (stores Z_0, Z_1 of this row to zcur)
             zprev = zcur;
         }
+        if (SPLIT) W4Z_LAST_ROW()
     }
-    // the last row's Z_2, Z_3
-#pragma unroll
-    for (int k = 0; k < 8; k++) W4Z_STORE1(z20, z21, 2, zprev, k)
-#pragma unroll
-    for (int k = 0; k < 8; k++) W4Z_STORE1(z30, z31, 3, zprev, k)
+    // the last row's Z_2, Z_3 (first the weight stream's last seven requests land: nobody waits for them -- conv_wino6.hip, r5)
+    if (!SPLIT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4Z_LAST_ROW()
+    }
+#undef W4Z_LAST_ROW
+#undef W4_PROLOGUE
 #undef W4Z_UPDATE
 #undef W4Z_POSITION
 #undef WGZ_
@@ -835,8 +876,16 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     if (steps & 2) {
         const size_t smem = G::LDS_BYTES;
         const int grid = nblocks < num_cus ? nblocks : num_cus;
-        w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N>), (int)smem);
-        hipLaunchKernelGGL((c6_wino4_gemm_kernel<N>), dim3(grid), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP);
+        // r5 -- rows instead of blocks as the unit of work while the blocks do not fill the chip four times over (conv_wino6.hip's c6_w6_dispatch);
+        // C6_W4_SPLIT = 0 / 1: a test hook that forces one form (tests/test_gpu_variants.py compares the two bit for bit)
+        static const int force = [] { const char *e = getenv("C6_W4_SPLIT"); return e ? atoi(e) : -1; }();
+        if (force >= 0 ? force != 0 : nblocks < 4 * num_cus) {
+            w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N, true>), (int)smem);
+            hipLaunchKernelGGL((c6_wino4_gemm_kernel<N, true>), dim3(grid, 6), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP);
+        } else {
+            w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N, false>), (int)smem);
+            hipLaunchKernelGGL((c6_wino4_gemm_kernel<N, false>), dim3(grid), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP);
+        }
     }
     if (steps & 16) {      // output transform of this layer (bias, residual if any, ReLU; activations stored if `out`) + input transform of the next: M -> V
         constexpr size_t mid_smem = (size_t)6 * (4 * G::TW + 2) * W4_C * 4;

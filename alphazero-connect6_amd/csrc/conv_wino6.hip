@@ -278,8 +278,14 @@ constexpr int w6_wait(int i, bool stores) {
     return W6_PF + dmas + st;
 }
 static_assert(w6_store_group(15) < 32 - W6_PF, "a position's stores are older than every request that is waited for in the next one");
-// the LAST position of a split job (below): the weight stream ends with the row -- groups i + 1 .. 31 are the only weight requests younger than group i's
-constexpr int w6_wait_last(int i, bool stores) { return w6_wait(i, stores) - W6_PF + (31 - i < W6_PF ? 31 - i : W6_PF); }
+// the LAST position of a split job (below): the weight stream ends with the row and no next position is fetched -- younger than group i's request are
+// only the groups i + 1 .. 31 and the result stores issued since
+constexpr int w6_wait_last(int i) {
+    int st = 0;
+    for (int k = 0; k < 16; k++)
+        if (w6_store_group(k) < i && w6_store_group(k) >= i - W6_PF) st++;
+    return (31 - i < W6_PF ? 31 - i : W6_PF) + st;
+}
 
 // DP = false: the blocks [first, nblocks) of the classes with rows of six positions (A, B, B', D: 708 of a board's 788 positions); DP = true: the blocks of
 // class D' (rows of five: 80 positions).  Two instantiations, two launches: with both row forms in one kernel the register allocator spilled 121 registers of the accumulators.
@@ -326,8 +332,8 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
     int ub = b, ungt = npos_of(b) * NG;      // the weight stream runs ahead of the multiplications: its own block and group counters
     const float *uptr = wbase_of(b);
     int gi = 0;
-    // SPLIT: every (block, row) is a job of its own and nothing wraps -- the weight stream ends with the row (W6Z_GROUP's LP), the row's last position
-    // fetches the tile slots' next row of V (behind a block's last position: the slots' padding row W6_NPV - 1), which nobody reads
+    // SPLIT: every (block, row) is a job of its own and nothing wraps -- the weight stream ends with the row and the row's last position fetches no
+    // next one (W6Z_GROUP's LP)
 #define W6_UNEXT()                                                       \
     {                                                                    \
         uptr += 256;                                                     \
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
                     m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : m0, 0, 0, 0); \
                     m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : m1, 0, 0, 0); \
                 }                                                                                                \
-                if ((DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (BUF) ^ 1, (DMA));                                 \
+                if (!(LP) && (DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (BUF) ^ 1, (DMA));                        \
                 if ((JJ) == 5 && (u) >= 8 && (u) < 24) {      /* Z_0, Z_1 of this row */                          \
                     if ((u) < 16) W6Z_STORE1(z00, z01, 0, zcur, (u) - 8)                                         \
                     else W6Z_STORE1(z10, z11, 1, zcur, (u) - 16)                                                 \
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }
-#define W6GZ_(i, JJ, BUF, LP) W6Z_GROUP((i) & RM, (i), (LP) ? w6_wait_last((i), true) : w6_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5), (i), JJ, BUF, LP)
+#define W6GZ_(i, JJ, BUF, LP) W6Z_GROUP((i) & RM, (i), (LP) ? w6_wait_last((i)) : w6_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5), (i), JJ, BUF, LP)
 // one position of a block: JJ = its role in the row (0: the first point, accumulates into Z_0; 5: the last point, accumulates into the last
 // row sum; 1 .. 4: aside, folded in by W6Z_UPDATE / W6Z_UPDATE3), BUF = the LDS slab it reads (positions alternate), PP = its index in the
 // block, LAST = the block's last index

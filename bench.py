@@ -586,6 +586,11 @@ def main():
             # beside it: they converge to `value` only once the slots' game phases have decorrelated (many game lengths)
             out["games_per_s_counted_in_window"] = head["games_in_window"] / head["dt"]
             out["stones_per_finished_game_in_window"] = head["stones_in_window"] / head["games_in_window"]
+        if is_net and probe_file:      # the divisor's own uncertainty travels with it (config 3's probe is 70-odd games, config 2's 1024)
+            se = probe_file.get("standard_error") or (probe_file["stones_std"] / max(probe_file["games"], 1) ** 0.5)
+            out["config"]["stones_per_game_games"] = probe_file["games"]
+            out["config"]["stones_per_game_standard_error"] = se
+            out["value_relative_standard_error_from_stones"] = se / probe_file["stones_per_game"]
         if live:
             out["config"]["stones_per_game_live_probe"] = live
             if is_net:

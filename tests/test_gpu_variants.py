@@ -10,7 +10,7 @@
 * C6_NO_VMM=1 (child process) -- the record pools as plain allocations of their initial size, what a device without HIP virtual memory
   management gets (engine.cpp: VmRange): the pool cannot grow, so deep trees end as partial games with the reason said -- never silently.
 
-* C6_W6_SPLIT=0 / 1 (child processes) -- the two work decompositions of conv_wino6.hip's GEMM kernel: a block of 64 tiles per workgroup (the
+* C6_W6_SPLIT=0 / 1, C6_W4_SPLIT=0 / 1 (child processes) -- the two work decompositions of conv_wino6.hip's / conv_wino4.hip's GEMM kernel: a block of 64 tiles per workgroup (the
   benchmark's batches) or one ROW of a block's positions per workgroup (small batches: a block is a chain of up to 48 positions on one CU).
   The same instruction stream per position, so the net's outputs are equal BIT FOR BIT at every batch size.
 
@@ -168,6 +168,40 @@ def test_trainer_default_precision_is_the_engines():
         out.append((float(t.step(*batch)), t.gradients(), t.export_weights()))
         t.close()
     assert out[0][0] == out[1][0] and (out[0][1] == out[1][1]).all() and (out[0][2] == out[1][2]).all()
+
+
+W4_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from c6amd_loader import load_package
+import __graft_entry__ as ge
+pkg = load_package()
+out = {}
+for n, blocks in ((15, 3), (9, 4), (19, 2)):      # (19 x 19 with one residual block: conv_wino4.hip's tiling, conv_wino6.hip needs two)
+    blob = ge.make_random_blob(n, 256, blocks, np.random.default_rng(6))
+    for num in (1, 13, 300, 2000):
+        boards = np.random.default_rng(num).integers(-1, 2, size=(num, n * n)).astype(np.int8)
+        pol, val = pkg.net_forward(n, 256, blocks, blob, boards, 1 if num %% 2 else -1, precision=pkg.PREC_FP32)
+        out["p%%d_%%d" %% (n, num)] = pol
+        out["v%%d_%%d" %% (n, num)] = val
+np.savez(sys.argv[1], **out)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_w4_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
+    """conv_wino4.hip: c6_wino4_gemm_kernel<N, true> (a row of positions per workgroup) against <N, false> (a block per workgroup) through
+    c6_net_forward at 15 x 15, 9 x 9 and (two-block tower) 19 x 19, 1 .. 2000 boards: equal bit for bit."""
+    need_gpu()
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for form in ("0", "1"):
+            out = os.path.join(td, f"w4_{form}.npz")
+            subprocess.run([sys.executable, "-c", W4_CHILD, out], check=True, env=dict(os.environ, C6_W4_SPLIT=form), timeout=600)
+            res[form] = dict(np.load(out))
+    assert sorted(res["0"]) == sorted(res["1"]) and len(res["0"]) == 24
+    for k in res["0"]:
+        assert np.isfinite(res["0"][k]).all()
+        assert np.array_equal(res["0"][k], res["1"][k]), k
 
 
 W6_CHILD = r"""
