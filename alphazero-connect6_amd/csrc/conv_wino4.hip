@@ -876,10 +876,10 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     if (steps & 2) {
         const size_t smem = G::LDS_BYTES;
         const int grid = nblocks < num_cus ? nblocks : num_cus;
-        // r5 -- rows instead of blocks as the unit of work while the blocks do not fill the chip four times over (conv_wino6.hip's c6_w6_dispatch);
+        // r5 -- rows instead of blocks as the unit of work while a CU gets fewer than eight blocks (conv_wino6.hip's c6_w6_dispatch);
         // C6_W4_SPLIT = 0 / 1: a test hook that forces one form (tests/test_gpu_variants.py compares the two bit for bit)
         static const int force = [] { const char *e = getenv("C6_W4_SPLIT"); return e ? atoi(e) : -1; }();
-        if (force >= 0 ? force != 0 : nblocks < 4 * num_cus) {
+        if (force >= 0 ? force != 0 : nblocks < 8 * num_cus) {
             w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N, true>), (int)smem);
             hipLaunchKernelGGL((c6_wino4_gemm_kernel<N, true>), dim3(grid, 6), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP);
         } else {

@@ -989,11 +989,13 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
         w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, false>), (int)smem);
         w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false, true>), (int)smem);
         w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, true>), (int)smem);
-        // r5 -- rows instead of blocks as the unit of work while the blocks do not fill the chip four times over (up to ~400 games): a block is a chain of
-        // 36 .. 48 positions on ONE CU whatever the batch (one game: 0.66 ms per layer on 4 CUs; split: 28 rows on 28 CUs)
+        // r5 -- rows instead of blocks as the unit of work while a CU gets fewer than eight blocks (up to ~800 games): a block is a chain of 36 .. 48
+        // positions on ONE CU whatever the batch (one game: 0.66 ms per layer on 4 CUs; split: 28 rows on 28 CUs), and with a few blocks per CU the block form
+        // rounds up (256 games = 2.5 blocks per CU: 18.3 ms per round against 13.8).  From ~1000 games on the block form is as fast or faster (no prologue per
+        // row: 4096 games 202.9 against 207.4 ms) -- profiles/r05_split_threshold.txt
         // (C6_W6_SPLIT = 0 / 1: a test hook that forces one form -- tests/test_gpu_net.py compares the two bit for bit)
         static const int force = [] { const char *e = getenv("C6_W6_SPLIT"); return e ? atoi(e) : -1; }();
-        const bool split = force >= 0 ? force != 0 : n6 < 4 * num_cus;
+        const bool split = force >= 0 ? force != 0 : n6 < 8 * num_cus;
         // Beside a SMALL batch (the first launch leaves CUs idle: fewer than two rounds of blocks) the D' launch -- a tenth of the layer's products -- does
         // not wait for the other one: it goes to a side stream (fork / join by events) and takes the free CUs.  In order on one stream the second launch
         // cost one block's time after the other's (0.71 + 0.56 ms per layer at 64 games: 8.9 -> 5.5 ms per round; 128 games: 13.2 -> 9.8).  At the
