@@ -186,8 +186,32 @@ __global__ __launch_bounds__(256) void c6_head_policy_kernel(const float *__rest
         float acc1[HB], acc2[HB];
 #pragma unroll
         for (int q = 0; q < HB; q++) { acc1[q] = bias[c1]; acc2[q] = bias[c2]; }
+        // r5: the weights of eight k at a time, requested one block ahead -- the loop was a chain of 722 dependent L2 round trips, 180 us for a
+        // workgroup on its own (one game's eight boards); the multiply-adds keep their order (k ascending per output: bit-identical results)
+        constexpr int KB = 8;
         if (cells > 256) {
-            for (int k = 0; k < K; k++) {
+            float wa[KB], wb[KB];
+#pragma unroll
+            for (int u = 0; u < KB; u++) { wa[u] = wT[(size_t)u * cells + c1]; wb[u] = wT[(size_t)u * cells + c2]; }      // (K >= 8)
+            int k = 0;
+            for (; k + KB <= K; k += KB) {
+                float na[KB], nb_[KB];
+                const int kn = k + KB + KB <= K ? k + KB : k;      // the next whole block (the last one: itself again, not used)
+#pragma unroll
+                for (int u = 0; u < KB; u++) { na[u] = wT[(size_t)(kn + u) * cells + c1]; nb_[u] = wT[(size_t)(kn + u) * cells + c2]; }
+#pragma unroll
+                for (int u = 0; u < KB; u++) {
+#pragma unroll
+                    for (int q = 0; q < HB; q++) {
+                        const float xv = x[q * K + k + u];
+                        acc1[q] = __builtin_fmaf(wa[u], xv, acc1[q]);
+                        acc2[q] = __builtin_fmaf(wb[u], xv, acc2[q]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KB; u++) { wa[u] = na[u]; wb[u] = nb_[u]; }
+            }
+            for (; k < K; k++) {
                 const float w1 = wT[(size_t)k * cells + c1], w2 = wT[(size_t)k * cells + c2];
 #pragma unroll
                 for (int q = 0; q < HB; q++) {
@@ -197,7 +221,24 @@ __global__ __launch_bounds__(256) void c6_head_policy_kernel(const float *__rest
                 }
             }
         } else {
-            for (int k = 0; k < K; k++) {
+            float wa[KB];
+#pragma unroll
+            for (int u = 0; u < KB; u++) wa[u] = wT[(size_t)u * cells + c1];
+            int k = 0;
+            for (; k + KB <= K; k += KB) {
+                float na[KB];
+                const int kn = k + KB + KB <= K ? k + KB : k;
+#pragma unroll
+                for (int u = 0; u < KB; u++) na[u] = wT[(size_t)(kn + u) * cells + c1];
+#pragma unroll
+                for (int u = 0; u < KB; u++) {
+#pragma unroll
+                    for (int q = 0; q < HB; q++) acc1[q] = __builtin_fmaf(wa[u], x[q * K + k + u], acc1[q]);
+                }
+#pragma unroll
+                for (int u = 0; u < KB; u++) wa[u] = na[u];
+            }
+            for (; k < K; k++) {
                 const float w1 = wT[(size_t)k * cells + c1];
 #pragma unroll
                 for (int q = 0; q < HB; q++) acc1[q] = __builtin_fmaf(w1, x[q * K + k], acc1[q]);
@@ -246,10 +287,30 @@ __global__ __launch_bounds__(256) void c6_head_value_kernel(const float *__restr
     float acc[HB];
 #pragma unroll
     for (int q = 0; q < HB; q++) acc[q] = b1[hdn];
-    for (int k = 0; k < cells; k++) {
-        const float w = w1T[(size_t)k * 256 + hdn];
+    {      // (r5: eight weights at a time, one block ahead, as in the policy head; same order of the multiply-adds)
+        constexpr int KB = 8;
+        float wa[KB];
 #pragma unroll
-        for (int q = 0; q < HB; q++) acc[q] = __builtin_fmaf(w, x[q * cells + k], acc[q]);
+        for (int u = 0; u < KB; u++) wa[u] = w1T[(size_t)u * 256 + hdn];
+        int k = 0;
+        for (; k + KB <= cells; k += KB) {
+            float na[KB];
+            const int kn = k + KB + KB <= cells ? k + KB : k;
+#pragma unroll
+            for (int u = 0; u < KB; u++) na[u] = w1T[(size_t)(kn + u) * 256 + hdn];
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+#pragma unroll
+                for (int q = 0; q < HB; q++) acc[q] = __builtin_fmaf(wa[u], x[q * cells + k + u], acc[q]);
+            }
+#pragma unroll
+            for (int u = 0; u < KB; u++) wa[u] = na[u];
+        }
+        for (; k < cells; k++) {
+            const float w = w1T[(size_t)k * 256 + hdn];
+#pragma unroll
+            for (int q = 0; q < HB; q++) acc[q] = __builtin_fmaf(w, x[q * cells + k], acc[q]);
+        }
     }
     const float w2h = w2[hdn];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
