@@ -25,8 +25,16 @@ def test_records_from_before_round_4_are_c6rng_v4():
     assert d is not None and d["file"] == "r03_stones_probe_s400.json" and "rng" not in json.load(open(os.path.join(ROOT, "profiles", d["file"])))
 
 
+def test_config3_has_a_probe_at_its_own_budget():
+    """r5: 72 complete games of the 8-block net at 800 simulations per move -- a small probe, so its standard error is part of the record"""
+    d = bench.committed_stones_probe("config3", 800, "C6RNG v5")
+    assert d is not None and d["file"] == "r05_stones_probe_config3_s800.json" and d["net_blocks"] == 8 and d["num_simulation"] == 800 and d["precision"] == "fp32"
+    assert d["games"] >= 64 and 130 < d["stones_per_game"] < 190 and 0.0 < d["standard_error"] < 8.0
+
+
 def test_no_probe_at_the_workloads_own_budget_means_no_value():
-    assert bench.committed_stones_probe("config3", 800, "C6RNG v5") is None      # bench.py then prints value: null and sims_per_s
+    assert bench.committed_stones_probe("config3", 400, "C6RNG v5") is None      # bench.py then prints value: null and sims_per_s
+    assert bench.committed_stones_probe("config3", 800, "C6RNG v4") is None
     assert bench.committed_stones_probe("config2", 800, "C6RNG v5") is None
     assert bench.committed_stones_probe("config2", 400, "C6RNG v6") is None
 
