@@ -1,6 +1,9 @@
 """The reference's C ABI (cpp_self_play / cpp_play, N = 15) served by the GPU engine.
 Reference tests mirrored: test_cppbind/main.cpp:46-57 (K-11) and the deterministic cpp_play vectors."""
+import json
 import os
+import shutil
+import subprocess
 import numpy as np
 import pytest
 
@@ -8,6 +11,7 @@ import c6oracle as o
 from gpu_common import need_gpu, pkg
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = 15
 
 
@@ -273,3 +277,18 @@ def test_python_face_runs_the_reference_sample(threads, capfd):
         for winner, path in res:
             _check_ref_result(winner, path)
     assert calls and all(k % 8 == 0 for k in calls)          # always the 8 dihedral images (x games that share the side to move)
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_cpp_caller_self_play_with_a_host_callback(tmp_path):
+    """The boundary from a compiled C++ caller (tools/cpp/dropin_rate.cpp: include/connect6_amd.h, `cpp_self_play` with an evaluator callback
+    of the reference's shape, connect6.hpp:14 -- the reference's own sample is compiled in tests/test_abi_cpu.py, here one RUNS on the GPU):
+    every game comes back, every simulation went through the callback (8 boards per game and round)."""
+    need_gpu()
+    exe = tmp_path / "dropin_rate"
+    libdir = os.path.join(ROOT, "alphazero-connect6_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cpp", "dropin_rate.cpp"),
+                           "-L" + libdir, "-lconnect6_amd", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    r = json.loads(subprocess.check_output([str(exe), "5", "6"], text=True, timeout=300).strip().splitlines()[-1])
+    assert r["games"] == 5 and r["sims_per_move"] == 6 and r["stones"] >= 5 * 11 and r["callback_calls"] > 0
+    assert r["boards_per_s"] > 0 and r["sims_per_s"] > 0
