@@ -593,7 +593,8 @@ struct c6_engine {
     uint32_t *own_tuple_count = nullptr;
     uint64_t rounds = 0;
     int round_in_move = 0;
-    unsigned long long fetched = 0;   // finished games already handed to the caller
+    unsigned long long fetched = 0;   // entries of the finished-games queue already handed to the caller (c6_engine_fetch_games)
+    bool said_finq = false;
     // the pools of record pages and table chunks (c6_engine.h): four arrays that grow by mapping more memory behind them
     VmRange vm_prior, vm_stat, vm_ht, vm_tag;
     size_t pages_max = 0, chunks_max = 0;      // what the rings / page_free / the address ranges are sized for
@@ -1362,16 +1363,28 @@ extern "C" int c6_engine_fetch_games(c6_engine *e, int cap, int *count, int *win
     { int rc_ = range_status(e->net); if (rc_ != C6_OK) return rc_; }
     unsigned long long q = 0;
     HIPCHK(hipMemcpy(&q, d.counters + C6_CNT_FETCHQ, sizeof q, hipMemcpyDeviceToHost));
-    if (q > (unsigned long long)d.finq_cap) q = d.finq_cap;
-    const int n = (int)std::min<unsigned long long>(q, (unsigned long long)std::max(cap, 0));
-    if (n > 0) {
-        HIPCHK(hipMemcpy(winners, d.fin_winner, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(lens, d.fin_len, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-        if (uids) HIPCHK(hipMemcpy(uids, d.fin_uid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        if (moves) HIPCHK(hipMemcpy(moves, d.fin_moves, (size_t)n * d.cells * sizeof(int16_t), hipMemcpyDeviceToHost));
+    if (q > (unsigned long long)d.finq_cap) {
+        // the device keeps the first finq_cap (= max(4 G, 1024)) results between two drains and counts the rest: said, not hidden
+        if (!e->said_finq) fprintf(stderr, "[connect6_amd] c6_engine_fetch_games: %llu finished games since the queue was last drained, it holds %d -- fetch more often\n", q, d.finq_cap);
+        e->said_finq = true;
+        q = d.finq_cap;
     }
-    // the queue is drained as a whole: callers pass cap >= the number of finished games
-    if ((unsigned long long)n == q) HIPCHK(hipMemset(d.counters + C6_CNT_FETCHQ, 0, sizeof(unsigned long long)));
+    // r5: a caller with room for fewer games than are queued gets the NEXT `cap` of them at every call (e->fetched = the queue entries already
+    // handed out); before, it was handed the first `cap` again and again.  The queue restarts at slot 0 once all of it has been handed out.
+    const unsigned long long head = std::min<unsigned long long>(e->fetched, q);
+    const int n = (int)std::min<unsigned long long>(q - head, (unsigned long long)std::max(cap, 0));
+    if (n > 0) {
+        if (!winners || !lens) return fail(C6_ERR_BAD_ARG, "c6_engine_fetch_games: winners / lens are null");
+        HIPCHK(hipMemcpy(winners, d.fin_winner + head, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lens, d.fin_len + head, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (uids) HIPCHK(hipMemcpy(uids, d.fin_uid + head, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (moves) HIPCHK(hipMemcpy(moves, d.fin_moves + (size_t)head * d.cells, (size_t)n * d.cells * sizeof(int16_t), hipMemcpyDeviceToHost));
+    }
+    e->fetched = head + (unsigned long long)n;
+    if (e->fetched == q) {
+        HIPCHK(hipMemset(d.counters + C6_CNT_FETCHQ, 0, sizeof(unsigned long long)));
+        e->fetched = 0;
+    }
     *count = n;
     return C6_OK;
 }

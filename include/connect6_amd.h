@@ -287,7 +287,9 @@ int c6_engine_pool_audit(c6_engine *e, c6_pool_audit *out);
 
 /* finished games (winner, moves): agent::PlayResult, agent/agent_impl/mod.rs:41-44.
  * Copies up to `cap` finished, not yet fetched games: winners[i], lens[i], uids[i],
- * moves[i*N*N + k] = cell of stone k.  Returns the number copied in *count. */
+ * moves[i*N*N + k] = cell of stone k.  Returns the number copied in *count; a caller with room for fewer games than are
+ * queued gets the next `cap` of them at every call (0: none left).  The device keeps at most max(4 G, 1024) results between
+ * two full drains (steady-state mode: fetch at least that often; an overflow is said on stderr, c6_stats.games_finished counts all). */
 int c6_engine_fetch_games(c6_engine *e, int cap, int *count, int *winners, int *lens, uint32_t *uids,
                           int16_t *moves);
 

@@ -175,3 +175,30 @@ def test_tables_beyond_the_lds_tag_row_stay_exact():
         assert st["overflow_games"] == 0 and st["max_records_used"] > 4096 + S, st      # 2 x (live + S) > 8192 slots: tags in memory
         ref = o.self_play(n, num=G, threads=1, num_simulation=S, seed=seed, epsilon=eps, eval_kind=o.EVAL_CUSTOM, eval_fn=oracle_stress)
         check_games(n, G, games, ref)
+
+
+def test_fetch_games_in_pieces_hands_out_every_game_once():
+    """c6_engine_fetch_games with room for fewer games than are queued (r5): every call returns the NEXT games -- before, a caller whose
+    `cap` was smaller than the queue was handed the first `cap` games again at every call.  The pieces together are the single full fetch."""
+    need_gpu()
+    n, G, S, seed = 9, 7, 8, 99
+    def play():
+        eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_RANDOM)
+        eng.run()
+        return eng
+    e1 = play()
+    whole = e1.fetch_games()
+    assert len(whole) == G and e1.fetch_games() == []
+    e1.close()
+    e2 = play()
+    pieces = []
+    for cap in (3, 3, 3, 3):
+        got = e2.fetch_games(cap=cap)
+        assert len(got) <= cap
+        pieces += got
+    assert e2.fetch_games(cap=3) == []
+    e2.close()
+    assert len(pieces) == G and sorted(g["uid"] for g in pieces) == list(range(G))
+    key = lambda g: g["uid"]
+    for a, b in zip(sorted(whole, key=key), sorted(pieces, key=key)):
+        assert a["winner"] == b["winner"] and list(a["moves"]) == list(b["moves"])
