@@ -1397,9 +1397,21 @@ extern "C" int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, v
     if (!d.tuple_buf) { *count = 0; return C6_OK; }
     uint32_t n = 0;
     HIPCHK(hipMemcpy(&n, d.tuple_count, sizeof n, hipMemcpyDeviceToHost));
-    size_t m = std::min<size_t>(std::min<size_t>(n, d.tuple_cap), cap);
+    const size_t have = std::min<size_t>(n, d.tuple_cap);      // (the engine stops writing at tuple_cap: records beyond it were never stored)
+    size_t m = std::min<size_t>(have, cap);
     if (m && host_buf) HIPCHK(hipMemcpy(host_buf, d.tuple_buf, m * d.tuple_stride, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(d.tuple_count, 0, sizeof(uint32_t)));
+    // r5: a caller with room for fewer records than the buffer holds keeps the rest for its next call (they were dropped with the reset):
+    // the remainder moves to the front through a temporary (the ranges overlap)
+    uint32_t left = host_buf ? (uint32_t)(have - m) : 0u;
+    if (left > 0) {
+        TmpDev t;
+        uint8_t *tmp = t.get<uint8_t>((size_t)left * d.tuple_stride);
+        if (!tmp) return fail(C6_ERR_HIP, "hipMalloc failed");
+        HIPCHK(hipMemcpy(tmp, d.tuple_buf + m * d.tuple_stride, (size_t)left * d.tuple_stride, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(d.tuple_buf, tmp, (size_t)left * d.tuple_stride, hipMemcpyDeviceToDevice));
+        HIPCHK(hipDeviceSynchronize());
+    }
+    HIPCHK(hipMemcpy(d.tuple_count, &left, sizeof left, hipMemcpyHostToDevice));
     *count = m;
     return C6_OK;
 }

@@ -309,7 +309,8 @@ int c6_engine_swap_tuple_buffer(c6_engine *e, void *dev_buf, size_t capacity_rec
 /* the HIP stream (hipStream_t as void*) every engine launch goes to: record / wait events on it to order other streams against
  * the engine's rounds without a host synchronisation */
 void *c6_engine_stream(c6_engine *e);
-int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, void *host_buf); /* copies + resets */
+/* copies up to `cap` records to host_buf and removes them from the buffer; records beyond `cap` stay for the next call (host_buf NULL: discards all) */
+int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, void *host_buf);
 
 /* inspection for parity tests: the root of game `g`, synchronises.
  * visits[c] = child visit (-1 where the cell is occupied), q[c] = child q_value, prior[c] = child n_prob */

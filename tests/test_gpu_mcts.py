@@ -202,3 +202,32 @@ def test_fetch_games_in_pieces_hands_out_every_game_once():
     key = lambda g: g["uid"]
     for a, b in zip(sorted(whole, key=key), sorted(pieces, key=key)):
         assert a["winner"] == b["winner"] and list(a["moves"]) == list(b["moves"])
+
+
+def test_fetch_tuples_in_pieces_keeps_the_rest():
+    """c6_engine_fetch_tuples with room for fewer records than the buffer holds (r5): the rest stays for the next call (the reset used to drop
+    it); the pieces in order are the single full fetch."""
+    need_gpu()
+    n, G, S, seed = 9, 4, 8, 5
+    def play():
+        eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_RANDOM)
+        eng.enable_tuples(G * n * n)
+        eng.run()
+        return eng
+    e1 = play()
+    whole = e1.fetch_tuples(G * n * n)
+    total = whole["state"].shape[0]
+    assert total > 3 * 17 and e1.fetch_tuples(8)["state"].shape[0] == 0
+    e1.close()
+    e2 = play()
+    parts = []
+    while True:
+        t = e2.fetch_tuples(17)
+        if t["state"].shape[0] == 0:
+            break
+        assert t["state"].shape[0] <= 17
+        parts.append(t)
+    e2.close()
+    assert sum(p["state"].shape[0] for p in parts) == total
+    for k in whole:
+        assert np.array_equal(np.concatenate([p[k] for p in parts], axis=0), whole[k]), k
