@@ -1530,9 +1530,11 @@ extern "C" int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *b
     C6Dev &d = e->d;
     const int cells = d.cells;
     HIPCHK(hipStreamSynchronize(e->stream));
-    int32_t *dv; float *dq, *dp, *drf; int *drs;
-    HIPCHK(hipMalloc(&dv, cells * 4)); HIPCHK(hipMalloc(&dq, cells * 4)); HIPCHK(hipMalloc(&dp, cells * 4));
-    HIPCHK(hipMalloc(&drs, 8)); HIPCHK(hipMalloc(&drf, 12));
+    TmpDev tmp;      // (freed on every path out of the function)
+    int32_t *dv = tmp.get<int32_t>(cells);
+    float *dq = tmp.get<float>(cells), *dp = tmp.get<float>(cells), *drf = tmp.get<float>(3);
+    int *drs = tmp.get<int>(2);
+    if (!dv || !dq || !dp || !drf || !drs) return fail(C6_ERR_HIP, "hipMalloc failed");
     hipLaunchKernelGGL(c6_root_probe_kernel, dim3((cells + 63) / 64), dim3(64), 0, e->stream, d, g, dv, dq, dp, drs, drf);
     std::vector<int32_t> hv(cells); std::vector<float> hq(cells), hp(cells);
     int rs[2]; float rf[3];
@@ -1541,7 +1543,6 @@ extern "C" int c6_engine_root(c6_engine *e, int g, c6_root_info *info, int8_t *b
     HIPCHK(hipMemcpy(hp.data(), dp, cells * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rs, drs, 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rf, drf, 12, hipMemcpyDeviceToHost));
-    hipFree(dv); hipFree(dq); hipFree(dp); hipFree(drs); hipFree(drf);
     if (visits) memcpy(visits, hv.data(), cells * 4);
     if (q) memcpy(q, hq.data(), cells * 4);
     if (prior) memcpy(prior, hp.data(), cells * 4);
