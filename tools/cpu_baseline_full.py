@@ -20,7 +20,8 @@ import c6oracle as o
 name = sys.argv[1] if len(sys.argv) > 1 else "config2"
 moves = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 wl = bench.WORKLOADS[name]
-probe = bench.committed_stones_probe(name, bench.WORKLOADS[name]['sims'])
+from c6amd_loader import load_package      # (only for the library's random-stream specification: which probe record counts)
+probe = bench.committed_stones_probe(name if name != "config4" else "config2", bench.WORKLOADS[name]['sims'], load_package().rng_spec())
 stones = float(sys.argv[3]) if len(sys.argv) > 3 else (probe["stones_per_game"] if probe else wl["stones_prior"])
 cores = bench.usable_cores()
 n, S = wl["n"], wl["sims"]
