@@ -78,7 +78,11 @@ __device__ __forceinline__ float w4_stem_plane(const C6StemSrc &S, long b, float
 
 #define W4_ULOAD(dst, voff, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
 #define W4_UWAIT(dst, n) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dst) : "n"(n) : "memory")
-#define W4_STORE(voff, data, base, imm) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #imm ::"v"(voff), "v"(data), "s"(base) : "memory")
+// The store reads its four data registers a few cycles AFTER it issues, and nothing interlocks a vector instruction that overwrites them meanwhile (the
+// compiler knows the hazard for its own stores, not for inline asm): the two wait states are part of the SAME asm statement, so that nothing can be scheduled
+// between the store and them.  (r5: as a statement of their own -- `asm volatile("s_nop 1")` behind the store -- they let the compiler put the NEXT store's data
+// computation, into the same registers, in between: the four-wave jobs' third row sum came out wrong in 8 of its 16 registers.)
+#define W4_STORE(voff, data, base, imm) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #imm "\n\ts_nop 1" ::"v"(voff), "v"(data), "s"(base) : "memory")
 
 // sum over the wave, valid in lanes 48 .. 63: four butterfly steps inside the rows of 16 lanes, then row 0 -> 1 and 2 -> 3 (row_bcast:15) and
 // rows 0 + 1 -> 3 (row_bcast:31) -- six DPP additions

@@ -326,8 +326,7 @@ static bool w4_has_tail(int nboards) {
 //    this kernel, -19 % on the boundary kernels (same box, in the engine: 248.4 -> 236.8 ms per round).  Stores: Z_0, Z_1 during position
 //    j = 5 of their row, Z_2, Z_3 during j = 0 of the next.  Result: Zo[block][tile 64][row i 6][b 4][C].
 constexpr int w4_store_group(int k) { return 8 + k; }      // store k (0 .. 15) of a storing position goes out in group 8 + k
-constexpr int w4_wait(int i, bool stores) {
-    const int nd = 8;
+constexpr int w4_wait(int i, bool stores, int nd = 8) {      // nd: slab DMAs per wave and position (8 waves: 8; the four-wave jobs of the tiniest batches: 16)
     const int lo = i - W4_PF > 0 ? i - W4_PF : 0, hi = (nd - 1 < i - 1) ? nd - 1 : i - 1;
     const int dmas = hi >= lo ? hi - lo + 1 : 0;
     int st = 0;
@@ -349,20 +348,23 @@ constexpr int w4_wait_last(int i) {
 // SPLIT (r5, as conv_wino6.hip's c6_w6_gemm_kernel<., true>): the job is a ROW of a block's positions (blockIdx.y), not the block -- a row's four row
 // sums depend on its own six positions only, and a block is a chain of up to 36 positions on one CU whatever the batch.  Same instruction stream per
 // position, bit-identical sums; every job has its own prologue, its last position requests nothing beyond the row (LP).  For small batches.
-template <int N, bool SPLIT>
-__global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
-                                                                         float *__restrict__ Zo, int nblocks, int blkB, int blkBP) {
+// HW (split form only): half-width jobs of FOUR waves (128 of the 256 output channels, blockIdx.z) for the tiniest batches, as conv_wino6.hip's.
+template <int N, bool SPLIT, bool HW = false>
+__global__ __launch_bounds__(HW ? 256 : 64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
+                                                                                    float *__restrict__ Zo, int nblocks, int blkB, int blkBP) {
     using G = W4Geom<N>;
-    constexpr int C = G::C, CP = G::CP, SLAB = G::SLAB, WAVES = G::WAVES, NG = G::NG, PF = W4_PF;
+    static_assert(!HW || SPLIT, "half-width jobs exist in the split form only");
+    constexpr int C = G::C, CP = G::CP, SLAB = G::SLAB, WAVES = HW ? 4 : G::WAVES, NG = G::NG, PF = W4_PF;
     constexpr int ND = W4_BT / WAVES;
-    static_assert(PF == 7 && NG == 32 && ND == 8, "ring of 8 weight groups; 8 DMAs per position");
+    static_assert(PF == 7 && NG == 32 && (ND == 8 || ND == 16), "ring of 8 weight groups; 8 (four waves: 16) DMAs per wave and position");
     constexpr int RM = PF;
     constexpr int ZTILE = 24 * C;                    // floats of a tile in Zo
     constexpr size_t ZBLOCK = (size_t)W4_BT * ZTILE;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int n4 = wave * 32 + 4 * h;
+    const int cw = HW ? wave + 4 * (int)blockIdx.z : wave;      // the wave's group of 32 output channels
+    const int n4 = cw * 32 + 4 * h;
     int b = blockIdx.x;
     if (b >= nblocks) return;
     const int row0 = SPLIT ? (int)blockIdx.y : 0;
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
     // weight sets at 36 C^2 and 66 C^2); a set is packed [wave][position][group][lane][4]
     auto rows_of = [&](int blk) { return blk < blkB ? 6 : 5; };
     auto wbase_of = [&](int blk) {
-        return blk < blkB ? U + (size_t)wave * (W4_NP * NG * 256)
-                          : U + (size_t)(blk < blkBP ? W4_NP : W4_NP + W4_NP_EDGE) * C * C + (size_t)wave * (W4_NP_EDGE * NG * 256);
+        return blk < blkB ? U + (size_t)cw * (W4_NP * NG * 256)
+                          : U + (size_t)(blk < blkBP ? W4_NP : W4_NP + W4_NP_EDGE) * C * C + (size_t)cw * (W4_NP_EDGE * NG * 256);
     };
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned zoff0 = (unsigned)(((size_t)j * ZTILE + n4) * 4), zoff1 = zoff0 + (unsigned)((size_t)32 * ZTILE * 4);
@@ -430,7 +432,6 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
         else if (((k) & 3) == 1) W4_STORE(zo_, a, d_, 32);                                                       \
         else if (((k) & 3) == 2) W4_STORE(zo_, a, d_, 64);                                                       \
         else W4_STORE(zo_, a, d_, 96);                                                                           \
-        asm volatile("s_nop 1" ::: "memory");                                                                    \
     }
 #define W4Z_LAST_ROW()                                                                                           \
     {                                                                                                            \
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(64 * (W4_C / 32)) void c6_wino4_gemm_kernel(const f
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }
-#define WGZ_(i, JJ, BUF) W4Z_GROUP((i) & RM, (i), (SPLIT && (JJ) == 5) ? w4_wait_last((i)) : w4_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5), (i), JJ, BUF, SPLIT && (JJ) == 5)
+#define WGZ_(i, JJ, BUF) W4Z_GROUP((i) & RM, (i), (SPLIT && (JJ) == 5) ? w4_wait_last((i)) : w4_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5, ND), (i), JJ, BUF, SPLIT && (JJ) == 5)
     // one position (row i_, column JJ): slab in LDS buffer JJ & 1
 #define W4Z_POSITION(i_, JJ)                                                                                     \
         {                                                                                                        \
@@ -879,7 +880,12 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
         // r5 -- rows instead of blocks as the unit of work while a CU gets fewer than eight blocks (conv_wino6.hip's c6_w6_dispatch);
         // C6_W4_SPLIT = 0 / 1: a test hook that forces one form (tests/test_gpu_variants.py compares the two bit for bit)
         static const int force = [] { const char *e = getenv("C6_W4_SPLIT"); return e ? atoi(e) : -1; }();
-        if (force >= 0 ? force != 0 : nblocks < 8 * num_cus) {
+        static const int force_hw = [] { const char *e = getenv("C6_W4_HALF"); return e ? atoi(e) : -1; }();
+        const bool split = force >= 0 ? force != 0 : nblocks < 8 * num_cus;
+        if (split && (force_hw >= 0 ? force_hw != 0 : 2 * 6 * nblocks <= num_cus)) {      // the tiniest batches: half-width jobs of four waves
+            w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N, true, true>), (int)smem);
+            hipLaunchKernelGGL((c6_wino4_gemm_kernel<N, true, true>), dim3(grid, 6, 2), dim3(256), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP);
+        } else if (split) {
             w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_gemm_kernel<N, true>), (int)smem);
             hipLaunchKernelGGL((c6_wino4_gemm_kernel<N, true>), dim3(grid, 6), dim3(G::THREADS), smem, s, Vb, wp, Mb, nblocks, (int)map.blkB, (int)map.blkBP);
         } else {

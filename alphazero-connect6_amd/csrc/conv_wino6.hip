@@ -267,8 +267,7 @@ static bool w6_has_tail(int nboards) {
 // over four classes: rows of positions 6 / 5 / 5 / 8, weight sets at 0 / 36 / 66 / 96 C^2, tile slots of 48 positions in V and 32 row
 // sums in Z.  The schedule, the hand-issued memory operations and their wait counts are the original's (see there).
 constexpr int w6_store_group(int k) { return 8 + k; }
-constexpr int w6_wait(int i, bool stores) {
-    const int nd = 8;
+constexpr int w6_wait(int i, bool stores, int nd = 8) {      // nd: slab DMAs per wave and position (8 waves: 8; the 4-wave jobs of tiny batches: 16)
     const int lo = i - W6_PF > 0 ? i - W6_PF : 0, hi = (nd - 1 < i - 1) ? nd - 1 : i - 1;
     const int dmas = hi >= lo ? hi - lo + 1 : 0;
     int st = 0;
@@ -294,17 +293,22 @@ constexpr int w6_wait_last(int i) {
 // positions).  A block on one CU is a chain of 48 positions x 13.7 us, whatever the batch: one game's eight boards took 0.66 ms per layer on 4 of the
 // 256 CUs.  Split, its 28 rows run on 28 CUs at once.  Same instruction stream per position (same waits), only the addresses of the V rows, of the
 // weight groups and of Z differ; the launcher takes this form while the blocks do not fill the chip a few times over (c6_w6_dispatch).
-template <bool DP, bool SPLIT>
-__global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo,
-                                                                      int first, int nblocks, int blkB, int blkBP, int blkD) {
-    constexpr int C = W6_C, CP = C + 4, SLAB = W6_BT * CP, WAVES = C / 32, NG = C / 8, PF = W6_PF;
+// HW (r5, split form only): half-width jobs for the tiniest batches -- a workgroup of FOUR waves multiplies a row for 128 of the 256 output channels
+// (blockIdx.z picks the half), one wave per SIMD instead of two: a position takes 6.8 instead of 13.7 us, twice as many jobs.  Each wave fetches 16 of the
+// slab's 64 rows (ND = 16: the wait counts take the DMA count as a parameter).  Same per-wave instruction stream: bit-identical sums.
+template <bool DP, bool SPLIT, bool HW = false>
+__global__ __launch_bounds__(HW ? 256 : 64 * (W6_C / 32)) void c6_w6_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo,
+                                                                                 int first, int nblocks, int blkB, int blkBP, int blkD) {
+    static_assert(!HW || SPLIT, "half-width jobs exist in the split form only");
+    constexpr int C = W6_C, CP = C + 4, SLAB = W6_BT * CP, WAVES = HW ? 4 : C / 32, NG = C / 8, PF = W6_PF;
     constexpr int ND = W6_BT / WAVES;
-    static_assert(PF == 7 && NG == 32 && ND == 8, "ring of 8 weight groups; 8 DMAs per position");
+    static_assert(PF == 7 && NG == 32 && (ND == 8 || ND == 16), "ring of 8 weight groups; 8 (four waves: 16) DMAs per wave and position");
     constexpr int RM = PF;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int n4 = wave * 32 + 4 * h;
+    const int cw = HW ? wave + 4 * (int)blockIdx.z : wave;      // the wave's group of 32 output channels
+    const int n4 = cw * 32 + 4 * h;
     // SPLIT: blockIdx.y is the row this workgroup multiplies in each of its blocks
     int b = first + (int)blockIdx.x;
     if (b >= nblocks) return;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
     auto npos_of = [&](int blk) { return DP ? 40 : blk < blkB ? 36 : blk < blkD ? 30 : 48; };
     auto wbase_of = [&](int blk) {
         const int fs = DP ? 144 : blk < blkB ? 0 : blk < blkBP ? 36 : blk < blkD ? 66 : 96;
-        return U + (size_t)fs * C * C + (size_t)wave * ((size_t)npos_of(blk) * NG * 256);
+        return U + (size_t)fs * C * C + (size_t)cw * ((size_t)npos_of(blk) * NG * 256);
     };
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned zoff0 = (unsigned)(((size_t)j * W6_ZTILE + n4) * 4), zoff1 = zoff0 + (unsigned)((size_t)32 * W6_ZTILE * 4);
@@ -374,7 +378,6 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
         else if (((k) & 3) == 1) W4_STORE(zo_, a, d_, 32);                                                       \
         else if (((k) & 3) == 2) W4_STORE(zo_, a, d_, 64);                                                       \
         else W4_STORE(zo_, a, d_, 96);                                                                           \
-        asm volatile("s_nop 1" ::: "memory");                                                                    \
     }
 #define W6Z_LAST_ROW()                                                                                           \
     {                                                                                                            \
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_kernel(const floa
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
             }
-#define W6GZ_(i, JJ, BUF, LP) W6Z_GROUP((i) & RM, (i), (LP) ? w6_wait_last((i)) : w6_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5), (i), JJ, BUF, LP)
+#define W6GZ_(i, JJ, BUF, LP) W6Z_GROUP((i) & RM, (i), (LP) ? w6_wait_last((i)) : w6_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5, ND), (i), JJ, BUF, LP)
 // one position of a block: JJ = its role in the row (0: the first point, accumulates into Z_0; 5: the last point, accumulates into the last
 // row sum; 1 .. 4: aside, folded in by W6Z_UPDATE / W6Z_UPDATE3), BUF = the LDS slab it reads (positions alternate), PP = its index in the
 // block, LAST = the block's last index
@@ -1002,7 +1005,15 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
         // benchmark's batch the chip is full either way and the launches stay in order on the caller's stream (21.7 + 2.5 ms).
         W6Side *side = n5 > 0 && n6 < 2 * num_cus ? w6_side_of(s) : nullptr;
         if (side) hipEventRecord(side->fork, s);
-        if (split) {
+        // the tiniest batches (a handful of games: twice the jobs still leave CUs idle): half-width jobs of four waves, a position in half the time
+        static const int force_hw = [] { const char *e = getenv("C6_W6_HALF"); return e ? atoi(e) : -1; }();      // (test hook, as C6_W6_SPLIT)
+        const bool half = split && (force_hw >= 0 ? force_hw != 0 : 2 * 8 * (n6 + n5) <= num_cus);
+        if (half) {
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false, true, true>), (int)smem);
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, true, true>), (int)smem);
+            hipLaunchKernelGGL((c6_w6_gemm_kernel<false, true, true>), dim3(n6 < num_cus ? n6 : num_cus, 8, 2), dim3(256), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB,
+                               (int)map.blkBP, (int)map.blkD);
+        } else if (split) {
             hipLaunchKernelGGL((c6_w6_gemm_kernel<false, true>), dim3(n6 < num_cus ? n6 : num_cus, 8), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB,
                                (int)map.blkBP, (int)map.blkD);
         } else
@@ -1011,7 +1022,10 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
         if (n5 > 0) {
             hipStream_t s5 = side ? side->stream : s;
             if (side) hipStreamWaitEvent(s5, side->fork, 0);
-            if (split)
+            if (half)
+                hipLaunchKernelGGL((c6_w6_gemm_kernel<true, true, true>), dim3(n5 < num_cus ? n5 : num_cus, 8, 2), dim3(256), smem, s5, Vb, wp, Mb, n6, nblocks, (int)map.blkB,
+                                   (int)map.blkBP, (int)map.blkD);
+            else if (split)
                 hipLaunchKernelGGL((c6_w6_gemm_kernel<true, true>), dim3(n5 < num_cus ? n5 : num_cus, 8), dim3(64 * (W6_C / 32)), smem, s5, Vb, wp, Mb, n6, nblocks, (int)map.blkB,
                                    (int)map.blkBP, (int)map.blkD);
             else

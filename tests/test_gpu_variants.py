@@ -189,19 +189,20 @@ np.savez(sys.argv[1], **out)
 
 
 def test_w4_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
-    """conv_wino4.hip: c6_wino4_gemm_kernel<N, true> (a row of positions per workgroup) against <N, false> (a block per workgroup) through
+    """conv_wino4.hip: c6_wino4_gemm_kernel<N, true> (a row of positions per workgroup; and its four-wave half-width jobs) against <N, false> (a block per workgroup) through
     c6_net_forward at 15 x 15, 9 x 9 and (two-block tower) 19 x 19, 1 .. 2000 boards: equal bit for bit."""
     need_gpu()
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for form in ("0", "1"):
+        for form, env in (("block", dict(C6_W4_SPLIT="0")), ("split", dict(C6_W4_SPLIT="1", C6_W4_HALF="0")), ("half", dict(C6_W4_SPLIT="1", C6_W4_HALF="1"))):
             out = os.path.join(td, f"w4_{form}.npz")
-            subprocess.run([sys.executable, "-c", W4_CHILD, out], check=True, env=dict(os.environ, C6_W4_SPLIT=form), timeout=600)
+            subprocess.run([sys.executable, "-c", W4_CHILD, out], check=True, env=dict(os.environ, **env), timeout=600)
             res[form] = dict(np.load(out))
-    assert sorted(res["0"]) == sorted(res["1"]) and len(res["0"]) == 24
-    for k in res["0"]:
-        assert np.isfinite(res["0"][k]).all()
-        assert np.array_equal(res["0"][k], res["1"][k]), k
+    assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) and len(res["block"]) == 24
+    for k in res["block"]:
+        assert np.isfinite(res["block"][k]).all()
+        assert np.array_equal(res["block"][k], res["split"][k]), k
+        assert np.array_equal(res["block"][k], res["half"][k]), k
 
 
 W6_CHILD = r"""
@@ -223,17 +224,20 @@ np.savez(sys.argv[1], **out)
 
 
 def test_w6_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
-    """conv_wino6.hip: c6_w6_gemm_kernel<., true> (r5: a row of positions per workgroup -- one game's boards on 28 CUs instead of 4) against
+    """conv_wino6.hip: c6_w6_gemm_kernel<., true> (r5: a row of positions per workgroup -- one game's boards on 28 CUs instead of 4; and <., true, true>, the
+    four-wave half-width jobs of the tiniest batches, forced at every size) against
     <., false> (a block per workgroup) through c6_net_forward at 1 .. 1100 boards (1 board: every region's block nearly empty; 333: full and
     partial blocks; 1100 boards: 344 + 35 blocks -- the block loop of both forms runs more than once), stem + 3 and stem + 7 blocks."""
     need_gpu()
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for form in ("0", "1"):
+        # block form / split form with eight-wave jobs / split form with the four-wave half-width jobs of the tiniest batches (forced at every size)
+        for form, env in (("block", dict(C6_W6_SPLIT="0")), ("split", dict(C6_W6_SPLIT="1", C6_W6_HALF="0")), ("half", dict(C6_W6_SPLIT="1", C6_W6_HALF="1"))):
             out = os.path.join(td, f"w6_{form}.npz")
-            subprocess.run([sys.executable, "-c", W6_CHILD, out], check=True, env=dict(os.environ, C6_W6_SPLIT=form), timeout=600)
+            subprocess.run([sys.executable, "-c", W6_CHILD, out], check=True, env=dict(os.environ, **env), timeout=600)
             res[form] = dict(np.load(out))
-    assert sorted(res["0"]) == sorted(res["1"]) and len(res["0"]) == 20
-    for k in res["0"]:
-        assert np.isfinite(res["0"][k]).all()
-        assert np.array_equal(res["0"][k], res["1"][k]), k
+    assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) and len(res["block"]) == 20
+    for k in res["block"]:
+        assert np.isfinite(res["block"][k]).all()
+        assert np.array_equal(res["block"][k], res["split"][k]), k
+        assert np.array_equal(res["block"][k], res["half"][k]), k

@@ -48,14 +48,27 @@ int main(int argc, char **argv) {
         CK(hipDeviceSynchronize());
         printf("split form <true> done (%d items)\n", 4 * n5); fflush(stdout);
     }
+    if (which & 4) {      // the half-width jobs (four waves, 128 output channels each): both kernels again, into Z1
+        CK(hipMemset(Z1, 0xff, zfl * 4));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((c6_w6_gemm_kernel<false, true, true>), dim3(n6 < cus ? n6 : cus, 8, 2), dim3(256), smem, 0, V, U, Z1, 0, n6, (int)map.blkB, (int)map.blkBP, (int)map.blkD);
+        hipLaunchKernelGGL((c6_w6_gemm_kernel<true, true, true>), dim3(n5 < cus ? n5 : cus, 8, 2), dim3(256), smem, 0, V, U, Z1, n6, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD);
+        CK(hipDeviceSynchronize());
+        printf("half-width split form done\n"); fflush(stdout);
+    }
     std::vector<float> h0(zfl), h1(zfl);
     CK(hipMemcpy(h0.data(), Z0, zfl * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), Z1, zfl * 4, hipMemcpyDeviceToHost));
     size_t diff = 0, first = 0;
-    const size_t lo = (which & 1) ? 0 : (size_t)n6 * W6_ZBLOCK, hi = (which & 2) ? zfl : (size_t)n6 * W6_ZBLOCK;
+    const size_t lo = (which & 5) ? 0 : (size_t)n6 * W6_ZBLOCK, hi = (which & 6) ? zfl : (size_t)n6 * W6_ZBLOCK;
     for (size_t i = lo; i < hi; i++) if (memcmp(&h0[i], &h1[i], 4)) { if (!diff) first = i; diff++; }
     {
         std::vector<size_t> byblk(nblocks, 0); size_t byb[4] = {0, 0, 0, 0}, byhalf[2] = {0, 0}, byrow[9] = {0};
         for (size_t i = lo; i < hi; i++) if (memcmp(&h0[i], &h1[i], 4)) { byblk[i / W6_ZBLOCK]++; const size_t r = i % W6_ZTILE / W6_C; byb[r & 3]++; byrow[r >> 2]++; byhalf[(i % W6_ZBLOCK / W6_ZTILE) >> 5]++; }
+        size_t bych[256] = {0};
+        for (size_t i = lo; i < hi; i++) if (memcmp(&h0[i], &h1[i], 4)) bych[i % W6_C]++;
+        printf("by output channel (nonzero):"); for (int k = 0; k < 256; k++) if (bych[k]) printf(" %d:%zu", k, bych[k]);
+        printf("\n");
         printf("by block:"); for (int k = 0; k < nblocks; k++) printf(" %zu", byblk[k]);
         printf("\nby b: %zu %zu %zu %zu; by tile half: %zu %zu; by row:", byb[0], byb[1], byb[2], byb[3], byhalf[0], byhalf[1]);
         for (int k = 0; k < 9; k++) printf(" %zu", byrow[k]);
