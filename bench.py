@@ -49,7 +49,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, description)
-    "fp32": ("c6_w6_gemm_kernel<false, false>", "FP32 Winograd, tiles 4 x {6, 6, 4, 3} across a 19-wide board (F(4,3) down, F(6,3) / F(4,3) / F(3,3) across; F(3,3) down in the "
+    "fp32": ("c6_w6_gemm_kernel<false, false, false>", "FP32 Winograd, tiles 4 x {6, 6, 4, 3} across a 19-wide board (F(4,3) down, F(6,3) / F(4,3) / F(3,3) across; F(3,3) down in the "
              "last tile row): the 48 / 40 / 36 / 30 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, the F(4) half of the output transform accumulated in "
              "registers; the transforms between the layers' GEMMs are HBM-bound kernels of their own (c6_w6_mid_kernel: output transform of a layer + "
              "input transform of the next)"),
@@ -507,7 +507,7 @@ def main():
             ach = exe if name.startswith("fp32") else alg
             traffic = rec.get("hbm_bytes_per_launch")
             if name == "fp32" and traffic is not None:      # a layer's GEMM is two launches: the blocks with rows of six positions (<false>, 708 of a board's 788 positions) and of five (<true>, 80)
-                traffic += pmc_record("c6_w6_gemm_kernel<true, false>").get("hbm_bytes_per_launch", 0.0)
+                traffic += pmc_record("c6_w6_gemm_kernel<true, false, false>").get("hbm_bytes_per_launch", 0.0)
             r = {"bound": "mfma", "kernel": f"{kern} ({desc})", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                  "traffic": traffic, "avg_launch_ms": gemm_ms / L, "launches": prof["conv_launches"],
                  "algorithmic_flops_per_launch": prof["conv_flops"] / L, "executed_flops_per_launch": prof["conv_exec_flops"] / L,
@@ -518,7 +518,7 @@ def main():
             # alternate: their times add)
             r["layer_frac"] = prof["conv_exec_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 / peak
             if name == "fp32":
-                r["note"] = ("a layer's GEMM is two launches of one kernel template -- c6_w6_gemm_kernel<false, false> (the tile classes with rows of six positions: 708 of a board's "
+                r["note"] = ("a layer's GEMM is two launches of one kernel template -- c6_w6_gemm_kernel<false, false, false> (the tile classes with rows of six positions: 708 of a board's "
                              "788 products) then <true> (class D', rows of five: 80) -- timed together: avg_launch_ms, achieved and traffic are per layer = the pair; "
                              "achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + "
                              "boundary-kernel time; algorithmic_tflops / algorithmic_ratio count 2*9*C^2*N^2 per board and layer (SURVEY 8d), of which this Winograd "

@@ -52,7 +52,7 @@ def test_pmc_summary_is_keyed_to_the_convolution_sources():
     assert s["src_hash_of"] == list(bench.CONV_SOURCES)
     # (equal while conv_wino6.hip / c6_wino.h / net_kernels.hip are the profiled ones: then bench.py replays the counters as `traffic`)
     if s["src_hash"] == bench.kernel_source_hash(bench.CONV_SOURCES):
-        rec = bench.pmc_record("c6_w6_gemm_kernel<false, false>")
+        rec = bench.pmc_record("c6_w6_gemm_kernel<false, false, false>")
         assert rec["hbm_bytes_per_launch"] > 3e10 and 0.8 < rec["mfma_util"] < 1.0
     else:
-        assert bench.pmc_record("c6_w6_gemm_kernel<false, false>") == {}
+        assert bench.pmc_record("c6_w6_gemm_kernel<false, false, false>") == {}

@@ -1,5 +1,5 @@
 // Probe (round 5): do the REAL kernels of the FP32 Winograd tower overlap when they share a CU?
-//   G  = c6_w6_gemm_kernel<true, false> (the 200-register instantiation: 8 waves, 133 KB of LDS -- leaves 112 registers per SIMD lane)
+//   G  = c6_w6_gemm_kernel<true, false, false> (the 200-register instantiation: 8 waves, 133 KB of LDS -- leaves 112 registers per SIMD lane)
 //   O  = the tower's last output transform (c6_w6_out_kernel's body) compiled for <= 112 registers, 4 waves per workgroup, persistent grid
 // so that one workgroup of each fits on a CU together.  Times: G alone, O alone, O launched first (its waves are the OLDER ones) then G on
 // another stream, G first then O.  together ~ max => the boundary kernel's memory time hides under the matrix work; ~ sum => it does not.
@@ -181,11 +181,11 @@ int main(int argc, char **argv) {
     const C6HeadFuse hd{hw, scal, 0.1f, scal + 8, scal + 512, ph, vh};
     const long tiles = (long)nboards * W6_T;
     constexpr size_t gsmem = (size_t)2 * W6_BT * (W6_C + 4) * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gsmem));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gsmem));
     hipStream_t sg, so; CK(hipStreamCreateWithFlags(&sg, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&so, hipStreamNonBlocking));
     const size_t osmem = 24 * 1024;
     // every block treated as a D' block (rows of five positions, 40 per tile): the instantiation that leaves registers free
-    auto gemm = [&]() { hipLaunchKernelGGL(c6_w6_gemm_kernel<true, false>, dim3(cus), dim3(512), gsmem, sg, V, U, Z, 0, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD); };
+    auto gemm = [&]() { hipLaunchKernelGGL(c6_w6_gemm_kernel<true, false, false>, dim3(cus), dim3(512), gsmem, sg, V, U, Z, 0, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD); };
     auto outp = [&](int grid) { for (int r = 0; r < out_reps; r++) hipLaunchKernelGGL(out_lo_kernel, dim3(grid), dim3(256), osmem, so, Z2, bias, (const float *)nullptr, tiles, hd, 0); };
     auto outfull = [&]() { for (int r = 0; r < out_reps; r++) hipLaunchKernelGGL(c6_w6_out_kernel, dim3(cus * 8), dim3(256), 0, so, Z2, bias, (const float *)nullptr, tiles, hd); };
     auto timeit = [&](auto &&f) {
@@ -213,7 +213,7 @@ int main(int argc, char **argv) {
             S.stop(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / it);
         };
         loop("idle (host sleeps 50 ms)", [&] { std::this_thread::sleep_for(std::chrono::milliseconds(50)); });
-        loop("G: c6_w6_gemm_kernel<true, false>, all blocks", [&] { gemm(); });
+        loop("G: c6_w6_gemm_kernel<true, false, false>, all blocks", [&] { gemm(); });
         loop("O: c6_w6_out_kernel x reps (reads Z)", [&] { outfull(); });
         loop("X: read-transform-write stand-in x reps", [&] { for (int r = 0; r < out_reps; r++) hipLaunchKernelGGL(xcopy_kernel<6>, dim3(cus * 8), dim3(256), 0, so, (const f32x4 *)Z2, (f32x4 *)V2, n4, 0); });
         loop("G then X, one stream's worth (a layer: matrix phase + HBM phase)", [&] { gemm(); hipStreamSynchronize(sg); for (int r = 0; r < 2; r++) hipLaunchKernelGGL(xcopy_kernel<6>, dim3(cus * 8), dim3(256), 0, so, (const f32x4 *)Z2, (f32x4 *)V2, n4, 0); });
@@ -222,7 +222,7 @@ int main(int argc, char **argv) {
 
     const double tg = timeit([&] { gemm(); });
     const double flops = 2.0 * 40.0 * nblocks * W6_BT * 256.0 * 256.0;
-    printf("G alone (c6_w6_gemm_kernel<true, false>, all blocks as rows of five): %8.3f ms  %6.1f TFLOP/s\n", tg, flops / tg / 1e9);
+    printf("G alone (c6_w6_gemm_kernel<true, false, false>, all blocks as rows of five): %8.3f ms  %6.1f TFLOP/s\n", tg, flops / tg / 1e9);
     const double zbytes = (double)tiles * 32 * 1024 * out_reps;
     const double tof = timeit([&] { outfull(); });
     printf("the product's c6_w6_out_kernel (8 workgroups per CU) alone:     %8.3f ms  %5.2f TB/s\n", tof, zbytes / tof / 1e9);
