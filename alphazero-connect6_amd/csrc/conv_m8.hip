@@ -291,6 +291,10 @@ __global__ __launch_bounds__(64 * (C / 32)) void c6_conv3x3_m8_kernel(const floa
     }   // ks
 
         M8_MFMA_DRAIN();      // MFMA results -> VALU / store reads
+        // (r5: every accumulator tile passes through an empty asm BEHIND the drain -- volatile statements keep their order, so no read of a tile can be
+        //  scheduled between the last MFMA and the wait states; without it only the statement order, not a dependence, stood between them)
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) { asm volatile("" : "+v"(acc[0][pt])); asm volatile("" : "+v"(acc[1][pt])); }
         // epilogue: + bias, ReLU, 16-byte stores straight from the accumulators (rows with x == N are junk); the stores
         // drain behind the next board's first slice
         float *outb = out + b * (size_t)CELLS * C;
