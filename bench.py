@@ -486,6 +486,16 @@ def main():
                      "sims_per_s": c5["games"] * k / tm["dt"], "abandoned_games": tm["st"]["abandoned_games"],
                      "note": "bound by the vector ALU (noise sampler) and small HBM transactions, not by streaming bandwidth (DESIGN 5.3)"}
 
+    # ---- the same net at the small end of the batch axis (N = 1, net workloads): what a round costs for one game and for 64 (r5: the GEMM's split form) ------
+    small_side = None
+    if world == 1 and is_net and not args.no_probe and not args.games:
+        small_side = {"what": "ms per simulation round of this workload's net with few concurrent games (same kernels; below ~800 games the convolution's GEMM "
+                              "hands a row of a block's positions to a workgroup instead of the block, for a handful of games to four waves: DESIGN 5.1b)",
+                      "cases": []}
+        for g_small in (1, 64):
+            sm = measure(prec, 100, 20, geom=(n, g_small, S))
+            small_side["cases"].append({"games": g_small, "ms_per_round": 1000.0 * sm["dt"] / 100, "sims_per_s": g_small * 100 / sm["dt"]})
+
     if rank == 0:
         def line(m):
             sims = m["sims_in_window"] * world / m["dt"] if world == 1 else args.steps * G * world / m["dt"]
@@ -640,6 +650,8 @@ def main():
             out["board_kernel"] = board_side
         if tree_side:
             out["tree_kernel"] = tree_side
+        if small_side:
+            out["small_batches"] = small_side
         out["phase_ms"] = {k: head["prof"][k] for k in ("conv_ms", "conv_pre_ms", "conv_post_ms", "select_ms", "expand_ms", "eval_other_ms", "move_ms")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, stones, args.cpu_seconds)      # (stones None: its value is null too, sims_per_s stays)

@@ -26,7 +26,7 @@ def test_records_from_before_round_4_are_c6rng_v4():
 
 
 def test_config3_has_a_probe_at_its_own_budget():
-    """r5: 152 complete games of the 8-block net at 800 simulations per move -- a small probe, so its standard error is part of the record"""
+    """r5: 200 complete games of the 8-block net at 800 simulations per move -- a small probe, so its standard error is part of the record"""
     d = bench.committed_stones_probe("config3", 800, "C6RNG v5")
     assert d is not None and d["file"] == "r05_stones_probe_config3_s800.json" and d["net_blocks"] == 8 and d["num_simulation"] == 800 and d["precision"] == "fp32"
     assert d["games"] >= 64 and 130 < d["stones_per_game"] < 190 and 0.0 < d["standard_error"] < 8.0
