@@ -299,275 +299,36 @@ constexpr int w6_wait_last(int i) {
 template <bool DP, bool SPLIT, bool HW = false>
 __global__ __launch_bounds__(HW ? 256 : 64 * (W6_C / 32)) void c6_w6_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo,
                                                                                  int first, int nblocks, int blkB, int blkBP, int blkD) {
-    static_assert(!HW || SPLIT, "half-width jobs exist in the split form only");
-    constexpr int C = W6_C, CP = C + 4, SLAB = W6_BT * CP, WAVES = HW ? 4 : C / 32, NG = C / 8, PF = W6_PF;
-    constexpr int ND = W6_BT / WAVES;
-    static_assert(PF == 7 && NG == 32 && (ND == 8 || ND == 16), "ring of 8 weight groups; 8 (four waves: 16) DMAs per wave and position");
-    constexpr int RM = PF;
-    extern __shared__ __attribute__((aligned(16))) float wsm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const int cw = HW ? wave + 4 * (int)blockIdx.z : wave;      // the wave's group of 32 output channels
-    const int n4 = cw * 32 + 4 * h;
-    // SPLIT: blockIdx.y is the row this workgroup multiplies in each of its blocks
-    int b = first + (int)blockIdx.x;
-    if (b >= nblocks) return;
-    const int row0 = SPLIT ? (int)blockIdx.y : 0;
+#define W6_BX ((int)blockIdx.x)
+#define W6_GX ((int)gridDim.x)
+#include "conv_wino6_gemm.inc"
+#undef W6_BX
+#undef W6_GX
+}
+template <bool DP, bool SPLIT, bool HW>
+__device__ __forceinline__ void c6_w6_gemm_body(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo, int first, int nblocks, int blkB, int blkBP,
+                                                int blkD, const int bx, const int gx) {
+#define W6_BX bx
+#define W6_GX gx
+#include "conv_wino6_gemm.inc"
+#undef W6_BX
+#undef W6_GX
+}
+// The half-width jobs of BOTH row forms in one launch (r5): at a handful of games a layer's two GEMM launches took 50 and 42 us side by side on two streams,
+// and the fork / join between the streams cost as much again (12 .. 27 us before and after, profiles/r05_kernel_stats_1game.csv).  The first g6 workgroups
+// along x run the rows of six, the rest the rows of five of class D' -- two inlined bodies behind a branch that is uniform over the workgroup, each with
+// its own instruction stream and wait counts (four waves per workgroup: the register file has room for the larger of the two).
+__global__ __launch_bounds__(256) void c6_w6_gemm_half_pair_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo, int n6, int nblocks,
+                                                                    int blkB, int blkBP, int blkD, int g6) {
+    if ((int)blockIdx.x < g6) c6_w6_gemm_body<false, true, true>(V, U, Zo, 0, n6, blkB, blkBP, blkD, (int)blockIdx.x, g6);
+    else c6_w6_gemm_body<true, true, true>(V, U, Zo, n6, nblocks, blkB, blkBP, blkD, (int)blockIdx.x - g6, (int)gridDim.x - g6);
+}
 
-    // blocks [0, blkB): class A, 6 rows of 6 positions; [blkB, blkD): B and B', 5 rows of 6; [blkD, ...): D, 8 rows of 6; the DP instantiation: D', 8 rows
-    // of FIVE positions (r4: F(3) down the board in the six-wide tiles of the last tile row -- 40 instead of 48 positions)
-    auto rows_of = [&](int blk) { return DP ? 8 : blk < blkB ? 6 : blk < blkD ? 5 : 8; };
-    auto npos_of = [&](int blk) { return DP ? 40 : blk < blkB ? 36 : blk < blkD ? 30 : 48; };
-    auto wbase_of = [&](int blk) {
-        const int fs = DP ? 144 : blk < blkB ? 0 : blk < blkBP ? 36 : blk < blkD ? 66 : 96;
-        return U + (size_t)fs * C * C + (size_t)cw * ((size_t)npos_of(blk) * NG * 256);
-    };
-    const unsigned lane16 = (unsigned)lane * 16u;
-    const unsigned zoff0 = (unsigned)(((size_t)j * W6_ZTILE + n4) * 4), zoff1 = zoff0 + (unsigned)((size_t)32 * W6_ZTILE * 4);
-
-    auto dma_chunk = [&](const float *src, int buf, int c0) {
-        const int c = c0 * WAVES + wave;
-        const float *gp = src + (size_t)c * W6_VTILE;
-        const int lds_off = (buf * SLAB + c * CP) * 4;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lds_off) : "memory");
-    };
-    constexpr int RL = DP ? 5 : 6;      // positions per row
-    f32x4 ring[PF + 1];
-    int ub = b, ungt = npos_of(b) * NG;      // the weight stream runs ahead of the multiplications: its own block and group counters
-    const float *uptr = wbase_of(b);
-    int gi = 0;
-    // SPLIT: every (block, row) is a job of its own and nothing wraps -- the weight stream ends with the row and the row's last position fetches no
-    // next one (W6Z_GROUP's LP)
-#define W6_UNEXT()                                                       \
-    {                                                                    \
-        uptr += 256;                                                     \
-        if (!SPLIT) {                                                    \
-            gi += 1;                                                     \
-            if (gi == ungt) {                                            \
-                gi = 0;                                                  \
-                ub = ub + (int)gridDim.x < nblocks ? ub + (int)gridDim.x : ub; \
-                ungt = npos_of(ub) * NG;                                 \
-                uptr = wbase_of(ub);                                     \
-            }                                                            \
-        }                                                                \
-    }
-    // the first position's V rows into slab 0, the first seven weight groups into the ring
-#define W6_PROLOGUE(ROW)                                                                                         \
-    {                                                                                                            \
-        _Pragma("unroll") for (int c0 = 0; c0 < ND; c0++) dma_chunk(V + (size_t)b * W6_VBLOCK + (size_t)(RL * (ROW)) * C, 0, c0); \
-        uptr = wbase_of(b) + (size_t)(RL * (ROW)) * (NG * 256);                                                  \
-        if (SPLIT) asm volatile("" : "+s"(uptr));      /* (D': the same for every block of the loop -- hoisted, the row's 160 group addresses took every scalar register and 568 spill lanes) */ \
-        _Pragma("unroll") for (int q = 0; q < PF; q++) { W4_ULOAD(ring[q], lane16, uptr); W6_UNEXT() }           \
-    }
-    if (!SPLIT) W6_PROLOGUE(0)
-
-    f32x16 z00, z01, z10, z11, z20, z21, z30, z31, m0, m1;
-    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    z20 = z16; z21 = z16; z30 = z16; z31 = z16;
-    const float *zprev = Zo + (size_t)b * W6_ZBLOCK;          // row base of the row whose Z_2, Z_3 are still to be stored
-    const float *zcur = zprev;                                  // row base of the row being accumulated
-
-#define W6Z_STORE1(SET0, SET1, BIDX, DST, k)                                                                     \
-    {                                                                                                            \
-        const f32x16 &sv = ((k) & 4) ? SET1 : SET0;                                                              \
-        const f32x4 a = {sv[4 * ((k) & 3)], sv[4 * ((k) & 3) + 1], sv[4 * ((k) & 3) + 2], sv[4 * ((k) & 3) + 3]}; \
-        /* SPLIT: the second tile half's offset rides in the scalar base (one vector register less: that kernel has none to spare) */ \
-        const float *d_ = (DST) + (size_t)(BIDX) * C + (SPLIT && ((k) & 4) ? (size_t)32 * W6_ZTILE : (size_t)0); \
-        const unsigned zo_ = SPLIT ? zoff0 : ((k) & 4) ? zoff1 : zoff0;                                          \
-        if (((k) & 3) == 0) W4_STORE(zo_, a, d_, 0);                                                             \
-        else if (((k) & 3) == 1) W4_STORE(zo_, a, d_, 32);                                                       \
-        else if (((k) & 3) == 2) W4_STORE(zo_, a, d_, 64);                                                       \
-        else W4_STORE(zo_, a, d_, 96);                                                                           \
-    }
-#define W6Z_LAST_ROW()                                                                                           \
-    {                                                                                                            \
-        _Pragma("unroll") for (int k = 0; k < 8; k++) W6Z_STORE1(z20, z21, 2, zprev, k)                           \
-        _Pragma("unroll") for (int k = 0; k < 8; k++) W6Z_STORE1(z30, z31, 3, zprev, k)                           \
-    }
-#define W6Z_GROUP(q, u, NWAIT, DMA, JJ, BUF, LP)                                                                 \
-            {                                                                                                    \
-                if (!(LP) || (u) + PF < NG) {      /* (LP: a split job's last position requests nothing beyond its row -- a request nobody waits for lands in */ \
-                    W4_ULOAD(ring[((q) + PF) & RM], lane16, uptr);      /* registers the compiler has long given to something else) */ \
-                    W6_UNEXT()                                                                                   \
-                }                                                                                                \
-                if ((u) + 1 < NG) {                                                                              \
-                    va[((u) + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(vb + 8 * ((u) + 1));                 \
-                    va[((u) + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP + 8 * ((u) + 1));       \
-                }                                                                                                \
-                W4_UWAIT(ring[(q)], NWAIT);                                                                      \
-                const f32x4 w = ring[(q)];                                                                       \
-                __builtin_amdgcn_sched_barrier(0);                                                               \
-                if ((JJ) == 0) {                                                                                 \
-                    z00 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : z00, 0, 0, 0); \
-                    z01 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : z01, 0, 0, 0); \
-                } else if ((JJ) == 5) {                                                                          \
-                    z30 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], z30, 0, 0, 0);           \
-                    z31 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], z31, 0, 0, 0);           \
-                } else {                                                                                         \
-                    m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][0][0], (u) == 0 ? z16 : m0, 0, 0, 0); \
-                    m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], va[(u) & 1][1][0], (u) == 0 ? z16 : m1, 0, 0, 0); \
-                }                                                                                                \
-                if (!(LP) && (DMA) >= 0 && (DMA) < ND) dma_chunk(nsrc, (BUF) ^ 1, (DMA));                        \
-                if ((JJ) == 5 && (u) >= 8 && (u) < 24) {      /* Z_0, Z_1 of this row */                          \
-                    if ((u) < 16) W6Z_STORE1(z00, z01, 0, zcur, (u) - 8)                                         \
-                    else W6Z_STORE1(z10, z11, 1, zcur, (u) - 16)                                                 \
-                }                                                                                                \
-                if (!SPLIT && (JJ) == 0 && (u) >= 8 && (u) < 24) {      /* Z_2, Z_3 of the previous row (SPLIT: one row, no previous one) */ \
-                    if ((u) < 16) W6Z_STORE1(z20, z21, 2, zprev, (u) - 8)                                        \
-                    else W6Z_STORE1(z30, z31, 3, zprev, (u) - 16)                                                \
-                }                                                                                                \
-                _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                  \
-                    if ((JJ) == 0) {                                                                             \
-                        z00 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], z00, 0, 0, 0);       \
-                        z01 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], z01, 0, 0, 0);       \
-                    } else if ((JJ) == 5) {                                                                      \
-                        z30 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], z30, 0, 0, 0);       \
-                        z31 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], z31, 0, 0, 0);       \
-                    } else {                                                                                     \
-                        m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][0][r], m0, 0, 0, 0);         \
-                        m1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], va[(u) & 1][1][r], m1, 0, 0, 0);         \
-                    }                                                                                            \
-                }                                                                                                \
-                __builtin_amdgcn_sched_barrier(0);                                                               \
-            }
-#define W6GZ_(i, JJ, BUF, LP) W6Z_GROUP((i) & RM, (i), (LP) ? w6_wait_last((i)) : w6_wait((i), (!SPLIT && (JJ) == 0) || (JJ) == 5, ND), (i), JJ, BUF, LP)
-// one position of a block: JJ = its role in the row (0: the first point, accumulates into Z_0; 5: the last point, accumulates into the last
-// row sum; 1 .. 4: aside, folded in by W6Z_UPDATE / W6Z_UPDATE3), BUF = the LDS slab it reads (positions alternate), PP = its index in the
-// block, LAST = the block's last index
-#define W6Z_POSITION_AT(JJ, BUF, PP, LAST) W6Z_POSITION_LP(JJ, BUF, PP, LAST, false)
-#define W6Z_POSITION_LP(JJ, BUF, PP, LAST, LP)                                                                   \
-        {                                                                                                        \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");                                            \
-            __builtin_amdgcn_s_barrier();                                                                        \
-            const float *nsrc;                                                                                   \
-            {                                                                                                    \
-                const int pp = (PP);                                                                             \
-                if (SPLIT) nsrc = V + (size_t)b * W6_VBLOCK + (size_t)(pp + 1) * C;                              \
-                else {                                                                                           \
-                    int nb = pp < (LAST) ? b : b + (int)gridDim.x;                                               \
-                    nb = nb < nblocks ? nb : b;                                                                  \
-                    nsrc = V + (size_t)nb * W6_VBLOCK + (size_t)(pp < (LAST) ? pp + 1 : 0) * C;                  \
-                }                                                                                                \
-            }                                                                                                    \
-            const float *vb = wsm + (BUF) * SLAB + j * CP + 4 * h;                                               \
-            f32x4 va[2][2];                                                                                      \
-            va[0][0] = *reinterpret_cast<const f32x4 *>(vb);                                                     \
-            va[0][1] = *reinterpret_cast<const f32x4 *>(vb + 32 * CP);                                           \
-            W6GZ_(0, JJ, BUF, LP) W6GZ_(1, JJ, BUF, LP) W6GZ_(2, JJ, BUF, LP) W6GZ_(3, JJ, BUF, LP)                                     \
-            W6GZ_(4, JJ, BUF, LP) W6GZ_(5, JJ, BUF, LP) W6GZ_(6, JJ, BUF, LP) W6GZ_(7, JJ, BUF, LP)                                     \
-            W6GZ_(8, JJ, BUF, LP) W6GZ_(9, JJ, BUF, LP) W6GZ_(10, JJ, BUF, LP) W6GZ_(11, JJ, BUF, LP)                                   \
-            W6GZ_(12, JJ, BUF, LP) W6GZ_(13, JJ, BUF, LP) W6GZ_(14, JJ, BUF, LP) W6GZ_(15, JJ, BUF, LP)                                 \
-            W6GZ_(16, JJ, BUF, LP) W6GZ_(17, JJ, BUF, LP) W6GZ_(18, JJ, BUF, LP) W6GZ_(19, JJ, BUF, LP)                                 \
-            W6GZ_(20, JJ, BUF, LP) W6GZ_(21, JJ, BUF, LP) W6GZ_(22, JJ, BUF, LP) W6GZ_(23, JJ, BUF, LP)                                 \
-            W6GZ_(24, JJ, BUF, LP) W6GZ_(25, JJ, BUF, LP) W6GZ_(26, JJ, BUF, LP) W6GZ_(27, JJ, BUF, LP)                                 \
-            W6GZ_(28, JJ, BUF, LP) W6GZ_(29, JJ, BUF, LP) W6GZ_(30, JJ, BUF, LP) W6GZ_(31, JJ, BUF, LP)                                 \
-        }
-#define W6Z_POSITION(i_, JJ) W6Z_POSITION_LP(JJ, (JJ) & 1, 6 * (i_) + (JJ), SPLIT ? 6 * (i_) + 5 : 6 * R - 1, SPLIT && (JJ) == 5)
-// rows of FIVE positions (class D': F(3)'s points 0, 1, -1, 2, inf; A3^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 1]): the first point takes the JJ = 0
-// path, the last the JJ = 5 path -- F(3)'s third row sum lives in the registers (and in Z's slot b = 3) of F(4)'s fourth; b = 2 is not used
-#define W6Z_UPDATE3(IDX)                                                                                         \
-        _Pragma("unroll") for (int v = 0; v < 16; v++) {                                                         \
-            z00[v] += m0[v]; z01[v] += m1[v];                                                                    \
-            if ((IDX) == 1) { z10[v] = m0[v]; z11[v] = m1[v]; z30[v] = m0[v]; z31[v] = m1[v]; }                  \
-            if ((IDX) == 2) { z10[v] -= m0[v]; z11[v] -= m1[v]; z30[v] += m0[v]; z31[v] += m1[v]; }              \
-            if ((IDX) == 3) {                                                                                    \
-                z10[v] = __builtin_fmaf(2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(2.f, m1[v], z11[v]);        \
-                z30[v] = __builtin_fmaf(4.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(4.f, m1[v], z31[v]);        \
-            }                                                                                                    \
-        }                                                                                                        \
-        if (SPLIT) __builtin_amdgcn_sched_barrier(0);
-#define W6Z_UPDATE(JJ)                                                                                           \
-        _Pragma("unroll") for (int v = 0; v < 16; v++) {                                                         \
-            z00[v] += m0[v]; z01[v] += m1[v];                                                                    \
-            if ((JJ) == 1) { z10[v] = m0[v]; z11[v] = m1[v]; z20[v] = m0[v]; z21[v] = m1[v]; z30[v] = m0[v]; z31[v] = m1[v]; } \
-            if ((JJ) == 2) { z10[v] -= m0[v]; z11[v] -= m1[v]; z20[v] += m0[v]; z21[v] += m1[v]; z30[v] -= m0[v]; z31[v] -= m1[v]; } \
-            if ((JJ) == 3) {                                                                                     \
-                z10[v] = __builtin_fmaf(2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(2.f, m1[v], z11[v]);        \
-                z20[v] = __builtin_fmaf(4.f, m0[v], z20[v]); z21[v] = __builtin_fmaf(4.f, m1[v], z21[v]);        \
-                z30[v] = __builtin_fmaf(8.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(8.f, m1[v], z31[v]);        \
-            }                                                                                                    \
-            if ((JJ) == 4) {                                                                                     \
-                z10[v] = __builtin_fmaf(-2.f, m0[v], z10[v]); z11[v] = __builtin_fmaf(-2.f, m1[v], z11[v]);      \
-                z20[v] = __builtin_fmaf(4.f, m0[v], z20[v]); z21[v] = __builtin_fmaf(4.f, m1[v], z21[v]);        \
-                z30[v] = __builtin_fmaf(-8.f, m0[v], z30[v]); z31[v] = __builtin_fmaf(-8.f, m1[v], z31[v]);      \
-            }                                                                                                    \
-        }                                                                                                        \
-        if (SPLIT) __builtin_amdgcn_sched_barrier(0);
-
-    // SPLIT: one trip (the grid has a workgroup per item; an item's last position fetches its own first one again -- the same instruction stream, nothing
-    // waits for it)
-#pragma unroll 1
-    for (; b < nblocks; b += gridDim.x) {
-        const int i_lo = row0, i_hi = SPLIT ? row0 + 1 : DP ? 8 : rows_of(b);
-        if (SPLIT) {
-            if (row0 >= (DP ? 8 : rows_of(b))) continue;      // (a class with fewer rows than the grid has: uniform over the workgroup)
-            W6_PROLOGUE(row0)      // (what the previous job left in flight -- its last Z stores, the stream's seven groups, its last position's fetch into slab 0 -- is
-        }                          //  older than these requests and retires before them)
-        const int R = SPLIT ? 0 : i_hi;      // (the macros' LAST: 6 R - 1 = the block's last position; SPLIT passes the item's own)
-        if (DP && SPLIT) {      // one row of five positions: the job's first position is in slab 0 (its own prologue put it there)
-            const int i = row0, last5 = 5 * i + 4;
-            zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
-            W6Z_POSITION_AT(0, 0, 5 * i + 0, last5)
-            W6Z_POSITION_AT(1, 1, 5 * i + 1, last5) W6Z_UPDATE3(1)
-            W6Z_POSITION_AT(2, 0, 5 * i + 2, last5) W6Z_UPDATE3(2)
-            W6Z_POSITION_AT(3, 1, 5 * i + 3, last5) W6Z_UPDATE3(3)
-            W6Z_POSITION_LP(5, 0, 5 * i + 4, last5, true)
-            zprev = zcur;
-            W6Z_LAST_ROW()
-            continue;
-        }
-        if (DP) {      // D': two rows of five positions per trip, so that the LDS slab of every position is a constant
-#pragma unroll 1
-            for (int i = i_lo; i < i_hi; i += 2) {
-                zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
-                const int last5 = 39;
-                W6Z_POSITION_AT(0, 0, 5 * i + 0, last5)
-                W6Z_POSITION_AT(1, 1, 5 * i + 1, last5) W6Z_UPDATE3(1)
-                W6Z_POSITION_AT(2, 0, 5 * i + 2, last5) W6Z_UPDATE3(2)
-                W6Z_POSITION_AT(3, 1, 5 * i + 3, last5) W6Z_UPDATE3(3)
-                W6Z_POSITION_AT(5, 0, 5 * i + 4, last5)
-                zprev = zcur;
-                zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)(i + 1) * (4 * C);
-                W6Z_POSITION_AT(0, 1, 5 * i + 5, last5)
-                W6Z_POSITION_AT(1, 0, 5 * i + 6, last5) W6Z_UPDATE3(1)
-                W6Z_POSITION_AT(2, 1, 5 * i + 7, last5) W6Z_UPDATE3(2)
-                W6Z_POSITION_AT(3, 0, 5 * i + 8, last5) W6Z_UPDATE3(3)
-                W6Z_POSITION_AT(5, 1, 5 * i + 9, last5)
-                zprev = zcur;
-            }
-            continue;
-        }
-#pragma unroll 1
-        for (int i = i_lo; i < i_hi; i++) {
-            zcur = Zo + (size_t)b * W6_ZBLOCK + (size_t)i * (4 * C);
-            W6Z_POSITION(i, 0)            // (stores Z_2, Z_3 of the previous row to zprev)
-            W6Z_POSITION(i, 1) W6Z_UPDATE(1)
-            W6Z_POSITION(i, 2) W6Z_UPDATE(2)
-            W6Z_POSITION(i, 3) W6Z_UPDATE(3)
-            W6Z_POSITION(i, 4) W6Z_UPDATE(4)
-            W6Z_POSITION(i, 5)            // (stores Z_0, Z_1 of this row to zcur)
-            zprev = zcur;
-        }
-        if (SPLIT) W6Z_LAST_ROW()
-    }
-    // the last row's Z_2, Z_3 (first the weight stream's last seven requests land: nobody waits for them, and a register the compiler hands to
-    // something else while a request into it is in flight is overwritten when it arrives -- r5, found in the split form)
-    if (!SPLIT) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W6Z_LAST_ROW()
-    }
-#undef W6Z_UPDATE
-#undef W6Z_UPDATE3
-#undef W6Z_POSITION
-#undef W6Z_POSITION_AT
-#undef W6Z_POSITION_LP
-#undef W6GZ_
-#undef W6Z_GROUP
-#undef W6Z_STORE1
-#undef W6Z_LAST_ROW
-#undef W6_PROLOGUE
-#undef W6_UNEXT
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// (the same for the eight-wave split jobs of small batches: both bodies fit the 256 registers of the larger one)
+__global__ __launch_bounds__(64 * (W6_C / 32)) void c6_w6_gemm_split_pair_kernel(const float *__restrict__ V, const float *__restrict__ U, float *__restrict__ Zo, int n6, int nblocks,
+                                                                                 int blkB, int blkBP, int blkD, int g6) {
+    if ((int)blockIdx.x < g6) c6_w6_gemm_body<false, true, false>(V, U, Zo, 0, n6, blkB, blkBP, blkD, (int)blockIdx.x, g6);
+    else c6_w6_gemm_body<true, true, false>(V, U, Zo, n6, nblocks, blkB, blkBP, blkD, (int)blockIdx.x - g6, (int)gridDim.x - g6);
 }
 
 // ---- output transform, the half the GEMM kernel left ------------------------------------------------------------------------------
@@ -999,33 +760,36 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
         // (C6_W6_SPLIT = 0 / 1: a test hook that forces one form -- tests/test_gpu_net.py compares the two bit for bit)
         static const int force = [] { const char *e = getenv("C6_W6_SPLIT"); return e ? atoi(e) : -1; }();
         const bool split = force >= 0 ? force != 0 : n6 < 8 * num_cus;
-        // Beside a SMALL batch (the first launch leaves CUs idle: fewer than two rounds of blocks) the D' launch -- a tenth of the layer's products -- does
-        // not wait for the other one: it goes to a side stream (fork / join by events) and takes the free CUs.  In order on one stream the second launch
-        // cost one block's time after the other's (0.71 + 0.56 ms per layer at 64 games: 8.9 -> 5.5 ms per round; 128 games: 13.2 -> 9.8).  At the
-        // benchmark's batch the chip is full either way and the launches stay in order on the caller's stream (21.7 + 2.5 ms).
-        W6Side *side = n5 > 0 && n6 < 2 * num_cus ? w6_side_of(s) : nullptr;
-        if (side) hipEventRecord(side->fork, s);
         // the tiniest batches (a handful of games: twice the jobs still leave CUs idle): half-width jobs of four waves, a position in half the time
         static const int force_hw = [] { const char *e = getenv("C6_W6_HALF"); return e ? atoi(e) : -1; }();      // (test hook, as C6_W6_SPLIT)
         const bool half = split && (force_hw >= 0 ? force_hw != 0 : 2 * 8 * (n6 + n5) <= num_cus);
+        // The split forms run BOTH row forms in one launch (c6_w6_gemm_split_pair_kernel / c6_w6_gemm_half_pair_kernel): D' -- a tenth of the layer's
+        // products -- takes the CUs the other classes' jobs leave idle without a second stream.  (As two launches on two streams, fork / join by events,
+        // the layer had been 8.9 -> 5.5 ms per round at 64 games against the launches in order; the fork / join itself cost 12 .. 27 us either side of the
+        // GEMMs: one launch, 1 game 1.11 -> 0.95 ms per round, 8 games 1.33 -> 1.21, 64 .. 768 games -1 .. 2 %, profiles/r05_pair_ab.txt.)
+        // C6_W6_PAIR=0 (test / A-B hook): the split form as the two launches it was.  The block form at a small batch (C6_W6_SPLIT=0 only) keeps the side
+        // stream; at the benchmark's batch the chip is full either way and the launches stay in order on the caller's stream (21.7 + 2.5 ms).
+        static const int force_pair = [] { const char *e = getenv("C6_W6_PAIR"); return e ? atoi(e) : -1; }();
+        const bool pair = half || (split && force_pair != 0);
+        W6Side *side = !pair && n5 > 0 && n6 < 2 * num_cus ? w6_side_of(s) : nullptr;
+        if (side) hipEventRecord(side->fork, s);
+        const int g6 = n6 < num_cus ? n6 : num_cus, g5 = n5 < num_cus ? n5 : num_cus;
         if (half) {
-            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<false, true, true>), (int)smem);
-            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_kernel<true, true, true>), (int)smem);
-            hipLaunchKernelGGL((c6_w6_gemm_kernel<false, true, true>), dim3(n6 < num_cus ? n6 : num_cus, 8, 2), dim3(256), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB,
-                               (int)map.blkBP, (int)map.blkD);
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_half_pair_kernel), (int)smem);
+            hipLaunchKernelGGL(c6_w6_gemm_half_pair_kernel, dim3(g6 + g5, 8, 2), dim3(256), smem, s, Vb, wp, Mb, n6, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD, g6);
+        } else if (pair) {
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_gemm_split_pair_kernel), (int)smem);
+            hipLaunchKernelGGL(c6_w6_gemm_split_pair_kernel, dim3(g6 + g5, 8), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, n6, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD, g6);
         } else if (split) {
             hipLaunchKernelGGL((c6_w6_gemm_kernel<false, true>), dim3(n6 < num_cus ? n6 : num_cus, 8), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB,
                                (int)map.blkBP, (int)map.blkD);
         } else
             hipLaunchKernelGGL((c6_w6_gemm_kernel<false, false>), dim3(n6 < num_cus ? n6 : num_cus), dim3(64 * (W6_C / 32)), smem, s, Vb, wp, Mb, 0, n6, (int)map.blkB, (int)map.blkBP,
                                (int)map.blkD);
-        if (n5 > 0) {
+        if (n5 > 0 && !pair) {
             hipStream_t s5 = side ? side->stream : s;
             if (side) hipStreamWaitEvent(s5, side->fork, 0);
-            if (half)
-                hipLaunchKernelGGL((c6_w6_gemm_kernel<true, true, true>), dim3(n5 < num_cus ? n5 : num_cus, 8, 2), dim3(256), smem, s5, Vb, wp, Mb, n6, nblocks, (int)map.blkB,
-                                   (int)map.blkBP, (int)map.blkD);
-            else if (split)
+            if (split)
                 hipLaunchKernelGGL((c6_w6_gemm_kernel<true, true>), dim3(n5 < num_cus ? n5 : num_cus, 8), dim3(64 * (W6_C / 32)), smem, s5, Vb, wp, Mb, n6, nblocks, (int)map.blkB,
                                    (int)map.blkBP, (int)map.blkD);
             else

@@ -66,7 +66,7 @@ def net_flops_per_board(n, C, blocks):
     return 2 * 9 * 2 * C * n2 + (blocks - 1) * 2 * (2 * 9 * C * C * n2) + heads
 
 
-CONV_SOURCES = ("conv_wino6.hip", "c6_wino.h", "net_kernels.hip")      # what the FP32 tower's kernels (the ones the PMC summary describes) are compiled from
+CONV_SOURCES = ("conv_wino6.hip", "conv_wino6_gemm.inc", "c6_wino.h", "net_kernels.hip")      # what the FP32 tower's kernels (the ones the PMC summary describes) are compiled from
 
 
 def kernel_source_hash(names=None):
@@ -74,7 +74,7 @@ def kernel_source_hash(names=None):
     (`names=CONV_SOURCES`: an edit of the tree kernels does not make the convolution kernels' counters stale)"""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "alphazero-connect6_amd", "csrc", "*"))):
-        if f.endswith((".hip", ".h", ".cpp")) and (names is None or os.path.basename(f) in names):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")) and (names is None or os.path.basename(f) in names):
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -232,12 +232,15 @@ def test_w6_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
     res = {}
     with tempfile.TemporaryDirectory() as td:
         # block form / split form with eight-wave jobs / split form with the four-wave half-width jobs of the tiniest batches (forced at every size)
-        for form, env in (("block", dict(C6_W6_SPLIT="0")), ("split", dict(C6_W6_SPLIT="1", C6_W6_HALF="0")), ("half", dict(C6_W6_SPLIT="1", C6_W6_HALF="1"))):
+        # (split / half: both row forms in ONE launch, c6_w6_gemm_split_pair_kernel / c6_w6_gemm_half_pair_kernel; split2: the split form as the two launches it was)
+        for form, env in (("block", dict(C6_W6_SPLIT="0")), ("split", dict(C6_W6_SPLIT="1", C6_W6_HALF="0")), ("half", dict(C6_W6_SPLIT="1", C6_W6_HALF="1")),
+                          ("split2", dict(C6_W6_SPLIT="1", C6_W6_HALF="0", C6_W6_PAIR="0"))):
             out = os.path.join(td, f"w6_{form}.npz")
             subprocess.run([sys.executable, "-c", W6_CHILD, out], check=True, env=dict(os.environ, **env), timeout=600)
             res[form] = dict(np.load(out))
-    assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) and len(res["block"]) == 20
+    assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) == sorted(res["split2"]) and len(res["block"]) == 20
     for k in res["block"]:
         assert np.isfinite(res["block"][k]).all()
         assert np.array_equal(res["block"][k], res["split"][k]), k
         assert np.array_equal(res["block"][k], res["half"][k]), k
+        assert np.array_equal(res["block"][k], res["split2"][k]), k

@@ -57,10 +57,26 @@ int main(int argc, char **argv) {
         CK(hipDeviceSynchronize());
         printf("half-width split form done\n"); fflush(stdout);
     }
+    if (which & 8) {      // the same jobs, both row forms in ONE launch (c6_w6_gemm_half_pair_kernel: what the library launches for a handful of games)
+        CK(hipMemset(Z1, 0xff, zfl * 4));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_w6_gemm_half_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int g6 = n6 < cus ? n6 : cus, g5 = n5 < cus ? n5 : cus;
+        hipLaunchKernelGGL(c6_w6_gemm_half_pair_kernel, dim3(g6 + g5, 8, 2), dim3(256), smem, 0, V, U, Z1, n6, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD, g6);
+        CK(hipDeviceSynchronize());
+        printf("half-width jobs, one launch: done\n"); fflush(stdout);
+    }
+    if (which & 16) {      // ... and the eight-wave split jobs in one launch (c6_w6_gemm_split_pair_kernel)
+        CK(hipMemset(Z1, 0xff, zfl * 4));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&c6_w6_gemm_split_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int g6 = n6 < cus ? n6 : cus, g5 = n5 < cus ? n5 : cus;
+        hipLaunchKernelGGL(c6_w6_gemm_split_pair_kernel, dim3(g6 + g5, 8), dim3(512), smem, 0, V, U, Z1, n6, nblocks, (int)map.blkB, (int)map.blkBP, (int)map.blkD, g6);
+        CK(hipDeviceSynchronize());
+        printf("split jobs, one launch: done\n"); fflush(stdout);
+    }
     std::vector<float> h0(zfl), h1(zfl);
     CK(hipMemcpy(h0.data(), Z0, zfl * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), Z1, zfl * 4, hipMemcpyDeviceToHost));
     size_t diff = 0, first = 0;
-    const size_t lo = (which & 5) ? 0 : (size_t)n6 * W6_ZBLOCK, hi = (which & 6) ? zfl : (size_t)n6 * W6_ZBLOCK;
+    const size_t lo = (which & 29) ? 0 : (size_t)n6 * W6_ZBLOCK, hi = (which & 30) ? zfl : (size_t)n6 * W6_ZBLOCK;
     for (size_t i = lo; i < hi; i++) if (memcmp(&h0[i], &h1[i], 4)) { if (!diff) first = i; diff++; }
     {
         std::vector<size_t> byblk(nblocks, 0); size_t byb[4] = {0, 0, 0, 0}, byhalf[2] = {0, 0}, byrow[9] = {0};
