@@ -811,7 +811,8 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
             w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<false>), (int)win_smem);
             hipLaunchKernelGGL((c6_w6_mid_kernel<false>), dim3(grid_b), dim3(W6_MID_THREADS), win_smem, s, Mb, bias, res, act, Vb, nboards, C6StemSrc{});
         }
-        if (tail) hipLaunchKernelGGL(c6_w6_tail_kernel, dim3(256), dim3(256), 0, s, Vb, nboards);
+        // (no c6_w6_tail_kernel here: the boundary kernel writes the tiles of the batch and nothing else, so the tail the pass's first step zeroed in this
+        //  same V is still zero -- five launches less per pass, 5 us + a launch gap each, which a one-game round of 0.95 ms does notice)
     }
     if (steps & 4) {
         const long tiles = (long)nboards * W6_T, want = (2 * tiles + 3) / 4;

@@ -186,13 +186,14 @@ __global__ __launch_bounds__(256) void c6_head_policy_kernel(const float *__rest
         float acc1[HB], acc2[HB];
 #pragma unroll
         for (int q = 0; q < HB; q++) { acc1[q] = bias[c1]; acc2[q] = bias[c2]; }
-        // r5: the weights of eight k at a time, requested one block ahead -- the loop was a chain of 722 dependent L2 round trips, 180 us for a
+        // r5: the weights of sixteen k at a time, requested one block ahead -- the loop was a chain of 722 dependent L2 round trips, 180 us for a
         // workgroup on its own (one game's eight boards); the multiply-adds keep their order (k ascending per output: bit-identical results)
-        constexpr int KB = 8;
+        // (blocks of sixteen, then at most one half block of eight whose loads go out together, then < 8 single k: 722 = 45 x 16 + 2)
+        constexpr int KB = 16, KH = 8;
         if (cells > 256) {
             float wa[KB], wb[KB];
 #pragma unroll
-            for (int u = 0; u < KB; u++) { wa[u] = wT[(size_t)u * cells + c1]; wb[u] = wT[(size_t)u * cells + c2]; }      // (K >= 8)
+            for (int u = 0; u < KB; u++) { wa[u] = wT[(size_t)u * cells + c1]; wb[u] = wT[(size_t)u * cells + c2]; }      // (K = 2 cells >= 162: a whole first block)
             int k = 0;
             for (; k + KB <= K; k += KB) {
                 float na[KB], nb_[KB];
@@ -210,6 +211,21 @@ __global__ __launch_bounds__(256) void c6_head_policy_kernel(const float *__rest
                 }
 #pragma unroll
                 for (int u = 0; u < KB; u++) { wa[u] = na[u]; wb[u] = nb_[u]; }
+            }
+            if (k + KH <= K) {
+                float ra[KH], rb[KH];
+#pragma unroll
+                for (int u = 0; u < KH; u++) { ra[u] = wT[(size_t)(k + u) * cells + c1]; rb[u] = wT[(size_t)(k + u) * cells + c2]; }
+#pragma unroll
+                for (int u = 0; u < KH; u++) {
+#pragma unroll
+                    for (int q = 0; q < HB; q++) {
+                        const float xv = x[q * K + k + u];
+                        acc1[q] = __builtin_fmaf(ra[u], xv, acc1[q]);
+                        acc2[q] = __builtin_fmaf(rb[u], xv, acc2[q]);
+                    }
+                }
+                k += KH;
             }
             for (; k < K; k++) {
                 const float w1 = wT[(size_t)k * cells + c1], w2 = wT[(size_t)k * cells + c2];
@@ -237,6 +253,17 @@ __global__ __launch_bounds__(256) void c6_head_policy_kernel(const float *__rest
                 }
 #pragma unroll
                 for (int u = 0; u < KB; u++) wa[u] = na[u];
+            }
+            if (k + KH <= K) {
+                float ra[KH];
+#pragma unroll
+                for (int u = 0; u < KH; u++) ra[u] = wT[(size_t)(k + u) * cells + c1];
+#pragma unroll
+                for (int u = 0; u < KH; u++) {
+#pragma unroll
+                    for (int q = 0; q < HB; q++) acc1[q] = __builtin_fmaf(ra[u], x[q * K + k + u], acc1[q]);
+                }
+                k += KH;
             }
             for (; k < K; k++) {
                 const float w1 = wT[(size_t)k * cells + c1];
@@ -287,8 +314,8 @@ __global__ __launch_bounds__(256) void c6_head_value_kernel(const float *__restr
     float acc[HB];
 #pragma unroll
     for (int q = 0; q < HB; q++) acc[q] = b1[hdn];
-    {      // (r5: eight weights at a time, one block ahead, as in the policy head; same order of the multiply-adds)
-        constexpr int KB = 8;
+    {      // (r5: sixteen weights at a time, one block ahead, as in the policy head; same order of the multiply-adds)
+        constexpr int KB = 16, KH = 8;
         float wa[KB];
 #pragma unroll
         for (int u = 0; u < KB; u++) wa[u] = w1T[(size_t)u * 256 + hdn];
@@ -305,6 +332,17 @@ __global__ __launch_bounds__(256) void c6_head_value_kernel(const float *__restr
             }
 #pragma unroll
             for (int u = 0; u < KB; u++) wa[u] = na[u];
+        }
+        if (k + KH <= cells) {      // (361 = 22 x 16 + 8 + 1)
+            float ra[KH];
+#pragma unroll
+            for (int u = 0; u < KH; u++) ra[u] = w1T[(size_t)(k + u) * 256 + hdn];
+#pragma unroll
+            for (int u = 0; u < KH; u++) {
+#pragma unroll
+                for (int q = 0; q < HB; q++) acc[q] = __builtin_fmaf(ra[u], x[q * cells + k + u], acc[q]);
+            }
+            k += KH;
         }
         for (; k < cells; k++) {
             const float w = w1T[(size_t)k * 256 + hdn];
