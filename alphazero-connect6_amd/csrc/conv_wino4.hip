@@ -904,7 +904,8 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
             w4_smem_once(reinterpret_cast<const void *>(&c6_wino4_mid_kernel<N, false>), (int)mid_smem);
             hipLaunchKernelGGL((c6_wino4_mid_kernel<N, false>), dim3(grid_mid), dim3(64 * G::TW), mid_smem, s, Mb, bias, res, out, Vb, nboards, C6StemSrc{});
         }
-        if (tail) hipLaunchKernelGGL((c6_wino4_tail_kernel<N>), dim3(256), dim3(256), 0, s, Vb, nboards);
+        // (no tail kernel here, as in conv_wino6.hip: this kernel writes the batch's tiles only, and every chain that reaches it began with a step-1 launch
+        //  into this V for this batch, which zeroed the tail)
     }
     if (steps & 4) {
         const long want = (tiles + 3) / 4;
