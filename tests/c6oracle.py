@@ -20,6 +20,9 @@ EVAL_CUSTOM, EVAL_RANDOM, EVAL_UNIFORM = 0, 1, 2
 
 
 def build(force=False):
+    # C6_ORACLE_SO: another build of the same sources (the AddressSanitizer / UBSan one of tools/oracle_sanitize.sh)
+    if os.environ.get("C6_ORACLE_SO"):
+        return os.environ["C6_ORACLE_SO"]
     srcs = [os.path.join(ODIR, f) for f in ("c6_oracle.c", "c6_oracle_net.c", "c6_default.c", "c6_oracle.h", "Makefile")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
         subprocess.check_call(["make", "-C", ODIR], stdout=subprocess.DEVNULL)
