@@ -36,6 +36,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool: the host driver shares device memory across processes as dmabuf handles only (RCCL's setup needs it); the
+# launcher's environment exports this already -- kept here so that a bare `torchrun bench.py` has it too (read when the HIP runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WORKLOADS = {
     # name: board, games/GPU, sims, net blocks (reference num_block), channels, evaluator, stones/game PRIOR (SURVEY 8d scratch estimate;
