@@ -98,3 +98,18 @@ def test_z_rows_are_half_of_the_output_transform():
     z1 = m[:, 1] - m[:, 2] + 2 * m[:, 3]
     z3 = m[:, 1] + m[:, 2] + 4 * m[:, 3] + m[:, 4]
     assert np.abs(np.stack([z0, z1, z3], 1) - m @ F[3][0].T).max() < 1e-12
+
+
+def test_candidate_tilings_position_counts():
+    """DESIGN 9.1 (not built): F(6,3) both ways on the 19x19 board -- 19 = 6 + 6 + 4 + 3 down as well as across -- is exact and takes 27^2 = 729
+    positions per channel pair and board (today 788: -7.5 % matrix work; its f32 error is 1.4 x today's, tools/wino_tile_error.py); the reference's
+    own 15x15 board as 6 + 6 + 3 both ways would take 21^2 = 441 (today's F(4,3) tiling: 534), and with F(4,3) kept down the board 23 x 21 = 483."""
+    rng = np.random.default_rng(3)
+    same = lambda ty, tx, mv, mh: (mv, mh)
+    for n, rows, cols, want in ((19, [(0, 6, 6), (6, 6, 6), (12, 4, 4), (16, 3, 3)], [(0, 6, 6), (6, 6, 6), (12, 4, 4), (16, 3, 3)], 729),
+                                (15, [(0, 6, 6), (6, 6, 6), (12, 3, 3)], [(0, 6, 6), (6, 6, 6), (12, 3, 3)], 441),
+                                (15, [(0, 4, 4), (4, 4, 4), (8, 4, 4), (12, 3, 3)], [(0, 6, 6), (6, 6, 6), (12, 3, 3)], 483)):
+        x, g = rng.standard_normal((n, n)), rng.standard_normal((3, 3))
+        ref, xp = direct(x, g)
+        out, npos = tiled(xp, g, n, rows, cols, same)
+        assert npos == want and np.abs(out - ref).max() < 1e-10, (n, npos)
