@@ -80,3 +80,44 @@ def test_planted_lines_in_noise(n):
             t[r0 + k * dr, c0 + k * dc] = p
         want = brute_force_winner(t)
         assert want != 0 and o.search(t) == want
+
+
+def test_random_stone_sequences_against_a_python_model_of_game_set(n):
+    """game_impl/mod.rs:125-169, restated as a few lines of Python: Black opens with ONE stone, then two per turn; a position outside the board is
+    InvalidPosition, an occupied one AlreadySetPosition, and neither changes the game; SetResult carries the mover and the stones it has left
+    BEFORE the turn switches.  Random sequences with both kinds of illegal stones mixed in, to the end of the board; the winner after every stone
+    against the direct count above."""
+    rng = np.random.default_rng(500 + n)
+    for _ in range(6):
+        g = o.new_game(n)
+        board, turn, remain = np.zeros((n, n), np.int8), o.BLACK, 1
+        res = o.SetResult()
+        stones = 0
+        while stones < n * n:
+            kind = rng.random()
+            if kind < 0.08:
+                r, c = (int(rng.integers(n, n + 3)), int(rng.integers(0, n + 3))) if rng.random() < 0.5 else (int(rng.integers(0, n + 3)), int(rng.integers(n, n + 3)))
+            elif kind < 0.2 and stones:
+                rr, cc = np.nonzero(board)
+                k = int(rng.integers(0, len(rr)))
+                r, c = int(rr[k]), int(cc[k])
+            else:
+                rr, cc = np.nonzero(board == 0)
+                k = int(rng.integers(0, len(rr)))
+                r, c = int(rr[k]), int(cc[k])
+            rc = o.lib().c6o_game_set(g, r, c, res)
+            if r >= n or c >= n:
+                assert rc == o.ERR_INVALID
+            elif board[r, c] != 0:
+                assert rc == o.ERR_ALREADY
+            else:
+                assert rc == o.OK
+                board[r, c] = turn
+                remain -= 1
+                assert (res.player, res.num_remain, res.row, res.col) == (turn, remain, r, c)
+                if remain <= 0:
+                    remain, turn = 2, -turn
+                stones += 1
+            assert (g.turn, g.num_remain) == (turn, remain) and (g.np_board() == board).all()
+            if stones % 7 == 0 or stones > n * n - 3:
+                assert o.lib().c6o_game_is_end(g) == brute_force_winner(board)
