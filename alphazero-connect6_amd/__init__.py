@@ -47,7 +47,11 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_rng_spec", "c6_device_count
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",
                   "c6_trainer_last_error", "c6_trainer_set_precision", "c6_conv_wgrad_op", "c6_engine_boards", "c6_engine_play_match", "c6_engine_apply_moves", "c6_engine_last_moves",
                   "c6_rollout_create", "c6_rollout_destroy", "c6_rollout_reset", "c6_rollout_next", "c6_rollout_slot_info",
-                  "c6_rollout_node", "c6_rollout_bench_playouts"]
+                  "c6_rollout_node", "c6_rollout_bench_playouts",
+                  "c6_group_create", "c6_group_destroy", "c6_group_size", "c6_group_engine", "c6_group_member_info", "c6_group_uses_rccl",
+                  "c6_group_load_weights", "c6_group_set_callback", "c6_group_step", "c6_group_run", "c6_group_sync", "c6_group_stats",
+                  "c6_group_fetch_games", "c6_group_enable_tuples", "c6_group_pool_begin", "c6_group_pool_end", "c6_group_pool_tuples",
+                  "c6_group_pooled", "c6_group_fetch_pooled", "c6_group_push_pooled"]
 
 
 class C6Error(RuntimeError):
@@ -209,6 +213,29 @@ def lib():
     L.c6_trainer_loss.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, f32p]
     L.c6_trainer_step_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, f32p]
     L.c6_trainer_last_error.restype = C.c_char_p
+    if hasattr(L, "c6_group_create"):      # (absent from A/B libraries built from earlier rounds' sources)
+        L.c6_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.c6_group_destroy.argtypes = [C.c_void_p]
+        L.c6_group_size.argtypes = [C.c_void_p]
+        L.c6_group_engine.argtypes = [C.c_void_p, C.c_int]
+        L.c6_group_engine.restype = C.c_void_p
+        L.c6_group_member_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), u32p, C.POINTER(C.c_int)]
+        L.c6_group_uses_rccl.argtypes = [C.c_void_p]
+        L.c6_group_load_weights.argtypes = [C.c_void_p, f32p, C.c_size_t]
+        L.c6_group_set_callback.argtypes = [C.c_void_p, CALLBACK, C.c_int]
+        L.c6_group_step.argtypes = [C.c_void_p, C.c_int]
+        L.c6_group_run.argtypes = [C.c_void_p, C.c_long]
+        L.c6_group_sync.argtypes = [C.c_void_p]
+        L.c6_group_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.c6_group_fetch_games.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), i32p, i32p, u32p, i16p]
+        L.c6_group_enable_tuples.argtypes = [C.c_void_p, C.c_size_t]
+        L.c6_group_pool_begin.argtypes = [C.c_void_p]
+        L.c6_group_pool_end.argtypes = [C.c_void_p, u32p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+        L.c6_group_pool_tuples.argtypes = [C.c_void_p, u32p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+        L.c6_group_pooled.argtypes = [C.c_void_p, C.c_int]
+        L.c6_group_pooled.restype = C.c_void_p
+        L.c6_group_fetch_pooled.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+        L.c6_group_push_pooled.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.cpp_self_play.restype = Vec
     L.cpp_self_play.argtypes = [CALLBACK, ALLOC_PATH, ALLOC_RESULT, C.c_int, C.c_float, C.c_double, C.c_float, C.c_bool, C.c_int]
     L.cpp_play.restype = Vec
@@ -606,6 +633,122 @@ class Engine:
         p = Profile()
         _chk(lib().c6_engine_profile_read(self.h, C.byref(p), int(reset)))
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+class Group:
+    """c6_group (include/connect6_amd.h part 6): one engine + one host thread per device behind the C ABI, games sharded by uid, training tuples
+    pooled over the members by ncclAllGather (host-staged when members share a device) -- the library-side counterpart of AsyncAgent::run's
+    thread pool + mpsc collection (agent/async_agent/mod.rs:100-137).  `devices`: HIP ordinals, repeats allowed; None = every visible device."""
+
+    def __init__(self, devices=None, board_size=15, num_games=1, num_simulation=800, epsilon=0.25, dirichlet_alpha=0.03, c_puct=1.0, seed=0,
+                 evaluator=EVAL_RANDOM, net_channels=256, net_blocks=4, records_per_game=0, recycle=False, stagger=False, game_uid_base=0,
+                 net_chunk_boards=0, net_precision=0, max_records_per_game=0, stress_every=0):
+        cfg = Config()
+        lib().c6_default_config(C.byref(cfg))
+        for k, v in dict(board_size=board_size, num_games=num_games, num_simulation=num_simulation, epsilon=epsilon, dirichlet_alpha=dirichlet_alpha,
+                         c_puct=c_puct, seed=seed, evaluator=evaluator, net_channels=net_channels, net_blocks=net_blocks,
+                         records_per_game=records_per_game, recycle=int(recycle), stagger=int(stagger), game_uid_base=game_uid_base,
+                         net_chunk_boards=net_chunk_boards, net_precision=net_precision, max_records_per_game=max_records_per_game,
+                         stress_every=stress_every).items():
+            setattr(cfg, k, v)
+        self.n, self.cells, self.G = board_size, board_size * board_size, num_games
+        self.h = C.c_void_p()
+        dv = (C.c_int * len(devices))(*devices) if devices else None
+        _chk(lib().c6_group_create(C.byref(cfg), dv, len(devices) if devices else 0, C.byref(self.h)))
+        self.size = lib().c6_group_size(self.h)
+        self.stride = int(lib().c6_tuple_stride(board_size))
+        self._cb = None
+
+    def close(self):
+        if self.h:
+            lib().c6_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def uses_rccl(self):
+        return bool(lib().c6_group_uses_rccl(self.h))
+
+    def member_info(self, r):
+        dev, first, games = C.c_int(), C.c_uint32(), C.c_int()
+        _chk(lib().c6_group_member_info(self.h, r, C.byref(dev), C.byref(first), C.byref(games)))
+        return dict(device=dev.value, first_uid=first.value, games=games.value)
+
+    def engine_root(self, member, g=0):
+        """root of slot g of member `member` (c6_engine_root on the member's engine)"""
+        e = Engine.__new__(Engine)
+        e.h, e.n, e.cells = C.c_void_p(lib().c6_group_engine(self.h, member)), self.n, self.cells
+        try:
+            return Engine.root(e, g)
+        finally:
+            e.h = None      # borrowed: the group owns the engine
+
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, np.float32)
+        _chk(lib().c6_group_load_weights(self.h, _p(blob, C.c_float), blob.size))
+
+    def set_callback(self, fn, concurrent=False):
+        """fn(player, boards int8 [len, N*N]) -> (values [len], policies [len, N*N]) as Engine.set_callback; called from the members' host threads"""
+        n2 = self.cells
+
+        def tramp(player, values, policies, n):
+            b = np.ctypeslib.as_array(policies, shape=(n, n2))
+            v, p = fn(player, b.astype(np.int8))
+            np.ctypeslib.as_array(values, shape=(n,))[:] = np.asarray(v, np.float32).reshape(n)
+            b[:] = np.asarray(p, np.float32).reshape(n, n2)
+        self._cb = CALLBACK(tramp)
+        _chk(lib().c6_group_set_callback(self.h, self._cb, int(concurrent)))
+
+    def step(self, rounds=1):
+        _chk(lib().c6_group_step(self.h, rounds))
+
+    def run(self, max_rounds=0):
+        _chk(lib().c6_group_run(self.h, max_rounds))
+
+    def sync(self):
+        _chk(lib().c6_group_sync(self.h))
+
+    def stats(self):
+        s = Stats()
+        _chk(lib().c6_group_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def fetch_games(self, cap=None):
+        cap = cap or max(4 * self.G, 1024)
+        winners, lens = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        uids, moves = np.zeros(cap, np.uint32), np.zeros((cap, self.cells), np.int16)
+        cnt = C.c_int()
+        _chk(lib().c6_group_fetch_games(self.h, cap, C.byref(cnt), _p(winners, C.c_int32), _p(lens, C.c_int32), _p(uids, C.c_uint32), _p(moves, C.c_int16)))
+        return [dict(winner=int(winners[i]), uid=int(uids[i]), moves=moves[i, :lens[i]].copy()) for i in range(cnt.value)]
+
+    def enable_tuples(self, capacity):
+        _chk(lib().c6_group_enable_tuples(self.h, capacity))
+
+    def pool_begin(self):
+        _chk(lib().c6_group_pool_begin(self.h))
+
+    def pool_end(self):
+        counts = np.zeros(self.size, np.uint32)
+        padded, dropped = C.c_size_t(), C.c_uint64()
+        _chk(lib().c6_group_pool_end(self.h, _p(counts, C.c_uint32), C.byref(padded), C.byref(dropped)))
+        return dict(counts=counts, padded=padded.value, dropped=dropped.value)
+
+    def pool_tuples(self):
+        self.pool_begin()
+        return self.pool_end()
+
+    def fetch_pooled(self, member=0, cap=None):
+        """the valid records of member `member`'s copy of the last pool: uint8 [count, stride]"""
+        cap = cap or self.G * self.cells
+        buf = np.zeros((cap, self.stride), np.uint8)
+        cnt = C.c_size_t()
+        _chk(lib().c6_group_fetch_pooled(self.h, member, cap, C.byref(cnt), buf.ctypes.data_as(C.c_void_p)))
+        return buf[:cnt.value]
+
+    def push_pooled(self, member, replay):
+        _chk(lib().c6_group_push_pooled(self.h, member, replay.h))
 
 
 def decode_tuples(buf, n):

@@ -49,6 +49,7 @@ static c6_play_result make_result(int winner, int len, const int16_t *moves, c6_
 }
 
 static void print_board(const int8_t *board);
+std::vector<int> c6_dropin_devices(int num_games);      // group.cpp: C6_DEVICES / C6_GROUP_MIN_GAMES
 
 // "{player:?} ({row}, {col}), remain {n}, {s}.{ms} elapsed", agent_impl/mod.rs:147-160 (num_remain: after the decrement,
 // before the reset -- SetResult, game_impl/mod.rs:158-160)
@@ -74,11 +75,38 @@ extern "C" c6_vec cpp_self_play(c6_callback callback, c6_alloc_path alloc_path, 
     // per game, doubled on demand up to 65000)
     if (const char *r = std::getenv("C6_RECORDS")) cfg.records_per_game = std::atoi(r);
     if (const char *r = std::getenv("C6_MAX_RECORDS")) cfg.max_records_per_game = std::atoi(r);
+    const int G = cfg.num_games;
+    const auto t_start = std::chrono::steady_clock::now();
+    // AsyncAgent::run fans the games out over every core inside the library (async_agent/mod.rs:100-137, lib.rs:110-122): here over every visible GPU
+    // -- a c6_group (group.cpp: one engine + host thread per device, games sharded by uid) -- when the call brings enough games to fill more than one
+    const std::vector<int> devs = c6_dropin_devices(G);
+    if (devs.size() > 1) {
+        c6_group *grp = nullptr;
+        if (c6_group_create(&cfg, devs.data(), (int)devs.size(), &grp) != C6_OK) die("cpp_self_play: group");
+        const char *cc = std::getenv("C6_CALLBACK_CONCURRENT");
+        c6_group_set_callback(grp, callback, cc && cc[0] == '1');
+        const int grc = c6_group_run(grp, 0);
+        if (grc == C6_ERR_OVERFLOW) std::fprintf(stderr, "libconnect6_amd: cpp_self_play: %s\n", c6_last_error());
+        else if (grc != C6_OK) die("cpp_self_play: run");
+        std::vector<int> winners(G), lens(G);
+        std::vector<int16_t> moves((size_t)G * CELLS);
+        int count = 0;
+        if (c6_group_fetch_games(grp, G, &count, winners.data(), lens.data(), nullptr, moves.data()) != C6_OK) die("cpp_self_play: fetch");
+        const long long ms_all = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
+        c6_vec v;
+        v.len = count;
+        v.vec = alloc_result(count);
+        for (int i = 0; i < count; i++) {
+            v.vec[i] = make_result(winners[i], lens[i], &moves[(size_t)i * CELLS], alloc_path);
+            if (debug) std::printf("run: %d, elapsed %lld.%llds\n", i, ms_all / 1000, ms_all % 1000);      // async_agent/mod.rs:117-124
+        }
+        c6_group_destroy(grp);
+        return v;
+    }
+    cfg.device = devs[0];
     c6_engine *e = nullptr;
     if (c6_engine_create(&cfg, &e) != C6_OK) die("cpp_self_play: engine");
     c6_engine_set_callback(e, callback);
-    const int G = cfg.num_games;
-    const auto t_start = std::chrono::steady_clock::now();
     int rc = C6_OK;
     if (debug && G == 1) {
         // lib.rs:98-108: one game on the caller's thread through Agent::debug -- the board before every stone, one line per

@@ -591,6 +591,7 @@ struct c6_engine {
     // owned tuple buffer
     uint8_t *own_tuple = nullptr;
     uint32_t *own_tuple_count = nullptr;
+    size_t tuple_head = 0;            // records at the front of the tuple buffer already handed out by c6_engine_fetch_tuples (partial fetches)
     uint64_t rounds = 0;
     int round_in_move = 0;
     unsigned long long fetched = 0;   // entries of the finished-games queue already handed to the caller (c6_engine_fetch_games)
@@ -837,6 +838,7 @@ extern "C" int c6_engine_set_tuple_buffer(c6_engine *e, void *dev_buf, size_t ca
     e->d.tuple_buf = reinterpret_cast<uint8_t *>(dev_buf);
     e->d.tuple_cap = capacity_records;
     e->d.tuple_count = count_dev;
+    e->tuple_head = 0;
     return C6_OK;
 }
 
@@ -845,6 +847,7 @@ extern "C" int c6_engine_swap_tuple_buffer(c6_engine *e, void *dev_buf, size_t c
     e->d.tuple_buf = reinterpret_cast<uint8_t *>(dev_buf);      // C6Dev travels by value with every launch: no drain needed
     e->d.tuple_cap = capacity_records;
     e->d.tuple_count = count_dev;
+    e->tuple_head = 0;
     return C6_OK;
 }
 
@@ -879,7 +882,7 @@ static int evaluate_callback(c6_engine *e) {
     if (!e->cb) return fail(C6_ERR_BAD_ARG, "evaluator is C6_EVAL_CALLBACK but no callback is set");
     c6_launch_augment(d, e->img_boards, e->stream);
     e->h_kind.resize(G); e->h_turn.resize(G);
-    if (!e->h_img.resize((size_t)G * 8 * cells) || !e->h_pol.resize((size_t)G * 8 * cells) || !e->h_val.resize((size_t)G * 8)) return fail(C6_ERR_HIP, "callback staging: out of host memory");
+    if (!e->h_img.resize((size_t)G * 8 * cells) || !e->h_val.resize((size_t)G * 8)) return fail(C6_ERR_HIP, "callback staging: out of host memory");
     e->h_hdr.resize(G);
     HIPCHK(hipMemcpyAsync(e->h_hdr.data(), d.hdr, (size_t)G * sizeof(C6GameHdr), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(e->h_img.data(), e->img_boards, e->h_img.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -897,6 +900,9 @@ static int evaluate_callback(c6_engine *e) {
         c6_launch_recover(d, e->stream);
         return C6_OK;
     }
+    // mixed sides (or games without a leaf to evaluate): gather per side, scatter into a second staging buffer -- page-locked only now (the
+    // common path above never touches it; 47 MB at 4096 games of 19x19)
+    if (!e->h_pol.resize((size_t)G * 8 * cells)) return fail(C6_ERR_HIP, "callback staging: out of host memory");
     for (int player = -1; player <= 1; player += 2) {
         std::vector<int> idx;
         for (int g = 0; g < G; g++)
@@ -1389,30 +1395,44 @@ extern "C" int c6_engine_fetch_games(c6_engine *e, int cap, int *count, int *win
     return C6_OK;
 }
 
+// Records [0, tuple_head) of the buffer have been handed out already.  Moves the rest to the front (the ranges may overlap: through a
+// temporary) and rewrites the device counter.  Stream drained by the caller.
+static int compact_tuples(c6_engine *e, size_t have) {
+    C6Dev &d = e->d;
+    const size_t head = std::min(e->tuple_head, have), left = have - head;
+    if (head && left) {
+        TmpDev t;
+        uint8_t *tmp = t.get<uint8_t>(left * d.tuple_stride);
+        if (!tmp) return fail(C6_ERR_HIP, "hipMalloc failed");
+        HIPCHK(hipMemcpyAsync(tmp, d.tuple_buf + head * d.tuple_stride, left * d.tuple_stride, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(d.tuple_buf, tmp, left * d.tuple_stride, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    const uint32_t l32 = (uint32_t)left;
+    HIPCHK(hipMemcpy(d.tuple_count, &l32, sizeof l32, hipMemcpyHostToDevice));
+    e->tuple_head = 0;
+    return C6_OK;
+}
+
 extern "C" int c6_engine_fetch_tuples(c6_engine *e, size_t cap, size_t *count, void *host_buf) {
     if (!e || !count) return fail(C6_ERR_BAD_ARG, "null argument");
     C6Dev &d = e->d;
+    HIPCHK(hipSetDevice(e->cfg.device));
     HIPCHK(hipStreamSynchronize(e->stream));
     { int rc_ = range_status(e->net); if (rc_ != C6_OK) return rc_; }
     if (!d.tuple_buf) { *count = 0; return C6_OK; }
     uint32_t n = 0;
     HIPCHK(hipMemcpy(&n, d.tuple_count, sizeof n, hipMemcpyDeviceToHost));
     const size_t have = std::min<size_t>(n, d.tuple_cap);      // (the engine stops writing at tuple_cap: records beyond it were never stored)
-    size_t m = std::min<size_t>(have, cap);
-    if (m && host_buf) HIPCHK(hipMemcpy(host_buf, d.tuple_buf, m * d.tuple_stride, hipMemcpyDeviceToHost));
-    // r5: a caller with room for fewer records than the buffer holds keeps the rest for its next call (they were dropped with the reset):
-    // the remainder moves to the front through a temporary (the ranges overlap)
-    uint32_t left = host_buf ? (uint32_t)(have - m) : 0u;
-    if (left > 0) {
-        TmpDev t;
-        uint8_t *tmp = t.get<uint8_t>((size_t)left * d.tuple_stride);
-        if (!tmp) return fail(C6_ERR_HIP, "hipMalloc failed");
-        HIPCHK(hipMemcpy(tmp, d.tuple_buf + m * d.tuple_stride, (size_t)left * d.tuple_stride, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy(d.tuple_buf, tmp, (size_t)left * d.tuple_stride, hipMemcpyDeviceToDevice));
-        HIPCHK(hipDeviceSynchronize());
-    }
-    HIPCHK(hipMemcpy(d.tuple_count, &left, sizeof left, hipMemcpyHostToDevice));
+    const size_t head = std::min(e->tuple_head, have);
+    const size_t m = host_buf ? std::min<size_t>(have - head, cap) : have - head;      // host_buf NULL: discards all
+    if (m && host_buf) HIPCHK(hipMemcpy(host_buf, d.tuple_buf + head * d.tuple_stride, m * d.tuple_stride, hipMemcpyDeviceToHost));
+    // A caller with room for fewer records than the buffer holds keeps the rest for its next call.  ADVICE r5: the remainder is no longer moved to the
+    // front at every partial fetch (an allocation + two copies per call: O(n^2 / cap) for a caller draining in small pieces) -- a read offset advances
+    // instead; the buffer is compacted only once the handed-out prefix passes half of it, and reset when it is drained.
+    e->tuple_head = head + m;
     *count = m;
+    if (e->tuple_head >= have || 2 * e->tuple_head > d.tuple_cap) return compact_tuples(e, have);
     return C6_OK;
 }
 
@@ -1422,6 +1442,12 @@ extern "C" int c6_engine_push_tuples(c6_engine *e, c6_replay *r) {
     C6Dev &d = e->d;
     if (!d.tuple_buf) return fail(C6_ERR_BAD_ARG, "no tuple buffer: call c6_engine_enable_tuples / c6_engine_set_tuple_buffer first");
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->tuple_head) {      // records a partial c6_engine_fetch_tuples has handed out already are not pushed again
+        uint32_t n = 0;
+        HIPCHK(hipMemcpy(&n, d.tuple_count, sizeof n, hipMemcpyDeviceToHost));
+        int rc_ = compact_tuples(e, std::min<size_t>(n, d.tuple_cap));
+        if (rc_ != C6_OK) return rc_;
+    }
     int rc = c6_replay_push_dev(r, d.tuple_buf, d.tuple_count, (size_t)d.tuple_cap);
     if (rc != C6_OK) return fail(rc, "c6_replay_push_dev failed");
     HIPCHK(hipDeviceSynchronize());

@@ -66,9 +66,15 @@ class TuplePool:
 
     QUANTUM = 64
 
-    def __init__(self, eng, cap, world, backend="nccl", group=None, consumer=None, keep=True):
+    def __init__(self, eng, cap, world, backend="nccl", group=None, consumer=None, keep=True, collective=None):
         from . import lib
         self.eng, self.cap, self.world, self.backend, self.group, self.consumer = eng, int(cap), world, backend, group, consumer
+        # collective: issue the all-gathers.  Default: whenever there is more than one rank.  True with world == 1 (and an initialised
+        # one-rank nccl group) sends a single GPU through the very same RCCL calls, streams and events as a rank of eight -- what a
+        # one-GPU box can execute of the N > 1 branch (tests/test_gpu_configs.py::test_config4_per_gpu_workload)
+        self.collective = (world > 1) if collective is None else bool(collective)
+        if self.collective and not dist.is_initialized():
+            raise RuntimeError("TuplePool(collective=True) needs an initialised torch.distributed process group")
         self.stride = int(lib().c6_tuple_stride(eng.n))
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.bufs = [torch.zeros((self.cap, self.stride), dtype=torch.uint8, device=self.dev) for _ in range(2)]
@@ -93,7 +99,7 @@ class TuplePool:
         belongs into somebody's timed region."""
         with torch.cuda.stream(self.side):
             cnt = torch.zeros(1, dtype=torch.int32, device=self.dev)
-            if self.world > 1 and self.backend == "nccl":
+            if self.collective and self.backend == "nccl":
                 d = torch.empty(self.world, dtype=torch.int32, device=self.dev)
                 dist.all_gather_into_tensor(d, cnt, group=self.group)
                 p = torch.empty((self.world, self.QUANTUM, self.stride), dtype=torch.uint8, device=self.dev)
@@ -111,7 +117,7 @@ class TuplePool:
             ev2 = torch.cuda.Event()
             ev2.record(self.eng_stream)
             self.side.wait_event(ev2)
-        if self.world > 1 and self.backend != "nccl":
+        if self.collective and self.backend != "nccl":
             c = torch.empty(self.world, dtype=torch.int32)
             dist.all_gather_into_tensor(c, torch.zeros(1, dtype=torch.int32), group=self.group)
         torch.cuda.synchronize()
@@ -140,7 +146,7 @@ class TuplePool:
         if self.backend != "nccl":
             ev.synchronize()
             n_raw = int(cnt.item())
-            if self.world > 1:
+            if self.collective:
                 counts = torch.empty(self.world, dtype=torch.int32)
                 dist.all_gather_into_tensor(counts, torch.tensor([n_raw], dtype=torch.int32), group=self.group)
                 counts = counts.tolist()
@@ -151,7 +157,7 @@ class TuplePool:
             m = self._padded(max(counts))
             if m:
                 mine = buf[:m].cpu()
-                if self.world > 1:
+                if self.collective:
                     pooled = torch.empty((self.world, m, self.stride), dtype=torch.uint8)
                     dist.all_gather_into_tensor(pooled.view(-1), mine.view(-1), group=self.group)
                 else:
@@ -163,7 +169,7 @@ class TuplePool:
             return
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            if self.world > 1:
+            if self.collective:
                 dcounts = torch.empty(self.world, dtype=torch.int32, device=self.dev)
                 dist.all_gather_into_tensor(dcounts, cnt, group=self.group)
             else:
@@ -174,7 +180,7 @@ class TuplePool:
             counts = [min(c, self.cap) for c in raw]
             m = self._padded(max(counts))
             if m:                                                    # every rank takes the same branch: counts are pooled
-                if self.world > 1:
+                if self.collective:
                     pooled = torch.empty((self.world, m, self.stride), dtype=torch.uint8, device=self.dev)
                     dist.all_gather_into_tensor(pooled.view(-1), buf[:m].reshape(-1), group=self.group)
                 else:

@@ -266,6 +266,26 @@ def cpu_baseline(wl, stones, seconds_budget=20.0):
                       + (f"games/s = searches/s / ({wl['sims']} * {stones:.1f} measured stones/game)" if stones else "no game length measured at this budget: searches/s only")}
 
 
+def rank_topology(torch, dist, world, local_rank, backend):
+    """{ranks, backend, distinct_devices, rccl_ranks, devices}: every rank's (host, device identity) all-gathered; distinct_devices is what
+    `n_gpus` reports.  rccl_ranks = the size of the RCCL communicator the tuple exchange runs on (0: no RCCL collective in this run)."""
+    import socket
+    p = torch.cuda.get_device_properties(local_rank)
+    ident = (socket.gethostname(), str(getattr(p, "uuid", "")), int(getattr(p, "pci_domain_id", -1)), int(getattr(p, "pci_bus_id", -1)),
+             int(getattr(p, "pci_device_id", -1)), local_rank if not hasattr(p, "pci_bus_id") and not hasattr(p, "uuid") else -1)
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    else:
+        idents = [ident]
+    distinct = len({tuple(i) for i in idents})
+    is_rccl = world > 1 and backend == "nccl"
+    return {"ranks": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank, no collective)",
+            "distinct_devices": distinct, "rccl_ranks": dist.get_world_size() if is_rccl else 0,
+            "rehearsal": bool(world > 1 and (distinct < world or not is_rccl)),
+            "devices": sorted({f"{i[0]}:{i[2]:04x}:{i[3]:02x}:{i[4]:02x}" if i[3] >= 0 else f"{i[0]}:{i[1] or i[5]}" for i in idents})}
+
+
 def under_profiler():
     """rocprofv3 preloads its tool library into the process it runs"""
     return "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ)
@@ -323,6 +343,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    # what the ranks really run on: the line says it, so that a rehearsal (several ranks sharing a GPU, or gloo carrying the all-gathers)
+    # can never be read as a multi-GPU RCCL measurement
+    topo = rank_topology(torch, dist, world, local_rank, args.backend)
 
     n, G, S = wl["n"], wl["games"], wl["sims"]
     is_net = wl["evaluator"] == "net"
@@ -398,7 +422,8 @@ def main():
         pool.exchange()
         pool.exchange()
         pooled = pool.pooled_total()
-        r = dict(dt=dt, prof=prof, st=s1, pooled=pooled, exchanges=pool.exchanges, payload_gathers=pool.payload_gathers,
+        free_b, total_b = torch.cuda.mem_get_info()
+        r = dict(dt=dt, prof=prof, st=s1, pooled=pooled, hbm_used_bytes=total_b - free_b, hbm_total_bytes=total_b, exchanges=pool.exchanges, payload_gathers=pool.payload_gathers,
                  games_in_window=s1["games_finished"] - s0["games_finished"], stones_in_window=s1["stones"] - s0["stones"],
                  sims_in_window=s1["simulations"] - s0["simulations"])
         eng.close()
@@ -502,6 +527,20 @@ def main():
         except Exception as ex:
             small_side["error"] = repr(ex)
 
+    # ---- north_star's target in the driver's own line: >= 10 k concurrent 19x19 games at 400 simulations per move on ONE MI355X ----------------
+    many_side = None
+    if world == 1 and is_net and not args.no_probe and not args.games and args.workload == "config2":
+        many_side = {"what": "this workload's net and budget with 16 384 concurrent games on the one GPU (4 net passes of 32 768 dihedral images per round): "
+                             "north_star's target is >= 10 000 concurrent 19x19 games at 400 simulations per move", "games": 16384}
+        try:      # (a side report: its failure must not cost the line)
+            mg = measure(prec, 5, 2, geom=(n, 16384, S))
+            sims_mg = mg["sims_in_window"] / mg["dt"]
+            many_side.update(ms_per_round=1000.0 * mg["dt"] / 5, sims_per_s=sims_mg, rounds_timed=5,
+                             pool_bytes=mg["st"]["pool_bytes"], hbm_used_bytes=mg["hbm_used_bytes"], hbm_total_bytes=mg["hbm_total_bytes"],
+                             live_games=mg["st"]["live_games"], overflow_games=mg["st"]["overflow_games"], abandoned_games=mg["st"]["abandoned_games"])
+        except Exception as ex:
+            many_side["error"] = repr(ex)
+
     if rank == 0:
         def line(m):
             sims = m["sims_in_window"] * world / m["dt"] if world == 1 else args.steps * G * world / m["dt"]
@@ -577,7 +616,7 @@ def main():
         out = {
             "metric": "self-play games/sec at 400 sims/move, 19x19, 1/2/4/8 MI355X" if args.workload in ("config2", "config4")
                       else f"self-play games/sec ({args.workload})",
-            "value": games_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": games_s, "unit": "games/s", "n_gpus": topo["distinct_devices"], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * head["dt"] / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPES[args.precision] if is_net else "f32/f64 (tree arithmetic), int8 boards",
             "data": "synthetic (random-init weights, self-generated positions)",
@@ -587,8 +626,15 @@ def main():
                        "stones_per_game": stones, "stones_per_game_source": stones_src,
                        "step": ("one simulation round over all games (8 dihedral net evaluations per game), staggered move phases" if is_net else
                                 "one simulation round over all games, staggered move phases, measured in the steady state (after one game length of rounds)"),
-                       "parallelism": (f"games sharded over {world} GPU(s); training tuples pooled by an RCCL all-gather on a side stream every "
-                                       f"{gather_every} round(s) (shard.TuplePool)") if world > 1 else "1 GPU"},
+                       "parallelism": "1 GPU" if world == 1 else
+                                      (f"games sharded over {world} ranks on {topo['distinct_devices']} distinct GPU(s); training tuples pooled every {gather_every} round(s) by "
+                                       + ("an RCCL all-gather on a side stream" if topo["rccl_ranks"] else f"a {args.backend} all-gather through host copies")
+                                       + " (shard.TuplePool)"
+                                       + (" -- a REHEARSAL of the N > 1 path, not a multi-GPU measurement: " + ("the ranks share a GPU" if topo["distinct_devices"] < world else "")
+                                          + ("; " if topo["distinct_devices"] < world and not topo["rccl_ranks"] else "") + ("no RCCL" if not topo["rccl_ranks"] else "")
+                                          if topo["rehearsal"] else ""))},
+            "ranks": topo["ranks"], "backend": topo["backend"], "distinct_devices": topo["distinct_devices"], "rccl_ranks": topo["rccl_ranks"],
+            "rehearsal": topo["rehearsal"], "devices": topo["devices"],
             "sims_per_s": sims_s, "boards_per_s": sims_s * 8,
             "measured_in_window": {"games_finished": head["games_in_window"], "stones": head["stones_in_window"], "simulations": head["sims_in_window"],
                                    "seconds": head["dt"]},
@@ -658,6 +704,11 @@ def main():
             out["tree_kernel"] = tree_side
         if small_side:
             out["small_batches"] = small_side
+        if many_side:
+            if "sims_per_s" in many_side:
+                many_side["value"] = many_side["sims_per_s"] / (S * stones) if stones else None
+                many_side["per_game_rate_vs_headline"] = many_side["sims_per_s"] / sims_s
+            out["many_games"] = many_side
         out["phase_ms"] = {k: head["prof"][k] for k in ("conv_ms", "conv_pre_ms", "conv_post_ms", "select_ms", "expand_ms", "eval_other_ms", "move_ms")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, stones, args.cpu_seconds)      # (stones None: its value is null too, sims_per_s stays)

@@ -494,6 +494,62 @@ int c6_rollout_node(c6_rollout *r, int g, const int8_t *board, int *found, int *
  * *steps = stones placed per launch, winners int8 [num_games] of the last launch (may be NULL) */
 int c6_rollout_bench_playouts(c6_rollout *r, const int8_t *boards, int iters, double *avg_ms, double *steps, int8_t *winners);
 
+/* =====================================================================================================================
+ * Part 6 -- several GPUs behind the boundary.  The reference fans its games out over every core INSIDE the
+ * library (AsyncAgent::run, agent/async_agent/mod.rs:100-137, entered from cppbind/libcppconnect6/src/lib.rs:110-122) and gathers the
+ * results over an mpsc channel (:129-134).  A c6_group is that for GPUs: one engine and one host thread per device, games sharded by uid
+ * (member r of n plays uids [first_r, first_r + games_r) of the SAME seeded game set a single engine would play -- a recycled slot advances
+ * by the total -- so the union over the members does not depend on how many devices there are), no exchange while playing, and the
+ * training tuples pooled over the members by an RCCL all-gather (ncclAllGather over xGMI, one communicator per member from
+ * ncclCommInitAll; librccl is opened when the first group with more than zero distinct devices is created).  Members that share a
+ * device (devices = {0, 0}: a one-GPU rehearsal) pool through host memory instead -- RCCL admits one rank per device.
+ * cpp_self_play itself uses a group when more than one device is visible and the call brings enough games (environment: C6_DEVICES =
+ * "all" | "0,1,.." | unset; C6_GROUP_MIN_GAMES = games per device below which fewer devices are used, default 64).
+ * ===================================================================================================================== */
+typedef struct c6_group c6_group;
+
+/* cfg->num_games = games over ALL members; cfg->device / game_uid_base / game_uid_stride are ignored (the group sets them per member).
+ * devices[ndev]: HIP ordinals, repeats allowed (rehearsal).  ndev <= 0 or devices NULL: every visible device. */
+int c6_group_create(const c6_config *cfg, const int *devices, int ndev, c6_group **out);
+void c6_group_destroy(c6_group *g);
+int c6_group_size(const c6_group *g);
+/* member r's engine / device / shard (first uid, games): the engine is a full c6_engine (c6_engine_root, _stats, ... work on it) */
+c6_engine *c6_group_engine(c6_group *g, int member);
+int c6_group_member_info(const c6_group *g, int member, int *device, uint32_t *first_uid, int *games);
+/* 1: the members' tuple pooling runs on RCCL (all devices distinct and librccl loaded); 0: through host memory */
+int c6_group_uses_rccl(const c6_group *g);
+
+int c6_group_load_weights(c6_group *g, const float *blob, size_t nfloats);   /* every member (weights are replicated: 14-34 MB) */
+/* C6_EVAL_CALLBACK: the members' host threads call `cb` -- one at a time unless concurrent != 0 (the reference calls it from all
+ * pool threads with no lock, lib.rs:110-122; serialised is the stricter, always-compatible default) */
+int c6_group_set_callback(c6_group *g, c6_callback cb, int concurrent);
+
+/* c6_engine_step / c6_engine_run on every member at once, one host thread per member; returns the first non-OK status (message:
+ * c6_last_error() of the calling thread) after ALL members have returned */
+int c6_group_step(c6_group *g, int rounds);
+int c6_group_run(c6_group *g, long max_rounds);
+int c6_group_sync(c6_group *g);
+/* sums over the members (max_* fields: maxima) */
+int c6_group_stats(c6_group *g, c6_stats *out);
+/* finished games of all members, member by member (AsyncAgent::run hands results back in completion order, i.e. any order) */
+int c6_group_fetch_games(c6_group *g, int cap, int *count, int *winners, int *lens, uint32_t *uids, int16_t *moves);
+
+/* training tuples: every member records into group-owned double buffers of `capacity_records` each */
+int c6_group_enable_tuples(c6_group *g, size_t capacity_records);
+/* Pools what the members recorded since the last pool: afterwards EVERY member's device holds the same [ndev][padded][stride] array
+ * (c6_group_pooled), counts[r] of member r's segment valid.  _begin retires the buffers (the engines continue into the other set at
+ * once: rounds enqueued after it overlap the exchange), _end waits for the retired rounds, reads the counts and runs the all-gather on
+ * the members' side streams.  c6_group_pool_tuples = _begin + _end.  dropped: records beyond capacity_records since the last pool. */
+int c6_group_pool_begin(c6_group *g);
+int c6_group_pool_end(c6_group *g, uint32_t *counts, size_t *padded, uint64_t *dropped);
+int c6_group_pool_tuples(c6_group *g, uint32_t *counts, size_t *padded, uint64_t *dropped);
+/* member r's copy of the last pool (device memory on its device; valid until the next pool) */
+const void *c6_group_pooled(const c6_group *g, int member);
+/* the valid records of member r's copy, compacted, to the host; *count = records copied (all members' segments, in member order) */
+int c6_group_fetch_pooled(c6_group *g, int member, size_t cap, size_t *count, void *host_buf);
+/* ... and device to device into a replay buffer living on member r's device (ReplayBuffer::push_game for every record) */
+int c6_group_push_pooled(c6_group *g, int member, c6_replay *r);
+
 #ifdef __cplusplus
 }
 #endif

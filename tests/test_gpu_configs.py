@@ -248,16 +248,39 @@ def test_multi_process_engine_shard_on_one_gpu(tmp_path, world, per_rank):
     assert sorted(len(g_["path"]) for g_ in ref) == sorted(len(g["moves"]) for g in games)
 
 
-def _spawn_ranks(tmp_path, world, n, per_rank, S, seed, backend, mode, devices):
+def _spawn_ranks(tmp_path, world, n, per_rank, S, seed, backend, mode, devices, evaluator="random"):
     port = _free_port()
-    outs = [str(tmp_path / f"{mode}_rank{r}.npz") for r in range(world)]
+    outs = [str(tmp_path / f"{mode}_{evaluator}_rank{r}.npz") for r in range(world)]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), str(r), str(world), str(port), str(n),
-                               str(per_rank), str(S), str(seed), outs[r], str(devices[r]), backend, mode], env=env) for r in range(world)]
+                               str(per_rank), str(S), str(seed), outs[r], str(devices[r]), backend, mode, evaluator], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=900) == 0
     return [np.load(f) for f in outs]
+
+
+def _check_net_samples(got, n, S, seed):
+    """the roots a net-driven rank stored (shard_worker.props) against the oracle driven by its own FP32 net: visits exactly,
+    priors / q / value to 1e-5 (north_star's tolerance for the net)"""
+    import __graft_entry__ as ge
+    import shard_worker as sw
+    blob = ge.make_random_blob(n, sw.NET_C, sw.NET_BLOCKS, np.random.default_rng(sw.NET_BLOB_SEED))
+    net = o.Net(n, sw.NET_C, sw.NET_BLOCKS, blob)
+    fn, ctx = net.eval_fn()
+    empty = np.zeros((n, n), np.int8)
+    for i, uid in enumerate(got["sample_uids"]):
+        az = o.AlphaZero(n, num_simulation=S, eval_kind=o.EVAL_CUSTOM, eval_fn=fn, ctx=ctx, seed=seed, game_uid=int(uid))
+        s = o.sim_from_game(o.new_game(n))
+        az.init(s)
+        for _ in range(sw.PROPS_ROUNDS):
+            az.search(s)
+        vis, q, p = az.children(empty)
+        assert (got["sample_visits"][i] == vis).all(), (int(uid), np.flatnonzero(got["sample_visits"][i]), np.flatnonzero(vis))
+        assert np.abs(got["sample_q"][i] - q).max() <= 1e-5 and np.abs(got["sample_prior"][i] - p).max() <= 1e-5, int(uid)
+        assert abs(float(got["sample_value"][i]) - az.node_info(empty).value) <= 1e-5, int(uid)
+        az.close()
+    net.close()
 
 
 def _config4_checks(tmp_path, backend, devices, per_rank_props):
@@ -300,6 +323,48 @@ def test_config4_two_gpu_rccl(tmp_path):
     if pkg.device_count() < 2:
         pytest.skip("needs 2 GPUs: RCCL wants one device per rank")
     _config4_checks(tmp_path, "nccl", (0, 1), 8192)
+
+
+def test_config4_per_gpu_workload(tmp_path):
+    """BASELINE config 4's PER-GPU workload assembled in one process (missing 4): Engine(n = 19, G = 8192, S = 400,
+    EVAL_NET, C = 256, stem + 3 residual blocks) + shard.TuplePool on the nccl backend.  The rank builds a ONE-rank RCCL group and the pool
+    issues its all-gathers through it (collective=True), so the device-tensor branch -- counts, then max(count) records, on the side stream,
+    ordered against the engine's stream by events -- executes exactly as a rank of eight would execute it, as far as one GPU can.
+    6 rounds of 65 536 dihedral images; root invariants on samples; the scripted 11-stone game finished from outside so that the side
+    stream carries a payload; four sampled games (first / last leaves of the two net passes) against the oracle and its own FP32 net."""
+    need_gpu()
+    n, G, S, seed = 19, 8192, 400, 79
+    got = _spawn_ranks(tmp_path, 1, n, G, S, seed, "nccl", "props", (0,), evaluator="net")[0]
+    assert int(got["ok"]) == 1 and int(got["collective"]) == 1
+    assert int(got["gathers"]) >= 1 and int(got["dropped"]) == 0 and int(got["exchanges"]) >= 3
+    assert int(got["finished"]) == 1 and int(got["winner"]) == 1
+    assert int(got["pooled"]) == 11 and int(got["total"]) == 11
+    # the pooled records ARE the scripted game: 11 states, each the replay of the script's prefix
+    tup = pkg.decode_tuples(got["records"], n)
+    script = [(0, 0), (5, 0), (5, 1), (0, 1), (0, 2), (5, 2), (5, 3), (0, 3), (0, 4), (5, 4), (5, 5)]
+    want = list(pkg.replay_moves(n, [r * n + c for r, c in script]))
+    order = np.argsort((tup["state"].reshape(len(want), -1) != 0).sum(axis=1), kind="stable")
+    for k, i in enumerate(order):
+        turn, board, cell = want[k]
+        assert (tup["state"][i] == board).all() and int(tup["turn"][i]) == turn and int(tup["pos"][i]) == cell and int(tup["z"][i]) == 1
+    assert list(got["sample_slots"]) == [0, G // 2 - 1, G // 2, G - 1]
+    _check_net_samples(got, n, S, seed)
+
+
+def test_config4_two_ranks_one_gpu_gloo_with_the_net(tmp_path):
+    """the two-rank stand-in with the RESIDENT NET on both ranks (round 5's stand-in ran the random evaluator only): 2 x 2048 games of
+    config 4's shape on GPU 0, tuples pooled over gloo, both ranks' sampled roots against the oracle -- rank 1's uids start at 2048
+    (shard.uid_plan), so its games are not rank 0's"""
+    need_gpu()
+    n, per_rank, S, seed = 19, 2048, 400, 80
+    got = _spawn_ranks(tmp_path, 2, n, per_rank, S, seed, "gloo", "props", (0, 0), evaluator="net")
+    for r in range(2):
+        assert int(got[r]["ok"]) == 1 and int(got[r]["dropped"]) == 0 and int(got[r]["gathers"]) >= 1
+        assert int(got[r]["finished"]) == 1 and int(got[r]["winner"]) == 1 and int(got[r]["pooled"]) == 22 and int(got[r]["total"]) == 22
+        assert list(got[r]["sample_uids"]) == [r * per_rank + g for g in (0, per_rank // 2 - 1, per_rank // 2, per_rank - 1)]
+    assert sorted(bytes(x) for x in got[0]["records"]) == sorted(bytes(x) for x in got[1]["records"])
+    _check_net_samples(got[0], n, S, seed)
+    _check_net_samples({k: got[1][k][-1:] for k in ("sample_uids", "sample_visits", "sample_q", "sample_prior", "sample_value")}, n, S, seed)
 
 
 def test_config4_two_ranks_one_gpu_gloo(tmp_path):

@@ -171,3 +171,62 @@ def test_config2_exact():
         az.close()
     net.close()
     eng.close()
+
+
+def test_config2_engine_on_distinct_midgame_boards():
+    """test_config2_exact's leaves are the empty board and one-stone boards, whose eight dihedral images nearly
+    coincide.  Here the SAME engine (n = 19, G = 4096, S = 400, EVAL_NET, C = 256, stem + 3 residual blocks, FP32 Winograd F(6,3)) first
+    receives a different random position in every game -- 1 to 40 stones per game through c6_engine_apply_moves (Game::set's 1-2-2 turn
+    order, so the side to move differs from game to game and both colours sit in one net pass) -- and then searches 3 rounds: every leaf of
+    all 3 x 32 768-image passes is a distinct mid-game board.  Invariants on every 511th game; eight sampled games (first / last leaves,
+    the 64-tile block seams, few and many stones) against the seeded oracle and its own FP32 net: visits exactly, priors / q / value to 1e-5."""
+    need_gpu()
+    import __graft_entry__ as ge
+    n, G, S, C, blocks, R, seed, kmax = 19, 4096, 400, 256, 4, 3, 2025, 40
+    cells = n * n
+    rng = np.random.default_rng(77)
+    nst = rng.integers(1, kmax + 1, G)
+    nst[:4] = (1, 2, 39, 40)
+    seq = np.stack([rng.permutation(cells)[:kmax] for _ in range(G)]).astype(np.int32)
+    # no position may already hold a six (the game would be over): replay on the host and cut a game short of its winning stone
+    for g in range(G):
+        for k, (turn, board, cell) in enumerate(pkg.replay_moves(n, seq[g, :nst[g]])):
+            b = board.copy().reshape(-1)
+            b[cell] = turn
+            if o.search(b.reshape(n, n)) != 0:
+                nst[g] = k
+                break
+    assert nst.min() >= 1
+    blob = ge.make_random_blob(n, C, blocks, np.random.default_rng(12))
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks)
+    eng.load_weights(blob)
+    for k in range(kmax):
+        eng.apply_moves(np.where(k < nst, seq[:, k], -2).astype(np.int32))
+    eng.step(R)
+    st = eng.stats()
+    assert st["simulations"] == G * R and st["overflow_games"] == 0 and st["live_games"] == G
+    for g in list(range(0, G, 511)) + [G - 1]:
+        r = eng.root(g)
+        assert r["root_visit"] == R and r["visits"][r["visits"] >= 0].sum() == R - 1 and r["stones"] == nst[g] and r["nsearch"] == R
+    net = o.Net(n, C, blocks, blob)
+    fn, ctx = net.eval_fn()
+    for g in (0, 1, 2, 3, 799, 2048, 3333, G - 1):
+        az = o.AlphaZero(n, num_simulation=S, eval_kind=o.EVAL_CUSTOM, eval_fn=fn, ctx=ctx, seed=seed, game_uid=g)
+        game = o.new_game(n)
+        for cell in seq[g, :nst[g]]:
+            o.game_set(game, int(cell) // n, int(cell) % n)
+        s = o.sim_from_game(game)
+        az.init(s)
+        for _ in range(R):
+            az.search(s)
+        board = game.np_board()
+        r = eng.root(g)
+        assert (r["board"] == board).all() and r["turn"] == game.turn, g
+        vis, q, p = az.children(board)
+        empty = board.reshape(-1) == 0
+        assert (r["visits"][empty] == vis[empty]).all(), (g, np.flatnonzero(r["visits"] > 0), np.flatnonzero(vis > 0))
+        assert np.abs(r["q"][empty] - q[empty]).max() <= 1e-5 and np.abs(r["prior"][empty] - p[empty]).max() <= 1e-5, g
+        assert abs(r["root_value"] - az.node_info(board).value) <= 1e-5, g
+        az.close()
+    net.close()
+    eng.close()

@@ -214,7 +214,9 @@ pkg = load_package()
 out = {}
 for blocks in (4, 8):
     blob = ge.make_random_blob(19, 256, blocks, np.random.default_rng(5))
-    for num in (1, 13, 40, 333, 1100):
+    # (10 000 boards, stem + 3 blocks only: 313 blocks of class D' > the 256 workgroups of a grid row -- the forced split form's block loop makes a SECOND
+    #  trip in the five-position row form too, ADVICE r5)
+    for num in (1, 13, 40, 333, 1100) + ((10000,) if blocks == 4 else ()):
         boards = np.random.default_rng(num).integers(-1, 2, size=(num, 361)).astype(np.int8)
         pol, val = pkg.net_forward(19, 256, blocks, blob, boards, 1 if num %% 2 else -1, precision=pkg.PREC_FP32)
         out["p%%d_%%d" %% (blocks, num)] = pol
@@ -227,7 +229,8 @@ def test_w6_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
     """conv_wino6.hip: c6_w6_gemm_kernel<., true> (r5: a row of positions per workgroup -- one game's boards on 28 CUs instead of 4; and <., true, true>, the
     four-wave half-width jobs of the tiniest batches, forced at every size) against
     <., false> (a block per workgroup) through c6_net_forward at 1 .. 1100 boards (1 board: every region's block nearly empty; 333: full and
-    partial blocks; 1100 boards: 344 + 35 blocks -- the block loop of both forms runs more than once), stem + 3 and stem + 7 blocks."""
+    partial blocks; 1100 boards: 344 + 35 blocks -- the block loop of both forms runs more than once; 10 000 boards: 313 blocks of class D', more than a
+    grid row of workgroups, so the five-position split jobs make a second trip too), stem + 3 and stem + 7 blocks."""
     need_gpu()
     res = {}
     with tempfile.TemporaryDirectory() as td:
@@ -238,7 +241,7 @@ def test_w6_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
             out = os.path.join(td, f"w6_{form}.npz")
             subprocess.run([sys.executable, "-c", W6_CHILD, out], check=True, env=dict(os.environ, **env), timeout=600)
             res[form] = dict(np.load(out))
-    assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) == sorted(res["split2"]) and len(res["block"]) == 20
+    assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) == sorted(res["split2"]) and len(res["block"]) == 22
     for k in res["block"]:
         assert np.isfinite(res["block"][k]).all()
         assert np.array_equal(res["block"][k], res["split"][k]), k

@@ -20,8 +20,12 @@ import c6oracle as o
 name = sys.argv[1] if len(sys.argv) > 1 else "config2"
 moves = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 wl = bench.WORKLOADS[name]
-from c6amd_loader import load_package      # (only for the library's random-stream specification: which probe record counts)
-probe = bench.committed_stones_probe(name if name != "config4" else "config2", bench.WORKLOADS[name]['sims'], load_package().rng_spec())
+try:      # (only for the library's random-stream specification: which probe record counts)
+    from c6amd_loader import load_package
+    rng_spec = load_package().rng_spec()
+except Exception:      # a CPU-only box without the GPU library: the oracle's own statement of the specification it implements
+    rng_spec = o.rng_spec() if hasattr(o, "rng_spec") else "C6RNG v5"
+probe = bench.committed_stones_probe(name if name != "config4" else "config2", bench.WORKLOADS[name]['sims'], rng_spec)
 stones = float(sys.argv[3]) if len(sys.argv) > 3 else (probe["stones_per_game"] if probe else wl["stones_prior"])
 cores = bench.usable_cores()
 n, S = wl["n"], wl["sims"]
