@@ -47,6 +47,9 @@ WORKLOADS = {
     "config3": dict(n=19, games=16384, sims=800, blocks=8, channels=256, evaluator="net", stones_prior=208.0),
     "config4": dict(n=19, games=8192, sims=400, blocks=4, channels=256, evaluator="net", stones_prior=208.0),
     "config5": dict(n=9, games=32768, sims=100, blocks=0, channels=0, evaluator="uniform", stones_prior=68.0),
+    # the REFERENCE's own shape at batch (missing 3): BOARD_SIZE = 15 (Connect6/libconnect6/src/lib.rs:21), model(10) = stem + 9 residual blocks
+    # (AlphaZero/cpp_weighted/main.cpp:12, model.hpp:44-49), HyperParameter::default's 800 simulations per move (alphazero_policy/mod.rs:98-108)
+    "ref15": dict(n=15, games=4096, sims=800, blocks=10, channels=256, evaluator="net", stones_prior=139.0),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, Peak BF16 / FP16 MFMA, dense
@@ -60,6 +63,19 @@ KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, des
     "bf16x3": ("c6_conv3x3_b3s_kernel<256, 19, true, false>", "split-bf16 implicit GEMM, v_mfma_f32_16x16x32_bf16, 3 MFMAs per product"),
     "f16f8": ("c6_conv3x3_m8_kernel<256, 19, false>", "fp16 main term + MX-fp8 cross terms, v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4"),
 }
+
+
+def conv_kernel_of(name, n):
+    """(kernel as rocprofv3 names it, description) of the 3x3 convolution's dominant kernel for a precision and a board size"""
+    if name == "fp32" and n != 19:
+        tw = (n + 3) // 4
+        edge = 2 * tw - 1 if n % 4 == 3 else 0
+        return ("c6_wino4_gemm_kernel<%d, false, false>" % n,
+                f"FP32 Winograd F(4x4,3x3) ({tw} x {tw} tiles per {n}x{n} board, F(3,3) in the last tile row / column: {36 * (tw * tw - edge) + 30 * edge} positions per channel "
+                "pair and board): the 36 / 30 GEMMs of a 64-tile block on v_mfma_f32_32x32x2_f32, the F(4) half of the output transform accumulated in registers "
+                "(conv_wino4.hip); HBM-bound boundary kernels between the layers (c6_wino4_mid_kernel)")
+    k, d = KERNELS[name]
+    return k.replace("256, 19", "256, %d" % n), d
 
 
 def net_flops_per_board(n, C, blocks):
@@ -441,7 +457,7 @@ def main():
     settle = 0 if is_net else int(S * wl["stones_prior"])      # tree-only workload: one game length of rounds, so that mid-game trees are timed
     head = measure(prec, args.steps, args.warmup, settle_rounds=settle)
     others, relaxed = [], None
-    if is_net and world == 1 and not args.single_precision:
+    if is_net and world == 1 and not args.single_precision and n == 19:      # (the other arithmetics' side reports are the 19x19 benchmark's)
         for name, o_prec in PRECS.items():      # measured in the same run, reported beside `value`
             if o_prec != prec:
                 try:
@@ -548,7 +564,7 @@ def main():
 
         def conv_roofline(m, name):
             prof, dt_ = m["prof"], m["dt"]
-            kern, desc = KERNELS[name]
+            kern, desc = conv_kernel_of(name, n)
             gemm_ms = prof["conv_ms"] - prof["conv_pre_ms"] - prof.get("conv_post_ms", 0.0)
             peak = PEAK_FP32_MFMA_TFLOPS if name.startswith("fp32") else PEAK_BF16_MFMA_TFLOPS
             L = max(prof["conv_launches"], 1)
@@ -572,7 +588,10 @@ def main():
             # the layer as a whole: the same executed FLOPs over GEMM + boundary-kernel time (an MFMA-bound phase and an HBM-bound phase that
             # alternate: their times add)
             r["layer_frac"] = prof["conv_exec_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 / peak
-            if name == "fp32":
+            if name == "fp32" and n != 19:
+                r["note"] = ("achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + boundary-kernel "
+                             "time; algorithmic_tflops counts 2*9*C^2*N^2 per board and layer (SURVEY 8d)")
+            if name == "fp32" and n == 19:
                 r["note"] = ("a layer's GEMM is two launches of one kernel template -- c6_w6_gemm_kernel<false, false, false> (the tile classes with rows of six positions: 708 of a board's "
                              "788 products) then <true> (class D', rows of five: 80) -- timed together: avg_launch_ms, achieved and traffic are per layer = the pair; "
                              "achieved / frac = EXECUTED matrix FLOP/s of the GEMM kernel over the dense FP32-MFMA peak; layer_frac = the same FLOPs over GEMM + "
