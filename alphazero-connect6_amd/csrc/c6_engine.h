@@ -302,16 +302,16 @@ double c6_conv_wino4_exec_flops(int C, int N, int nboards);
 size_t c6_conv_wino4_wgrad_partial_floats(int C, int N, int nboards, int num_cus);
 bool c6_conv_wino4_wgrad(int C, int N, int nboards, const float *dy, const float *x, float *vbuf, float *partial, float *dw, int num_cus, hipStream_t s,
                          const float *vkept = nullptr);      // vkept: B^T x B of this layer as the forward pass left it (then x is not transformed again)
-// the evaluator's tower at 19x19, C = 256, >= 2 residual blocks (conv_wino6.hip): the same F(4x4) Winograd pipeline on tiles six pixels wide
+// the evaluator's tower at 19x19 and (r6) 15x15, C = 256, >= 2 residual blocks (conv_wino6.hip): the same F(4x4) Winograd pipeline on tiles six pixels wide
 bool c6_w6_available(int C, int N, int blocks);
 size_t c6_w6_packed_floats(void);
 void c6_w6_pack_weights(const float *w_oihw_folded, float *packed);
-size_t c6_w6_vbuf_floats(int nboards);
+size_t c6_w6_vbuf_floats(int N, int nboards);
 // steps: 1 the first layer's input transform from the boards (`stem`), 2 the GEMMs, 16 the boundary kernel (bias, residual `res` or the
 // recomputed stem, activations to `act` if given), 4 the last output transform with the heads' filters
-bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float *res, float *act, float *vbuf, int num_cus, hipStream_t s, int steps,
+bool c6_w6_dispatch(int N, int nboards, const float *wp, const float *bias, const float *res, float *act, float *vbuf, int num_cus, hipStream_t s, int steps,
                     const C6HeadFuse *heads = nullptr, const C6StemSrc *stem = nullptr);
-double c6_w6_exec_flops(int nboards);
+double c6_w6_exec_flops(int N, int nboards);
 // FP32 direct (conv_f32n.hip)
 size_t c6_conv_packed_f32n_floats(int C);
 void c6_pack_conv_weights_f32n(int C, const float *w_oihw_folded, float *packed);

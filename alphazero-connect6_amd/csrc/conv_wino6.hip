@@ -29,44 +29,48 @@
 
 #define W6_BT 64          // tiles per block
 #define W6_C 256
-#define W6_N 19
-#define W6_TWX 4
-#define W6_TWY 5
-#define W6_T 20           // tiles per board
 #define W6_NPV 49         // 1-KiB rows of a tile's slot in V: 48 positions (class D uses all of them) + one of padding -- tile rows of a GEMM slab
 #define W6_NZ 33          // and of its slot in Z: 32 row sums + one of padding -- then lie an ODD number of KiB apart (48 / 32 KiB strides
                           // put the 64 rows of a slab on a fraction of the memory channels)
-#define W6_COLS 22        // window columns: board columns -1 .. 20
-#define W6_ROWF (W6_COLS * W6_C)
 #define W6_PF 7
 enum { W6_CLS_A = 0, W6_CLS_B = 1, W6_CLS_BP = 2, W6_CLS_D = 3, W6_CLS_DP = 4 };
-#define W6_NA 4
-#define W6_NB 4
-#define W6_NBP 2
-#define W6_ND 8
-#define W6_NDP 2
 #define W6_SETS_POS (36 + 30 + 30 + 48 + 40)      // position matrices of the five weight sets
 
-__host__ __device__ __forceinline__ int w6_x0(int tx) { return tx == 0 ? 0 : tx == 1 ? 6 : tx == 2 ? 12 : 16; }
-__host__ __device__ __forceinline__ int w6_width(int tx) { return tx < 2 ? 6 : tx == 2 ? 4 : 3; }
-__host__ __device__ __forceinline__ int w6_cls(int ty, int tx) {
-    return tx < 2 ? (ty == W6_TWY - 1 ? W6_CLS_DP : W6_CLS_D) : ty == W6_TWY - 1 ? W6_CLS_BP : tx == 2 ? W6_CLS_A : W6_CLS_B;
-}
-struct W6Map {
+// The board's cut into tiles.  19 = 6 + 6 + 4 + 3 across, 4 + 4 + 4 + 4 + 3 down: 20 tiles, 788 positions (the benchmark's board).
+// r6 -- 15 = 6 + 6 + 3 across, 4 + 4 + 4 + 3 down: 12 tiles, 6 x 48 + 2 x 40 + 3 x 30 + 30 = 488 positions, the REFERENCE's board
+// (Connect6/libconnect6/src/lib.rs:21; conv_wino4.hip's F(4x4) tiling of it has 534): no class-A tile, everything else the same kernels.
+// NA .. NDP: tiles of a class per board; COLS: window columns (board columns -1 .. N + 1).
+template <int N> struct W6G;
+template <> struct W6G<19> {
+    static constexpr int N = 19, TWX = 4, TWY = 5, T = 20, NA = 4, NB = 4, NBP = 2, ND = 8, NDP = 2, COLS = 22, ROWF = COLS * W6_C;
+    __host__ __device__ static constexpr int x0(int tx) { return tx == 0 ? 0 : tx == 1 ? 6 : tx == 2 ? 12 : 16; }
+    __host__ __device__ static constexpr int width(int tx) { return tx < 2 ? 6 : tx == 2 ? 4 : 3; }
+    __host__ __device__ static constexpr int cls(int ty, int tx) {
+        return tx < 2 ? (ty == TWY - 1 ? W6_CLS_DP : W6_CLS_D) : ty == TWY - 1 ? W6_CLS_BP : tx == 2 ? W6_CLS_A : W6_CLS_B;
+    }
+};
+template <> struct W6G<15> {
+    static constexpr int N = 15, TWX = 3, TWY = 4, T = 12, NA = 0, NB = 3, NBP = 1, ND = 6, NDP = 2, COLS = 18, ROWF = COLS * W6_C;
+    __host__ __device__ static constexpr int x0(int tx) { return 6 * tx; }
+    __host__ __device__ static constexpr int width(int tx) { return tx < 2 ? 6 : 3; }
+    __host__ __device__ static constexpr int cls(int ty, int tx) { return tx < 2 ? (ty == TWY - 1 ? W6_CLS_DP : W6_CLS_D) : ty == TWY - 1 ? W6_CLS_BP : W6_CLS_B; }
+};
+template <int N> struct W6Map {
+    using G = W6G<N>;
     long blkB, blkBP, blkD, blkDP, nblocks;
     __host__ __device__ explicit W6Map(long nboards) {
-        blkB = (nboards * W6_NA + W6_BT - 1) / W6_BT;
-        blkBP = blkB + (nboards * W6_NB + W6_BT - 1) / W6_BT;
-        blkD = blkBP + (nboards * W6_NBP + W6_BT - 1) / W6_BT;
-        blkDP = blkD + (nboards * W6_ND + W6_BT - 1) / W6_BT;
-        nblocks = blkDP + (nboards * W6_NDP + W6_BT - 1) / W6_BT;
+        blkB = (nboards * G::NA + W6_BT - 1) / W6_BT;
+        blkBP = blkB + (nboards * G::NB + W6_BT - 1) / W6_BT;
+        blkD = blkBP + (nboards * G::NBP + W6_BT - 1) / W6_BT;
+        blkDP = blkD + (nboards * G::ND + W6_BT - 1) / W6_BT;
+        nblocks = blkDP + (nboards * G::NDP + W6_BT - 1) / W6_BT;
     }
     // the tile's slot: block slot / 64, tile slot % 64 of the block
     __host__ __device__ __forceinline__ long slot(long bd, int ty, int tx) const {
-        if (tx < 2) return ty == W6_TWY - 1 ? blkDP * W6_BT + bd * W6_NDP + tx : blkD * W6_BT + bd * W6_ND + ty * 2 + tx;
-        if (ty == W6_TWY - 1) return blkBP * W6_BT + bd * W6_NBP + (tx - 2);
-        if (tx == 2) return bd * W6_NA + ty;
-        return blkB * W6_BT + bd * W6_NB + ty;
+        if (tx < 2) return ty == G::TWY - 1 ? blkDP * W6_BT + bd * G::NDP + tx : blkD * W6_BT + bd * G::ND + ty * 2 + tx;
+        if (ty == G::TWY - 1) return blkBP * W6_BT + bd * G::NBP + (tx - 2);
+        if (G::NA && tx == 2) return bd * G::NA + ty;
+        return blkB * W6_BT + bd * G::NB + ty;
     }
 };
 #define W6_VTILE ((size_t)W6_NPV * W6_C)
@@ -178,9 +182,10 @@ __device__ __forceinline__ void w6_patch_transform(const float *wc, const int (&
     }
 }
 // window slot offsets of the six patch rows of tile row ty (board rows 4 ty - 1 .. 4 ty + 4; row y lives in slot (y + 1) % 6)
+template <int N>
 __device__ __forceinline__ void w6_slots(int ty, int (&slot)[6]) {
 #pragma unroll
-    for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * W6_ROWF;
+    for (int a = 0; a < 6; a++) slot[a] = ((4 * ty + a) % 6) * W6G<N>::ROWF;
 }
 
 // The boundary kernels' barriers order accesses to the LDS window only: wait for the wave's LDS operations, not for its global loads and
@@ -193,17 +198,19 @@ __device__ __forceinline__ void w6_slots(int ty, int (&slot)[6]) {
     } while (0)
 
 // ---- first layer: the stem computed into the window, input transform -> V -----------------------------------------------------------
-#define W6_THREADS 512      // 8 waves: wave = (tile column, channel half).  r4: with four waves (a wave per tile column, both halves) the kernel kept ONE
+#define W6_THREADS(N) (128 * W6G<N>::TWX)      // 8 waves (15 x 15: 6): wave = (tile column, channel half).  r4: with four waves (a wave per tile column, both halves) the kernel kept ONE
                             // wave per SIMD, not waiting 69 % of the time -- the stem's arithmetic, the transform and the store issue all hung on it
-__global__ __launch_bounds__(W6_THREADS) void c6_w6_stem_in_kernel(C6StemSrc S, float *__restrict__ V, int nboards) {
-    constexpr int C = W6_C, N = W6_N, LPT = C / 4, P = N + 2, ROWF = W6_ROWF;
+template <int N>
+__global__ __launch_bounds__(W6_THREADS(N)) void c6_w6_stem_in_kernel(C6StemSrc S, float *__restrict__ V, int nboards) {
+    using G = W6G<N>;
+    constexpr int C = W6_C, LPT = C / 4, P = N + 2, ROWF = G::ROWF, NT = W6_THREADS(N);
     extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] + the player-plane sums [9][C] + the board plane [P][P]
     float *s0 = win + 6 * ROWF, *bd = s0 + 9 * C;
-    const int tid = threadIdx.x, cq = tid % LPT, wv = tid / LPT, tx = wv & 3, hh = wv >> 2;
-    const W6Map map(nboards);
+    const int tid = threadIdx.x, cq = tid % LPT, wv = tid / LPT, tx = wv % G::TWX, hh = wv / G::TWX;
+    const W6Map<N> map(nboards);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = tid; k < 6 * ROWF / 4; k += W6_THREADS) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
-    for (int k = tid; k < P * P; k += W6_THREADS) bd[k] = 0.f;
+    for (int k = tid; k < 6 * ROWF / 4; k += NT) reinterpret_cast<f32x4 *>(win)[k] = zero4;      // halo columns stay zero
+    for (int k = tid; k < P * P; k += NT) bd[k] = 0.f;
     f32x4 sw[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) sw[t] = *reinterpret_cast<const f32x4 *>(S.w + (t * 2 + 1) * C + cq * 4);
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(W6_THREADS) void c6_w6_stem_in_kernel(C6StemSrc S, 
     float pv = 0.f;
     // rows y0 .. y0 + nr - 1 of the stem's output into the window (rows outside the board are zeros)
     auto fill = [&](int y0, int nr) {
-        for (int k = tid; k < nr * N * LPT; k += W6_THREADS) {
+        for (int k = tid; k < nr * N * LPT; k += NT) {
             const int r = k / (N * LPT), px = (k / LPT) % N, y = y0 + r;
             const bool inb = y >= 0 && y < N;
             const f32x4 v = inb ? w4_stem_pixel<N>(bd, w4_fma(pv, *reinterpret_cast<const f32x4 *>(s0 + w4_border_class(y, px, N) * C + cq * 4), zero4), y, px, sb,
@@ -224,20 +231,20 @@ __global__ __launch_bounds__(W6_THREADS) void c6_w6_stem_in_kernel(C6StemSrc S, 
 #pragma unroll 1
     for (int b = blockIdx.x; b < nboards; b += gridDim.x) {
         W6_LDS_BARRIER();                                            // the previous board's last reads (and the zero fills)
-        pv = w4_stem_plane<N>(S, b, bd, tid, W6_THREADS);
+        pv = w4_stem_plane<N>(S, b, bd, tid, NT);
         W6_LDS_BARRIER();
         fill(-1, 6);
 #pragma unroll 1
-        for (int ty = 0; ty < W6_TWY; ty++) {
+        for (int ty = 0; ty < G::TWY; ty++) {
             W6_LDS_BARRIER();                                        // rows 4 ty - 1 .. 4 ty + 4 are in the window
             {
                 const long t = map.slot(b, ty, tx);
                 float *vb = V + (size_t)(t / W6_BT) * W6_VBLOCK + (size_t)(t % W6_BT) * W6_VTILE;
                 int slot[6];
-                w6_slots(ty, slot);
-                w6_patch_transform(win + w6_x0(tx) * C, slot, vb, cq, w6_cls(ty, tx), hh, hh + 1);
+                w6_slots<N>(ty, slot);
+                w6_patch_transform(win + G::x0(tx) * C, slot, vb, cq, G::cls(ty, tx), hh, hh + 1);
             }
-            if (ty + 1 < W6_TWY) {
+            if (ty + 1 < G::TWY) {
                 W6_LDS_BARRIER();                                    // rows 4 ty - 1 .. 4 ty + 2 are read no more
                 fill(4 * ty + 5, 4);
             }
@@ -246,10 +253,12 @@ __global__ __launch_bounds__(W6_THREADS) void c6_w6_stem_in_kernel(C6StemSrc S, 
 }
 
 // the tail of a region's last block (tiles beyond the batch) is never written by the kernels above: zero it once per launch
+template <int N>
 __global__ void c6_w6_tail_kernel(float *__restrict__ V, int nboards) {
-    const W6Map map(nboards);
+    using G = W6G<N>;
+    const W6Map<N> map(nboards);
     const long first_blk[5] = {0, map.blkB, map.blkBP, map.blkD, map.blkDP},
-               count[5] = {(long)nboards * W6_NA, (long)nboards * W6_NB, (long)nboards * W6_NBP, (long)nboards * W6_ND, (long)nboards * W6_NDP};
+               count[5] = {(long)nboards * G::NA, (long)nboards * G::NB, (long)nboards * G::NBP, (long)nboards * G::ND, (long)nboards * G::NDP};
     for (int r = 0; r < 5; r++) {
         const int used = (int)(count[r] % W6_BT);
         if (used == 0) continue;
@@ -258,9 +267,10 @@ __global__ void c6_w6_tail_kernel(float *__restrict__ V, int nboards) {
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) blk[i] = 0.f;
     }
 }
-static bool w6_has_tail(int nboards) {
-    return ((long)nboards * W6_NA) % W6_BT || ((long)nboards * W6_NB) % W6_BT || ((long)nboards * W6_NBP) % W6_BT || ((long)nboards * W6_ND) % W6_BT ||
-           ((long)nboards * W6_NDP) % W6_BT;
+template <int N> static bool w6_has_tail(int nboards) {
+    using G = W6G<N>;
+    return ((long)nboards * G::NA) % W6_BT || ((long)nboards * G::NB) % W6_BT || ((long)nboards * G::NBP) % W6_BT || ((long)nboards * G::ND) % W6_BT ||
+           ((long)nboards * G::NDP) % W6_BT;
 }
 
 // ---- the GEMMs of a block, with the column half of the output transform ("Z rows"): conv_wino4.hip's c6_wino4_gemm_kernel ----------
@@ -376,9 +386,9 @@ struct W6OutCtx {
 #define W6_SLICE_OK(CLS, b) (!((CLS) == W6_CLS_DP && (b) == 2))
 #define W6_SLICE_ROW(CLS, b) ((CLS) == W6_CLS_DP && (b) == 3 ? 2 : (b))
 // one tile of class CLS: everything about the class is a constant here (no run-time indexing of the register arrays)
-template <int CLS>
+template <int N, int CLS>
 __device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, long bd, int ty, int x0, int wd, int lane, int b0) {
-    constexpr int C = W6_C, N = W6_N;
+    constexpr int C = W6_C;
     constexpr int rows = CLS == W6_CLS_D || CLS == W6_CLS_DP ? 8 : CLS == W6_CLS_A ? 6 : 5;
     constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_DP || CLS == W6_CLS_B;      // the slice's pixels run along a row of the tile (else: along a column)
     constexpr int npx = CLS == W6_CLS_D || CLS == W6_CLS_DP ? 6 : CLS == W6_CLS_A ? 4 : 3;
@@ -442,8 +452,10 @@ __device__ __forceinline__ void w6_out_tile(const W6OutCtx &X, const float *zb, 
         }
     }
 }
+template <int N>
 __global__ __launch_bounds__(256) void c6_w6_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
                                                         long total_tiles, C6HeadFuse hd) {
+    using G = W6G<N>;
     constexpr int C = W6_C;
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -454,20 +466,20 @@ __global__ __launch_bounds__(256) void c6_w6_out_kernel(const float *__restrict_
     X.hw2 = *reinterpret_cast<const f32x4 *>(hd.w + 2 * C + lane * 4);
     X.res = res;
     X.hd = hd;
-    const W6Map map(total_tiles / W6_T);
+    const W6Map<N> map(total_tiles / G::T);
 #pragma unroll 1
     for (long it = wave0; it < 2 * total_tiles; it += nwaves) {      // item = half a tile: two of its four slices
         const long t = it >> 1;
         const int b0 = (int)(it & 1) * 2;
-        const long bd = t / W6_T;
-        const int tt = (int)(t - bd * W6_T), ty = tt / W6_TWX, tx = tt - ty * W6_TWX, cls = w6_cls(ty, tx);
-        const int x0 = w6_x0(tx), wd = w6_width(tx);
+        const long bd = t / G::T;
+        const int tt = (int)(t - bd * G::T), ty = tt / G::TWX, tx = tt - ty * G::TWX, cls = G::cls(ty, tx);
+        const int x0 = G::x0(tx), wd = G::width(tx);
         const float *zb = M + (size_t)map.slot(bd, ty, tx) * W6_ZTILE + lane * 4;
-        if (cls == W6_CLS_D) w6_out_tile<W6_CLS_D>(X, zb, bd, ty, x0, wd, lane, b0);
-        else if (cls == W6_CLS_DP) w6_out_tile<W6_CLS_DP>(X, zb, bd, ty, x0, wd, lane, b0);
-        else if (cls == W6_CLS_A) w6_out_tile<W6_CLS_A>(X, zb, bd, ty, x0, wd, lane, b0);
-        else if (cls == W6_CLS_B) w6_out_tile<W6_CLS_B>(X, zb, bd, ty, x0, wd, lane, b0);
-        else w6_out_tile<W6_CLS_BP>(X, zb, bd, ty, x0, wd, lane, b0);
+        if (cls == W6_CLS_D) w6_out_tile<N, W6_CLS_D>(X, zb, bd, ty, x0, wd, lane, b0);
+        else if (cls == W6_CLS_DP) w6_out_tile<N, W6_CLS_DP>(X, zb, bd, ty, x0, wd, lane, b0);
+        else if (G::NA && cls == W6_CLS_A) w6_out_tile<N, W6_CLS_A>(X, zb, bd, ty, x0, wd, lane, b0);
+        else if (cls == W6_CLS_B) w6_out_tile<N, W6_CLS_B>(X, zb, bd, ty, x0, wd, lane, b0);
+        else w6_out_tile<N, W6_CLS_BP>(X, zb, bd, ty, x0, wd, lane, b0);
     }
 }
 
@@ -482,10 +494,10 @@ __global__ __launch_bounds__(256) void c6_w6_out_kernel(const float *__restrict_
 //   phase p  producers  compute the pixels of tile row p + 1 (p = 4: the zero row below the board; p = 5: tile row 0 of the NEXT board),
 //                       after X write the three rows kept from phase p - 1 and the first row of this phase's tile into the window
 //            consumers  transform the patches of tile row p - 1 (window rows 4p - 5 .. 4p), p >= 1
-template <int CLS, bool RS>
+template <int N, int CLS, bool RS>
 __device__ __forceinline__ void w6_produce_tile(const float *zb, long bd, int t, int x0, int wd, int c, f32x2 bi, const float *res, float *act, const float *plane, float pv,
                                                 const float *swl, const float *s0, f32x2 sb, f32x2 (&r0)[6], f32x2 (&kn)[3][6]) {
-    constexpr int C = W6_C, N = W6_N;
+    constexpr int C = W6_C;
     constexpr int rows = CLS == W6_CLS_D || CLS == W6_CLS_DP ? 8 : CLS == W6_CLS_A ? 6 : 5;
     constexpr bool along_row = CLS == W6_CLS_D || CLS == W6_CLS_DP || CLS == W6_CLS_B;
     constexpr int npx = CLS == W6_CLS_D || CLS == W6_CLS_DP ? 6 : CLS == W6_CLS_A ? 4 : 3;
@@ -553,18 +565,19 @@ __device__ __forceinline__ void w6_produce_tile(const float *zb, long bd, int t,
         }
     }
 }
-#define W6_MID_THREADS 768
-template <bool RS>
-__global__ __launch_bounds__(W6_MID_THREADS) void c6_w6_mid_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
+#define W6_MID_THREADS(N) (192 * W6G<N>::TWX)      // 19 x 19: 8 + 4 waves; 15 x 15: 6 + 3
+template <int N, bool RS>
+__global__ __launch_bounds__(W6_MID_THREADS(N)) void c6_w6_mid_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
                                                                       float *__restrict__ act, float *__restrict__ V, int nboards, C6StemSrc S) {
-    constexpr int C = W6_C, N = W6_N, ROWF = W6_ROWF, NT = W6_MID_THREADS, PP = (N + 2) * (N + 2);
+    using G = W6G<N>;
+    constexpr int C = W6_C, ROWF = G::ROWF, NT = W6_MID_THREADS(N), PP = (N + 2) * (N + 2), TWX = G::TWX, TWY = G::TWY;
     extern __shared__ __attribute__((aligned(16))) float win[];                // [6][COLS][C] (+ RS: the stem's weights, sums and two board planes)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = w < 8;
-    const int tx = producer ? (w & 3) : (w - 8);
-    const int x0 = w6_x0(tx), wd = w6_width(tx);
-    const int c = ((w >> 2) & 1) * (C / 2) + lane * 2;                         // a producer's channel pair
-    const W6Map map(nboards);
+    const bool producer = w < 2 * TWX;
+    const int tx = producer ? w % TWX : w - 2 * TWX;
+    const int x0 = G::x0(tx), wd = G::width(tx);
+    const int c = (producer ? w / TWX : 0) * (C / 2) + lane * 2;                         // a producer's channel pair
+    const W6Map<N> map(nboards);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x2 zero2 = f32x2{0.f, 0.f};
     const f32x2 bi = bias ? *reinterpret_cast<const f32x2 *>(bias + c) : zero2;
@@ -579,12 +592,12 @@ __global__ __launch_bounds__(W6_MID_THREADS) void c6_w6_mid_kernel(const float *
         sb = *reinterpret_cast<const f32x2 *>(S.bias + c);
     }
     long cur = -1, nxt = blockIdx.x;
-    int p = 5;
+    int p = TWY;
     W6_LDS_BARRIER();
     // The two roles run separate loops (nothing of one role's state is alive in the other's registers); both pass the same barriers:
     // X = this phase's window reads are done, Y = the window holds the next phase's rows.
     if (producer) {
-        constexpr int NP = 512;                              // the producers' threads: tid 0 .. 511
+        constexpr int NP = 128 * TWX;                        // the producers' threads: tid 0 .. NP - 1
         int pbuf = 0;
         float pvc = 0.f, pvn = 0.f;
         if (RS && nxt < nboards) pvn = w4_stem_plane<N>(S, nxt, planes + (pbuf ^ 1) * PP, tid, NP);
@@ -594,25 +607,25 @@ __global__ __launch_bounds__(W6_MID_THREADS) void c6_w6_mid_kernel(const float *
         for (int k = 0; k < 6; k++) { r0[k] = zero2; ko[0][k] = zero2; ko[1][k] = zero2; ko[2][k] = zero2; kn[0][k] = zero2; kn[1][k] = zero2; kn[2][k] = zero2; }
 #pragma unroll 1
         for (;;) {
-            const long b = p == 5 ? nxt : cur;
-            const int t = p == 5 ? 0 : p + 1;
-            if (p != 4 && b >= 0 && b < nboards) {
-                const int cls = w6_cls(t, tx);
+            const long b = p == TWY ? nxt : cur;
+            const int t = p == TWY ? 0 : p + 1;
+            if (p != TWY - 1 && b >= 0 && b < nboards) {
+                const int cls = G::cls(t, tx);
                 const float *zb = M + (size_t)map.slot(b, t, tx) * W6_ZTILE + c;
-                const float *plane = planes + (p == 5 ? pbuf ^ 1 : pbuf) * PP;
-                const float pv = p == 5 ? pvn : pvc;
-                if (cls == W6_CLS_D) w6_produce_tile<W6_CLS_D, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
-                else if (cls == W6_CLS_DP) w6_produce_tile<W6_CLS_DP, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
-                else if (cls == W6_CLS_A) w6_produce_tile<W6_CLS_A, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
-                else if (cls == W6_CLS_B) w6_produce_tile<W6_CLS_B, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
-                else w6_produce_tile<W6_CLS_BP, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
-            } else if (p == 4) {
+                const float *plane = planes + (p == TWY ? pbuf ^ 1 : pbuf) * PP;
+                const float pv = p == TWY ? pvn : pvc;
+                if (cls == W6_CLS_D) w6_produce_tile<N, W6_CLS_D, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+                else if (cls == W6_CLS_DP) w6_produce_tile<N, W6_CLS_DP, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+                else if (G::NA && cls == W6_CLS_A) w6_produce_tile<N, W6_CLS_A, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+                else if (cls == W6_CLS_B) w6_produce_tile<N, W6_CLS_B, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+                else w6_produce_tile<N, W6_CLS_BP, RS>(zb, b, t, x0, wd, c, bi, res, act, plane, pv, swl, s0, sb, r0, kn);
+            } else if (p == TWY - 1) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) r0[k] = zero2;                     // row 4 TWY: below the board
                 if (RS && nxt < nboards) pvn = w4_stem_plane<N>(S, nxt, planes + (pbuf ^ 1) * PP, tid, NP);      // (last read in phase 3 of the board before)
             }
             W6_LDS_BARRIER();                                // X
-            if (p == 5) {
+            if (p == TWY) {
 #pragma unroll
                 for (int k = 0; k < 6; k++)
                     if (k < wd) {
@@ -634,7 +647,7 @@ __global__ __launch_bounds__(W6_MID_THREADS) void c6_w6_mid_kernel(const float *
 #pragma unroll
                 for (int k = 0; k < 6; k++) ko[a][k] = kn[a][k];
             W6_LDS_BARRIER();                                // Y
-            if (p == 5) {
+            if (p == TWY) {
                 if (nxt >= nboards) break;
                 cur = nxt;
                 nxt += gridDim.x;
@@ -652,12 +665,12 @@ __global__ __launch_bounds__(W6_MID_THREADS) void c6_w6_mid_kernel(const float *
                 const long tt = map.slot(cur, ty, tx);
                 float *vb = V + (size_t)(tt / W6_BT) * W6_VBLOCK + (size_t)(tt % W6_BT) * W6_VTILE;
                 int slot[6];
-                w6_slots(ty, slot);
-                w6_patch_transform(win + x0 * C, slot, vb, lane, w6_cls(ty, tx));
+                w6_slots<N>(ty, slot);
+                w6_patch_transform(win + x0 * C, slot, vb, lane, G::cls(ty, tx));
             }
             W6_LDS_BARRIER();                                // X
             W6_LDS_BARRIER();                                // Y
-            if (p == 5) {
+            if (p == TWY) {
                 if (nxt >= nboards) break;
                 cur = nxt;
                 nxt += gridDim.x;
@@ -668,11 +681,16 @@ __global__ __launch_bounds__(W6_MID_THREADS) void c6_w6_mid_kernel(const float *
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
-bool c6_w6_available(int C, int N, int blocks) { return C == W6_C && N == W6_N && blocks - 1 >= 2; }
+bool c6_w6_available(int C, int N, int blocks) {
+    // (C6_W6_N15=0: a test hook -- 15 x 15 towers stay on conv_wino4.hip's F(4x4) tiling, which the trainer and the 9 x 9 / two-block towers use anyway;
+    //  tests/test_gpu_variants.py compares the two tilings' outputs and keeps conv_wino4.hip's work decompositions covered at 15 x 15)
+    static const bool n15 = [] { const char *e = getenv("C6_W6_N15"); return !(e && e[0] == '0'); }();
+    return C == W6_C && (N == 19 || (N == 15 && n15)) && blocks - 1 >= 2;
+}
 size_t c6_w6_packed_floats(void) { return (size_t)W6_SETS_POS * W6_C * W6_C; }
-static long w6_nblocks(int nboards) { return W6Map(nboards).nblocks; }
+static long w6_nblocks(int N, int nboards) { return N == 19 ? W6Map<19>(nboards).nblocks : W6Map<15>(nboards).nblocks; }
 // V and Z, one behind the other
-size_t c6_w6_vbuf_floats(int nboards) { return (size_t)w6_nblocks(nboards) * (W6_VBLOCK + W6_ZBLOCK); }
+size_t c6_w6_vbuf_floats(int N, int nboards) { return (size_t)w6_nblocks(N, nboards) * (W6_VBLOCK + W6_ZBLOCK); }
 
 // Transformed weights U = G_v g G_h^T (double, rounded once), four sets one behind the other: A (36 positions p = 6 i + j: F(4)'s G both
 // ways), B (30, p = 6 j + i: G4 vertically, G3 horizontally), B' (30, p = 6 i + j: G3 vertically, G4 horizontally), D (48, p = 6 j + i: G4
@@ -731,20 +749,22 @@ static W6Side *w6_side_of(hipStream_t s) {
 }
 
 // steps: 1 the first layer's input transform from the boards, 2 the GEMMs, 16 the boundary kernel, 4 the last output transform + heads
-bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float *res, float *act, float *vbuf, int num_cus, hipStream_t s, int steps,
-                    const C6HeadFuse *heads, const C6StemSrc *stem) {
+template <int N>
+static bool w6_dispatch(int nboards, const float *wp, const float *bias, const float *res, float *act, float *vbuf, int num_cus, hipStream_t s, int steps,
+                        const C6HeadFuse *heads, const C6StemSrc *stem) {
+    using G = W6G<N>;
     if (nboards <= 0) return true;
-    const W6Map map(nboards);
+    const W6Map<N> map(nboards);
     const int nblocks = (int)map.nblocks;
-    const bool tail = w6_has_tail(nboards);
+    const bool tail = w6_has_tail<N>(nboards);
     float *Vb = vbuf, *Mb = vbuf + (size_t)nblocks * W6_VBLOCK;
-    constexpr size_t win_smem = (size_t)6 * W6_ROWF * 4;
+    constexpr size_t win_smem = (size_t)6 * G::ROWF * 4;
     const int grid_b = nboards < num_cus ? nboards : num_cus;
     if (steps & 1) {
-        constexpr size_t smem = win_smem + (size_t)9 * W6_C * 4 + (size_t)(W6_N + 2) * (W6_N + 2) * 4;
-        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_stem_in_kernel), (int)smem);
-        hipLaunchKernelGGL(c6_w6_stem_in_kernel, dim3(grid_b), dim3(W6_THREADS), smem, s, *stem, Vb, nboards);
-        if (tail) hipLaunchKernelGGL(c6_w6_tail_kernel, dim3(256), dim3(256), 0, s, Vb, nboards);
+        constexpr size_t smem = win_smem + (size_t)9 * W6_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
+        w4_smem_once(reinterpret_cast<const void *>(&c6_w6_stem_in_kernel<N>), (int)smem);
+        hipLaunchKernelGGL(c6_w6_stem_in_kernel<N>, dim3(grid_b), dim3(W6_THREADS(N)), smem, s, *stem, Vb, nboards);
+        if (tail) hipLaunchKernelGGL(c6_w6_tail_kernel<N>, dim3(256), dim3(256), 0, s, Vb, nboards);
     }
     if (steps & 2) {
         constexpr size_t smem = (size_t)2 * W6_BT * (W6_C + 4) * 4;
@@ -802,29 +822,35 @@ bool c6_w6_dispatch(int nboards, const float *wp, const float *bias, const float
         }
     }
     if (steps & 16) {
-        constexpr size_t rs_smem = win_smem + (size_t)18 * W6_C * 4 + (size_t)(W6_N + 2) * (W6_N + 2) * 4;
+        constexpr size_t rs_smem = win_smem + (size_t)18 * W6_C * 4 + (size_t)(N + 2) * (N + 2) * 4;
         if (stem) {      // the residual is the stem's output, recomputed from the boards
-            constexpr size_t rs12 = rs_smem + (size_t)(W6_N + 2) * (W6_N + 2) * 4;
-            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<true>), (int)rs12);
-            hipLaunchKernelGGL((c6_w6_mid_kernel<true>), dim3(grid_b), dim3(W6_MID_THREADS), rs12, s, Mb, bias, res, act, Vb, nboards, *stem);
+            constexpr size_t rs12 = rs_smem + (size_t)(N + 2) * (N + 2) * 4;
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<N, true>), (int)rs12);
+            hipLaunchKernelGGL((c6_w6_mid_kernel<N, true>), dim3(grid_b), dim3(W6_MID_THREADS(N)), rs12, s, Mb, bias, res, act, Vb, nboards, *stem);
         } else {
-            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<false>), (int)win_smem);
-            hipLaunchKernelGGL((c6_w6_mid_kernel<false>), dim3(grid_b), dim3(W6_MID_THREADS), win_smem, s, Mb, bias, res, act, Vb, nboards, C6StemSrc{});
+            w4_smem_once(reinterpret_cast<const void *>(&c6_w6_mid_kernel<N, false>), (int)win_smem);
+            hipLaunchKernelGGL((c6_w6_mid_kernel<N, false>), dim3(grid_b), dim3(W6_MID_THREADS(N)), win_smem, s, Mb, bias, res, act, Vb, nboards, C6StemSrc{});
         }
         // (no c6_w6_tail_kernel here: the boundary kernel writes the tiles of the batch and nothing else, so the tail the pass's first step zeroed in this
         //  same V is still zero -- five launches less per pass, 5 us + a launch gap each, which a one-game round of 0.95 ms does notice)
     }
     if (steps & 4) {
-        const long tiles = (long)nboards * W6_T, want = (2 * tiles + 3) / 4;
+        const long tiles = (long)nboards * G::T, want = (2 * tiles + 3) / 4;
         const int grid_out = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
-        hipLaunchKernelGGL(c6_w6_out_kernel, dim3(grid_out), dim3(256), 0, s, Mb, bias, res, tiles, *heads);
+        hipLaunchKernelGGL(c6_w6_out_kernel<N>, dim3(grid_out), dim3(256), 0, s, Mb, bias, res, tiles, *heads);
     }
     const hipError_t le = hipGetLastError();      // a rejected launch (e.g. its LDS request): noted for c6_launch_status, and the caller stops the pass
     c6_note_hip(le, "launch of a c6_w6 kernel");
     return le == hipSuccess;
 }
+bool c6_w6_dispatch(int N, int nboards, const float *wp, const float *bias, const float *res, float *act, float *vbuf, int num_cus, hipStream_t s, int steps,
+                    const C6HeadFuse *heads, const C6StemSrc *stem) {
+    return N == 19 ? w6_dispatch<19>(nboards, wp, bias, res, act, vbuf, num_cus, s, steps, heads, stem)
+                   : w6_dispatch<15>(nboards, wp, bias, res, act, vbuf, num_cus, s, steps, heads, stem);
+}
 // matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 / 30 / 30 / 48 / 40 positions x C x C MACs)
-double c6_w6_exec_flops(int nboards) {
-    const W6Map m(nboards);
+template <int N> static double w6_exec_flops(int nboards) {
+    const W6Map<N> m(nboards);
     return 2.0 * (36.0 * m.blkB + 30.0 * (m.blkD - m.blkB) + 48.0 * (m.blkDP - m.blkD) + 40.0 * (m.nblocks - m.blkDP)) * W6_BT * (double)W6_C * W6_C;
 }
+double c6_w6_exec_flops(int N, int nboards) { return N == 19 ? w6_exec_flops<19>(nboards) : w6_exec_flops<15>(nboards); }

@@ -778,7 +778,7 @@ static int engine_alloc(c6_engine *e) {
         ALLOC(e->ph, nb * 2 * cells); ALLOC(e->vh, nb * cells);
         if (conv_variant(c.net_precision) == C6_CONV_WINO) {
             // the largest buffer of the net (16/4 of an activation): not zero-filled, every float the GEMM reads is written first
-            const size_t vf = c6_w6_available(c.net_channels, N, c.net_blocks) ? c6_w6_vbuf_floats((int)nb) : c6_conv_wino_vbuf_floats(c.net_channels, N, (int)nb);
+            const size_t vf = c6_w6_available(c.net_channels, N, c.net_blocks) ? c6_w6_vbuf_floats(N, (int)nb) : c6_conv_wino_vbuf_floats(c.net_channels, N, (int)nb);
             int rc_ = pool.alloc(&e->vbuf, vf, false);
             if (rc_ != C6_OK) return rc_;
         }
@@ -1773,7 +1773,7 @@ extern "C" int c6_net_forward_prec(int n, int C, int blocks, int precision, cons
     int16_t *dm = t.get<int16_t>(aug.size(), aug.data());
     float *a0 = t.get<float>(act), *a1 = t.get<float>(act), *a2 = t.get<float>(act), *ph = t.get<float>((size_t)num * 2 * cells),
           *vh = t.get<float>((size_t)num * cells), *dp = t.get<float>((size_t)num * cells), *dv = t.get<float>(num);
-    float *vb = nh.dev.variant == C6_CONV_WINO ? t.get<float>(nh.dev.wino6 ? c6_w6_vbuf_floats(num) : c6_conv_wino_vbuf_floats(C, n, num)) : a0;
+    float *vb = nh.dev.variant == C6_CONV_WINO ? t.get<float>(nh.dev.wino6 ? c6_w6_vbuf_floats(n, num) : c6_conv_wino_vbuf_floats(C, n, num)) : a0;
     if (!db || !dpl || !dm || !a0 || !a1 || !a2 || !ph || !vh || !dp || !dv || !vb) { nh.pool.release(); return fail(C6_ERR_HIP, "hipMalloc failed"); }
     c6_net_forward_dev(nh.dev, num, 1, db, cells, dpl, 1, dm, a0, a1, a2, vb, ph, vh, dp, dv, nullptr, nullptr);
     c6_note_hip(hipGetLastError(), "c6_net_forward");

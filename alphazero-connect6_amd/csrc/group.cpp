@@ -370,6 +370,7 @@ extern "C" int c6_group_enable_tuples(c6_group *g, size_t capacity_records) {
         GHIP(hipSetDevice(mb.device));
         for (int i = 0; i < 2; i++) {
             GHIP(hipMalloc(&mb.buf[i], capacity_records * g->stride));
+            GHIP(hipMemset(mb.buf[i], 0, capacity_records * g->stride));      // (a record's padding bytes are never written: zero, as in an engine-owned buffer)
             GHIP(hipMalloc(&mb.cnt[i], sizeof(uint32_t)));
             GHIP(hipMemset(mb.cnt[i], 0, sizeof(uint32_t)));
         }

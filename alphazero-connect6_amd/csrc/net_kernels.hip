@@ -414,23 +414,23 @@ void c6_net_forward_dev(const C6NetDev &net, int nleaf, int images, const int8_t
             const int half = l & 1;
             hipEvent_t e0 = nullptr, e1 = nullptr, em = nullptr, eg = nullptr;
             if (timed) { e0 = timer_event(timers); e1 = timer_event(timers); hipEventRecord(e0, s); }
-            if (l == 0 && !c6_w6_dispatch(nb, nullptr, nullptr, nullptr, nullptr, vbuf, net.num_cus, s, 1, nullptr, &stem_src)) return;      // (noted: c6_launch_status)
+            if (l == 0 && !c6_w6_dispatch(net.N, nb, nullptr, nullptr, nullptr, nullptr, vbuf, net.num_cus, s, 1, nullptr, &stem_src)) return;      // (noted: c6_launch_status)
             if (timed) {
                 em = timer_event(timers);
                 hipEventRecord(em, s);
                 timers->pre.emplace_back(e0, em);
-                timers->exec_flops += c6_w6_exec_flops(nb);
+                timers->exec_flops += c6_w6_exec_flops(net.N, nb);
             }
-            if (!c6_w6_dispatch(nb, net.conv_ww + (size_t)l * wwf, nullptr, nullptr, nullptr, vbuf, net.num_cus, s, 2)) return;
+            if (!c6_w6_dispatch(net.N, nb, net.conv_ww + (size_t)l * wwf, nullptr, nullptr, nullptr, vbuf, net.num_cus, s, 2)) return;
             if (timed) { eg = timer_event(timers); hipEventRecord(eg, s); }
             const float *cb = net.conv_b + (size_t)l * C;
             // residual of the block's second convolution: the block's input = the previous block's output (x), or the stem for block 0
             const float *cres = half == 0 ? nullptr : x;
             if (l < Lw - 1) {
                 float *cout = half == 0 ? nullptr : z;      // a block's output is stored: the next block's residual
-                if (!c6_w6_dispatch(nb, nullptr, cb, l == 1 ? nullptr : cres, cout, vbuf, net.num_cus, s, 16, nullptr, l == 1 ? &stem_src : nullptr)) return;
+                if (!c6_w6_dispatch(net.N, nb, nullptr, cb, l == 1 ? nullptr : cres, cout, vbuf, net.num_cus, s, 16, nullptr, l == 1 ? &stem_src : nullptr)) return;
             } else
-                if (!c6_w6_dispatch(nb, nullptr, cb, Lw == 2 ? nullptr : cres, nullptr, vbuf, net.num_cus, s, 4, &hf)) return;
+                if (!c6_w6_dispatch(net.N, nb, nullptr, cb, Lw == 2 ? nullptr : cres, nullptr, vbuf, net.num_cus, s, 4, &hf)) return;
             if (timed) {
                 hipEvent_t eo = timer_event(timers);
                 hipEventRecord(eo, s);

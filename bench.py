@@ -67,6 +67,12 @@ KERNELS = {      # precision name -> (dominant kernel as rocprofv3 names it, des
 
 def conv_kernel_of(name, n):
     """(kernel as rocprofv3 names it, description) of the 3x3 convolution's dominant kernel for a precision and a board size"""
+    if name == "fp32" and n == 15:
+        return ("c6_w6_gemm_kernel<false, false, false>",
+                "FP32 Winograd, conv_wino6.hip's tiling of the reference's 15x15 board: tiles 4 x {6, 6, 3} (F(4,3) down, F(6,3) / F(3,3) across; F(3,3) down in the last tile "
+                "row): 6 x 48 + 2 x 40 + 3 x 30 + 30 = 488 positions per channel pair and board (conv_wino4.hip's F(4x4) tiling: 534), the same GEMM kernels as the 19x19 "
+                "benchmark (c6_w6_gemm_kernel<false> for the rows of six positions, <true> for class D') on v_mfma_f32_32x32x2_f32; HBM-bound boundary kernels between "
+                "the layers (c6_w6_mid_kernel<15, .>)")
     if name == "fp32" and n != 19:
         tw = (n + 3) // 4
         edge = 2 * tw - 1 if n % 4 == 3 else 0
@@ -196,9 +202,11 @@ def usable_cores():
     return n
 
 
-def stones_probe(pkg, wl, games, sims, precision, seed=7, device=0, progress=False):
+def stones_probe(pkg, wl, games, sims, precision, seed=7, device=0, progress=False, partial_path=None):
     """complete self-play games of the workload's net (same random-init weights, same noise) at `sims` simulations per move: the
-    measured game length that turns simulations/s into games/s"""
+    measured game length that turns simulations/s into games/s.  partial_path: the games finished so far are written there at every progress
+    tick (a run is bounded by its LONGEST game; a call cut off by its time limit then still leaves its finished games and the number of
+    unfinished ones behind -- a censored sample, labelled as such, never mixed into a mean)"""
     import __graft_entry__ as ge
     n = wl["n"]
     ev = pkg.EVAL_NET if wl["evaluator"] == "net" else pkg.EVAL_UNIFORM
@@ -207,17 +215,23 @@ def stones_probe(pkg, wl, games, sims, precision, seed=7, device=0, progress=Fal
     if ev == pkg.EVAL_NET:
         eng.load_weights(ge.make_random_blob(n, wl["channels"], wl["blocks"], np.random.default_rng(0)))
     t0 = time.perf_counter()
+    gs = []
     if progress:      # long probes report as they go (a silent GPU job is taken to be hung)
         while True:
             eng.run(max_rounds=256)
             st = eng.stats()
             print(f"[stones_probe] round {st['rounds']}: {st['games_finished']} / {games} games finished, {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+            if partial_path and (st["rounds"] // 256) % 16 == 0:
+                gs += eng.fetch_games()
+                json.dump({"censored": True, "games_started": games, "games_finished": len(gs), "rounds": st["rounds"], "num_simulation": sims, "seed": seed,
+                           "lengths_of_finished": [len(g["moves"]) for g in gs], "winners_of_finished": [g["winner"] for g in gs],
+                           "unfinished_have_at_least_stones": int(st["rounds"] // sims)}, open(partial_path, "w"))
             if st["live_games"] == 0:
                 break
     eng.run()
     dt = time.perf_counter() - t0
     st = eng.stats()
-    gs = eng.fetch_games()
+    gs += eng.fetch_games()
     eng.close()
     lens = np.array([len(g["moves"]) for g in gs], np.float64)
     wins = np.array([g["winner"] for g in gs])

@@ -196,7 +196,8 @@ def test_w4_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
     with tempfile.TemporaryDirectory() as td:
         for form, env in (("block", dict(C6_W4_SPLIT="0")), ("split", dict(C6_W4_SPLIT="1", C6_W4_HALF="0")), ("half", dict(C6_W4_SPLIT="1", C6_W4_HALF="1"))):
             out = os.path.join(td, f"w4_{form}.npz")
-            subprocess.run([sys.executable, "-c", W4_CHILD, out], check=True, env=dict(os.environ, **env), timeout=600)
+            # (C6_W6_N15=0: since r6 a 15 x 15 tower with >= 2 residual blocks runs conv_wino6.hip's tiling; the hook keeps it on the kernels under test)
+            subprocess.run([sys.executable, "-c", W4_CHILD, out], check=True, env=dict(os.environ, C6_W6_N15="0", **env), timeout=600)
             res[form] = dict(np.load(out))
     assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) and len(res["block"]) == 24
     for k in res["block"]:
@@ -212,15 +213,15 @@ from c6amd_loader import load_package
 import __graft_entry__ as ge
 pkg = load_package()
 out = {}
-for blocks in (4, 8):
-    blob = ge.make_random_blob(19, 256, blocks, np.random.default_rng(5))
+for n, blocks in ((19, 4), (19, 8), (15, 10)):      # (r6: the reference's own shape, 15 x 15 with stem + 9 blocks, runs the same GEMM kernels over its own tiling)
+    blob = ge.make_random_blob(n, 256, blocks, np.random.default_rng(5))
     # (10 000 boards, stem + 3 blocks only: 313 blocks of class D' > the 256 workgroups of a grid row -- the forced split form's block loop makes a SECOND
     #  trip in the five-position row form too, ADVICE r5)
     for num in (1, 13, 40, 333, 1100) + ((10000,) if blocks == 4 else ()):
-        boards = np.random.default_rng(num).integers(-1, 2, size=(num, 361)).astype(np.int8)
-        pol, val = pkg.net_forward(19, 256, blocks, blob, boards, 1 if num %% 2 else -1, precision=pkg.PREC_FP32)
-        out["p%%d_%%d" %% (blocks, num)] = pol
-        out["v%%d_%%d" %% (blocks, num)] = val
+        boards = np.random.default_rng(num).integers(-1, 2, size=(num, n * n)).astype(np.int8)
+        pol, val = pkg.net_forward(n, 256, blocks, blob, boards, 1 if num %% 2 else -1, precision=pkg.PREC_FP32)
+        out["p%%d_%%d_%%d" %% (n, blocks, num)] = pol
+        out["v%%d_%%d_%%d" %% (n, blocks, num)] = val
 np.savez(sys.argv[1], **out)
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
@@ -241,9 +242,56 @@ def test_w6_gemm_rows_as_work_items_equal_blocks_bit_for_bit():
             out = os.path.join(td, f"w6_{form}.npz")
             subprocess.run([sys.executable, "-c", W6_CHILD, out], check=True, env=dict(os.environ, **env), timeout=600)
             res[form] = dict(np.load(out))
-    assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) == sorted(res["split2"]) and len(res["block"]) == 22
+    assert sorted(res["block"]) == sorted(res["split"]) == sorted(res["half"]) == sorted(res["split2"]) and len(res["block"]) == 32
     for k in res["block"]:
         assert np.isfinite(res["block"][k]).all()
         assert np.array_equal(res["block"][k], res["split"][k]), k
         assert np.array_equal(res["block"][k], res["half"][k]), k
         assert np.array_equal(res["block"][k], res["split2"][k]), k
+
+
+N15_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from c6amd_loader import load_package
+import __graft_entry__ as ge
+pkg = load_package()
+out = {}
+for blocks in (3, 10):
+    blob = ge.make_random_blob(15, 256, blocks, np.random.default_rng(8))
+    for num in (5, 333):
+        boards = np.random.default_rng(num).integers(-1, 2, size=(num, 225)).astype(np.int8)
+        pol, val = pkg.net_forward(15, 256, blocks, blob, boards, 1 if num %% 2 else -1, precision=pkg.PREC_FP32)
+        out["p%%d_%%d" %% (blocks, num)] = pol
+        out["v%%d_%%d" %% (blocks, num)] = val
+np.savez(sys.argv[1], **out)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def test_15x15_tilings_agree_and_match_the_oracle():
+    """r6: the 15 x 15 tower (the reference's board: Connect6/libconnect6/src/lib.rs:21) on conv_wino6.hip's tiling -- 6 + 6 + 3 across, 4 + 4 + 4 + 3 down,
+    488 positions per board -- against conv_wino4.hip's F(4x4) tiling of the same board (534 positions; C6_W6_N15=0) and against the CPU oracle's direct
+    convolution: two different Winograd decompositions and a direct sum of the same f32 net, all within 1e-5 (north_star's tolerance), stem + 2 and the
+    reference's stem + 9 blocks, a handful of boards and full + partial blocks of every tile class."""
+    need_gpu()
+    import __graft_entry__ as ge
+    import c6oracle as o
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for form, env in (("w6", {}), ("w4", dict(C6_W6_N15="0"))):
+            out = os.path.join(td, f"n15_{form}.npz")
+            subprocess.run([sys.executable, "-c", N15_CHILD, out], check=True, env=dict(os.environ, **env), timeout=600)
+            res[form] = dict(np.load(out))
+    assert sorted(res["w6"]) == sorted(res["w4"]) and len(res["w6"]) == 8
+    differ = 0
+    for k in res["w6"]:
+        assert np.isfinite(res["w6"][k]).all()
+        assert np.abs(res["w6"][k] - res["w4"][k]).max() <= 1e-5, k
+        differ += not np.array_equal(res["w6"][k], res["w4"][k])
+    assert differ > 0      # (two tilings round differently: identical bits would mean the hook did not switch anything)
+    for blocks in (3, 10):
+        net = o.Net(15, 256, blocks, ge.make_random_blob(15, 256, blocks, np.random.default_rng(8)))
+        boards = np.random.default_rng(5).integers(-1, 2, size=(5, 225)).astype(np.int8)
+        rpol, rval = net.forward(1.0, boards.astype(np.float32))
+        assert np.abs(res["w6"][f"p{blocks}_5"] - rpol).max() <= 1e-5 and np.abs(res["w6"][f"v{blocks}_5"] - rval).max() <= 1e-5, blocks
+        net.close()

@@ -68,6 +68,21 @@ def test_wino6_tiling_of_the_19_board():
     assert npos == 804 and np.abs(out - ref).max() < 1e-11
 
 
+def test_wino6_tiling_of_the_15_board():
+    """r6: conv_wino6.hip's tiling of the reference's 15x15 board (W6G<15>): columns 6 + 6 + 3, rows 4 + 4 + 4 + 3; classes D (F(4) down x F(6) across, 6 tiles),
+    D' (F(3) x F(6), 2), B (F(4) x F(3), 3) and the corner as B' (F(3) down, F(4) across, three of its four columns used: the class it is at 19x19).
+    488 positions per channel pair and board -- conv_wino4.hip's F(4x4) tiling of the same board has 534."""
+    rng = np.random.default_rng(4)
+    n = 15
+    x, g = rng.standard_normal((n, n)), rng.standard_normal((3, 3))
+    ref, xp = direct(x, g)
+    cols = [(0, 6, 6), (6, 6, 6), (12, 3, 3)]
+    rows = [(0, 4, 4), (4, 4, 4), (8, 4, 4), (12, 3, 3)]
+    out, npos = tiled(xp, g, n, rows, cols, lambda ty, tx, mv, mh: (mv, 4 if (ty == 3 and tx == 2) else mh))
+    assert npos == 488 == 6 * 48 + 2 * 40 + 3 * 30 + 30
+    assert np.abs(out - ref).max() < 1e-11
+
+
 def test_wino4_tiling_of_the_19_and_15_boards():
     rng = np.random.default_rng(2)
     for n, want in ((19, 846), (15, 534)):      # 16 x 36 + 9 x 30 and 9 x 36 + 7 x 30

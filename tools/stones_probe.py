@@ -20,7 +20,7 @@ seed = int(sys.argv[5]) if len(sys.argv) > 5 else 7
 pname = sys.argv[6] if len(sys.argv) > 6 else "fp32"
 prec = {"fp32": pkg.PREC_FP32, "bf16x3": pkg.PREC_BF16X3}[pname]
 wl = bench.WORKLOADS[name]
-r = bench.stones_probe(pkg, wl, games, sims, prec, seed=seed, progress=True)
+r = bench.stones_probe(pkg, wl, games, sims, prec, seed=seed, progress=True, partial_path=os.environ.get("C6_PROBE_PARTIAL"))
 r["seed"] = seed
 r.update(workload=name, precision=pname, board=wl["n"], net_blocks=wl["blocks"], net_channels=wl["channels"], src_hash=bench.kernel_source_hash(), rng=pkg.rng_spec())
 if also:      # how the game length moves with the simulation budget: further budgets on fewer games
