@@ -173,6 +173,30 @@ void free_member_buffers(Member &mb) {
 
 }      // namespace
 
+// RCCL: one communicator per member, all created by this process -- when the group first needs them (c6_group_enable_tuples): a group that only
+// plays (cpp_self_play) never pays for ncclCommInitAll.  C6_GROUP_NO_RCCL=1 forces the host-staged exchange (A/B, debugging).
+static void group_init_rccl(c6_group *g) {
+    const int n = (int)g->m.size();
+    const char *no = std::getenv("C6_GROUP_NO_RCCL");
+    if (!g->distinct || (no && no[0] == '1') || g->use_rccl) return;
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    Rccl &R = rccl();
+    if (!R.load()) {
+        if (n > 1) std::fprintf(stderr, "[connect6_amd] c6_group: %s -- tuples are pooled through host memory\n", R.err.c_str());
+        return;
+    }
+    std::vector<ncclComm_t> comms(n);
+    std::vector<int> dev(n);
+    for (int r = 0; r < n; r++) dev[r] = g->m[r].device;
+    const ncclResult_t nr = R.CommInitAll(comms.data(), n, dev.data());
+    if (nr != ncclSuccess) {
+        std::fprintf(stderr, "[connect6_amd] c6_group: ncclCommInitAll over %d device(s): %s -- tuples are pooled through host memory\n", n, R.GetErrorString(nr));
+        return;
+    }
+    for (int r = 0; r < n; r++) g->m[r].comm = comms[r];
+    g->use_rccl = true;
+}
+
 extern "C" int c6_group_create(const c6_config *cfg, const int *devices, int ndev, c6_group **out) {
     if (!cfg || !out) return gfail(C6_ERR_BAD_ARG, "null argument");
     const int visible = c6_device_count();
@@ -215,24 +239,6 @@ extern "C" int c6_group_create(const c6_config *cfg, const int *devices, int nde
         const std::string keep = c6_last_error();
         c6_group_destroy(g);
         return gfail(rc, keep);
-    }
-    // RCCL: one communicator per member, all created by this process.  C6_GROUP_NO_RCCL=1 forces the host-staged exchange (A/B, debugging).
-    const char *no = std::getenv("C6_GROUP_NO_RCCL");
-    if (g->distinct && !(no && no[0] == '1')) {
-        std::lock_guard<std::mutex> lk(g_rccl_mu);
-        Rccl &R = rccl();
-        if (!R.load()) {
-            if (n > 1) std::fprintf(stderr, "[connect6_amd] c6_group: %s -- tuples are pooled through host memory\n", R.err.c_str());
-        } else {
-            std::vector<ncclComm_t> comms(n);
-            const ncclResult_t nr = R.CommInitAll(comms.data(), n, dev.data());
-            if (nr != ncclSuccess) {
-                std::fprintf(stderr, "[connect6_amd] c6_group: ncclCommInitAll over %d device(s): %s -- tuples are pooled through host memory\n", n, R.GetErrorString(nr));
-            } else {
-                for (int r = 0; r < n; r++) g->m[r].comm = comms[r];
-                g->use_rccl = true;
-            }
-        }
     }
     *out = g;
     return C6_OK;
@@ -366,6 +372,7 @@ extern "C" int c6_group_enable_tuples(c6_group *g, size_t capacity_records) {
     if (!g || capacity_records == 0) return gfail(C6_ERR_BAD_ARG, "c6_group_enable_tuples: null group / zero capacity");
     if (g->cap) return gfail(C6_ERR_BAD_ARG, "c6_group_enable_tuples: already enabled");
     const size_t n = g->m.size();
+    group_init_rccl(g);
     for (Member &mb : g->m) {
         GHIP(hipSetDevice(mb.device));
         for (int i = 0; i < 2; i++) {

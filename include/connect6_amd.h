@@ -501,7 +501,7 @@ int c6_rollout_bench_playouts(c6_rollout *r, const int8_t *boards, int iters, do
  * (member r of n plays uids [first_r, first_r + games_r) of the SAME seeded game set a single engine would play -- a recycled slot advances
  * by the total -- so the union over the members does not depend on how many devices there are), no exchange while playing, and the
  * training tuples pooled over the members by an RCCL all-gather (ncclAllGather over xGMI, one communicator per member from
- * ncclCommInitAll; librccl is opened when the first group with more than zero distinct devices is created).  Members that share a
+ * ncclCommInitAll; librccl is opened, and the communicators are made, when a group first enables tuples).  Members that share a
  * device (devices = {0, 0}: a one-GPU rehearsal) pool through host memory instead -- RCCL admits one rank per device.
  * cpp_self_play itself uses a group when more than one device is visible and the call brings enough games (environment: C6_DEVICES =
  * "all" | "0,1,.." | unset; C6_GROUP_MIN_GAMES = games per device below which fewer devices are used, default 64).
@@ -516,7 +516,8 @@ int c6_group_size(const c6_group *g);
 /* member r's engine / device / shard (first uid, games): the engine is a full c6_engine (c6_engine_root, _stats, ... work on it) */
 c6_engine *c6_group_engine(c6_group *g, int member);
 int c6_group_member_info(const c6_group *g, int member, int *device, uint32_t *first_uid, int *games);
-/* 1: the members' tuple pooling runs on RCCL (all devices distinct and librccl loaded); 0: through host memory */
+/* after c6_group_enable_tuples (the communicators are created there) -- 1: the members' tuple pooling runs on RCCL (all devices distinct and
+ * librccl loaded); 0: through host memory */
 int c6_group_uses_rccl(const c6_group *g);
 
 int c6_group_load_weights(c6_group *g, const float *blob, size_t nfloats);   /* every member (weights are replicated: 14-34 MB) */

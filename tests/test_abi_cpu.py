@@ -45,6 +45,25 @@ def test_no_gpu_fails_loudly():
         pkg.search_winner(9, np.zeros((81, 4), np.int8))
     with pytest.raises(pkg.C6Error, match="no HIP device"):       # the trainer has no CPU fallback either
         pkg.Trainer(9, 64, 2, 8)
+    with pytest.raises(pkg.C6Error, match="no gfx950 device"):    # nor does the multi-device group behind the C ABI (csrc/group.cpp)
+        pkg.Group(devices=[0, 0], board_size=9, num_games=4)
+
+
+def test_group_shard_plan_matches_the_python_hosts():
+    """c6_group_create's shard plan (csrc/group.cpp) restated here against alphazero-connect6_amd/shard.py, the plan bench.py's ranks use: member r of n gets
+    shard_games(total, n, r) slots starting at uid `first`, and a recycled slot advances by the total -- for equal shards exactly uid_plan's (base, stride)."""
+    from alphazero_connect6_amd import shard
+    for total, n in ((12, 2), (7, 3), (65536, 8), (4096, 1), (100, 6)):
+        per, rem = total // n, total % n
+        first = 0
+        for r in range(n):
+            mine = per + (1 if r < rem else 0)                  # group.cpp: mb.games
+            f = r * per + min(r, rem)                           # group.cpp: mb.first_uid
+            assert (mine, f) == shard.shard_games(total, n, r) and f == first
+            if rem == 0:
+                assert shard.uid_plan(per, n, r) == (f, total)  # (base, stride): c.game_uid_base, c.game_uid_stride = cfg->num_games
+            first += mine
+        assert first == total
 
 
 def test_raw_path_hooks():  # rawobj.cpp:5-65

@@ -44,8 +44,6 @@ def run_one_engine(n, G, S, seed, evaluator=None, blob=None, **kw):
 def check_group_equals_engine(devices, n, G, S, seed, evaluator=None, blob=None, expect_rccl=None, **kw):
     grp = pkg.Group(devices=devices, board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=evaluator or pkg.EVAL_RANDOM, **kw)
     assert grp.size == len(devices)
-    if expect_rccl is not None:
-        assert grp.uses_rccl == expect_rccl
     if blob is not None:
         grp.load_weights(blob)
     # the shard plan: a partition of [0, G) in member order, the first G % members members one game longer (shard.shard_games)
@@ -55,7 +53,10 @@ def check_group_equals_engine(devices, n, G, S, seed, evaluator=None, blob=None,
         assert mi["device"] == devices[r] and mi["first_uid"] == first and mi["games"] == G // grp.size + (1 if r < G % grp.size else 0)
         first += mi["games"]
     assert first == G
+    assert not grp.uses_rccl                                                      # (the communicators are made when tuples are enabled)
     grp.enable_tuples(G * n * n)
+    if expect_rccl is not None:
+        assert grp.uses_rccl == expect_rccl
     grp.run()
     st = grp.stats()
     assert st["games_finished"] == G and st["live_games"] == 0 and st["overflow_games"] == 0

@@ -116,7 +116,7 @@ def test_z_rows_are_half_of_the_output_transform():
 
 
 def test_candidate_tilings_position_counts():
-    """DESIGN 9.1 (not built): F(6,3) both ways on the 19x19 board -- 19 = 6 + 6 + 4 + 3 down as well as across -- is exact and takes 27^2 = 729
+    """DESIGN 9, lever L2 (not built): F(6,3) both ways on the 19x19 board -- 19 = 6 + 6 + 4 + 3 down as well as across -- is exact and takes 27^2 = 729
     positions per channel pair and board (today 788: -7.5 % matrix work; its f32 error is 1.4 x today's, tools/wino_tile_error.py); the reference's
     own 15x15 board as 6 + 6 + 3 both ways would take 21^2 = 441 (today's F(4,3) tiling: 534), and with F(4,3) kept down the board 23 x 21 = 483."""
     rng = np.random.default_rng(3)
