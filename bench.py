@@ -339,6 +339,8 @@ def main():
                          "and reported beside it unless --single-precision")
     ap.add_argument("--single-precision", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the live stones-per-game probe and the steady-state tree measurement")
+    ap.add_argument("--no-side-reports", action="store_true", help="skip the side reports that build engines of their own (small_batches: 1 and 64 games; many_games: 16 384 games) "
+                    "-- ADVICE r5: they lengthen the default run by about 15 s")
     ap.add_argument("--probe-games", type=int, default=256)
     ap.add_argument("--gather-every", type=int, default=0, help="rounds between tuple exchanges at N > 1 (0: 1 for net workloads, 64 otherwise)")
     ap.add_argument("--exchange-always", action="store_true", help="run the tuple exchange every --gather-every rounds at N = 1 too (its cost on one GPU: "
@@ -546,7 +548,7 @@ def main():
 
     # ---- the same net at the small end of the batch axis (N = 1, net workloads): what a round costs for one game and for 64 (r5: the GEMM's split form) ------
     small_side = None
-    if world == 1 and is_net and not args.no_probe and not args.games:
+    if world == 1 and is_net and not args.no_probe and not args.games and not args.no_side_reports:
         small_side = {"what": "ms per simulation round of this workload's net with few concurrent games (same kernels; below ~800 games the convolution's GEMM "
                               "hands a row of a block's positions to a workgroup instead of the block, for a handful of games to four waves: DESIGN 5.1b)",
                       "cases": []}
@@ -559,7 +561,7 @@ def main():
 
     # ---- north_star's target in the driver's own line: >= 10 k concurrent 19x19 games at 400 simulations per move on ONE MI355X ----------------
     many_side = None
-    if world == 1 and is_net and not args.no_probe and not args.games and args.workload == "config2":
+    if world == 1 and is_net and not args.no_probe and not args.games and args.workload == "config2" and not args.no_side_reports:
         many_side = {"what": "this workload's net and budget with 16 384 concurrent games on the one GPU (4 net passes of 32 768 dihedral images per round): "
                              "north_star's target is >= 10 000 concurrent 19x19 games at 400 simulations per move", "games": 16384}
         try:      # (a side report: its failure must not cost the line)
@@ -632,7 +634,7 @@ def main():
                                               "c6_w6_out_kernel (last layer + heads): HBM bound",
                                    "avg_ms_per_layer": tr_ms, "algorithmic_bytes_per_layer": tr_bytes / nl,
                                    "achieved_gbs": tr_bytes / nl / max(tr_ms, 1e-9) / 1e6,
-                                   "traffic_mid_kernel": pmc_record("c6_w6_mid_kernel<false>").get("hbm_bytes_per_launch") if std else None}
+                                   "traffic_mid_kernel": pmc_record("c6_w6_mid_kernel<19, false>").get("hbm_bytes_per_launch") if std else None}
                 r["conv_layer_tflops_algorithmic"] = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
             if name == "bf16x3":
                 r.update(mfma_flops_per_algorithmic_flop=3, executed_mfma_tflops=3 * alg, frac_executed=3 * alg / peak)

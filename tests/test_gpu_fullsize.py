@@ -230,3 +230,58 @@ def test_config2_engine_on_distinct_midgame_boards():
         az.close()
     net.close()
     eng.close()
+
+
+def test_config2_engine_moves_by_itself_with_the_net():
+    """Config 2 as bench.py runs it -- staggered phases: slot g starts its first move with g mod S simulations already counted, so every round about
+    G / S games make their move -- 6 rounds with the resident net (4096 games, S = 400, C = 256, stem + 3 blocks).  The games whose phase is S - 1 ... S - 6
+    have then played their OWN first stone (policy() on the root's child visits, K1, next()'s prune and re-rooting, all under EVAL_NET at the
+    benchmark's batch) and searched on from the new root: their leaves are one- and two-stone boards reached by the engine itself.  Sampled slots of
+    every such phase against the oracle doing the same thing -- S - k searches, policy, Game::set, prune, the remaining searches: the stone, then the new
+    root's child visits exactly and q / priors / value to 1e-5."""
+    need_gpu()
+    import __graft_entry__ as ge
+    n, G, S, C, blocks, R, seed = 19, 4096, 400, 256, 4, 6, 2026
+    blob = ge.make_random_blob(n, C, blocks, np.random.default_rng(12))
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks, stagger=True)
+    eng.load_weights(blob)
+    eng.step(R)
+    st = eng.stats()
+    moved = [g for g in range(G) if S - (g % S) <= R]
+    assert st["simulations"] == G * R and st["overflow_games"] == 0 and st["live_games"] == G and st["stones"] == len(moved) == 6 * (G // S) + sum(g % S >= S - 6 for g in range(G - G % S, G))
+    net = o.Net(n, C, blocks, blob)
+    fn, ctx = net.eval_fn()
+    for g in (394, 395, 396, 397, 398, 399, 799, 2397, 3999, 0, 1):
+        k = g % S
+        first = S - k                                            # searches before the slot's first move
+        az = o.AlphaZero(n, num_simulation=S, eval_kind=o.EVAL_CUSTOM, eval_fn=fn, ctx=ctx, seed=seed, game_uid=g)
+        game = o.new_game(n)
+        s = o.sim_from_game(game)
+        az.init(s)
+        for _ in range(min(first, R)):
+            az.search(s)
+        r = eng.root(g)
+        if first <= R:
+            cell = az.policy(s)
+            az.prune(s)
+            o.game_set(game, cell // n, cell % n)
+            s = o.sim_from_game(game)
+            az.init(s)
+            for _ in range(R - first):
+                az.search(s)
+            assert r["stones"] == 1 and r["board"].reshape(-1)[cell] == -1 and (r["board"] != 0).sum() == 1, (g, cell)
+        else:
+            assert r["stones"] == 0
+        board = game.np_board()
+        assert (r["board"] == board).all() and r["turn"] == game.turn and r["remain"] == game.num_remain, g
+        vis, q, p = az.children(board)
+        empty = board.reshape(-1) == 0
+        if az.node_info(board).found and az.node_info(board).has_prob:
+            assert (r["visits"][empty] == vis[empty]).all(), (g, np.flatnonzero(r["visits"] > 0), np.flatnonzero(vis > 0))
+            assert np.abs(r["q"][empty] - q[empty]).max() <= 1e-5 and np.abs(r["prior"][empty] - p[empty]).max() <= 1e-5, g
+            assert abs(r["root_value"] - az.node_info(board).value) <= 1e-5, g
+        else:      # (the slot moved in the last round: its new root has not been searched yet)
+            assert first == R and r["root_visit"] == 0, g
+        az.close()
+    net.close()
+    eng.close()

@@ -1,0 +1,67 @@
+"""profiles/rNN_boundary_bytes.md: the FP32 tower's kernels of one config-2 round, bytes against time (move layer_frac or show the floor
+with bytes).  Reads the committed rocprofv3 summaries of `tools/profile_round.sh` (kernel trace + FETCH_SIZE / WRITE_SIZE passes, profiles/summarize.py):
+    python tools/boundary_bytes.py r06 > profiles/r06_boundary_bytes.md
+Algorithmic bytes are DESIGN 4's: V = 788 positions x C x 4 B, Z = 536 row sums x C x 4 B, activations = 361 x C x 4 B per board, 32 768 boards per launch."""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")))["kernels"]
+stats = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")))}
+B, C = 32768, 256
+V, Z, A = 788 * C * 4 * B, 536 * C * 4 * B, 361 * C * 4 * B
+ROWS = [      # kernel (as rocprofv3 names it), launches per round (stem + 3 blocks = 6 layers), algorithmic bytes read / written, what it is
+    ("void c6_w6_stem_in_kernel<19>", 1, 0, V, "boards -> stem -> V of layer 1 (the stem's activations are computed, never stored)"),
+    ("void c6_w6_gemm_kernel<false, false, false>", 6, V * 708 // 788, Z * 708 // 788, "GEMM, rows of six positions (MFMA-bound: its bytes ride under the matrix time)"),
+    ("void c6_w6_gemm_kernel<true, false, false>", 6, V * 80 // 788, Z * 80 // 788, "GEMM, class D' (rows of five)"),
+    ("void c6_w6_mid_kernel<19, true>", 1, Z, V + A, "layer 2 -> 3: residual = the stem, recomputed; activations out"),
+    ("void c6_w6_mid_kernel<19, false>", 4, None, None, "3 inside a block (Z in, V out) + 1 across blocks (Z + residual in, activations + V out)"),
+    ("void c6_w6_out_kernel<19>", 1, Z + A, 0, "last layer: Z + residual in, the heads' three filter sums out"),
+]
+
+
+def find(table, name):
+    for k, v in table.items():
+        if k.strip() == name or k.strip().startswith(name):
+            return v
+    return None
+
+
+print(f"# {tag}: bytes and time of the FP32 tower's kernels, one round of config 2 (32 768 boards per launch, MI355X)\n")
+print("Counters: `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` in separate passes (FETCH doubled on gfx950, MI355X_MICROARCH.md); times: `--kernel-trace --stats`")
+print(f"of the same command (`profiles/{tag}_kernel_stats.csv`, `profiles/{tag}_pmc_summary.json`). Algorithmic bytes per launch: V {V / 1e9:.1f} GB, Z {Z / 1e9:.1f} GB,")
+print(f"activations / residual {A / 1e9:.1f} GB each (DESIGN 4).\n")
+print("| kernel | per round | ms | algorithmic GB (read + written) | FETCH GB | WRITE GB | counters / algorithmic | TB/s (counter bytes / time) | what |")
+print("|---|---|---|---|---|---|---|---|---|")
+tot_ms, tot_hbm_ms, tot_bytes = 0.0, 0.0, 0.0
+for name, per_round, rd, wr, what in ROWS:
+    p, s = find(pmc, name), find(stats, name)
+    if p is None or s is None:
+        print(f"| `{name}` | {per_round} | (not in the summaries) | | | | | | {what} |")
+        continue
+    ms = float(s["AverageNs"]) / 1e6
+    f, w = 2.0 * p.get("FETCH_SIZE_avg_KiB", 0.0) * 1024, p.get("WRITE_SIZE_avg_KiB", 0.0) * 1024
+    if rd is None:      # the four launches average three (Z, V) and one (Z + A, V + A) boundary
+        rd, wr = Z + A / 4.0, V + A / 4.0
+    alg = rd + wr
+    tot_ms += per_round * ms
+    if "gemm" not in name:
+        tot_hbm_ms += per_round * ms
+        tot_bytes += per_round * (f + w)
+    print(f"| `{name.replace('void ', '')}` | {per_round} | {ms:.2f} | {rd / 1e9:.1f} + {wr / 1e9:.1f} | {f / 1e9:.1f} | {w / 1e9:.1f} | {(f + w) / alg:.2f} | {(f + w) / ms / 1e9:.2f} | {what} |")
+print(f"\nSum over a round: {tot_ms:.1f} ms, of which {tot_hbm_ms:.1f} ms in the HBM-bound kernels moving {tot_bytes / 1e9:.0f} GB = {tot_bytes / tot_hbm_ms / 1e9:.2f} TB/s on average")
+print("(yardsticks on the same boxes, `tools/probe/hbm_write.hip`: float4 read loop 6.2-6.3 TB/s, write loop 4.9-5.4, copy 4.9-5.5; datasheet 8).\n")
+gemm = sum(float(find(stats, n)["AverageNs"]) / 1e6 for n in ("void c6_w6_gemm_kernel<false, false, false>", "void c6_w6_gemm_kernel<true, false, false>") if find(stats, n))
+bnd = tot_hbm_ms / 6.0
+print("## What each lever would return (per round of config 2; a layer = GEMM pair + one boundary launch)\n")
+print("| lever | bytes it removes | return at the measured rates | cost / why not |")
+print("|---|---|---|---|")
+print(f"| boundary kernels at the copy yardstick (5.5 TB/s) instead of their own rate | none | {tot_hbm_ms - tot_bytes / 5.5e9:.1f} ms of {tot_hbm_ms:.1f} | they already run at or above the plain copy loop; only `c6_w6_out_kernel` (reads only) sits below the read loop |")
+print(f"| `c6_w6_out_kernel` at the read yardstick (6.2 TB/s) | none | {float(find(stats, 'void c6_w6_out_kernel<19>')['AverageNs']) / 1e6 - (2.0 * find(pmc, 'void c6_w6_out_kernel<19>').get('FETCH_SIZE_avg_KiB', 0) * 1024) / 6.2e9:.1f} ms | fewer cross-lane additions in its filter sums (108 DPP adds per slice, a pairing tree needs ~55) |")
+print(f"| full output transform in the GEMM's epilogue (the boundary reads Y = {A / 1e9:.1f} GB instead of Z = {Z / 1e9:.1f} GB) | {(Z - A) / 1e9:.1f} GB read per layer (+ as much written by the GEMM, hidden under its matrix time) | {5 * (Z - A) / 5.5e9 / 1e-3:.1f} ms | A6^T needs all 8 row sums of a tile column at once: 8 x 4 x 32 accumulator registers per wave; the wave has 256 and the row sums in flight already take 160 |")
+print(f"| F(6,3) both ways (729 positions instead of 788) | 7.5 % of V ({0.075 * V / 1e9:.1f} GB per layer, read by the GEMM and written by the boundary) | {6 * gemm * 0.05:.1f} ms of GEMM (7.5 % fewer products, 2.5 % more row-sum arithmetic) + {6 * 0.075 * V / 5.5e9 / 1e-3:.1f} ms of boundary | a GEMM re-blocked for six row sums (32-tile wave tiles: twice the weight stream per FLOP), boundary kernels with an 8-row window, a sixth weight set |")
+print(f"| V and Z never leave the CU (a fused layer kernel) | {(V + Z) / 1e9:.1f} GB written and read back per layer | up to {tot_hbm_ms * (V + Z) / (V + Z + A):.0f} ms | a block of 64 tiles x 256 channels needs its whole input patch for every position: 64 x 48 pixels x 256 x 4 B = 3.1 MB against 160 KB of LDS, of which the GEMM's V slabs fill 133; and kernels sharing a CU with the FP32-MFMA waves take the SUM of their times (`profiles/r05_w6_overlap.txt`) |")
+print(f"\nA layer today: GEMM pair {gemm:.1f} ms (matrix-bound, 0.90 of the FP32-matrix peak) + boundary {bnd:.1f} ms (HBM-bound) -- the two phases alternate and their times add.")

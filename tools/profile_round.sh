@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_round.sh TAG  -- run ON THE GPU BOX (through gpurun): the rocprofv3 passes behind profiles/<TAG>_*.
+# tools/profile_round.sh TAG [bench.py arguments]  -- run ON THE GPU BOX (through gpurun): the rocprofv3 passes behind profiles/<TAG>_*.
 #   1. --kernel-trace --stats              -> per-kernel durations
 #   2. --pmc FETCH_SIZE                    -> HBM read bytes   (TCC: 3 slots)
 #   3. --pmc WRITE_SIZE                    -> HBM write bytes  (TCC: 2 slots; cannot share a pass with FETCH_SIZE)
@@ -7,13 +7,14 @@
 # Counter passes carry no trace options (gpurun refuses the combination).  Afterwards, in the build container:
 #   python profiles/summarize.py gpurun_out/prof_<TAG> <TAG>
 tag=${1:-r02}
+shift      # further arguments go to bench.py (e.g. --workload ref15)
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 # C6_NO_VMM=1: under rocprofv3 the record pools are plain allocations (a --kernel-trace run with hipMemMap'ed pools did not come back on this
 # pool's runtime); nothing the profiled kernels do depends on how the pools were allocated
 export C6_NO_VMM=1
-B="python3 bench.py --no-cpu-baseline --no-probe"
+B="python3 bench.py --no-cpu-baseline --no-probe $*"
 T="timeout -k 10 500"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- $B --steps 2 --warmup 1 > $out/bench_kt.json 2> $out/kt.err
 $T rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B --steps 1 --warmup 1 > $out/bench_pmc1.json 2> $out/pmc1.err
