@@ -59,9 +59,24 @@ bnd = tot_hbm_ms / 6.0
 print("## What each lever would return (per round of config 2; a layer = GEMM pair + one boundary launch)\n")
 print("| lever | bytes it removes | return at the measured rates | cost / why not |")
 print("|---|---|---|---|")
-print(f"| boundary kernels at the copy yardstick (5.5 TB/s) instead of their own rate | none | {tot_hbm_ms - tot_bytes / 5.5e9:.1f} ms of {tot_hbm_ms:.1f} | they already run at or above the plain copy loop; only `c6_w6_out_kernel` (reads only) sits below the read loop |")
-print(f"| `c6_w6_out_kernel` at the read yardstick (6.2 TB/s) | none | {float(find(stats, 'void c6_w6_out_kernel<19>')['AverageNs']) / 1e6 - (2.0 * find(pmc, 'void c6_w6_out_kernel<19>').get('FETCH_SIZE_avg_KiB', 0) * 1024) / 6.2e9:.1f} ms | fewer cross-lane additions in its filter sums (108 DPP adds per slice, a pairing tree needs ~55) |")
-print(f"| full output transform in the GEMM's epilogue (the boundary reads Y = {A / 1e9:.1f} GB instead of Z = {Z / 1e9:.1f} GB) | {(Z - A) / 1e9:.1f} GB read per layer (+ as much written by the GEMM, hidden under its matrix time) | {5 * (Z - A) / 5.5e9 / 1e-3:.1f} ms | A6^T needs all 8 row sums of a tile column at once: 8 x 4 x 32 accumulator registers per wave; the wave has 256 and the row sums in flight already take 160 |")
-print(f"| F(6,3) both ways (729 positions instead of 788) | 7.5 % of V ({0.075 * V / 1e9:.1f} GB per layer, read by the GEMM and written by the boundary) | {6 * gemm * 0.05:.1f} ms of GEMM (7.5 % fewer products, 2.5 % more row-sum arithmetic) + {6 * 0.075 * V / 5.5e9 / 1e-3:.1f} ms of boundary | a GEMM re-blocked for six row sums (32-tile wave tiles: twice the weight stream per FLOP), boundary kernels with an 8-row window, a sixth weight set |")
+print(f"| boundary kernels at the copy yardstick (5.5 TB/s) instead of their own rate | none | {max(tot_hbm_ms - tot_bytes / 5.5e12 * 1e3, 0.0):.1f} ms of {tot_hbm_ms:.1f} | they already run at or above the plain copy loop; only `c6_w6_out_kernel` (reads only) sits below the read loop |")
+print(f"| `c6_w6_out_kernel` at the read yardstick (6.2 TB/s) | none | {float(find(stats, 'void c6_w6_out_kernel<19>')['AverageNs']) / 1e6 - (2.0 * find(pmc, 'void c6_w6_out_kernel<19>').get('FETCH_SIZE_avg_KiB', 0) * 1024) / 6.2e12 * 1e3:.1f} ms | fewer cross-lane additions in its filter sums (108 DPP adds per slice, a pairing tree needs ~55) |")
+print(f"| full output transform in the GEMM's epilogue (the boundary reads Y = {A / 1e9:.1f} GB instead of Z = {Z / 1e9:.1f} GB) | {(Z - A) / 1e9:.1f} GB read per layer (+ as much written by the GEMM, hidden under its matrix time) | {5 * (Z - A) / 5.5e12 * 1e3:.1f} ms (5 boundary launches) | A6^T needs all 8 row sums of a tile column at once: 8 x 4 x 32 accumulator registers per wave; the wave has 256 and the row sums in flight already take 160 |")
+print(f"| F(6,3) both ways (729 positions instead of 788) | 7.5 % of V ({0.075 * V / 1e9:.1f} GB per layer, read by the GEMM and written by the boundary) | {6 * gemm * 0.05:.1f} ms of GEMM (7.5 % fewer products, 2.5 % more row-sum arithmetic) + {6 * 0.075 * V / 5.5e12 * 1e3:.1f} ms of boundary | a GEMM re-blocked for six row sums (32-tile wave tiles: twice the weight stream per FLOP), boundary kernels with an 8-row window, a sixth weight set |")
 print(f"| V and Z never leave the CU (a fused layer kernel) | {(V + Z) / 1e9:.1f} GB written and read back per layer | up to {tot_hbm_ms * (V + Z) / (V + Z + A):.0f} ms | a block of 64 tiles x 256 channels needs its whole input patch for every position: 64 x 48 pixels x 256 x 4 B = 3.1 MB against 160 KB of LDS, of which the GEMM's V slabs fill 133; and kernels sharing a CU with the FP32-MFMA waves take the SUM of their times (`profiles/r05_w6_overlap.txt`) |")
+print("\n## Why the GEMM's fraction of the NOMINAL peak stops near 0.9: the clock\n")
+print("| kernel | matrix pipes busy | effective clock (GRBM_GUI_ACTIVE / 8 / duration) | busy x clock / 2.4 GHz |")
+print("|---|---|---|---|")
+for t2, lab in ((tag, "19x19"), (tag + "ref15", "15x15")):
+    f2 = os.path.join(ROOT, "profiles", f"{t2}_pmc_summary.json")
+    if not os.path.exists(f2):
+        continue
+    k2 = json.load(open(f2))["kernels"]
+    for nm in ("void c6_w6_gemm_kernel<false, false, false>", "void c6_w6_gemm_kernel<true, false, false>"):
+        v = find(k2, nm)
+        if v and v.get("effective_clock_ghz"):
+            print(f"| `{nm.replace('void ', '')}` at {lab} | {v['mfma_util']:.3f} | {v['effective_clock_ghz']:.3f} GHz | {v['mfma_util'] * v['effective_clock_ghz'] / 2.4:.3f} |")
+print("\nThe peak of 157.3 TFLOP/s is quoted at 2.4 GHz.  Under these kernels the card draws 1 286 W of its 1 400 W cap (`profiles/r05_w6_power.txt`) and its power management clocks it at")
+print("2.19-2.38 GHz: with the pipes busy 0.93-0.95 of the cycles, `frac` = busy x clock / 2.4 = 0.87-0.90 is what the part gives for this instruction mix;")
+print("the denser 15x15 launch (0.949 busy) is clocked LOWER than the 19x19 one (0.934), so its fraction of the nominal peak is lower although its pipes idle less.")
 print(f"\nA layer today: GEMM pair {gemm:.1f} ms (matrix-bound, 0.90 of the FP32-matrix peak) + boundary {bnd:.1f} ms (HBM-bound) -- the two phases alternate and their times add.")
