@@ -41,7 +41,7 @@ ENGINE_SYMBOLS = ["c6_last_error", "c6_version", "c6_rng_spec", "c6_device_count
                   "c6_tuple_stride", "c6_engine_set_tuple_buffer", "c6_engine_swap_tuple_buffer", "c6_engine_stream", "c6_engine_enable_tuples", "c6_engine_fetch_tuples",
                   "c6_engine_root", "c6_engine_profile", "c6_engine_profile_read", "c6_board_step", "c6_search_winner",
                   "c6_legal_mask", "c6_augment8", "c6_recover8", "c6_net_forward", "c6_net_forward_prec", "c6_dirichlet_noise",
-                  "c6_bench_conv", "c6_bench_board", "c6_bench_board_scan", "c6_pool_ring_selftest", "c6_conv_pack_m8_bytes", "c6_conv_pack_m8", "c6_replay_create", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
+                  "c6_bench_conv", "c6_bench_board", "c6_bench_board_scan", "c6_pool_ring_selftest", "c6_conv_pack_m8_bytes", "c6_conv_pack_m8", "c6_replay_create", "c6_replay_create_on_device", "c6_replay_destroy", "c6_replay_push_dev", "c6_replay_push_host",
                   "c6_replay_clear", "c6_replay_size", "c6_replay_sample", "c6_engine_push_tuples", "c6_replay_sample_device",
                   "c6_replay_board_size", "c6_trainer_create", "c6_trainer_destroy", "c6_trainer_set_lr", "c6_trainer_load_weights",
                   "c6_trainer_export_weights", "c6_trainer_step", "c6_trainer_loss", "c6_trainer_step_replay", "c6_trainer_gradients",

@@ -84,6 +84,19 @@ extern "C" int c6_replay_create(int n, size_t max_size, c6_replay **out) {
     return C6_OK;
 }
 
+// the same on a named device (a host without the HIP headers -- the Rust side of a c6_group -- cannot select one itself)
+extern "C" int c6_replay_create_on_device(int n, size_t max_size, int device, c6_replay **out) {
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return rfail(C6_ERR_NO_GPU, "no HIP device visible; this library has no CPU fallback");
+    if (device < 0 || device >= nd) return rfail(C6_ERR_BAD_ARG, "c6_replay_create_on_device: no such device");
+    int prev = 0;
+    hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return rfail(C6_ERR_HIP, "hipSetDevice failed");
+    const int rc = c6_replay_create(n, max_size, out);
+    hipSetDevice(prev);
+    return rc;
+}
+
 extern "C" void c6_replay_destroy(c6_replay *r) {
     if (!r) return;
     hipSetDevice(r->device);

@@ -396,7 +396,8 @@ int c6_dirichlet_noise(int board_size, int num, double alpha, const uint32_t *k0
 
 /* ---- replay buffer: device-resident restatement of AlphaZero/cpp_weighted/ReplayBuffer.hpp ---- */
 typedef struct c6_replay c6_replay;
-int c6_replay_create(int board_size, size_t max_size, c6_replay **out);      /* ReplayBuffer(max_size, .), :12-20 */
+int c6_replay_create(int board_size, size_t max_size, c6_replay **out);      /* ReplayBuffer(max_size, .), :12-20; on the calling thread's current device */
+int c6_replay_create_on_device(int board_size, size_t max_size, int device, c6_replay **out);   /* ... on a named one (e.g. a c6_group member's) */
 void c6_replay_destroy(c6_replay *r);
 /* push_game (:22-29) for every record of a tuple buffer.  _dev: records and their count live on the device (e.g. the
  * all-gathered tuple buffer), count clamped to `cap`; no host synchronisation. */

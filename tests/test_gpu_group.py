@@ -223,3 +223,26 @@ def test_compiled_cpp_host_drives_a_group(tmp_path):
     # steady state with the exchange overlapped (recycle + stagger, pooled every 32 rounds): nothing dropped, every emitted tuple pooled
     r = json.loads(subprocess.check_output([str(exe), "0,0", str(n), "64", "6", "7", "uniform", "512", "32"], text=True, timeout=300).strip().splitlines()[-1])
     assert r["rounds"] == 512 and r["dropped"] == 0 and r["pooled_records"] == r["tuples"] > 0 and r["payload_pools"] >= 3 and r["copies_equal"] == 1, r
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_compiled_cpp_host_runs_the_reference_outer_loop(tmp_path):
+    """tools/cpp/group_loop.cpp: the reference trainer's outer loop (AlphaZero/cpp_weighted/main.cpp:138-168) as a C++ host over a group -- self-play
+    sharded over the members with the resident net, tuples pooled, member 0's copy pushed device to device into the replay buffer, SGD steps sampled
+    from it, the new weights loaded into the next epoch's group.  Two epochs on members {0, 0}: every stone played becomes exactly one pooled tuple and
+    one buffer record, the losses are finite numbers, nothing was dropped."""
+    need_gpu()
+    exe = tmp_path / "group_loop"
+    libdir = os.path.join(ROOT, "alphazero-connect6_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cpp", "group_loop.cpp"),
+                           "-L" + libdir, "-lconnect6_amd", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.check_output([str(exe), "0,0", "9", "64", "3", "48", "8", "2", "6", "128"], text=True, timeout=600)
+    lines = [json.loads(l) for l in out.strip().splitlines() if l.startswith("{")]
+    assert [l["epoch"] for l in lines] == [0, 1]
+    total = 0
+    for l in lines:
+        assert l["members"] == 2 and l["games_finished"] == 48 and l["dropped"] == 0
+        assert l["pooled"] == l["tuples"] == l["stones"] > 48 * 11
+        total += l["stones"]
+        assert l["buffer"] == total
+        assert np.isfinite(l["loss_first"]) and np.isfinite(l["loss_last"]) and 0 < l["loss_last"] < 20
