@@ -67,8 +67,8 @@ print(f"| V and Z never leave the CU (a fused layer kernel) | {(V + Z) / 1e9:.1f
 print("\n## Why the GEMM's fraction of the NOMINAL peak stops near 0.9: the clock\n")
 print("| kernel | matrix pipes busy | effective clock (GRBM_GUI_ACTIVE / 8 / duration) | busy x clock / 2.4 GHz |")
 print("|---|---|---|---|")
-for t2, lab in ((tag, "19x19"), (tag + "ref15", "15x15")):
-    f2 = os.path.join(ROOT, "profiles", f"{t2}_pmc_summary.json")
+for sub, lab in (("", "19x19"), ("ref15", "15x15")):      # (profiles/ref15/: the same passes of `bench.py --workload ref15`)
+    f2 = os.path.join(ROOT, "profiles", sub, f"{tag}_pmc_summary.json")
     if not os.path.exists(f2):
         continue
     k2 = json.load(open(f2))["kernels"]
