@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel trace of the training-step bench (run on the GPU box): per-kernel totals of tools/train_bench.py -> gpurun_out/prof_train/summary.txt
 out=gpurun_out/prof_train; mkdir -p $out; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 tools/train_bench.py --steps 3 > $out/kt.out 2> $out/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 tools/train_bench.py --steps 3 $* > $out/kt.out 2> $out/kt.err
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "*_agent_info.csv" -delete
 python3 - <<PY
 import csv, glob

@@ -13,7 +13,7 @@ import __graft_entry__ as ge
 ap = argparse.ArgumentParser()
 ap.add_argument("--board", type=int, default=15); ap.add_argument("--channels", type=int, default=256)
 ap.add_argument("--blocks", type=int, default=10); ap.add_argument("--batch", type=int, default=2048)
-ap.add_argument("--steps", type=int, default=5); ap.add_argument("--json", default="")
+ap.add_argument("--steps", type=int, default=5); ap.add_argument("--json", default=""); ap.add_argument("--only", default="", help="fp32 | bf16x3: one precision only (profiles)")
 a = ap.parse_args()
 pkg = load_package()
 n, C, nb, B = a.board, a.channels, a.blocks, a.batch
@@ -24,6 +24,8 @@ b = rng.integers(-1, 2, (B, n * n)).astype(np.float32); q = rng.integers(0, n * 
 flops = 3.0 * B * 2 * (nb - 1) * (2.0 * 9 * C * C * n * n)
 out = {"workload": f"train step: {n}x{n}, stem + {nb-1} residual blocks, C={C}, mini_batch {B}", "conv_flops_per_step": flops, "paths": {}}
 for name, prec in (("bf16x3", pkg.PREC_BF16X3), ("fp32", pkg.PREC_FP32)):
+    if a.only and a.only != name:
+        continue
     t = pkg.Trainer(n, C, nb, B, lr=1e-3, momentum=0.9, precision=prec)
     t.load_weights(blob)
     losses = [t.step(w, p, b, q)]                      # warm-up (includes first-touch allocation effects)
