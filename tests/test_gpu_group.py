@@ -246,3 +246,38 @@ def test_compiled_cpp_host_runs_the_reference_outer_loop(tmp_path):
         total += l["stones"]
         assert l["buffer"] == total
         assert np.isfinite(l["loss_first"]) and np.isfinite(l["loss_last"]) and 0 < l["loss_last"] < 20
+
+
+def test_group_argument_errors_are_reported_not_crashed():
+    """the group's entry points refuse what they cannot do with a status and a message (c6_last_error), never with a fault: a device that is not there,
+    fewer games than members, pooling before tuples are enabled, an _end without its _begin, tuples enabled twice; and a fetch with room for fewer
+    records than were pooled hands out the first `cap` of them"""
+    need_gpu()
+    import ctypes as C
+    L = pkg.lib()
+    with pytest.raises(pkg.C6Error, match="not visible"):
+        pkg.Group(devices=[0, 99], board_size=9, num_games=4)
+    with pytest.raises(pkg.C6Error, match="fewer games than members"):
+        pkg.Group(devices=[0, 0, 0], board_size=9, num_games=2)
+    grp = pkg.Group(devices=[0, 0], board_size=9, num_games=6, num_simulation=4, seed=1, evaluator=pkg.EVAL_UNIFORM)
+    with pytest.raises(pkg.C6Error, match="enable_tuples first"):
+        grp.pool_begin()
+    with pytest.raises(pkg.C6Error, match="without c6_group_pool_begin"):
+        grp.pool_end()
+    grp.enable_tuples(1000)
+    with pytest.raises(pkg.C6Error, match="already enabled"):
+        grp.enable_tuples(1000)
+    grp.pool_begin()
+    with pytest.raises(pkg.C6Error, match="has not been ended"):
+        grp.pool_begin()
+    p = grp.pool_end()
+    assert p["padded"] == 0 and int(p["counts"].sum()) == 0 and grp.fetch_pooled(0).shape[0] == 0      # nothing finished yet: nothing travels
+    assert L.c6_group_engine(grp.h, 2) is None and L.c6_group_member_info(grp.h, 5, None, None, None) != 0
+    grp.run()
+    p = grp.pool_tuples()
+    total = int(p["counts"].sum())
+    assert total == grp.stats()["tuples"] > 0
+    part = grp.fetch_pooled(1, cap=7)
+    assert part.shape[0] == 7 and (part == grp.fetch_pooled(1)[:7]).all()
+    grp.close()
+    grp.close()                                                                 # (idempotent)
