@@ -21,6 +21,13 @@ static void die(const char *what) {
     std::abort();
 }
 
+// the engine's entry points select their device on the calling thread: a caller that uses HIP itself (a libtorch trainer) finds its own current device again
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
 static uint64_t pick_seed() {
     if (const char *s = std::getenv("C6_SEED")) return std::strtoull(s, nullptr, 0);
     std::random_device rd;   // the reference seeds from the OS (thread_rng)
@@ -61,6 +68,7 @@ static void print_stone(int turn, int pos, int remain_before, long long ms) {
 
 extern "C" c6_vec cpp_self_play(c6_callback callback, c6_alloc_path alloc_path, c6_alloc_result alloc_result, int num_simulation,
                                 float epsilon, double dirichlet_alpha, float c_puct, bool debug, int num_game_thread) {
+    DeviceGuard dg_;
     c6_config cfg;
     c6_default_config(&cfg);
     cfg.board_size = N;
@@ -261,6 +269,7 @@ static bool read_human_move(int *row, int *col) {
 // "{player:?} ({row}, {col}), remain {n}, {s}.{ms} elapsed" (agent_impl/mod.rs:121-178).
 extern "C" c6_play_result cpp_play_with(c6_callback callback, c6_alloc_path alloc_path, int num_simulation, float epsilon, double dirichlet_alpha,
                                         float c_puct) {
+    DeviceGuard dg_;
     c6_config cfg;
     c6_default_config(&cfg);
     cfg.board_size = N;

@@ -39,6 +39,14 @@ int gfail(int code, const std::string &msg) { return c6_set_error(code, msg.c_st
         if (e_ != hipSuccess) return gfail(C6_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));       \
     } while (0)
 
+// The group's entry points select devices on the CALLING thread (HIP's current device is per thread): a host that uses HIP itself -- a libtorch trainer
+// calling cpp_self_play -- must find its own current device again afterwards, whichever member was touched last.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
 // ---- librccl, resolved at run time --------------------------------------------------------------------------------------
 struct Rccl {
     void *lib = nullptr;
@@ -198,6 +206,7 @@ static void group_init_rccl(c6_group *g) {
 }
 
 extern "C" int c6_group_create(const c6_config *cfg, const int *devices, int ndev, c6_group **out) {
+    DeviceGuard dg_;
     if (!cfg || !out) return gfail(C6_ERR_BAD_ARG, "null argument");
     const int visible = c6_device_count();
     if (visible < 1) return gfail(C6_ERR_NO_GPU, "no gfx950 device visible: libconnect6_amd has no CPU fallback");
@@ -218,23 +227,27 @@ extern "C" int c6_group_create(const c6_config *cfg, const int *devices, int nde
     // the shard plan of alphazero-connect6_amd/shard.py (shard_games + uid_plan): member r plays games [first, first + mine) of the call's G
     // games; a recycled slot continues with uid += G, so the union over the members is the game set of ONE engine with G slots
     const int per = cfg->num_games / n, rem = cfg->num_games % n;
-    int rc = C6_OK;
-    for (int r = 0; r < n && rc == C6_OK; r++) {
+    for (int r = 0; r < n; r++) {
         Member &mb = g->m[r];
         mb.device = dev[r];
         mb.games = per + (r < rem ? 1 : 0);
         mb.first_uid = cfg->game_uid_base + (uint32_t)(r * per + std::min(r, rem));
+    }
+    // the members' engines are built at the same time, each on its own host thread (pools of tens of GB per device: seconds each)
+    const int rc = for_members(g, [&](int r) {
+        Member &mb = g->m[r];
         c6_config c = *cfg;
         c.device = mb.device;
         c.num_games = mb.games;
         c.game_uid_base = mb.first_uid;
         c.game_uid_stride = (uint32_t)cfg->num_games;
-        rc = c6_engine_create(&c, &mb.eng);
-        if (rc == C6_OK && (hipSetDevice(mb.device) != hipSuccess || hipStreamCreateWithFlags(&mb.side, hipStreamNonBlocking) != hipSuccess ||
-                            hipEventCreateWithFlags(&mb.retired, hipEventDisableTiming) != hipSuccess ||
-                            hipEventCreateWithFlags(&mb.freed, hipEventDisableTiming) != hipSuccess))
-            rc = gfail(C6_ERR_HIP, "c6_group_create: side stream / event");
-    }
+        int rc_ = c6_engine_create(&c, &mb.eng);
+        if (rc_ != C6_OK) return rc_;
+        if (hipSetDevice(mb.device) != hipSuccess || hipStreamCreateWithFlags(&mb.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&mb.retired, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&mb.freed, hipEventDisableTiming) != hipSuccess)
+            return gfail(C6_ERR_HIP, "c6_group_create: side stream / event");
+        return (int)C6_OK;
+    });
     if (rc != C6_OK) {
         const std::string keep = c6_last_error();
         c6_group_destroy(g);
@@ -245,6 +258,7 @@ extern "C" int c6_group_create(const c6_config *cfg, const int *devices, int nde
 }
 
 extern "C" void c6_group_destroy(c6_group *g) {
+    DeviceGuard dg_;
     if (!g) return;
     {
         std::lock_guard<std::mutex> lk(g_cb_reg_mu);
@@ -283,6 +297,7 @@ extern "C" int c6_group_member_info(const c6_group *g, int member, int *device, 
 extern "C" int c6_group_uses_rccl(const c6_group *g) { return g && g->use_rccl ? 1 : 0; }
 
 extern "C" int c6_group_load_weights(c6_group *g, const float *blob, size_t nfloats) {
+    DeviceGuard dg_;
     if (!g || !blob) return gfail(C6_ERR_BAD_ARG, "null argument");
     return for_members(g, [&](int r) { return c6_engine_load_weights(g->m[r].eng, blob, nfloats); });
 }
@@ -304,17 +319,20 @@ extern "C" int c6_group_set_callback(c6_group *g, c6_callback cb, int concurrent
 }
 
 extern "C" int c6_group_step(c6_group *g, int rounds) {
+    DeviceGuard dg_;
     if (!g) return gfail(C6_ERR_BAD_ARG, "null group");
     return for_members(g, [&](int r) { return c6_engine_step(g->m[r].eng, rounds); });
 }
 
 extern "C" int c6_group_run(c6_group *g, long max_rounds) {
+    DeviceGuard dg_;
     if (!g) return gfail(C6_ERR_BAD_ARG, "null group");
     // every member to the end of its games, whatever the others do (a member with partial games -- C6_ERR_OVERFLOW -- does not stop the rest)
     return for_members(g, [&](int r) { return c6_engine_run(g->m[r].eng, max_rounds); });
 }
 
 extern "C" int c6_group_sync(c6_group *g) {
+    DeviceGuard dg_;
     if (!g) return gfail(C6_ERR_BAD_ARG, "null group");
     for (Member &mb : g->m) {
         GHIP(hipSetDevice(mb.device));
@@ -326,6 +344,7 @@ extern "C" int c6_group_sync(c6_group *g) {
 }
 
 extern "C" int c6_group_stats(c6_group *g, c6_stats *out) {
+    DeviceGuard dg_;
     if (!g || !out) return gfail(C6_ERR_BAD_ARG, "null argument");
     c6_stats s;
     std::memset(&s, 0, sizeof s);
@@ -352,6 +371,7 @@ extern "C" int c6_group_stats(c6_group *g, c6_stats *out) {
 }
 
 extern "C" int c6_group_fetch_games(c6_group *g, int cap, int *count, int *winners, int *lens, uint32_t *uids, int16_t *moves) {
+    DeviceGuard dg_;
     if (!g || !count) return gfail(C6_ERR_BAD_ARG, "null argument");
     const size_t cells = (size_t)g->cfg.board_size * g->cfg.board_size;
     int got = 0;
@@ -369,6 +389,7 @@ extern "C" int c6_group_fetch_games(c6_group *g, int cap, int *count, int *winne
 }
 
 extern "C" int c6_group_enable_tuples(c6_group *g, size_t capacity_records) {
+    DeviceGuard dg_;
     if (!g || capacity_records == 0) return gfail(C6_ERR_BAD_ARG, "c6_group_enable_tuples: null group / zero capacity");
     if (g->cap) return gfail(C6_ERR_BAD_ARG, "c6_group_enable_tuples: already enabled");
     const size_t n = g->m.size();
@@ -393,6 +414,7 @@ extern "C" int c6_group_enable_tuples(c6_group *g, size_t capacity_records) {
 }
 
 extern "C" int c6_group_pool_begin(c6_group *g) {
+    DeviceGuard dg_;
     if (!g) return gfail(C6_ERR_BAD_ARG, "null group");
     if (!g->cap) return gfail(C6_ERR_BAD_ARG, "c6_group_pool_begin: call c6_group_enable_tuples first");
     if (g->begun) return gfail(C6_ERR_BAD_ARG, "c6_group_pool_begin: the previous exchange has not been ended");
@@ -414,6 +436,7 @@ extern "C" int c6_group_pool_begin(c6_group *g) {
 }
 
 extern "C" int c6_group_pool_end(c6_group *g, uint32_t *counts, size_t *padded, uint64_t *dropped) {
+    DeviceGuard dg_;
     if (!g) return gfail(C6_ERR_BAD_ARG, "null group");
     if (!g->begun) return gfail(C6_ERR_BAD_ARG, "c6_group_pool_end without c6_group_pool_begin");
     const int old = g->cur ^ 1, n = (int)g->m.size();
@@ -495,6 +518,7 @@ extern "C" const void *c6_group_pooled(const c6_group *g, int member) {
 }
 
 extern "C" int c6_group_fetch_pooled(c6_group *g, int member, size_t cap, size_t *count, void *host_buf) {
+    DeviceGuard dg_;
     if (!g || !count || member < 0 || member >= (int)g->m.size()) return gfail(C6_ERR_BAD_ARG, "c6_group_fetch_pooled: bad argument");
     Member &mb = g->m[member];
     GHIP(hipSetDevice(mb.device));
@@ -510,6 +534,7 @@ extern "C" int c6_group_fetch_pooled(c6_group *g, int member, size_t cap, size_t
 }
 
 extern "C" int c6_group_push_pooled(c6_group *g, int member, c6_replay *rp) {
+    DeviceGuard dg_;
     if (!g || !rp || member < 0 || member >= (int)g->m.size()) return gfail(C6_ERR_BAD_ARG, "c6_group_push_pooled: bad argument");
     Member &mb = g->m[member];
     GHIP(hipSetDevice(mb.device));
