@@ -281,3 +281,31 @@ def test_group_argument_errors_are_reported_not_crashed():
     assert part.shape[0] == 7 and (part == grp.fetch_pooled(1)[:7]).all()
     grp.close()
     grp.close()                                                                 # (idempotent)
+
+
+def test_four_members_with_the_benchmark_net_equal_one_engine():
+    """four members sharing the GPU (four host threads, four engines with the benchmark's kernels: 19x19, C = 256, stem + 3 blocks, S = 400), 4 x 512 games,
+    6 rounds, against ONE engine with all 2048 slots: the same simulations, and slot i of member r has bit for bit the root of slot first_r + i -- a
+    board's net output does not depend on the batch it travels in, nor on which of the GEMM's work decompositions the batch size selects."""
+    need_gpu()
+    import __graft_entry__ as ge
+    n, C, blocks, G, S, R, seed = 19, 256, 4, 2048, 400, 6, 11
+    blob = ge.make_random_blob(n, C, blocks, np.random.default_rng(4))
+    grp = pkg.Group(devices=[0, 0, 0, 0], board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks)
+    grp.load_weights(blob)
+    grp.step(R)
+    grp.sync()
+    st = grp.stats()
+    assert st["simulations"] == G * R and st["live_games"] == G and st["overflow_games"] == 0
+    eng = pkg.Engine(board_size=n, num_games=G, num_simulation=S, seed=seed, evaluator=pkg.EVAL_NET, net_channels=C, net_blocks=blocks)
+    eng.load_weights(blob)
+    eng.step(R)
+    for member in range(4):
+        mi = grp.member_info(member)
+        assert mi["games"] == 512 and mi["first_uid"] == 512 * member
+        for slot in (0, 255, 511):
+            a, b = grp.engine_root(member, slot), eng.root(mi["first_uid"] + slot)
+            assert a["root_visit"] == b["root_visit"] == R and (a["visits"] == b["visits"]).all(), (member, slot)
+            assert (a["q"] == b["q"]).all() and (a["prior"] == b["prior"]).all() and a["root_value"] == b["root_value"], (member, slot)
+    eng.close()
+    grp.close()
