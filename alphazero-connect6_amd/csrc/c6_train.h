@@ -18,6 +18,9 @@ void c6t_bn_apply(size_t R, int C, const float *y, const float *mean, const floa
                   float *a, int relu, hipStream_t s);
 void c6t_bn_bwd_apply(size_t R, int C, const float *dout, const float *aout, const float *y, const float *mean, const float *var,
                       const float *gamma, const float *sum_dz, const float *sum_dzx, float *dy, float *dz_out, hipStream_t s);
+// ... with the column sums of dy (the bias gradient of the convolution in front) taken in the same pass (r6)
+void c6t_bn_bwd_apply_colsum(size_t R, int C, const float *dout, const float *aout, const float *y, const float *mean, const float *var, const float *gamma,
+                             const float *sum_dz, const float *sum_dzx, float *dy, float *dz_out, float *partial, float *bias_grad, hipStream_t s);
 void c6t_bn_running(int C, size_t R, const float *mean, const float *var, float *rmean, float *rvar, hipStream_t s);
 
 void c6t_head_conv_fwd(size_t R, int C, const float *a, const float *wp, const float *bp, const float *wv, const float *bv, float *yp, float *yv,

@@ -336,6 +336,66 @@ void c6t_bn_bwd_apply(size_t R, int C, const float *dout, const float *aout, con
     hipLaunchKernelGGL(c6t_bn_bwd_apply_kernel, dim3(2048), dim3(256), 0, s, R * C, R, C, dout, aout, y, mean, var, gamma, sum_dz, sum_dzx, dy, dz_out);
 }
 
+// r6: the same pass with the column sums of dy -- the gradient of the convolution's bias in front of this BatchNorm (model.hpp:61-78: conv has a bias) -- taken on
+// the way: a third pass over dy (c6t_colstats mode 2, 0.16 ms per tower layer) is gone.  Thread mapping, chunking and the order of every sum are
+// c6t_colstats4_kernel's (a thread owns four channels and every RL-th row of a 256-row chunk; row lanes added in lane order; chunks by the ordered
+// finalize kernel), and dy is computed by the same expression as above: dy AND the bias gradient are bit for bit what the two kernels gave.
+__global__ __launch_bounds__(256) void c6t_bn_bwd_apply4_kernel(size_t R, int C, const float *__restrict__ dout, const float *__restrict__ aout,
+                                                                const float *__restrict__ y, const float *__restrict__ mean, const float *__restrict__ var,
+                                                                const float *__restrict__ gamma, const float *__restrict__ sum_dz,
+                                                                const float *__restrict__ sum_dzx, float *__restrict__ dy, float *__restrict__ dz_out,
+                                                                float *__restrict__ partial) {
+    __shared__ f32x4 red[256];
+    const int CQ = C / 4, RL = 256 / CQ;
+    const int cq = threadIdx.x % CQ, rl = threadIdx.x / CQ, c = cq * 4;
+    const size_t r0 = (size_t)blockIdx.x * CS_ROWS;
+    const size_t r1 = r0 + CS_ROWS < R ? r0 + CS_ROWS : R;
+    const float invR = 1.0f / (float)R;
+    const f32x4 m = *reinterpret_cast<const f32x4 *>(mean + c), vv = *reinterpret_cast<const f32x4 *>(var + c), g = *reinterpret_cast<const f32x4 *>(gamma + c),
+                sdz = *reinterpret_cast<const f32x4 *>(sum_dz + c), sdzx = *reinterpret_cast<const f32x4 *>(sum_dzx + c);
+    f32x4 is;
+#pragma unroll
+    for (int q = 0; q < 4; q++) is[q] = 1.0f / sqrtf(vv[q] + BN_EPS);
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (size_t r = r0 + rl; r < r1; r += RL) {
+        f32x4 dz = *reinterpret_cast<const f32x4 *>(dout + r * C + c);
+        const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + r * C + c);
+        if (aout) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(aout + r * C + c);
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (!(a[q] > 0.f)) dz[q] = 0.f;
+        }
+        f32x4 d;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float xh = (yv[q] - m[q]) * is[q];
+            d[q] = g[q] * is[q] * (dz[q] - sdz[q] * invR - xh * sdzx[q] * invR);
+        }
+        *reinterpret_cast<f32x4 *>(dy + r * C + c) = d;
+        if (dz_out) *reinterpret_cast<f32x4 *>(dz_out + r * C + c) = dz;
+        s0 = s0 + d;
+    }
+    red[threadIdx.x] = s0;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < RL; l++) s0 = s0 + red[l * CQ + cq];
+        *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 0) * C + c) = s0;
+        *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 1) * C + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+// dy (and dz) as c6t_bn_bwd_apply, and bias_grad[c] = sum over the rows of dy[.][c]
+void c6t_bn_bwd_apply_colsum(size_t R, int C, const float *dout, const float *aout, const float *y, const float *mean, const float *var, const float *gamma,
+                             const float *sum_dz, const float *sum_dzx, float *dy, float *dz_out, float *partial, float *bias_grad, hipStream_t s) {
+    if (C == 64 || C == 128 || C == 256) {
+        const int nchunk = (int)((R + CS_ROWS - 1) / CS_ROWS);
+        hipLaunchKernelGGL(c6t_bn_bwd_apply4_kernel, dim3(nchunk), dim3(256), 0, s, R, C, dout, aout, y, mean, var, gamma, sum_dz, sum_dzx, dy, dz_out, partial);
+        hipLaunchKernelGGL(c6t_colstats_finalize_kernel, dim3((C + 31) / 32), dim3(32 * CSF_LANES), 0, s, 2, R, C, nchunk, partial, bias_grad, (float *)nullptr);
+    } else {
+        c6t_bn_bwd_apply(R, C, dout, aout, y, mean, var, gamma, sum_dz, sum_dzx, dy, dz_out, s);
+        c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, partial, bias_grad, nullptr, s);
+    }
+}
+
 // running = (1 - m) * running + m * batch   (variance: unbiased, as torch's BatchNorm), momentum 0.1
 __global__ void c6t_bn_running_kernel(int C, size_t R, const float *__restrict__ mean, const float *__restrict__ var, float *__restrict__ rmean,
                                       float *__restrict__ rvar) {

@@ -310,8 +310,7 @@ static int backward(c6_trainer *t) {
             const ConvBn &u = t->tower[l1];
             const float *m = t->mean + (size_t)(l1 + 1) * C, *v = t->var + (size_t)(l1 + 1) * C;
             c6t_colstats(1, R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, t->partial, G + u.be, G + u.g, s);
-            c6t_bn_bwd_apply(R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, dz, s);
-            c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, t->partial, G + u.b, nullptr, s);
+            c6t_bn_bwd_apply_colsum(R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, dz, t->partial, G + u.b, s);
             if (!wgrad(t, dy, t->a[l1], G + u.w, l1)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
             int rc = conv3x3(t, P + u.w, 1, dy, nullptr, nullptr, dmid);
             if (rc) return rc;
@@ -320,8 +319,7 @@ static int backward(c6_trainer *t) {
             const ConvBn &u = t->tower[l0];
             const float *m = t->mean + (size_t)(l0 + 1) * C, *v = t->var + (size_t)(l0 + 1) * C;
             c6t_colstats(1, R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, t->partial, G + u.be, G + u.g, s);
-            c6t_bn_bwd_apply(R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, nullptr, s);
-            c6t_colstats(2, R, C, dy, nullptr, nullptr, nullptr, nullptr, t->partial, G + u.b, nullptr, s);
+            c6t_bn_bwd_apply_colsum(R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, nullptr, t->partial, G + u.b, s);
             if (!wgrad(t, dy, t->a[l0], G + u.w, l0)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
             int rc = conv3x3(t, P + u.w, 1, dy, nullptr, dz /* + the skip connection's gradient */, cur);
             if (rc) return rc;
