@@ -295,7 +295,9 @@ void c6_pack_conv_weights_wino4_dev(int C, const float *w_oihw_dev, float *packe
 size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards);
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                             float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads = nullptr,
-                            const C6StemSrc *stem = nullptr, float *zsep = nullptr);      // zsep: `vbuf` holds V only (c6_conv_wino4_v_floats), Z goes here
+                            const C6StemSrc *stem = nullptr, float *zsep = nullptr,       // zsep: `vbuf` holds V only (c6_conv_wino4_v_floats), Z goes here
+                            float *stat_partial = nullptr);      // r6: per-workgroup column sums of the outputs and their squares, [c6_conv_wino4_out_grid][2][C]
+int c6_conv_wino4_out_grid(int N, int nboards, int num_cus);
 size_t c6_conv_wino4_v_floats(int C, int N, int nboards);
 double c6_conv_wino4_exec_flops(int C, int N, int nboards);
 // weight gradient of the same convolution in the Winograd domain (trainer, FP32): dW (OIHW, overwritten) from dy and the layer's input x

@@ -14,6 +14,7 @@ void c6t_stem_bwd(int N, int C, int B, const float *boards, const float *players
 size_t c6t_colstats_partial_floats(size_t R, int C);
 void c6t_colstats(int mode, size_t R, int C, const float *x, const float *aout, const float *y, const float *mean, const float *var,
                   float *partial, float *out0, float *out1, hipStream_t s);
+void c6t_colstats_finalize(int mode, size_t R, int C, int nchunk, const float *partial, float *out0, float *out1, hipStream_t s);
 void c6t_bn_apply(size_t R, int C, const float *y, const float *mean, const float *var, const float *gamma, const float *beta, const float *res,
                   float *a, int relu, hipStream_t s);
 void c6t_bn_bwd_apply(size_t R, int C, const float *dout, const float *aout, const float *y, const float *mean, const float *var,

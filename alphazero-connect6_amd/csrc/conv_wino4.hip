@@ -616,10 +616,15 @@ __device__ __forceinline__ void w4_tile_outputs(const float *zb, f32x4 (&y)[4][4
             }
     }
 }
-template <int N, bool HEADS>
+// STATS (r6, the trainer's forward pass): the per-channel sums of the outputs and of their squares -- the batch statistics of the BatchNorm behind the
+// convolution (model.hpp:61-78 in train mode) -- accumulated on the way out: partial[blockIdx.x][2][C], summed in block order by c6t_colstats_finalize_kernel.
+// A wave adds its tiles' pixels in the order it visits them, the four waves of a workgroup are added in wave order: a fixed order for a fixed grid, so a
+// step stays bit-reproducible.  (Before: a pass of its own over the stored outputs, 0.11 ms per layer at the reference trainer's shape.)
+template <int N, bool HEADS, bool STATS = false>
 __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
-                                                           float *__restrict__ out, long total_tiles, int relu, C6HeadFuse hd) {
+                                                           float *__restrict__ out, long total_tiles, int relu, C6HeadFuse hd, float *__restrict__ stat_partial = nullptr) {
     using G = W4Geom<N>;
+    f32x4 st0 = f32x4{0.f, 0.f, 0.f, 0.f}, st1 = st0;
     constexpr int C = G::C, T = G::T, TW = G::TW;
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -658,6 +663,11 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
                 if (res) v = v + *reinterpret_cast<const f32x4 *>(res + o);
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = v[r] > floor_ ? v[r] : floor_;
+                if (STATS) {
+                    st0 = st0 + v;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) st1[r] = __builtin_fmaf(v[r], v[r], st1[r]);
+                }
                 if (!HEADS) {
                     *reinterpret_cast<f32x4 *>(out + o) = v;
                 } else {
@@ -694,6 +704,18 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
                 const float vv = (m2 + hd.vc_b) * hd.vn_scale[p] + hd.vn_shift[p];
                 hd.vh[(size_t)bd * (N * N) + p] = vv > 0.f ? vv : 0.f;
             }
+        }
+    }
+    if (STATS) {
+        __shared__ f32x4 sred[2][4][64];
+        const int wv = threadIdx.x >> 6;
+        sred[0][wv][lane] = st0;
+        sred[1][wv][lane] = st1;
+        __syncthreads();
+        if (wv == 0) {
+            for (int w2 = 1; w2 < 4; w2++) { st0 = st0 + sred[0][w2][lane]; st1 = st1 + sred[1][w2][lane]; }
+            *reinterpret_cast<f32x4 *>(stat_partial + ((size_t)blockIdx.x * 2 + 0) * C + lane * 4) = st0;
+            *reinterpret_cast<f32x4 *>(stat_partial + ((size_t)blockIdx.x * 2 + 1) * C + lane * 4) = st1;
         }
     }
 }
@@ -854,7 +876,7 @@ size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards) { return C == W4_C ?
 
 template <int N>
 static void launch_w4(int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out, float *vbuf, int num_cus,
-                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep = nullptr) {
+                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep = nullptr, float *stat_partial = nullptr) {
     using G = W4Geom<N>;
     const long tiles = (long)nboards * G::T;
     const W4Map<N> map(nboards);
@@ -910,20 +932,26 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
     if (steps & 4) {
         const long want = (tiles + 3) / 4;
         const int grid_out = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
-        if (heads) hipLaunchKernelGGL((c6_wino4_out_kernel<N, true>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, *heads);
-        else hipLaunchKernelGGL((c6_wino4_out_kernel<N, false>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, C6HeadFuse{});
+        if (heads) hipLaunchKernelGGL((c6_wino4_out_kernel<N, true>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, *heads, (float *)nullptr);
+        else if (stat_partial) hipLaunchKernelGGL((c6_wino4_out_kernel<N, false, true>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, C6HeadFuse{}, stat_partial);
+        else hipLaunchKernelGGL((c6_wino4_out_kernel<N, false>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, C6HeadFuse{}, (float *)nullptr);
     }
 }
 
 // steps: bit 0 input transform, bit 1 GEMMs, bit 2 output transform (7 = the layer); bit 4: output transform fused with the NEXT layer's input transform
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep) {
+                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep, float *stat_partial) {
     if (C != W4_C) return false;
     if (nboards <= 0) return true;
-    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep); return true; }
-    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep); return true; }
-    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep); return true; }
+    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial); return true; }
+    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial); return true; }
+    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial); return true; }
     return false;
+}
+// workgroups of the output transform's launch (= the chunks of `stat_partial`: [chunks][2][C] floats)
+int c6_conv_wino4_out_grid(int N, int nboards, int num_cus) {
+    const long tiles = (long)nboards * (N == 19 ? W4Geom<19>::T : N == 15 ? W4Geom<15>::T : W4Geom<9>::T), want = (tiles + 3) / 4;
+    return (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
 }
 size_t c6_conv_wino4_v_floats(int C, int N, int nboards) { return C == W4_C ? w4_half_floats(N, nboards) : 0; }
 // matrix FLOPs the GEMM kernel executes for `nboards` boards (whole 64-tile blocks x 36 or 30 positions x C x C MACs)

@@ -289,6 +289,10 @@ __global__ __launch_bounds__(32 * CSF_LANES) void c6t_colstats_finalize_kernel(i
         if (out1) out1[c] = (float)s1;
     }
 }
+// the ordered finalisation alone, for partials a producing kernel left (r6: c6_wino4_out_kernel<., false, true>): [nchunk][2][C]
+void c6t_colstats_finalize(int mode, size_t R, int C, int nchunk, const float *partial, float *out0, float *out1, hipStream_t s) {
+    hipLaunchKernelGGL(c6t_colstats_finalize_kernel, dim3((C + 31) / 32), dim3(32 * CSF_LANES), 0, s, mode, R, C, nchunk, partial, out0, out1);
+}
 size_t c6t_colstats_partial_floats(size_t R, int C) { return ((R + CS_ROWS - 1) / CS_ROWS) * 2 * (size_t)C; }
 void c6t_colstats(int mode, size_t R, int C, const float *x, const float *aout, const float *y, const float *mean, const float *var,
                   float *partial, float *out0, float *out1, hipStream_t s) {

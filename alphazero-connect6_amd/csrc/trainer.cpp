@@ -139,6 +139,7 @@ extern "C" int c6_trainer_create(int board_size, int channels, int blocks, int b
     part = std::max(part, c6t_stem_bwd_partial_floats((int)C, (int)B));
     part = std::max(part, c6t_head_conv_bwd_partial_floats(R, (int)C));
     part = std::max(part, c6t_wgrad_partial_floats((int)C, (int)B));
+    part = std::max(part, (size_t)c6_conv_wino4_out_grid((int)board_size, (int)B, t->num_cus) * 2 * C);      // (r6: the forward convolutions' output kernel leaves the BatchNorm sums here)
     TA(t->partial, part);
     TA(t->sum0, std::max<size_t>(C, std::max<size_t>(n2, 256))); TA(t->sum1, std::max<size_t>(C, std::max<size_t>(n2, 256)));
     for (int q = 0; q < 4; q++) TA(t->X[q], t->act);
@@ -218,15 +219,21 @@ static bool wgrad(c6_trainer *t, const float *dy, const float *x, float *dw, int
     return c6t_wgrad(t->n, t->C, t->B, dy, x, t->partial, dw, t->stream, !is_f32(t));
 }
 // keep_layer >= 0: a forward convolution whose transformed input is kept for the weight gradient
-static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const float *in, const float *bias, const float *res, float *out, int keep_layer = -1) {
+// *stats_chunks (forward passes): set to the number of [2][C] partials of the outputs' column sums the convolution left in t->partial, or to 0 when the
+// kernel taken cannot leave them (the caller then runs c6t_colstats over the stored outputs)
+static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const float *in, const float *bias, const float *res, float *out, int keep_layer = -1,
+                   int *stats_chunks = nullptr) {
     bool ok;
+    if (stats_chunks) *stats_chunks = 0;
     if (t->precision == C6_PREC_FP32 && t->vbuf) {      // 256 channels: the evaluator's default FP32 form (2.2x fewer ms than the direct kernel here)
         c6_pack_conv_weights_wino4_dev(t->C, w_oihw, t->wpackw, transpose_flip, t->stream);
+        float *sp = stats_chunks ? t->partial : nullptr;
         if (keep_layer >= 0 && !t->vkeep.empty())
             ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vkeep[keep_layer], t->num_cus, t->stream, /*relu=*/0, 7, nullptr, nullptr,
-                                        t->vbuf + c6_conv_wino4_v_floats(t->C, t->n, t->B));
+                                        t->vbuf + c6_conv_wino4_v_floats(t->C, t->n, t->B), sp);
         else
-            ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vbuf, t->num_cus, t->stream, /*relu=*/0, 7);
+            ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vbuf, t->num_cus, t->stream, /*relu=*/0, 7, nullptr, nullptr, nullptr, sp);
+        if (ok && stats_chunks) *stats_chunks = c6_conv_wino4_out_grid(t->n, t->B, t->num_cus);
     } else if (is_f32(t)) {
         c6t_pack_f32n(t->C, w_oihw, t->wpack32, transpose_flip, t->stream);
         ok = c6_conv_f32n_dispatch(t->C, t->n, t->B, in, t->wpack32, bias, res, out, t->num_cus, t->stream, /*relu=*/0);
@@ -251,10 +258,12 @@ static int forward_loss(c6_trainer *t, bool want_grad_seed) {
     // tower
     for (int l = 0; l < L; l++) {
         const ConvBn &u = t->tower[l];
-        int rc = conv3x3(t, P + u.w, 0, t->a[l], P + u.b, nullptr, t->y[l + 1], l);
+        int chunks = 0;
+        int rc = conv3x3(t, P + u.w, 0, t->a[l], P + u.b, nullptr, t->y[l + 1], l, &chunks);
         if (rc) return rc;
         float *m = t->mean + (size_t)(l + 1) * C, *v = t->var + (size_t)(l + 1) * C;
-        c6t_colstats(0, R, C, t->y[l + 1], nullptr, nullptr, nullptr, nullptr, t->partial, m, v, s);
+        if (chunks) c6t_colstats_finalize(0, R, C, chunks, t->partial, m, v, s);      // (r6: the sums came with the convolution's outputs)
+        else c6t_colstats(0, R, C, t->y[l + 1], nullptr, nullptr, nullptr, nullptr, t->partial, m, v, s);
         const float *res = (l & 1) ? t->a[l - 1] : nullptr;              // second conv of a block: + block input, model.hpp:71
         c6t_bn_apply(R, C, t->y[l + 1], m, v, P + u.g, P + u.be, res, t->a[l + 1], 1, s);
         c6t_bn_running(C, R, m, v, P + u.rm, P + u.rv, s);
