@@ -296,7 +296,8 @@ size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards);
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
                             float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads = nullptr,
                             const C6StemSrc *stem = nullptr, float *zsep = nullptr,       // zsep: `vbuf` holds V only (c6_conv_wino4_v_floats), Z goes here
-                            float *stat_partial = nullptr);      // r6: per-workgroup column sums of the outputs and their squares, [c6_conv_wino4_out_grid][2][C]
+                            float *stat_partial = nullptr,       // r6: per-workgroup column sums of the outputs and their squares, [c6_conv_wino4_out_grid][2][C]
+                            const float *const *bn_bwd = nullptr);      // ... or, with {aout, y, mean, var} of the BatchNorm + ReLU unit the outputs are the gradient OF: its backward sums
 int c6_conv_wino4_out_grid(int N, int nboards, int num_cus);
 size_t c6_conv_wino4_v_floats(int C, int N, int nboards);
 double c6_conv_wino4_exec_flops(int C, int N, int nboards);

@@ -620,11 +620,22 @@ __device__ __forceinline__ void w4_tile_outputs(const float *zb, f32x4 (&y)[4][4
 // convolution (model.hpp:61-78 in train mode) -- accumulated on the way out: partial[blockIdx.x][2][C], summed in block order by c6t_colstats_finalize_kernel.
 // A wave adds its tiles' pixels in the order it visits them, the four waves of a workgroup are added in wave order: a fixed order for a fixed grid, so a
 // step stays bit-reproducible.  (Before: a pass of its own over the stored outputs, 0.11 ms per layer at the reference trainer's shape.)
-template <int N, bool HEADS, bool STATS = false>
+// STATS = 2 (the trainer's input-gradient pass): the outputs are the gradient `dout` that reaches a BatchNorm + ReLU unit; the two sums its backward pass
+// needs -- s0 = sum dz, s1 = sum dz * xhat with dz = dout * (aout > 0), xhat = (y - mean) * invstd (c6t_colstats mode 1) -- are taken here from the unit's
+// stored output `aout` and pre-norm input `y`: that pass over three tensors (0.25 ms per layer) is gone.
+struct C6BnBwdSrc { const float *aout, *y, *mean, *var; };
+template <int N, bool HEADS, int STATS = 0>
 __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, const float *__restrict__ res,
-                                                           float *__restrict__ out, long total_tiles, int relu, C6HeadFuse hd, float *__restrict__ stat_partial = nullptr) {
+                                                           float *__restrict__ out, long total_tiles, int relu, C6HeadFuse hd, float *__restrict__ stat_partial = nullptr,
+                                                           C6BnBwdSrc bn = C6BnBwdSrc{nullptr, nullptr, nullptr, nullptr}) {
     using G = W4Geom<N>;
-    f32x4 st0 = f32x4{0.f, 0.f, 0.f, 0.f}, st1 = st0;
+    f32x4 st0 = f32x4{0.f, 0.f, 0.f, 0.f}, st1 = st0, bm = st0, bis = st0;
+    if (STATS == 2) {
+        bm = *reinterpret_cast<const f32x4 *>(bn.mean + (threadIdx.x & 63) * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bn.var + (threadIdx.x & 63) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; r++) bis[r] = 1.0f / sqrtf(bv[r] + 1e-5f);      // (BN_EPS of train_kernels.hip: torch's BatchNorm default)
+    }
     constexpr int C = G::C, T = G::T, TW = G::TW;
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -663,10 +674,19 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
                 if (res) v = v + *reinterpret_cast<const f32x4 *>(res + o);
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = v[r] > floor_ ? v[r] : floor_;
-                if (STATS) {
+                if (STATS == 1) {
                     st0 = st0 + v;
 #pragma unroll
                     for (int r = 0; r < 4; r++) st1[r] = __builtin_fmaf(v[r], v[r], st1[r]);
+                }
+                if (STATS == 2) {
+                    const f32x4 av = *reinterpret_cast<const f32x4 *>(bn.aout + o), yy = *reinterpret_cast<const f32x4 *>(bn.y + o);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float dz = av[r] > 0.f ? v[r] : 0.f;
+                        st0[r] += dz;
+                        st1[r] = __builtin_fmaf(dz, (yy[r] - bm[r]) * bis[r], st1[r]);
+                    }
                 }
                 if (!HEADS) {
                     *reinterpret_cast<f32x4 *>(out + o) = v;
@@ -706,7 +726,7 @@ __global__ __launch_bounds__(256) void c6_wino4_out_kernel(const float *__restri
             }
         }
     }
-    if (STATS) {
+    if (STATS != 0) {
         __shared__ f32x4 sred[2][4][64];
         const int wv = threadIdx.x >> 6;
         sred[0][wv][lane] = st0;
@@ -876,7 +896,8 @@ size_t c6_conv_wino4_vbuf_floats(int C, int N, int nboards) { return C == W4_C ?
 
 template <int N>
 static void launch_w4(int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out, float *vbuf, int num_cus,
-                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep = nullptr, float *stat_partial = nullptr) {
+                      int relu, int steps, hipStream_t s, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep = nullptr, float *stat_partial = nullptr,
+                      const float *const *bn_bwd = nullptr) {
     using G = W4Geom<N>;
     const long tiles = (long)nboards * G::T;
     const W4Map<N> map(nboards);
@@ -933,19 +954,22 @@ static void launch_w4(int nboards, const float *in, const float *wp, const float
         const long want = (tiles + 3) / 4;
         const int grid_out = (int)(want < (long)num_cus * 8 ? want : (long)num_cus * 8);
         if (heads) hipLaunchKernelGGL((c6_wino4_out_kernel<N, true>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, *heads, (float *)nullptr);
-        else if (stat_partial) hipLaunchKernelGGL((c6_wino4_out_kernel<N, false, true>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, C6HeadFuse{}, stat_partial);
+        else if (stat_partial && bn_bwd)
+            hipLaunchKernelGGL((c6_wino4_out_kernel<N, false, 2>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, C6HeadFuse{}, stat_partial,
+                               C6BnBwdSrc{bn_bwd[0], bn_bwd[1], bn_bwd[2], bn_bwd[3]});
+        else if (stat_partial) hipLaunchKernelGGL((c6_wino4_out_kernel<N, false, 1>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, C6HeadFuse{}, stat_partial);
         else hipLaunchKernelGGL((c6_wino4_out_kernel<N, false>), dim3(grid_out), dim3(256), 0, s, Mb, bias, res, out, tiles, relu, C6HeadFuse{}, (float *)nullptr);
     }
 }
 
 // steps: bit 0 input transform, bit 1 GEMMs, bit 2 output transform (7 = the layer); bit 4: output transform fused with the NEXT layer's input transform
 bool c6_conv_wino4_dispatch(int C, int N, int nboards, const float *in, const float *wp, const float *bias, const float *res, float *out,
-                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep, float *stat_partial) {
+                            float *vbuf, int num_cus, hipStream_t s, int relu, int steps, const C6HeadFuse *heads, const C6StemSrc *stem, float *zsep, float *stat_partial, const float *const *bn_bwd) {
     if (C != W4_C) return false;
     if (nboards <= 0) return true;
-    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial); return true; }
-    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial); return true; }
-    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial); return true; }
+    if (N == 19) { launch_w4<19>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial, bn_bwd); return true; }
+    if (N == 15) { launch_w4<15>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial, bn_bwd); return true; }
+    if (N == 9) { launch_w4<9>(nboards, in, wp, bias, res, out, vbuf, num_cus, relu, steps, s, heads, stem, zsep, stat_partial, bn_bwd); return true; }
     return false;
 }
 // workgroups of the output transform's launch (= the chunks of `stat_partial`: [chunks][2][C] floats)

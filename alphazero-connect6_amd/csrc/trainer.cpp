@@ -221,8 +221,10 @@ static bool wgrad(c6_trainer *t, const float *dy, const float *x, float *dw, int
 // keep_layer >= 0: a forward convolution whose transformed input is kept for the weight gradient
 // *stats_chunks (forward passes): set to the number of [2][C] partials of the outputs' column sums the convolution left in t->partial, or to 0 when the
 // kernel taken cannot leave them (the caller then runs c6t_colstats over the stored outputs)
+// bn_bwd (input-gradient passes): {aout, y, mean, var} of the BatchNorm + ReLU unit whose output gradient this convolution produces -- the partials are then
+// that unit's backward sums (c6t_colstats mode 1) instead of the forward statistics
 static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const float *in, const float *bias, const float *res, float *out, int keep_layer = -1,
-                   int *stats_chunks = nullptr) {
+                   int *stats_chunks = nullptr, const float *const *bn_bwd = nullptr) {
     bool ok;
     if (stats_chunks) *stats_chunks = 0;
     if (t->precision == C6_PREC_FP32 && t->vbuf) {      // 256 channels: the evaluator's default FP32 form (2.2x fewer ms than the direct kernel here)
@@ -230,9 +232,9 @@ static int conv3x3(c6_trainer *t, const float *w_oihw, int transpose_flip, const
         float *sp = stats_chunks ? t->partial : nullptr;
         if (keep_layer >= 0 && !t->vkeep.empty())
             ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vkeep[keep_layer], t->num_cus, t->stream, /*relu=*/0, 7, nullptr, nullptr,
-                                        t->vbuf + c6_conv_wino4_v_floats(t->C, t->n, t->B), sp);
+                                        t->vbuf + c6_conv_wino4_v_floats(t->C, t->n, t->B), sp, bn_bwd);
         else
-            ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vbuf, t->num_cus, t->stream, /*relu=*/0, 7, nullptr, nullptr, nullptr, sp);
+            ok = c6_conv_wino4_dispatch(t->C, t->n, t->B, in, t->wpackw, bias, res, out, t->vbuf, t->num_cus, t->stream, /*relu=*/0, 7, nullptr, nullptr, nullptr, sp, bn_bwd);
         if (ok && stats_chunks) *stats_chunks = c6_conv_wino4_out_grid(t->n, t->B, t->num_cus);
     } else if (is_f32(t)) {
         c6t_pack_f32n(t->C, w_oihw, t->wpack32, transpose_flip, t->stream);
@@ -313,29 +315,37 @@ static int backward(c6_trainer *t) {
     c6t_colstats(2, R, 1, t->dyv, nullptr, nullptr, nullptr, nullptr, t->partial, G + t->vc_b, nullptr, s);
     // ---- tower, last block first
     float *dy = t->X[1], *dz = t->X[2], *dmid = t->X[3];
+    int chunks = 0;      // r6: > 0 when the convolution that produced the gradient at hand left the next BatchNorm's backward sums in t->partial
     for (int blk = t->nb - 2; blk >= 0; blk--) {
         const int l0 = 2 * blk, l1 = 2 * blk + 1;
         {   // second conv unit: a[l1+1] = relu(bn(conv(a[l1])) + a[l0])
             const ConvBn &u = t->tower[l1];
             const float *m = t->mean + (size_t)(l1 + 1) * C, *v = t->var + (size_t)(l1 + 1) * C;
-            c6t_colstats(1, R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, t->partial, G + u.be, G + u.g, s);
+            if (chunks) c6t_colstats_finalize(1, R, C, chunks, t->partial, G + u.be, G + u.g, s);
+            else c6t_colstats(1, R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, t->partial, G + u.be, G + u.g, s);
             c6t_bn_bwd_apply_colsum(R, C, cur, t->a[l1 + 1], t->y[l1 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, dz, t->partial, G + u.b, s);
             if (!wgrad(t, dy, t->a[l1], G + u.w, l1)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
-            int rc = conv3x3(t, P + u.w, 1, dy, nullptr, nullptr, dmid);
+            // dmid = the gradient that reaches the block's FIRST unit: its backward sums come with it
+            const float *nb_[4] = {t->a[l0 + 1], t->y[l0 + 1], t->mean + (size_t)(l0 + 1) * C, t->var + (size_t)(l0 + 1) * C};
+            int rc = conv3x3(t, P + u.w, 1, dy, nullptr, nullptr, dmid, -1, &chunks, nb_);
             if (rc) return rc;
         }
         {   // first conv unit: a[l0+1] = relu(bn(conv(a[l0])))
             const ConvBn &u = t->tower[l0];
             const float *m = t->mean + (size_t)(l0 + 1) * C, *v = t->var + (size_t)(l0 + 1) * C;
-            c6t_colstats(1, R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, t->partial, G + u.be, G + u.g, s);
+            if (chunks) c6t_colstats_finalize(1, R, C, chunks, t->partial, G + u.be, G + u.g, s);
+            else c6t_colstats(1, R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, t->partial, G + u.be, G + u.g, s);
             c6t_bn_bwd_apply_colsum(R, C, dmid, t->a[l0 + 1], t->y[l0 + 1], m, v, P + u.g, G + u.be, G + u.g, dy, nullptr, t->partial, G + u.b, s);
             if (!wgrad(t, dy, t->a[l0], G + u.w, l0)) return tfail(C6_ERR_BAD_ARG, "trainer: no weight-gradient kernel");
-            int rc = conv3x3(t, P + u.w, 1, dy, nullptr, dz /* + the skip connection's gradient */, cur);
+            // cur = the gradient that reaches the unit in front of this block: the previous block's second unit (output a[l0]), or the stem
+            const float *nb_[4] = {t->a[l0], t->y[l0], t->mean + (size_t)l0 * C, t->var + (size_t)l0 * C};
+            int rc = conv3x3(t, P + u.w, 1, dy, nullptr, dz /* + the skip connection's gradient */, cur, -1, &chunks, nb_);
             if (rc) return rc;
         }
     }
     // ---- stem
-    c6t_colstats(1, R, C, cur, t->a[0], t->y[0], t->mean, t->var, t->partial, G + t->stem.be, G + t->stem.g, s);
+    if (chunks) c6t_colstats_finalize(1, R, C, chunks, t->partial, G + t->stem.be, G + t->stem.g, s);
+    else c6t_colstats(1, R, C, cur, t->a[0], t->y[0], t->mean, t->var, t->partial, G + t->stem.be, G + t->stem.g, s);
     c6t_bn_bwd_apply(R, C, cur, t->a[0], t->y[0], t->mean, t->var, P + t->stem.g, G + t->stem.be, G + t->stem.g, dy, nullptr, s);
     c6t_stem_bwd(t->n, C, B, t->boards, t->players, dy, t->partial, G + t->stem.w, G + t->stem.b, s);
     return C6_OK;
