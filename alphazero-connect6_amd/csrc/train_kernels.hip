@@ -313,9 +313,31 @@ __global__ void c6t_bn_apply_kernel(size_t total, int C, const float *__restrict
         a[e] = relu ? (v > 0.f ? v : 0.f) : v;
     }
 }
+// the same, four channels per thread (16-byte loads and stores; C a multiple of 4: the tower's shapes) -- the same expression per element, so the same bits
+__global__ __launch_bounds__(256) void c6t_bn_apply4_kernel(size_t total4, int C, const float *__restrict__ y, const float *__restrict__ mean, const float *__restrict__ var,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ res,
+                                                            float *__restrict__ a, int relu) {
+    const int CQ = C / 4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % CQ) * 4;
+        const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + e * 4), m = *reinterpret_cast<const f32x4 *>(mean + c), vv = *reinterpret_cast<const f32x4 *>(var + c),
+                    g = *reinterpret_cast<const f32x4 *>(gamma + c), b = *reinterpret_cast<const f32x4 *>(beta + c);
+        f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (res) rv = *reinterpret_cast<const f32x4 *>(res + e * 4);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v = (yv[q] - m[q]) * (1.0f / sqrtf(vv[q] + BN_EPS)) * g[q] + b[q];
+            if (res) v += rv[q];
+            o[q] = relu ? (v > 0.f ? v : 0.f) : v;
+        }
+        *reinterpret_cast<f32x4 *>(a + e * 4) = o;
+    }
+}
 void c6t_bn_apply(size_t R, int C, const float *y, const float *mean, const float *var, const float *gamma, const float *beta, const float *res,
                   float *a, int relu, hipStream_t s) {
-    hipLaunchKernelGGL(c6t_bn_apply_kernel, dim3(2048), dim3(256), 0, s, R * C, C, y, mean, var, gamma, beta, res, a, relu);
+    if (C % 64 == 0) hipLaunchKernelGGL(c6t_bn_apply4_kernel, dim3(2048), dim3(256), 0, s, R * C / 4, C, y, mean, var, gamma, beta, res, a, relu);
+    else hipLaunchKernelGGL(c6t_bn_apply_kernel, dim3(2048), dim3(256), 0, s, R * C, C, y, mean, var, gamma, beta, res, a, relu);
 }
 
 // BatchNorm backward: dz = dout * (aout > 0); dy = gamma * invstd * (dz - sum_dz / R - xhat * sum_dzx / R); optionally
