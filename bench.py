@@ -369,6 +369,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (libconnect6_amd has no CPU fallback)")
     if os.environ.get("C6_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    ndev_visible = torch.cuda.device_count()
+    if local_rank >= ndev_visible:      # a launcher that gives every rank its own visibility mask (HIP_VISIBLE_DEVICES = one GPU): the rank's device is ordinal 0 there
+        local_rank = local_rank % max(ndev_visible, 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
