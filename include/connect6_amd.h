@@ -142,9 +142,10 @@ enum {
  * and so is the default. */
 enum {
     C6_PREC_DEFAULT = 0,     /* = C6_PREC_FP32 */
-    C6_PREC_FP32 = 1,        /* f32 operands, exact f32 products, f32 accumulate on v_mfma_f32_32x32x2_f32, evaluated as Winograd F(4x4,3x3)
-                                at 256 channels (3.6x fewer matrix FLOPs than the direct form at N = 19) and F(2x2,3x3) at 64 / 128 (2.03x): same
-                                arithmetic type, the whole FP32 range */
+    C6_PREC_FP32 = 1,        /* f32 operands, exact f32 products, f32 accumulate on v_mfma_f32_32x32x2_f32, evaluated in Winograd form: at 256
+                                channels tiles of F(6,3) / F(4,3) / F(3,3) across and F(4,3) / F(3,3) down a 19x19 or 15x15 board (4.1x fewer matrix
+                                products than the direct form), F(4x4,3x3) at 9x9 and in two-block towers, F(2x2,3x3) at 64 / 128 channels (2.03x):
+                                the same arithmetic type, the whole FP32 range */
     C6_PREC_BF16X3 = 3,      /* operands split hi+mid in bf16, x_hi*w_hi + x_hi*w_mid + x_mid*w_hi on bf16 MFMAs, f32 accumulate: error
                                 <= 3*2^-16 per product; covers the whole FP32 range.  Net outputs within 1e-5 of FP32 in the tests */
     C6_PREC_BF16 = 4,        /* plain bf16 products (x_hi*w_hi only): RELAXED tolerance -- net outputs agree with FP32 to ~1e-3, NOT the 1e-5
